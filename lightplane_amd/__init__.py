@@ -1,0 +1,30 @@
+"""lightplane_amd -- MI355X-native (gfx950) Renderer / Splatter hot path of Lightplane.
+
+Public surface mirrors the reference's ``lightplane/__init__.py:8-31`` for the
+hot path: ``Rays``, ``DecoderParams`` / ``SplatterParams`` and their helpers,
+the functional ``lightplane_renderer`` / ``lightplane_splatter`` /
+``lightplane_mlp_splatter`` and the ``LightplaneRenderer`` / ``LightplaneSplatter``
+/ ``LightplaneMLPSplatter`` modules.  The compute path is hand-written HIP behind
+a C-ABI shared library (``lightplane_amd/csrc`` -> ``liblightplane_hip.so``); there
+is no CPU or PyTorch fallback: a missing library raises at first use.
+"""
+from .grids import flatten_grid, unflatten_grid
+from .params import (
+    DecoderParams,
+    SplatterParams,
+    flatten_decoder_params,
+    flatten_splatter_params,
+    flattened_decoder_params_to_list,
+    flattened_triton_decoder_to_list,
+    get_triton_function_input_dims,
+    init_decoder_params,
+    init_splatter_params,
+)
+from .rays import Rays, calc_harmonic_embedding, calc_harmonic_embedding_dim, jitter_near_far
+
+__all__ = [
+    "Rays", "DecoderParams", "SplatterParams", "init_decoder_params", "init_splatter_params",
+    "flatten_decoder_params", "flatten_splatter_params", "flattened_decoder_params_to_list",
+    "flattened_triton_decoder_to_list", "get_triton_function_input_dims", "flatten_grid",
+    "unflatten_grid", "calc_harmonic_embedding", "calc_harmonic_embedding_dim", "jitter_near_far",
+]

@@ -1,0 +1,224 @@
+"""Seeded synthetic inputs shared by the golden generator, the parity tests and smoke().
+
+Recipes follow the reference's test fixtures (tests/utils.py:230-268 `random_rays`,
+:283-324 `random_grid`, :327-376 `random_mlp_decoder_params` -- Xavier init then
+overwritten with N(0, 0.01)), generated on the CPU so that the oracle and the
+GPU see identical bits.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from lightplane_amd import DecoderParams, Rays, SplatterParams
+from lightplane_amd.params import flatten_decoder_params, flatten_splatter_params
+
+
+def grid_sizes_for(base, is_triplane: bool):
+    """[B, D, H, W, C] -> list of sizes (one voxel grid or the three planes)."""
+    base = list(base)
+    if not is_triplane:
+        return [base]
+    out = []
+    for ax in (1, 2, 3):
+        s = list(base)
+        s[ax] = 1
+        out.append(s)
+    return out
+
+
+def random_rays(gen, n_rays, batch_size, enc_dim, one_ray=False) -> Rays:
+    def rn(c):
+        if one_ray:
+            return torch.randn(1, c, generator=gen).repeat(n_rays, 1)
+        return torch.randn(n_rays, c, generator=gen)
+
+    grid_idx = torch.randint(0, batch_size, (n_rays,), generator=gen, dtype=torch.long)
+    origins = rn(3) / 3.0
+    directions = -origins + rn(3) * 0.1
+    near = rn(1)[:, 0] * 0.1 + 0.1
+    far = rn(1)[:, 0].abs() * 0.1 + 3.0
+    enc = None if enc_dim is None else rn(enc_dim)
+    return Rays(directions=directions, origins=origins, grid_idx=grid_idx, near=near, far=far, encoding=enc)
+
+
+def random_grids(gen, sizes) -> List[torch.Tensor]:
+    return [torch.randn(*s, generator=gen) for s in sizes]
+
+
+def _rand_mlp(gen, n_layers, d_in, d_hidden, d_out, std):
+    ws, bs = [], []
+    for l in range(n_layers):
+        i = d_in if l == 0 else d_hidden
+        o = d_out if l == n_layers - 1 else d_hidden
+        ws.append(torch.randn(i, o, generator=gen) * std)
+        bs.append(torch.randn(o, generator=gen) * std)
+    return ws, bs
+
+
+def random_decoder(gen, n_layers_trunk, n_layers_opacity, n_layers_color, input_chn, hidden_chn,
+                   color_chn, use_separate_color_grid=False, std=0.01, pad_color=True) -> DecoderParams:
+    """N(0, std) weights AND biases in the reference's flat layout."""
+    if use_separate_color_grid:
+        n_layers_trunk = 0
+    wt, bt = _rand_mlp(gen, n_layers_trunk, input_chn, hidden_chn, hidden_chn, std) if n_layers_trunk else ([], [])
+    head_in = input_chn if use_separate_color_grid else hidden_chn
+    wo, bo = _rand_mlp(gen, n_layers_opacity, head_in, hidden_chn, 1, std)
+    wc, bc = _rand_mlp(gen, n_layers_color, head_in, hidden_chn, color_chn, std)
+    flat, nt, no, nc = flatten_decoder_params(wt, bt, wo, bo, wc, bc, pad_color)
+    return DecoderParams(flat, nt, no, nc, color_chn)
+
+
+def random_splatter_mlp(gen, n_layers, input_chn, hidden_chn, out_chn, std=0.01) -> SplatterParams:
+    w, b = _rand_mlp(gen, n_layers, input_chn, hidden_chn, out_chn, std)
+    return SplatterParams(*flatten_splatter_params(w, b))
+
+
+def pinhole_rays(height, width, cam_dist=2.7, enc_dim=None, gen=None, grid_idx=0,
+                 azimuth_deg=0.0, elevation_deg=0.0) -> Rays:
+    """Pinhole camera at distance ``cam_dist`` looking at the origin so that the
+    [-1,1]^3 cube fills the frame (SURVEY.md 8(d) cfg 2 recipe).  near/far bracket
+    the cube's bounding sphere.  Rays are emitted in row-major pixel order."""
+    import math
+
+    half = 1.0 / (cam_dist - 1.0)  # tan(fov/2): the cube's front face fills the frame
+    ys = (torch.arange(height, dtype=torch.float32) + 0.5) / height * 2 - 1
+    xs = (torch.arange(width, dtype=torch.float32) + 0.5) / width * 2 - 1
+    yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+    d_cam = torch.stack([xx * half, yy * half, -torch.ones_like(xx)], dim=-1).reshape(-1, 3)
+    az, el = math.radians(azimuth_deg), math.radians(elevation_deg)
+    # camera-to-world rotation: first elevate about x, then rotate about y
+    rx = torch.tensor([[1, 0, 0], [0, math.cos(el), -math.sin(el)], [0, math.sin(el), math.cos(el)]], dtype=torch.float32)
+    ry = torch.tensor([[math.cos(az), 0, math.sin(az)], [0, 1, 0], [-math.sin(az), 0, math.cos(az)]], dtype=torch.float32)
+    rot = ry @ rx
+    dirs = d_cam @ rot.T
+    origin = (rot @ torch.tensor([0.0, 0.0, cam_dist])).expand_as(dirs).contiguous()
+    n = dirs.shape[0]
+    r = math.sqrt(3.0)
+    near = torch.full((n,), cam_dist - r)
+    far = torch.full((n,), cam_dist + r)
+    enc = None
+    if enc_dim is not None:
+        enc = torch.randn(n, enc_dim, generator=gen)
+    return Rays(directions=dirs.contiguous(), origins=origin, grid_idx=torch.full((n,), grid_idx, dtype=torch.long),
+                near=near, far=far, encoding=enc)
+
+
+@dataclass
+class RendererCase:
+    """One seeded Renderer test case (inputs + config)."""
+
+    name: str
+    seed: int = 0
+    n_rays: int = 24
+    grid_base: tuple = (2, 5, 6, 7, 16)
+    is_triplane: bool = False
+    extra_voxel: bool = False  # triplane + one extra voxel grid in the same grid-list
+    n_layers: tuple = (2, 2, 2)  # trunk, opacity, color
+    hidden: int = 32
+    color_chn: int = 3
+    num_samples: int = 9
+    num_samples_inf: int = 0
+    gain: float = 1.0
+    mask_oob: bool = False
+    contract: bool = False
+    scaffold_size: Optional[tuple] = None  # (D, H, W)
+    separate_color_grid: bool = False
+    noise_sigma: float = 0.0
+    noise_seed: int = 0
+    param_std: float = 0.2
+    one_ray: bool = False
+
+    def build(self):
+        gen = torch.Generator().manual_seed(self.seed)
+        B, C = self.grid_base[0], self.grid_base[-1]
+        sizes = grid_sizes_for(self.grid_base, self.is_triplane)
+        if self.extra_voxel:
+            sizes = sizes + [[B, 4, 3, 5, C]]
+        grids = random_grids(gen, sizes)
+        color_grids = random_grids(gen, sizes) if self.separate_color_grid else None
+        dec = random_decoder(gen, *self.n_layers, input_chn=C, hidden_chn=self.hidden, color_chn=self.color_chn,
+                             use_separate_color_grid=self.separate_color_grid, std=self.param_std)
+        enc_dim = int(dec.n_hidden_color[0])
+        rays = random_rays(gen, self.n_rays, B, enc_dim, one_ray=self.one_ray)
+        scaffold = None
+        if self.scaffold_size is not None:
+            scaffold = (torch.rand(B, *self.scaffold_size, generator=gen) > 0.4).float()
+        cfg = dict(num_samples=self.num_samples, gain=self.gain, num_samples_inf=self.num_samples_inf,
+                   mask_out_of_bounds_samples=self.mask_oob, contract_coords=self.contract,
+                   inject_noise_sigma=self.noise_sigma, inject_noise_seed=self.noise_seed)
+        # upstream gradients for the backward check
+        g_len = torch.randn(self.n_rays, generator=gen)
+        g_nlt = torch.randn(self.n_rays, generator=gen)
+        g_feat = torch.randn(self.n_rays, self.color_chn, generator=gen)
+        return dict(rays=rays, grids=grids, color_grids=color_grids, decoder=dec, scaffold=scaffold, cfg=cfg,
+                    sizes=sizes, upstream=(g_len, g_nlt, g_feat))
+
+
+@dataclass
+class SplatterCase:
+    name: str
+    seed: int = 0
+    n_rays: int = 24
+    out_base: tuple = (2, 6, 5, 7, 32)
+    is_triplane: bool = False
+    num_samples: int = 9
+    num_samples_inf: int = 0
+    mask_oob: bool = False
+    contract: bool = False
+    # MLP splatter
+    use_mlp: bool = False
+    in_base: tuple = (2, 4, 6, 5, 32)
+    in_triplane: bool = False
+    n_layers: int = 3
+    hidden: int = 32
+    feat_dim: int = 32
+
+    def build(self):
+        gen = torch.Generator().manual_seed(self.seed)
+        B = self.out_base[0]
+        out_sizes = grid_sizes_for(self.out_base, self.is_triplane)
+        enc_dim = self.feat_dim if self.use_mlp else self.out_base[-1]
+        rays = random_rays(gen, self.n_rays, B, enc_dim)
+        rays.encoding = torch.rand(self.n_rays, enc_dim, generator=gen)
+        mlp, in_grids, in_sizes = None, None, None
+        if self.use_mlp:
+            in_base = list(self.in_base)
+            in_base[-1] = self.feat_dim
+            in_sizes = grid_sizes_for(in_base, self.in_triplane)
+            in_grids = random_grids(gen, in_sizes)
+            mlp = random_splatter_mlp(gen, self.n_layers, self.feat_dim, self.hidden, self.out_base[-1], std=0.2)
+        cfg = dict(num_samples=self.num_samples, num_samples_inf=self.num_samples_inf,
+                   mask_out_of_bounds_samples=self.mask_oob, contract_coords=self.contract)
+        up = [torch.randn(*s, generator=gen) for s in out_sizes]
+        return dict(rays=rays, out_sizes=out_sizes, mlp=mlp, in_grids=in_grids, in_sizes=in_sizes, cfg=cfg, upstream=up)
+
+
+RENDERER_CASES = [
+    RendererCase("voxel_basic"),
+    RendererCase("triplane_basic", seed=1, is_triplane=True),
+    RendererCase("triplane_plus_voxel", seed=2, is_triplane=True, extra_voxel=True, gain=3.0),
+    RendererCase("voxel_inf_contract", seed=3, num_samples_inf=4, contract=True),
+    RendererCase("triplane_mask", seed=4, is_triplane=True, mask_oob=True, num_samples_inf=3),
+    RendererCase("voxel_scaffold", seed=5, scaffold_size=(6, 4, 5), gain=3.0),
+    RendererCase("triplane_colorgrid", seed=6, is_triplane=True, separate_color_grid=True, n_layers=(0, 2, 2)),
+    RendererCase("voxel_noise", seed=7, noise_sigma=1.0, noise_seed=1234),
+    RendererCase("voxel_deep", seed=8, n_layers=(4, 2, 4), n_rays=17),
+    RendererCase("triplane_h16_c32", seed=9, is_triplane=True, grid_base=(1, 6, 5, 4, 32), hidden=16, n_layers=(1, 3, 2)),
+    RendererCase("single_sample", seed=10, num_samples=1, n_rays=5),
+    RendererCase("one_ray_repeated", seed=11, one_ray=True, is_triplane=True, n_rays=33),
+    RendererCase("color16", seed=12, color_chn=16, n_rays=8),
+]
+
+SPLATTER_CASES = [
+    SplatterCase("voxel_basic"),
+    SplatterCase("triplane_basic", seed=1, is_triplane=True),
+    SplatterCase("voxel_inf_contract", seed=2, num_samples_inf=4, contract=True),
+    SplatterCase("triplane_mask", seed=3, is_triplane=True, mask_oob=True, num_samples_inf=3),
+    SplatterCase("mlp_voxel", seed=4, use_mlp=True),
+    SplatterCase("mlp_triplane_in_triplane", seed=5, use_mlp=True, is_triplane=True, in_triplane=True, n_layers=4,
+                 hidden=64, feat_dim=64, mask_oob=True),
+    SplatterCase("single_ray", seed=6, n_rays=1),
+]

@@ -1,0 +1,107 @@
+"""Pin the CPU oracle (oracle/lightplane_oracle.py) against fixtures produced by the
+reference's own naive implementation (tests/golden/make_golden.py).  CPU only.
+
+Tolerance: the oracle is a re-statement with a different (but mathematically
+identical) operation order (explicit gathers instead of F.grid_sample, scatter via
+index_add), so agreement is at fp32 round-off: 2e-5 relative to the tensor scale.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lightplane_oracle as O
+from tests.synth import RENDERER_CASES, SPLATTER_CASES
+
+REL_TOL = 2e-5
+
+
+def _close(name, got, want, tol=REL_TOL):
+    got = torch.as_tensor(got, dtype=torch.float64)
+    want = torch.as_tensor(np.asarray(want), dtype=torch.float64)
+    assert got.shape == want.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(want.shape)}"
+    scale = max(want.abs().max().item(), 1e-6)
+    err = (got - want).abs().max().item() / scale
+    assert err <= tol, f"{name}: max err / scale = {err:.3e} > {tol}"
+
+
+def _check_inputs(d, z):
+    r = d["rays"]
+    for k in ("directions", "origins", "near", "far", "encoding"):
+        assert np.array_equal(getattr(r, k).numpy(), z[k]), f"seeded input {k} drifted from the golden file"
+    assert np.array_equal(r.grid_idx.numpy(), z["grid_idx"])
+
+
+@pytest.mark.parametrize("case", RENDERER_CASES, ids=lambda c: c.name)
+def test_renderer_oracle_matches_reference(case, golden_dir):
+    z = np.load(os.path.join(golden_dir, f"renderer__{case.name}.npz"))
+    d = case.build()
+    _check_inputs(d, z)
+    assert np.array_equal(d["decoder"].mlp_params.numpy(), z["mlp_params"])
+    rays, dec = d["rays"], d["decoder"]
+    rays.encoding = rays.encoding.clone().requires_grad_(True)
+    dec.mlp_params = dec.mlp_params.clone().requires_grad_(True)
+    grids = [g.clone().requires_grad_(True) for g in d["grids"]]
+    cgrids = None if d["color_grids"] is None else [g.clone().requires_grad_(True) for g in d["color_grids"]]
+    out = O.lightplane_renderer_naive(rays, grids, dec, scaffold=d["scaffold"], color_grid=cgrids, **d["cfg"])
+    _close("ray_length", out[0].detach(), z["ray_length"])
+    _close("neg_log_t", out[1].detach(), z["neg_log_t"])
+    _close("feature", out[2].detach(), z["feature"])
+    g_len, g_nlt, g_feat = d["upstream"]
+    ((out[0] * g_len).sum() + (out[1] * g_nlt).sum() + (out[2] * g_feat).sum()).backward()
+    _close("grad_mlp_params", dec.mlp_params.grad, z["grad_mlp_params"])
+    _close("grad_encoding", rays.encoding.grad, z["grad_encoding"])
+    for i, g in enumerate(grids):
+        _close(f"grad_grid{i}", g.grad, z[f"grad_grid{i}"])
+    if cgrids is not None:
+        for i, g in enumerate(cgrids):
+            _close(f"grad_cgrid{i}", g.grad, z[f"grad_cgrid{i}"])
+
+
+@pytest.mark.parametrize("case", SPLATTER_CASES, ids=lambda c: c.name)
+def test_splatter_oracle_matches_reference(case, golden_dir):
+    z = np.load(os.path.join(golden_dir, f"splatter__{case.name}.npz"))
+    d = case.build()
+    _check_inputs(d, z)
+    rays = d["rays"]
+    rays.encoding = rays.encoding.clone().requires_grad_(True)
+    if d["mlp"] is None:
+        out = O.lightplane_splatter_naive(rays, d["out_sizes"], **d["cfg"])
+        in_grids = None
+    else:
+        d["mlp"].mlp_params = d["mlp"].mlp_params.clone().requires_grad_(True)
+        in_grids = [g.clone().requires_grad_(True) for g in d["in_grids"]]
+        out = O.lightplane_mlp_splatter_naive(rays, d["out_sizes"], d["mlp"], in_grids, **d["cfg"])
+    for i, o in enumerate(out):
+        _close(f"out{i}", o.detach(), z[f"out{i}"])
+    sum((o * u).sum() for o, u in zip(out, d["upstream"])).backward()
+    _close("grad_encoding", rays.encoding.grad, z["grad_encoding"])
+    if in_grids is not None:
+        _close("grad_mlp_params", d["mlp"].mlp_params.grad, z["grad_mlp_params"])
+        for i, g in enumerate(in_grids):
+            _close(f"grad_in_grid{i}", g.grad, z[f"grad_in_grid{i}"])
+
+
+def test_hash_rng_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "randn.npz"))
+    x1, x2 = torch.from_numpy(z["x1"]), torch.from_numpy(z["x2"])
+    for seed in (0, 5, 123456):
+        got = O.int_to_randn(x1, x2, seed)
+        assert np.array_equal(got.numpy(), z[f"z_seed{seed}"]), f"seed {seed}: RNG not bit-identical"
+
+
+def test_oracle_fp64_close_to_fp32():
+    """The oracle runs in fp64 too (tighter reference for the HIP tolerance budget)."""
+    d = RENDERER_CASES[1].build()
+    rays, dec = d["rays"], d["decoder"]
+    out32 = O.lightplane_renderer_naive(rays, d["grids"], dec, **d["cfg"])
+    import copy
+    r64 = copy.copy(rays)
+    for k in ("directions", "origins", "near", "far", "encoding"):
+        setattr(r64, k, getattr(rays, k).double())
+    dec64 = copy.copy(dec)
+    dec64.mlp_params = dec.mlp_params.double()
+    out64 = O.lightplane_renderer_naive(r64, [g.double() for g in d["grids"]], dec64, **d["cfg"])
+    for a, b in zip(out32, out64):
+        _close("fp32-vs-fp64", a, b, tol=1e-5)
