@@ -1,0 +1,203 @@
+/*
+ * lightplane_hip.h -- C ABI of liblightplane_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary of the Renderer / Splatter hot path.  Every entry
+ * point replaces one Triton kernel launch site of the reference
+ * (facebookresearch/lightplane @ 2024-08-07):
+ *
+ *   lp_renderer_forward   <- LightplaneFunction.forward  fw_kernel[grid](...)
+ *                            lightplane/lightplane_renderer.py:505-555
+ *                            (kernel: lightplane/triton_src/templates/renderer_fw.py:85-375)
+ *   lp_renderer_backward  <- LightplaneFunction.backward bw_kernel[grid](...)
+ *                            lightplane/lightplane_renderer.py:657-711
+ *                            (kernel: lightplane/triton_src/templates/renderer_bw.py:89-627)
+ *   lp_splatter_forward   <- LightplaneSplatterFunction.forward, BOTH launches
+ *                            (features :505 and unit weights :507-539 in one march)
+ *                            lightplane/lightplane_splatter.py:503-539
+ *                            (kernels: templates/splatter_fw.py:71-165, :168-309 with MLP)
+ *   lp_splatter_normalize <- weight clamp + divide, lightplane_splatter.py:541,584
+ *   lp_splatter_backward  <- LightplaneSplatterFunction.backward bw_kernel[grid](...)
+ *                            lightplane/lightplane_splatter.py:608,664
+ *                            (kernels: templates/splatter_bw.py:75-180, :183-394 with MLP)
+ *   lp_hash_randn         <- int_to_randn_kernel, triton_src/shared/rand_util.py:20-35
+ *
+ * Conventions
+ *   - plain C: raw device pointers + host integers; no torch / C++ types.
+ *   - the library never allocates device memory and keeps no state besides a
+ *     thread-local error string; the caller owns every buffer.
+ *   - all tensors are fp32, contiguous, resident on the device of `stream`.
+ *   - accumulation targets (grad_*, splat feature/weight grids) MUST be zeroed by
+ *     the caller: kernels accumulate with atomics (reference does the same:
+ *     lightplane_renderer.py:470-476, 642-651; lightplane_splatter.py:404-410).
+ *   - every function returns 0 on success, a negative LP_E* code on invalid
+ *     arguments, or the positive hipError_t of a failed launch; lp_last_error()
+ *     describes the last failure of the calling thread.
+ *   - `stream` is a hipStream_t (NULL = default stream).  Calls are asynchronous.
+ *
+ * Grid-list layout (reference lightplane/misc_utils.py:25-46): one flat
+ * [sum_g B*D_g*H_g*W_g, C] channels-last tensor; grid g begins at row
+ * grids[g].row_offset, cell (b,z,y,x) is row ((b*D+z)*H+y)*W+x inside it.
+ * Coordinates: x<->W, y<->H, z<->D; a grid with exactly one singleton spatial
+ * dim is a plane sampled bilinearly (D==1: xy, H==1: xz, W==1: yz).
+ *
+ * MLP parameter layout (reference lightplane/mlp_utils.py:390-456): see LpMlp.
+ */
+#ifndef LIGHTPLANE_HIP_H
+#define LIGHTPLANE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LP_VERSION 100 /* 0.1.0 */
+
+#define LP_MAX_GRIDS 8   /* grids per grid-list                         */
+#define LP_MAX_LAYERS 8  /* layers per MLP                              */
+#define LP_MAX_WIDTH 128 /* widest layer / grid channel count supported */
+
+/* error codes (negative; positive values are hipError_t) */
+#define LP_OK 0
+#define LP_EINVAL (-1)      /* malformed argument (see lp_last_error)          */
+#define LP_EUNSUPPORTED (-2) /* shape outside what the kernels are built for    */
+#define LP_ENULL (-3)       /* required pointer is NULL                        */
+
+/* kernel selection hints (LpRendererArgs.kernel) */
+#define LP_KERNEL_AUTO 0    /* MFMA kernel when the shape allows it, else generic */
+#define LP_KERNEL_GENERIC 1 /* force the shape-generic VALU kernel               */
+#define LP_KERNEL_MFMA 2    /* force the MFMA kernel (LP_EUNSUPPORTED if n/a)    */
+
+typedef struct LpGrid {
+  int32_t B, D, H, W;  /* batch and spatial extent                         */
+  int64_t row_offset;  /* first row of this grid in the flat [rows,C] tensor */
+} LpGrid;
+
+typedef struct LpGridList {
+  const float* data;   /* [rows, channels] fp32 (may be NULL when n_grids == 0) */
+  int32_t n_grids;     /* 0 .. LP_MAX_GRIDS                                 */
+  int32_t channels;    /* C                                                  */
+  int64_t n_rows;      /* total rows (for bounds checks)                     */
+  LpGrid grids[LP_MAX_GRIDS];
+} LpGridList;
+
+/* rays: reference lightplane/ray_utils.py:19-57 */
+typedef struct LpRays {
+  int64_t n_rays;
+  const float* directions;  /* [N,3] */
+  const float* origins;     /* [N,3] */
+  const int32_t* grid_idx;  /* [N]   batch element each ray belongs to */
+  const float* near_t;      /* [N]   */
+  const float* far_t;       /* [N]   */
+  const float* encoding;    /* [N,encoding_dim] (Renderer: colour-MLP input width;
+                               Splatter: splatted feature) */
+  int32_t encoding_dim;
+  int32_t _pad;
+} LpRays;
+
+/* ray-march schedule: reference naive_renderer.py:218-257, ray_util.py:48-58 */
+typedef struct LpMarch {
+  int32_t num_samples;         /* S  : equispaced in [near, far], both ends included */
+  int32_t num_samples_inf;     /* S_inf : extra samples beyond far, linear in disparity */
+  int32_t mask_out_of_bounds;  /* zero samples outside [-1,1]^3                      */
+  int32_t contract_coords;     /* MeRF contraction (+ x0.5) before sampling          */
+  double disparity_at_inf;
+} LpMarch;
+
+/* one MLP inside a flat parameter vector: all weights W_0..W_{n-1} ([in,out]
+ * row-major, y = x @ W + b) followed by all biases b_0..b_{n-1}, starting at
+ * float index `offset`.  dims[0] = input width, dims[l+1] = output width of layer l. */
+typedef struct LpMlp {
+  int32_t n_layers;                /* 0 .. LP_MAX_LAYERS */
+  int32_t dims[LP_MAX_LAYERS + 1];
+  int64_t offset;
+} LpMlp;
+
+typedef struct LpRendererArgs {
+  LpRays rays;            /* encoding_dim == colour MLP input width            */
+  LpGridList grid;        /* feature grid-list                                  */
+  LpGridList color_grid;  /* n_grids == 0: single-grid mode (trunk MLP used)    */
+  const float* scaffold;  /* NULL or [B, D*H*W] occupancy (0/1 floats)          */
+  LpGrid scaffold_shape;  /* B,D,H,W of the scaffold (row_offset ignored)       */
+  LpMarch march;
+  /* decoder: trunk -> {opacity, color}; ReLU after every trunk layer and between
+   * head layers; opacity = gain*softplus(raw); color = sigmoid(raw)              */
+  const float* mlp_params;
+  int64_t n_mlp_params;
+  LpMlp trunk, opacity, color;
+  int32_t color_chn;      /* real colour channels (<= color.dims[last]; the
+                             remaining columns are zero padding, never evaluated) */
+  float gain;
+  float noise_sigma;      /* > 0: add sigma * hash_randn to the raw opacity      */
+  int32_t noise_seed;
+  int32_t kernel;         /* LP_KERNEL_*                                         */
+  int32_t _pad;
+  /* forward outputs (written, not accumulated) */
+  float* ray_length;      /* [N]                                                 */
+  float* neg_log_t;       /* [N]  negative log transmittance after the last sample */
+  float* feature;         /* [N, color_chn]                                      */
+  /* backward inputs: upstream gradients (NULL = zeros) + neg_log_t from forward */
+  const float* grad_ray_length; /* [N]            */
+  const float* grad_neg_log_t;  /* [N]            */
+  const float* grad_feature;    /* [N, color_chn] */
+  /* backward outputs, accumulated with atomics: caller zero-fills. NULL = skip. */
+  float* grad_grid;        /* like grid.data        */
+  float* grad_color_grid;  /* like color_grid.data  */
+  float* grad_mlp_params;  /* [n_mlp_params]        */
+  float* grad_encoding;    /* [N, encoding_dim] (written, not accumulated) */
+} LpRendererArgs;
+
+typedef struct LpSplatterArgs {
+  LpRays rays;             /* encoding = splatted feature [N, encoding_dim]       */
+  LpMarch march;
+  LpGridList out;          /* output grid-list shape; out.data = feature accumulator
+                              [rows, C] (zero-filled by caller)                   */
+  float* out_feature;      /* == (float*)out.data, writable alias                 */
+  float* out_weight;       /* [rows] splat-weight accumulator (zero-filled)       */
+  /* MLP-splatter only (mlp.n_layers > 0): MLP(sample(input_grid) + encoding) is
+   * splatted instead of the encoding                                            */
+  LpGridList input_grid;
+  const float* mlp_params;
+  int64_t n_mlp_params;
+  LpMlp mlp;               /* dims[0] == encoding_dim == input_grid.channels,
+                              dims[last] == out.channels                          */
+  int32_t kernel;
+  int32_t _pad;
+  /* backward */
+  const float* grad_out;   /* [rows, C] gradient w.r.t. the NORMALISED output grid */
+  const float* weight;     /* [rows] un-clamped splat weights saved by forward     */
+  float* grad_encoding;    /* [N, encoding_dim] (written)                          */
+  float* grad_input_grid;  /* like input_grid.data (accumulated; MLP-splatter)     */
+  float* grad_mlp_params;  /* [n_mlp_params]      (accumulated; MLP-splatter)      */
+} LpSplatterArgs;
+
+int lp_version(void);
+const char* lp_last_error(void);
+/* sizeof() of the ABI structs as compiled into the library, for binding self-checks:
+ * which = 0 LpGrid, 1 LpGridList, 2 LpRays, 3 LpMarch, 4 LpMlp, 5 LpRendererArgs,
+ * 6 LpSplatterArgs; anything else returns -1. */
+int lp_abi_sizeof(int which);
+
+int lp_renderer_forward(const LpRendererArgs* args, void* stream);
+int lp_renderer_backward(const LpRendererArgs* args, void* stream);
+
+int lp_splatter_forward(const LpSplatterArgs* args, void* stream);
+/* feature[r, :] /= max(weight[r], 1e-5) for r in [0, n_rows) (in place). */
+int lp_splatter_normalize(float* feature, const float* weight, int64_t n_rows, int32_t channels,
+                          void* stream);
+int lp_splatter_backward(const LpSplatterArgs* args, void* stream);
+
+/* out[i] = hash_randn(x1[i], x2[i], seed), i < n (test hook for the opacity-noise RNG). */
+int lp_hash_randn(const int32_t* x1, const int32_t* x2, float* out, int64_t n, int32_t seed,
+                  void* stream);
+
+/* Debug / parity hook: integer corner rows of the Renderer march.  For grid g of
+ * args->grid writes rows[(ray*S_tot + step)*K_tot + k] (int64, -1 = corner out of
+ * range), K_tot = sum over grids of 8 (voxel) / 4 (plane), grids concatenated in
+ * list order.  Used by the tests to prove bit-exact integer indexing vs the oracle. */
+int lp_renderer_corner_rows(const LpRendererArgs* args, int64_t* rows, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIGHTPLANE_HIP_H */

@@ -1,0 +1,207 @@
+"""ctypes binding of ``liblightplane_hip.so`` (C ABI: ``include/lightplane_hip.h``).
+
+The structures below mirror the header field for field.  There is NO fallback: if
+the shared library is missing, ``lib()`` raises -- build it with
+``python lightplane_amd/csrc/build.py`` (or ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+from .grids import GridDesc
+
+LP_MAX_GRIDS = 8
+LP_MAX_LAYERS = 8
+LP_MAX_WIDTH = 128
+
+LP_KERNEL_AUTO, LP_KERNEL_GENERIC, LP_KERNEL_MFMA = 0, 1, 2
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+
+
+class LpGrid(C.Structure):
+    _fields_ = [("B", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("row_offset", C.c_int64)]
+
+
+class LpGridList(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("n_grids", C.c_int32), ("channels", C.c_int32),
+                ("n_rows", C.c_int64), ("grids", LpGrid * LP_MAX_GRIDS)]
+
+
+class LpRays(C.Structure):
+    _fields_ = [("n_rays", C.c_int64), ("directions", C.c_void_p), ("origins", C.c_void_p),
+                ("grid_idx", C.c_void_p), ("near_t", C.c_void_p), ("far_t", C.c_void_p),
+                ("encoding", C.c_void_p), ("encoding_dim", C.c_int32), ("_pad", C.c_int32)]
+
+
+class LpMarch(C.Structure):
+    _fields_ = [("num_samples", C.c_int32), ("num_samples_inf", C.c_int32),
+                ("mask_out_of_bounds", C.c_int32), ("contract_coords", C.c_int32),
+                ("disparity_at_inf", C.c_double)]
+
+
+class LpMlp(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("dims", C.c_int32 * (LP_MAX_LAYERS + 1)),
+                ("offset", C.c_int64)]
+
+
+class LpRendererArgs(C.Structure):
+    _fields_ = [
+        ("rays", LpRays), ("grid", LpGridList), ("color_grid", LpGridList),
+        ("scaffold", C.c_void_p), ("scaffold_shape", LpGrid), ("march", LpMarch),
+        ("mlp_params", C.c_void_p), ("n_mlp_params", C.c_int64),
+        ("trunk", LpMlp), ("opacity", LpMlp), ("color", LpMlp),
+        ("color_chn", C.c_int32), ("gain", C.c_float), ("noise_sigma", C.c_float),
+        ("noise_seed", C.c_int32), ("kernel", C.c_int32), ("_pad", C.c_int32),
+        ("ray_length", C.c_void_p), ("neg_log_t", C.c_void_p), ("feature", C.c_void_p),
+        ("grad_ray_length", C.c_void_p), ("grad_neg_log_t", C.c_void_p), ("grad_feature", C.c_void_p),
+        ("grad_grid", C.c_void_p), ("grad_color_grid", C.c_void_p), ("grad_mlp_params", C.c_void_p),
+        ("grad_encoding", C.c_void_p),
+    ]
+
+
+class LpSplatterArgs(C.Structure):
+    _fields_ = [
+        ("rays", LpRays), ("march", LpMarch), ("out", LpGridList),
+        ("out_feature", C.c_void_p), ("out_weight", C.c_void_p),
+        ("input_grid", LpGridList), ("mlp_params", C.c_void_p), ("n_mlp_params", C.c_int64),
+        ("mlp", LpMlp), ("kernel", C.c_int32), ("_pad", C.c_int32),
+        ("grad_out", C.c_void_p), ("weight", C.c_void_p), ("grad_encoding", C.c_void_p),
+        ("grad_input_grid", C.c_void_p), ("grad_mlp_params", C.c_void_p),
+    ]
+
+
+_LIB = None
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblightplane_hip.so")
+
+#: every symbol include/lightplane_hip.h declares
+EXPORTS = (
+    "lp_version", "lp_last_error", "lp_abi_sizeof", "lp_renderer_forward", "lp_renderer_backward",
+    "lp_splatter_forward", "lp_splatter_normalize", "lp_splatter_backward", "lp_hash_randn",
+    "lp_renderer_corner_rows",
+)
+
+
+class LightplaneHipError(RuntimeError):
+    """A C-ABI call returned a non-zero code."""
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the HIP library; raise loudly if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise LightplaneHipError(
+            f"{LIB_PATH} not found: the HIP extension has not been built. Run "
+            "`python lightplane_amd/csrc/build.py` (there is no CPU / PyTorch fallback)."
+        )
+    L = C.CDLL(LIB_PATH)
+    L.lp_version.restype = C.c_int
+    L.lp_last_error.restype = C.c_char_p
+    for name in ("lp_renderer_forward", "lp_renderer_backward"):
+        fn = getattr(L, name)
+        fn.restype = C.c_int
+        fn.argtypes = [C.POINTER(LpRendererArgs), C.c_void_p]
+    for name in ("lp_splatter_forward", "lp_splatter_backward"):
+        fn = getattr(L, name)
+        fn.restype = C.c_int
+        fn.argtypes = [C.POINTER(LpSplatterArgs), C.c_void_p]
+    L.lp_splatter_normalize.restype = C.c_int
+    L.lp_splatter_normalize.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+    L.lp_hash_randn.restype = C.c_int
+    L.lp_hash_randn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+    L.lp_renderer_corner_rows.restype = C.c_int
+    L.lp_renderer_corner_rows.argtypes = [C.POINTER(LpRendererArgs), C.c_void_p, C.c_void_p]
+    L.lp_abi_sizeof.restype = C.c_int
+    L.lp_abi_sizeof.argtypes = [C.c_int]
+    for which, st in enumerate((LpGrid, LpGridList, LpRays, LpMarch, LpMlp, LpRendererArgs, LpSplatterArgs)):
+        if L.lp_abi_sizeof(which) != C.sizeof(st):
+            raise LightplaneHipError(
+                f"ABI mismatch: sizeof({st.__name__}) is {C.sizeof(st)} in the ctypes binding but "
+                f"{L.lp_abi_sizeof(which)} in {LIB_PATH}; rebuild the library"
+            )
+    _LIB = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().lp_last_error().decode(errors="replace")
+        kind = {-1: "invalid argument", -2: "unsupported shape", -3: "NULL pointer"}.get(rc, f"hipError {rc}")
+        err = LightplaneHipError(f"{what} failed ({kind}): {msg}")
+        if rc in (-1, -3):
+            # argument errors surface like the reference's Python-side asserts
+            raise AssertionError(str(err))
+        raise err
+
+
+# --------------------------------------------------------------------------------------
+# struct builders
+# --------------------------------------------------------------------------------------
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    assert t.is_contiguous(), "tensors handed to the HIP library must be contiguous"
+    return t.data_ptr()
+
+
+def current_stream(device: torch.device) -> Optional[int]:
+    if device.type != "cuda":
+        raise LightplaneHipError(
+            f"lightplane_amd kernels run on the GPU only (got tensors on '{device}'); "
+            "there is no CPU path -- the CPU oracle lives under oracle/ for tests."
+        )
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def make_rays(directions, origins, grid_idx_i32, near, far, encoding) -> LpRays:
+    r = LpRays()
+    r.n_rays = directions.shape[0]
+    r.directions, r.origins = ptr(directions), ptr(origins)
+    r.grid_idx, r.near_t, r.far_t = ptr(grid_idx_i32), ptr(near), ptr(far)
+    r.encoding = ptr(encoding)
+    r.encoding_dim = 0 if encoding is None else encoding.shape[1]
+    return r
+
+
+def make_march(num_samples, num_samples_inf, mask_out_of_bounds_samples, contract_coords, disparity_at_inf) -> LpMarch:
+    m = LpMarch()
+    m.num_samples, m.num_samples_inf = int(num_samples), int(num_samples_inf)
+    m.mask_out_of_bounds = int(bool(mask_out_of_bounds_samples))
+    m.contract_coords = int(bool(contract_coords))
+    m.disparity_at_inf = float(disparity_at_inf)
+    return m
+
+
+def make_grid_list(data: Optional[torch.Tensor], descs: Sequence[GridDesc], channels: int, n_rows: int) -> LpGridList:
+    gl = LpGridList()
+    assert len(descs) <= LP_MAX_GRIDS, f"at most {LP_MAX_GRIDS} grids per grid-list are supported"
+    gl.data = ptr(data)
+    gl.n_grids = len(descs)
+    gl.channels = int(channels)
+    gl.n_rows = int(n_rows)
+    for i, d in enumerate(descs):
+        gl.grids[i] = LpGrid(d.B, d.D, d.H, d.W, d.row_offset)
+    return gl
+
+
+def make_mlp(dims: Sequence[int], offset: int) -> LpMlp:
+    m = LpMlp()
+    dims = [int(v) for v in dims]
+    n_layers = max(len(dims) - 1, 0)
+    assert n_layers <= LP_MAX_LAYERS, f"at most {LP_MAX_LAYERS} layers per MLP are supported"
+    m.n_layers = n_layers
+    for i, v in enumerate(dims):
+        m.dims[i] = v
+    m.offset = int(offset)
+    return m

@@ -1,0 +1,12 @@
+"""Process-wide switches of the MI355X path (plain module attributes).
+
+``check_inputs``       validate ``rays.grid_idx`` against the grid batch size before launching
+                       (one device sync per call, like the reference's ``grid_idx.min()/max()``
+                       asserts, lightplane_renderer.py:464-467).  Default on.
+``check_finite_grads`` run the reference's post-backward ``isfinite`` asserts
+                       (lightplane_renderer.py:719-722; a device sync each).  Default off.
+"""
+import os
+
+check_inputs: bool = os.environ.get("LIGHTPLANE_AMD_CHECK_INPUTS", "1") != "0"
+check_finite_grads: bool = os.environ.get("LIGHTPLANE_AMD_CHECK_FINITE", "0") == "1"

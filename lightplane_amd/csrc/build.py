@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""Build liblightplane_hip.so for gfx950 with hipcc (no cmake, no torch extension machinery).
+
+    python lightplane_amd/csrc/build.py [--force] [--verbose]
+
+Output: lightplane_amd/liblightplane_hip.so (git-ignored; travels to the GPU box with gpurun).
+Flags: -ffp-contract=off keeps the coordinate/index arithmetic individually rounded (bit-exact
+integer indexing vs the oracle); FMAs in the MLP / interpolation math are explicit fmaf().
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+OUT = os.path.join(PKG, "liblightplane_hip.so")
+SOURCES = ["lp_api.hip", "lp_renderer_generic.hip", "lp_renderer_mfma.hip", "lp_splatter.hip"]
+HEADERS = ["lp_device.h", "lp_host.h", os.path.join("..", "..", "include", "lightplane_hip.h")]
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+    "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    objs = []
+    procs = []
+    for src in SOURCES:
+        s = os.path.join(HERE, src)
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = False
+    for src, p in procs:
+        out = p.communicate()[0].decode()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(f"--- {src} failed ---\n{out}\n")
+        elif out.strip() and verbose:
+            print(out)
+    if failed:
+        raise RuntimeError("hipcc failed")
+    if force or procs or _stale(OUT, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))

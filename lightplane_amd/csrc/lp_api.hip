@@ -1,0 +1,240 @@
+// lp_api.hip -- the extern "C" surface of liblightplane_hip.so (see include/lightplane_hip.h).
+// Argument validation, kernel selection and error reporting; no device code here.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "lp_host.h"
+
+namespace lp {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return LP_OK;
+  return set_error((int)e, "%s: %s", what, hipGetErrorString(e));
+}
+
+static int64_t mlp_numel(const LpMlp& m) {
+  int64_t n = 0;
+  for (int l = 0; l < m.n_layers; ++l) n += (int64_t)m.dims[l] * m.dims[l + 1] + m.dims[l + 1];
+  return n;
+}
+
+static int check_mlp(const char* name, const LpMlp& m, bool may_be_empty) {
+  if (m.n_layers < 0 || m.n_layers > LP_MAX_LAYERS)
+    return set_error(LP_EINVAL, "%s MLP: n_layers %d outside [0, %d]", name, m.n_layers, LP_MAX_LAYERS);
+  if (m.n_layers == 0 && !may_be_empty) return set_error(LP_EINVAL, "%s MLP has no layers", name);
+  for (int l = 0; l <= m.n_layers && m.n_layers > 0; ++l)
+    if (m.dims[l] < 1 || m.dims[l] > LP_MAX_WIDTH)
+      return set_error(LP_EUNSUPPORTED, "%s MLP: width %d of layer %d outside [1, %d]", name, m.dims[l], l,
+                       LP_MAX_WIDTH);
+  return LP_OK;
+}
+
+static int check_grid_list(const char* name, const LpGridList& gl, bool required) {
+  if (gl.n_grids < 0 || gl.n_grids > LP_MAX_GRIDS)
+    return set_error(LP_EINVAL, "%s: n_grids %d outside [0, %d]", name, gl.n_grids, LP_MAX_GRIDS);
+  if (gl.n_grids == 0) return required ? set_error(LP_EINVAL, "%s: empty grid-list", name) : LP_OK;
+  if (gl.channels < 1 || gl.channels > LP_MAX_WIDTH)
+    return set_error(LP_EUNSUPPORTED, "%s: %d channels outside [1, %d]", name, gl.channels, LP_MAX_WIDTH);
+  const int B = gl.grids[0].B;
+  for (int g = 0; g < gl.n_grids; ++g) {
+    const LpGrid& d = gl.grids[g];
+    if (d.B < 1 || d.D < 1 || d.H < 1 || d.W < 1)
+      return set_error(LP_EINVAL, "%s[%d]: non-positive extent [%d,%d,%d,%d]", name, g, d.B, d.D, d.H, d.W);
+    if (d.B != B) return set_error(LP_EINVAL, "%s[%d]: batch %d != %d", name, g, d.B, B);
+    const int ns = (d.D > 1) + (d.H > 1) + (d.W > 1);
+    if (ns < 2)
+      return set_error(LP_EINVAL, "%s[%d]: Unexpected n non-singular dim of input grid (%d)", name, g, ns);
+    const int64_t rows = (int64_t)d.B * d.D * d.H * d.W;
+    if (d.row_offset < 0 || d.row_offset + rows > gl.n_rows)
+      return set_error(LP_EINVAL, "%s[%d]: rows [%lld, %lld) outside the flat tensor (%lld rows)", name, g,
+                       (long long)d.row_offset, (long long)(d.row_offset + rows), (long long)gl.n_rows);
+  }
+  return LP_OK;
+}
+
+static int check_rays(const LpRays& r, bool need_encoding) {
+  if (r.n_rays < 0) return set_error(LP_EINVAL, "n_rays %lld < 0", (long long)r.n_rays);
+  if (r.n_rays == 0) return LP_OK;
+  if (!r.directions || !r.origins || !r.grid_idx || !r.near_t || !r.far_t)
+    return set_error(LP_ENULL, "rays: directions/origins/grid_idx/near/far must be non-NULL");
+  if (need_encoding && !r.encoding) return set_error(LP_ENULL, "rays.encoding is NULL");
+  if (r.encoding_dim < 0 || r.encoding_dim > LP_MAX_WIDTH)
+    return set_error(LP_EUNSUPPORTED, "rays.encoding_dim %d outside [0, %d]", r.encoding_dim, LP_MAX_WIDTH);
+  return LP_OK;
+}
+
+static int check_march(const LpMarch& m) {
+  if (m.num_samples < 1) return set_error(LP_EINVAL, "num_samples %d < 1", m.num_samples);
+  if (m.num_samples_inf < 0) return set_error(LP_EINVAL, "num_samples_inf %d < 0", m.num_samples_inf);
+  return LP_OK;
+}
+
+static int check_renderer(const LpRendererArgs& a, bool backward) {
+  int rc;
+  if ((rc = check_rays(a.rays, true))) return rc;
+  if ((rc = check_march(a.march))) return rc;
+  if ((rc = check_grid_list("grid", a.grid, true))) return rc;
+  if ((rc = check_grid_list("color_grid", a.color_grid, false))) return rc;
+  if (a.rays.n_rays > 0 && !a.grid.data) return set_error(LP_ENULL, "grid.data is NULL");
+  const bool two = a.color_grid.n_grids > 0;
+  if (two) {
+    if (!a.color_grid.data) return set_error(LP_ENULL, "color_grid.data is NULL");
+    if (a.color_grid.channels != a.grid.channels || a.color_grid.grids[0].B != a.grid.grids[0].B)
+      return set_error(LP_EINVAL, "color_grid must share batch size and channel count with grid");
+    if (a.trunk.n_layers != 0)
+      return set_error(LP_EINVAL, "mlp_n_layers_trunk has to be 0 when use_separate_color_grid");
+  }
+  if ((rc = check_mlp("trunk", a.trunk, true))) return rc;
+  if ((rc = check_mlp("opacity", a.opacity, false))) return rc;
+  if ((rc = check_mlp("color", a.color, false))) return rc;
+  const int C = a.grid.channels;
+  int head_in = C;
+  if (a.trunk.n_layers > 0) {
+    if (a.trunk.dims[0] != C)
+      return set_error(LP_EINVAL, "trunk MLP input width %d != grid channels %d", a.trunk.dims[0], C);
+    head_in = a.trunk.dims[a.trunk.n_layers];
+  }
+  if (a.opacity.dims[0] != head_in || a.color.dims[0] != head_in)
+    return set_error(LP_EINVAL, "head input widths (%d, %d) != %d", a.opacity.dims[0], a.color.dims[0], head_in);
+  if (a.opacity.dims[a.opacity.n_layers] != 1)
+    return set_error(LP_EINVAL, "opacity MLP must end in 1 output, got %d", a.opacity.dims[a.opacity.n_layers]);
+  if (a.color_chn < 1 || a.color_chn > a.color.dims[a.color.n_layers])
+    return set_error(LP_EINVAL, "color_chn %d outside [1, %d]", a.color_chn, a.color.dims[a.color.n_layers]);
+  if (a.rays.encoding_dim != head_in)
+    return set_error(LP_EINVAL, "ray_encoding should have the same dimension as dim_in_color (%d != %d)",
+                     a.rays.encoding_dim, head_in);
+  const int64_t expect = mlp_numel(a.trunk) + mlp_numel(a.opacity) + mlp_numel(a.color);
+  if (expect != a.n_mlp_params)
+    return set_error(LP_EINVAL, "The number of elements in mlp param should be %lld. Got %lld instead.",
+                     (long long)expect, (long long)a.n_mlp_params);
+  if (a.trunk.offset != 0 || a.opacity.offset != mlp_numel(a.trunk) ||
+      a.color.offset != mlp_numel(a.trunk) + mlp_numel(a.opacity))
+    return set_error(LP_EINVAL, "MLP offsets do not follow the trunk|opacity|color flat layout");
+  if (!a.mlp_params) return set_error(LP_ENULL, "mlp_params is NULL");
+  if (a.scaffold) {
+    const LpGrid& s = a.scaffold_shape;
+    if (s.B != a.grid.grids[0].B || s.D < 1 || s.H < 1 || s.W < 1)
+      return set_error(LP_EINVAL, "scaffold shape [%d,%d,%d,%d] incompatible with grid batch %d", s.B, s.D, s.H,
+                       s.W, a.grid.grids[0].B);
+  }
+  if (a.rays.n_rays > 0) {
+    if (!backward && (!a.ray_length || !a.neg_log_t || !a.feature))
+      return set_error(LP_ENULL, "forward outputs (ray_length, neg_log_t, feature) must be non-NULL");
+    if (backward && !a.neg_log_t)
+      return set_error(LP_ENULL, "backward needs neg_log_t saved by the forward pass");
+  }
+  return LP_OK;
+}
+
+static int check_splatter(const LpSplatterArgs& a, bool backward) {
+  int rc;
+  if ((rc = check_rays(a.rays, true))) return rc;
+  if ((rc = check_march(a.march))) return rc;
+  if ((rc = check_grid_list("out", a.out, true))) return rc;
+  if (a.mlp.n_layers > 0) return set_error(LP_EUNSUPPORTED, "MLP splatter: not built into this library yet");
+  if (a.rays.encoding_dim != a.out.channels)
+    return set_error(LP_EINVAL, "splatting feature width %d != output grid channels %d", a.rays.encoding_dim,
+                     a.out.channels);
+  if (a.rays.n_rays > 0) {
+    if (!backward && (!a.out_feature || !a.out_weight))
+      return set_error(LP_ENULL, "out_feature / out_weight must be non-NULL");
+    if (backward && (!a.grad_out || !a.weight || !a.grad_encoding))
+      return set_error(LP_ENULL, "grad_out / weight / grad_encoding must be non-NULL");
+  }
+  return LP_OK;
+}
+
+}  // namespace lp
+
+using namespace lp;
+
+extern "C" {
+
+int lp_version(void) { return LP_VERSION; }
+
+const char* lp_last_error(void) { return g_err; }
+
+int lp_abi_sizeof(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(LpGrid);
+    case 1: return (int)sizeof(LpGridList);
+    case 2: return (int)sizeof(LpRays);
+    case 3: return (int)sizeof(LpMarch);
+    case 4: return (int)sizeof(LpMlp);
+    case 5: return (int)sizeof(LpRendererArgs);
+    case 6: return (int)sizeof(LpSplatterArgs);
+    default: return -1;
+  }
+}
+
+int lp_renderer_forward(const LpRendererArgs* args, void* stream) {
+  if (!args) return set_error(LP_ENULL, "args is NULL");
+  int rc = check_renderer(*args, false);
+  if (rc) return rc;
+  const char* why = "";
+  const bool mfma_ok = renderer_mfma_supported(*args, &why);
+  if (args->kernel == LP_KERNEL_MFMA && !mfma_ok)
+    return set_error(LP_EUNSUPPORTED, "MFMA renderer kernel unavailable for this shape: %s", why);
+  if (mfma_ok && args->kernel != LP_KERNEL_GENERIC) return renderer_forward_mfma(*args, (hipStream_t)stream);
+  return renderer_forward_generic(*args, (hipStream_t)stream);
+}
+
+int lp_renderer_backward(const LpRendererArgs* args, void* stream) {
+  if (!args) return set_error(LP_ENULL, "args is NULL");
+  int rc = check_renderer(*args, true);
+  if (rc) return rc;
+  const char* why = "";
+  const bool mfma_ok = renderer_mfma_supported(*args, &why);
+  if (args->kernel == LP_KERNEL_MFMA && !mfma_ok)
+    return set_error(LP_EUNSUPPORTED, "MFMA renderer kernel unavailable for this shape: %s", why);
+  if (mfma_ok && args->kernel != LP_KERNEL_GENERIC) return renderer_backward_mfma(*args, (hipStream_t)stream);
+  return renderer_backward_generic(*args, (hipStream_t)stream);
+}
+
+int lp_renderer_corner_rows(const LpRendererArgs* args, int64_t* rows, void* stream) {
+  if (!args || !rows) return set_error(LP_ENULL, "args / rows is NULL");
+  int rc;
+  if ((rc = check_rays(args->rays, false))) return rc;
+  if ((rc = check_march(args->march))) return rc;
+  if ((rc = check_grid_list("grid", args->grid, true))) return rc;
+  return renderer_corner_rows_launch(*args, rows, (hipStream_t)stream);
+}
+
+int lp_splatter_forward(const LpSplatterArgs* args, void* stream) {
+  if (!args) return set_error(LP_ENULL, "args is NULL");
+  int rc = check_splatter(*args, false);
+  if (rc) return rc;
+  return splatter_forward_launch(*args, (hipStream_t)stream);
+}
+
+int lp_splatter_normalize(float* feature, const float* weight, int64_t n_rows, int32_t channels, void* stream) {
+  if (n_rows < 0 || channels < 1) return set_error(LP_EINVAL, "normalize: bad shape [%lld, %d]", (long long)n_rows, channels);
+  if (n_rows > 0 && (!feature || !weight)) return set_error(LP_ENULL, "normalize: NULL buffer");
+  return splatter_normalize_launch(feature, weight, n_rows, channels, (hipStream_t)stream);
+}
+
+int lp_splatter_backward(const LpSplatterArgs* args, void* stream) {
+  if (!args) return set_error(LP_ENULL, "args is NULL");
+  int rc = check_splatter(*args, true);
+  if (rc) return rc;
+  return splatter_backward_launch(*args, (hipStream_t)stream);
+}
+
+int lp_hash_randn(const int32_t* x1, const int32_t* x2, float* out, int64_t n, int32_t seed, void* stream) {
+  if (n < 0) return set_error(LP_EINVAL, "n < 0");
+  if (n > 0 && (!x1 || !x2 || !out)) return set_error(LP_ENULL, "hash_randn: NULL buffer");
+  return hash_randn_launch(x1, x2, out, n, seed, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,236 @@
+// lp_device.h -- device-side building blocks shared by all kernels (gfx950 only).
+//
+// Everything here follows the ORACLE semantics (reference naive_renderer.py /
+// naive_splatter.py), see SURVEY.md 8(a) "Semantics the HIP kernels must reproduce".
+// The translation units are compiled with -ffp-contract=off: every float operation in
+// the coordinate / index path is individually rounded (bit-exact integer indexing vs the
+// oracle); fused multiply-adds are written explicitly (fmaf) where we want them.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lightplane_hip.h"
+
+#define LP_DEV __device__ __forceinline__
+
+namespace lp {
+
+// ---------------------------------------------------------------------------------------
+// ray march schedule
+// ---------------------------------------------------------------------------------------
+
+struct Ray {
+  float ox, oy, oz, dx, dy, dz, near_t, far_t;
+  int b;  // grid batch index
+};
+
+LP_DEV Ray load_ray(const LpRays& r, int64_t i) {
+  Ray q;
+  q.ox = r.origins[3 * i + 0];
+  q.oy = r.origins[3 * i + 1];
+  q.oz = r.origins[3 * i + 2];
+  q.dx = r.directions[3 * i + 0];
+  q.dy = r.directions[3 * i + 1];
+  q.dz = r.directions[3 * i + 2];
+  q.near_t = r.near_t[i];
+  q.far_t = r.far_t[i];
+  q.b = r.grid_idx[i];
+  return q;
+}
+
+// linspace(0,1,S)[i], scalar torch formula: i < S/2 ? i*step : 1 - (S-1-i)*step
+LP_DEV float lin01(int i, int S) {
+  if (S <= 1) return 0.0f;
+  const float step = 1.0f / (float)(S - 1);
+  return (i < S / 2) ? step * (float)i : 1.0f - step * (float)(S - 1 - i);
+}
+
+// depth of sample `i` in [0, S + S_inf)  (naive_renderer.py:218-219, 239-247, 810-813)
+LP_DEV float sample_depth(int i, const LpMarch& m, float near_t, float far_t) {
+  if (i < m.num_samples) {
+    return near_t + lin01(i, m.num_samples) * (far_t - near_t);
+  }
+  // python-double arithmetic of the oracle, then one cast to f32
+  const int k = i - m.num_samples;
+  const double frac = (double)(k + 1) / (double)m.num_samples_inf;
+  const double n_disp = (m.disparity_at_inf - 1.0) * frac + 1.0;
+  return far_t * (float)(1.0 / n_disp);
+}
+
+// interval length of sample i (naive_renderer.py:252-257); depth_i must be sample_depth(i)
+LP_DEV float sample_delta(int i, const LpMarch& m, float near_t, float far_t, float depth_i) {
+  if (i == 0) {
+    return (m.num_samples > 1) ? (far_t - near_t) / (float)(m.num_samples - 1) : 1.0f;
+  }
+  return depth_i - sample_depth(i - 1, m, near_t, far_t);
+}
+
+LP_DEV float contract_one(float p, float n) {
+  const float a = fabsf(p);
+  if (fabsf(a - n) <= 1e-7f) {
+    return (2.0f - 1.0f / a) * (p / a);
+  }
+  return p / n;
+}
+
+// point on the ray, optionally MeRF-contracted (naive_renderer.py:249-250, 796-807)
+LP_DEV void sample_point(const Ray& r, float depth, bool contract, float& x, float& y, float& z) {
+  x = depth * r.dx + r.ox;
+  y = depth * r.dy + r.oy;
+  z = depth * r.dz + r.oz;
+  if (contract) {
+    const float n = fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z));
+    if (!(n <= 1.0f)) {
+      x = contract_one(x, n);
+      y = contract_one(y, n);
+      z = contract_one(z, n);
+    }
+    x = x / 2.0f;
+    y = y / 2.0f;
+    z = z / 2.0f;
+  }
+}
+
+LP_DEV bool point_in_bounds(float x, float y, float z) {
+  return fabsf(x) <= 1.0f && fabsf(y) <= 1.0f && fabsf(z) <= 1.0f;
+}
+
+// ---------------------------------------------------------------------------------------
+// grid addressing
+// ---------------------------------------------------------------------------------------
+
+// un-normalisation: Renderer = torch grid_sample ((x+1)*size-1)/2 ; Splatter = naive
+// splatter (x+1)/2*size - 0.5  
+template <bool SPLAT>
+LP_DEV float unnormalize(float c, int size) {
+  if (SPLAT) return (c + 1.0f) / 2.0f * (float)size - 0.5f;
+  return ((c + 1.0f) * (float)size - 1.0f) / 2.0f;
+}
+
+struct Axis {
+  int lo;      // floor index (may be -1 .. size-1 or further out)
+  float w_lo;  // weight of `lo`
+  float w_hi;  // weight of `lo + 1`
+};
+
+template <bool SPLAT>
+LP_DEV Axis axis_setup(float c, int size) {
+  const float t = unnormalize<SPLAT>(c, size);
+  const float f = floorf(t);
+  Axis a;
+  // clamp before the int conversion so that far-away / non-finite coordinates stay legal
+  a.lo = (int)fminf(fmaxf(f, -2.0f), (float)size);
+  a.w_hi = t - f;
+  a.w_lo = (f + 1.0f) - t;
+  if (!(f >= -2.0f && f <= (float)size)) {  // also catches NaN
+    a.w_hi = 0.0f;
+    a.w_lo = 0.0f;
+  }
+  return a;
+}
+
+// Corner set of one grid for one point.  K = 8 (voxel) or 4 (plane).  Corner k: bit j of k
+// selects the upper neighbour along the j-th *sampled* axis, axes ordered x, y, z.
+// row[k] < 0 marks an out-of-range corner (weight irrelevant).
+struct Corners {
+  int64_t row[8];
+  float w[8];
+  int n;
+};
+
+template <bool SPLAT>
+LP_DEV Corners grid_corners(const LpGrid& g, int b, float x, float y, float z) {
+  Corners c;
+  const bool sx = g.W > 1, sy = g.H > 1, sz = g.D > 1;
+  const bool voxel = sx && sy && sz;
+  Axis ax{0, 1.0f, 0.0f}, ay{0, 1.0f, 0.0f}, az{0, 1.0f, 0.0f};
+  if (sx) ax = axis_setup<SPLAT>(x, g.W);
+  if (sy) ay = axis_setup<SPLAT>(y, g.H);
+  if (sz) az = axis_setup<SPLAT>(z, g.D);
+  const int64_t base = g.row_offset + (int64_t)b * g.D * g.H * g.W;
+  c.n = voxel ? 8 : 4;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    // map corner bits onto the sampled axes
+    int ux, uy, uz;
+    if (voxel) {
+      ux = k & 1; uy = (k >> 1) & 1; uz = (k >> 2) & 1;
+    } else if (!sz) {  // xy plane
+      ux = k & 1; uy = (k >> 1) & 1; uz = 0;
+    } else if (!sy) {  // xz plane
+      ux = k & 1; uy = 0; uz = (k >> 1) & 1;
+    } else {           // yz plane
+      ux = 0; uy = k & 1; uz = (k >> 1) & 1;
+    }
+    const int ix = ax.lo + ux, iy = ay.lo + uy, iz = az.lo + uz;
+    const bool ok = (k < c.n) && ix >= 0 && ix < g.W && iy >= 0 && iy < g.H && iz >= 0 && iz < g.D;
+    float w = (sx ? (ux ? ax.w_hi : ax.w_lo) : 1.0f);
+    w = w * (sy ? (uy ? ay.w_hi : ay.w_lo) : 1.0f);
+    w = w * (sz ? (uz ? az.w_hi : az.w_lo) : 1.0f);
+    c.row[k] = ok ? base + ((int64_t)iz * g.H + iy) * g.W + ix : (int64_t)-1;
+    c.w[k] = ok ? w : 0.0f;
+  }
+  return c;
+}
+
+// nearest-neighbour scaffold lookup (round-half-even like F.grid_sample(mode="nearest")),
+// zero outside the grid, times the in-bounds mask (naive_renderer.py:484-499).
+LP_DEV float scaffold_lookup(const float* scaffold, const LpGrid& s, int b, float x, float y, float z) {
+  if (!point_in_bounds(x, y, z)) return 0.0f;
+  const float fx = rintf(unnormalize<false>(x, s.W));
+  const float fy = rintf(unnormalize<false>(y, s.H));
+  const float fz = rintf(unnormalize<false>(z, s.D));
+  if (!(fx >= 0.0f && fx <= (float)(s.W - 1) && fy >= 0.0f && fy <= (float)(s.H - 1) && fz >= 0.0f &&
+        fz <= (float)(s.D - 1)))
+    return 0.0f;
+  const int64_t row = (((int64_t)b * s.D + (int)fz) * s.H + (int)fy) * s.W + (int)fx;
+  return scaffold[row];
+}
+
+// ---------------------------------------------------------------------------------------
+// activations
+// ---------------------------------------------------------------------------------------
+
+LP_DEV float softplus_f(float x) { return (x > 20.0f) ? x : log1pf(__expf(x)); }
+LP_DEV float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// d softplus / dx (torch: threshold 20 -> 1)
+LP_DEV float d_softplus_f(float x) { return (x > 20.0f) ? 1.0f : sigmoid_f(x); }
+
+// ---------------------------------------------------------------------------------------
+// hash RNG (reference triton_src/shared/rand_util.py:39-80, 110-145): int32 wrap-around
+// ---------------------------------------------------------------------------------------
+
+LP_DEV int32_t hash32(int32_t x) {
+  x = (int32_t)((uint32_t)((x >> 16) ^ x) * 0x45D9F3Bu);
+  x = (int32_t)((uint32_t)((x >> 16) ^ x) * 0x45D9F3Bu);
+  return (x >> 16) ^ x;
+}
+LP_DEV int32_t pair_hash(int32_t x, int32_t h) {
+  const uint32_t u = (uint32_t)(h ^ x);
+  return (int32_t)((u << 24) + u * 0x193u);
+}
+LP_DEV float int32_to_u01(int32_t h) {
+  return (((float)h + 2147483648.0f) + 3.0f) / 4294967296.0f;
+}
+LP_DEV float hash_randn(int32_t x1, int32_t x2, int32_t seed) {
+  const int32_t prime = 105097564;
+  const int32_t h1 = pair_hash(pair_hash(prime, seed), hash32(x1));
+  const int32_t h2 = pair_hash(pair_hash(prime, seed + 1), hash32(x2));
+  const float u1 = int32_to_u01(h1), u2 = int32_to_u01(h2);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530718f * u2);
+}
+// noise of (ray, step): i1 = ray*S_tot + step + 1, i2 = i1 + max(N,16)*S_tot (naive_renderer.py:779-793)
+LP_DEV float sample_noise(int64_t ray, int step, int64_t n_rays, int s_tot, int32_t seed) {
+  const int64_t i1 = ray * s_tot + step + 1;
+  const int64_t pad = n_rays > 16 ? n_rays : 16;
+  const int64_t i2 = i1 + pad * s_tot;
+  return hash_randn((int32_t)(uint32_t)(uint64_t)i1, (int32_t)(uint32_t)(uint64_t)i2, seed);
+}
+
+// ---------------------------------------------------------------------------------------
+// atomics: hardware fp32 add, result unused (global_atomic_add_f32, no CAS loop)
+// ---------------------------------------------------------------------------------------
+LP_DEV void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+}  // namespace lp

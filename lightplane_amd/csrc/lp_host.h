@@ -1,0 +1,32 @@
+// lp_host.h -- host-side glue shared by the translation units of liblightplane_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/lightplane_hip.h"
+
+namespace lp {
+
+// Records a formatted message for lp_last_error() (thread-local) and returns `code`.
+int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+// hipGetLastError() -> LP_OK or the positive hipError_t (message recorded).
+int check_launch(const char* what);
+
+// generic (shape-agnostic) kernels: lp_renderer_generic.hip
+int renderer_forward_generic(const LpRendererArgs& a, hipStream_t stream);
+int renderer_backward_generic(const LpRendererArgs& a, hipStream_t stream);
+int renderer_corner_rows_launch(const LpRendererArgs& a, int64_t* rows, hipStream_t stream);
+
+// MFMA kernels: lp_renderer_mfma.hip
+bool renderer_mfma_supported(const LpRendererArgs& a, const char** why);
+int renderer_forward_mfma(const LpRendererArgs& a, hipStream_t stream);
+int renderer_backward_mfma(const LpRendererArgs& a, hipStream_t stream);
+
+// splatter: lp_splatter.hip
+int splatter_forward_launch(const LpSplatterArgs& a, hipStream_t stream);
+int splatter_backward_launch(const LpSplatterArgs& a, hipStream_t stream);
+int splatter_normalize_launch(float* feature, const float* weight, int64_t n_rows, int channels,
+                              hipStream_t stream);
+int hash_randn_launch(const int32_t* x1, const int32_t* x2, float* out, int64_t n, int32_t seed,
+                      hipStream_t stream);
+
+}  // namespace lp

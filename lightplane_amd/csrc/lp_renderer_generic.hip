@@ -1,0 +1,550 @@
+// lp_renderer_generic.hip -- shape-generic Renderer kernels (any layer count / width).
+//
+// One lane = one ray, one wave (64 lanes) = one workgroup.  Activations of the current
+// sample live in a per-lane private array; MLP weights are read through wave-uniform
+// (scalar) loads.  The backward kernel recomputes the forward per sample (far -> near),
+// reconstructs the transmittance from the saved final -log T and reduces the weight
+// gradients across the 64 rays of the wave with an LDS-staged outer product.
+//
+// This is the correctness anchor and the fallback for shapes the MFMA kernels
+// (lp_renderer_mfma.hip) are not specialised for.  Replaces the reference's Triton
+// fw_kernel / bw_kernel (templates/renderer_fw.py:85-375, renderer_bw.py:89-627) for
+// arbitrary (n_layers, width) without code generation.
+#include "lp_device.h"
+#include "lp_host.h"
+
+namespace lp {
+
+// Offsets (in floats) of every activation of one sample inside the private array.
+struct GenPlan {
+  int x0;                   // [C] summed grid sample (raw)
+  int cx0;                  // [C] colour-grid sample (raw) or -1
+  int trunk[LP_MAX_LAYERS]; // trunk layer outputs (post ReLU)
+  int op_in;                // opacity head input (post ReLU)
+  int col_in;               // colour head input (+ encoding)
+  int op[LP_MAX_LAYERS];    // opacity layer outputs (hidden: post ReLU, last: raw)
+  int col[LP_MAX_LAYERS];   // colour layer outputs (hidden: post ReLU, last: raw, color_chn used)
+  int total;
+  int head_w;               // width of the head inputs
+};
+
+struct GenArgs {
+  LpRendererArgs a;
+  GenPlan p;
+  int stage_ld;        // LDS staging row stride (floats), bwd only
+  int lds_param_accum; // 1: accumulate weight grads in LDS, flush once per block
+};
+
+// y[o] = b[o] + sum_i x[i] * W[i*ldw + o], o < n_out.  x, y: private arrays.
+LP_DEV void dense(const float* __restrict__ W, const float* __restrict__ b, int d_in, int ldw,
+                  int n_out, const float* x, float* y, bool relu) {
+  for (int o0 = 0; o0 < n_out; o0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = (o0 + k < n_out) ? b[o0 + k] : 0.0f;
+    for (int i = 0; i < d_in; ++i) {
+      const float xi = x[i];
+      const float* w = W + (int64_t)i * ldw + o0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (o0 + k < n_out) acc[k] = fmaf(xi, w[k], acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (o0 + k < n_out) y[o0 + k] = relu ? fmaxf(acc[k], 0.0f) : acc[k];
+  }
+}
+
+// dx[i] = sum_o dy[o] * W[i*ldw + o]  (o < n_out)
+LP_DEV void dense_bwd_input(const float* __restrict__ W, int d_in, int ldw, int n_out,
+                            const float* dy, float* dx) {
+  for (int i = 0; i < d_in; ++i) {
+    const float* w = W + (int64_t)i * ldw;
+    float s = 0.0f;
+    for (int o = 0; o < n_out; ++o) s = fmaf(dy[o], w[o], s);
+    dx[i] = s;
+  }
+}
+
+LP_DEV const float* mlp_w(const float* params, const LpMlp& m, int layer) {
+  int64_t off = m.offset;
+  for (int l = 0; l < layer; ++l) off += (int64_t)m.dims[l] * m.dims[l + 1];
+  return params + off;
+}
+LP_DEV const float* mlp_b(const float* params, const LpMlp& m, int layer) {
+  int64_t off = m.offset;
+  for (int l = 0; l < m.n_layers; ++l) off += (int64_t)m.dims[l] * m.dims[l + 1];
+  for (int l = 0; l < layer; ++l) off += m.dims[l + 1];
+  return params + off;
+}
+
+// Sample every grid of the list at (x,y,z) and sum into out[C].
+LP_DEV void sample_list(const LpGridList& gl, int b, float x, float y, float z, bool mask_oob,
+                        float* out) {
+  const int C = gl.channels;
+  for (int c = 0; c < C; ++c) out[c] = 0.0f;
+  if (mask_oob && !point_in_bounds(x, y, z)) return;
+  for (int g = 0; g < gl.n_grids; ++g) {
+    const Corners cs = grid_corners<false>(gl.grids[g], b, x, y, z);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < cs.n && cs.row[k] >= 0) {
+        const float w = cs.w[k];
+        const float* src = gl.data + cs.row[k] * C;
+        if ((C & 3) == 0) {
+          for (int c = 0; c < C; c += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(src + c);
+            out[c + 0] = fmaf(w, v.x, out[c + 0]);
+            out[c + 1] = fmaf(w, v.y, out[c + 1]);
+            out[c + 2] = fmaf(w, v.z, out[c + 2]);
+            out[c + 3] = fmaf(w, v.w, out[c + 3]);
+          }
+        } else {
+          for (int c = 0; c < C; ++c) out[c] = fmaf(w, src[c], out[c]);
+        }
+      }
+    }
+  }
+}
+
+LP_DEV void splat_list(const LpGridList& gl, float* grad, int b, float x, float y, float z,
+                       bool mask_oob, const float* d) {
+  const int C = gl.channels;
+  if (mask_oob && !point_in_bounds(x, y, z)) return;
+  for (int g = 0; g < gl.n_grids; ++g) {
+    const Corners cs = grid_corners<false>(gl.grids[g], b, x, y, z);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < cs.n && cs.row[k] >= 0) {
+        const float w = cs.w[k];
+        float* dst = grad + cs.row[k] * C;
+        for (int c = 0; c < C; ++c) atomic_add_f32(dst + c, w * d[c]);
+      }
+    }
+  }
+}
+
+// Full decoder of one sample.  Fills act[] per plan; returns the raw opacity (pre noise).
+// The raw colours are left in act[p.col[nC-1] .. +color_chn).
+LP_DEV float decode(const GenArgs& ga, const Ray& ray, float x, float y, float z,
+                    const float* enc, float* act) {
+  const LpRendererArgs& a = ga.a;
+  const GenPlan& p = ga.p;
+  const bool mask = a.march.mask_out_of_bounds != 0;
+  const bool two_grids = a.color_grid.n_grids > 0;
+  const int C = a.grid.channels;
+  sample_list(a.grid, ray.b, x, y, z, mask, act + p.x0);
+  if (two_grids) {
+    sample_list(a.color_grid, ray.b, x, y, z, mask, act + p.cx0);
+    for (int c = 0; c < C; ++c) {
+      act[p.op_in + c] = fmaxf(act[p.x0 + c], 0.0f);
+      act[p.col_in + c] = fmaxf(act[p.cx0 + c], 0.0f) + enc[c];
+    }
+  } else {
+    const float* cur = act + p.x0;
+    int w = C;
+    for (int l = 0; l < a.trunk.n_layers; ++l) {
+      dense(mlp_w(a.mlp_params, a.trunk, l), mlp_b(a.mlp_params, a.trunk, l), a.trunk.dims[l],
+            a.trunk.dims[l + 1], a.trunk.dims[l + 1], cur, act + p.trunk[l], true);
+      cur = act + p.trunk[l];
+      w = a.trunk.dims[l + 1];
+    }
+    if (a.trunk.n_layers == 0) {
+      for (int c = 0; c < C; ++c) act[p.op_in + c] = fmaxf(act[p.x0 + c], 0.0f);
+      cur = act + p.op_in;
+    }
+    for (int c = 0; c < w; ++c) act[p.col_in + c] = cur[c] + enc[c];
+  }
+  // opacity head
+  {
+    const float* cur = act + p.op_in;
+    const LpMlp& m = a.opacity;
+    for (int l = 0; l < m.n_layers; ++l) {
+      const bool last = (l == m.n_layers - 1);
+      dense(mlp_w(a.mlp_params, m, l), mlp_b(a.mlp_params, m, l), m.dims[l], m.dims[l + 1],
+            last ? 1 : m.dims[l + 1], cur, act + p.op[l], !last);
+      cur = act + p.op[l];
+    }
+  }
+  // colour head
+  {
+    const float* cur = act + p.col_in;
+    const LpMlp& m = a.color;
+    for (int l = 0; l < m.n_layers; ++l) {
+      const bool last = (l == m.n_layers - 1);
+      dense(mlp_w(a.mlp_params, m, l), mlp_b(a.mlp_params, m, l), m.dims[l], m.dims[l + 1],
+            last ? a.color_chn : m.dims[l + 1], cur, act + p.col[l], !last);
+      cur = act + p.col[l];
+    }
+  }
+  return act[p.op[a.opacity.n_layers - 1]];
+}
+
+template <int ACT_CAP>
+__global__ void __launch_bounds__(64) renderer_fwd_generic(const GenArgs ga) {
+  const LpRendererArgs& a = ga.a;
+  const GenPlan& p = ga.p;
+  const int64_t ray_id = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const bool valid = ray_id < a.rays.n_rays;
+  const int64_t rid = valid ? ray_id : 0;
+  float act[ACT_CAP];
+  float enc[LP_MAX_WIDTH];
+  float facc[LP_MAX_WIDTH];
+  const Ray ray = load_ray(a.rays, rid);
+  const int E = a.rays.encoding_dim;
+  for (int c = 0; c < E; ++c) enc[c] = a.rays.encoding[rid * E + c];
+  for (int c = 0; c < a.color_chn; ++c) facc[c] = 0.0f;
+  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
+  const bool contract = a.march.contract_coords != 0;
+  float nlt = 0.0f, t_prev = 1.0f, len = 0.0f, depth_prev = 0.0f;
+  const int craw = p.col[a.color.n_layers - 1];
+  for (int s = 0; s < s_tot; ++s) {
+    const float depth = sample_depth(s, a.march, ray.near_t, ray.far_t);
+    float delta;
+    if (s == 0)
+      delta = sample_delta(0, a.march, ray.near_t, ray.far_t, depth);
+    else
+      delta = depth - depth_prev;
+    depth_prev = depth;
+    float x, y, z;
+    sample_point(ray, depth, contract, x, y, z);
+    float occ = 1.0f;
+    if (a.scaffold) occ = scaffold_lookup(a.scaffold, a.scaffold_shape, ray.b, x, y, z);
+    float raw = decode(ga, ray, x, y, z, enc, act);
+    if (a.noise_sigma > 0.0f)
+      raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
+    const float opacity = a.gain * softplus_f(raw) * occ;
+    nlt = nlt + opacity * delta;
+    const float t = __expf(-nlt);
+    const float w = t_prev - t;
+    t_prev = t;
+    len = fmaf(w, depth, len);
+    for (int c = 0; c < a.color_chn; ++c)
+      facc[c] = fmaf(w, sigmoid_f(act[craw + c]) * occ, facc[c]);
+  }
+  if (valid) {
+    a.ray_length[ray_id] = len;
+    a.neg_log_t[ray_id] = nlt;
+    for (int c = 0; c < a.color_chn; ++c) a.feature[ray_id * a.color_chn + c] = facc[c];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------
+
+// Wave-level reduction of dW += X^T dY and db += sum dY over the 64 rays of the block.
+// Xs/Ys: LDS staging [64][ld].  gW/gb: accumulation targets (LDS or global).
+LP_DEV void stage(float* s, int ld, int lane, const float* v, int n, bool zero) {
+  for (int i = 0; i < n; ++i) s[lane * ld + i] = zero ? 0.0f : v[i];
+}
+
+template <bool LDS_ACC>
+LP_DEV void accum(float* target, float v) {
+  if (LDS_ACC)
+    *target += v;  // each (i,o) entry is owned by exactly one lane
+  else
+    atomic_add_f32(target, v);
+}
+
+template <bool LDS_ACC>
+LP_DEV void wave_outer(const float* Xs, const float* Ys, int ld, int d_in, int ldw, int n_out,
+                       float* gW, float* gb, int lane) {
+  __syncthreads();
+  const int n = d_in * n_out;
+  for (int e = lane; e < n; e += 64) {
+    const int i = e / n_out, o = e - i * n_out;
+    float s = 0.0f;
+    for (int r = 0; r < 64; ++r) s = fmaf(Xs[r * ld + i], Ys[r * ld + o], s);
+    accum<LDS_ACC>(gW + (int64_t)i * ldw + o, s);
+  }
+  for (int o = lane; o < n_out; o += 64) {
+    float s = 0.0f;
+    for (int r = 0; r < 64; ++r) s += Ys[r * ld + o];
+    accum<LDS_ACC>(gb + o, s);
+  }
+  __syncthreads();
+}
+
+// Backward through one MLP (layers last..first).  On entry dy[] holds the gradient w.r.t.
+// the MLP's (raw) output; on exit dx[] holds the gradient w.r.t. its input (pre input-ReLU).
+// in_slot / out_slots index act[].  Uses tmp as ping-pong.  `live`: lane contributes.
+template <bool LDS_ACC>
+LP_DEV void mlp_backward(const GenArgs& ga, const LpMlp& m, int n_out_last, int in_slot,
+                         const int* out_slots, const float* act, float* dy, float* dx,
+                         float* gparams, float* Xs, float* Ys, int lane, bool live) {
+  const LpRendererArgs& a = ga.a;
+  const int ld = ga.stage_ld;
+  for (int l = m.n_layers - 1; l >= 0; --l) {
+    const int d_in = m.dims[l], ldw = m.dims[l + 1];
+    const int n_out = (l == m.n_layers - 1) ? n_out_last : ldw;
+    const float* x = act + (l == 0 ? in_slot : out_slots[l - 1]);
+    // dy currently w.r.t. this layer's output post-activation; hidden layers: apply ReLU mask
+    if (l != m.n_layers - 1) {
+      const float* yv = act + out_slots[l];
+      for (int o = 0; o < n_out; ++o) dy[o] = (yv[o] > 0.0f) ? dy[o] : 0.0f;
+    }
+    if (gparams) {
+      stage(Xs, ld, lane, x, d_in, !live);
+      stage(Ys, ld, lane, dy, n_out, !live);
+      const int64_t w_off = mlp_w(a.mlp_params, m, l) - a.mlp_params;
+      const int64_t b_off = mlp_b(a.mlp_params, m, l) - a.mlp_params;
+      wave_outer<LDS_ACC>(Xs, Ys, ld, d_in, ldw, n_out, gparams + w_off, gparams + b_off, lane);
+    }
+    dense_bwd_input(mlp_w(a.mlp_params, m, l), d_in, ldw, n_out, dy, dx);
+    // the input gradient becomes the next (earlier) layer's output gradient
+    for (int i = 0; i < d_in; ++i) dy[i] = dx[i];
+  }
+}
+
+template <int ACT_CAP, bool LDS_ACC>
+__global__ void __launch_bounds__(64) renderer_bwd_generic(const GenArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const LpRendererArgs& a = ga.a;
+  const GenPlan& p = ga.p;
+  const int lane = threadIdx.x;
+  const int64_t ray_id = (int64_t)blockIdx.x * 64 + lane;
+  const bool valid = ray_id < a.rays.n_rays;
+  const int64_t rid = valid ? ray_id : 0;
+
+  float* Xs = lds;
+  float* Ys = lds + 64 * ga.stage_ld;
+  float* gparams_lds = lds + 128 * ga.stage_ld;
+  float* gparams = nullptr;
+  if (a.grad_mlp_params) {
+    if (LDS_ACC) {
+      for (int64_t i = lane; i < a.n_mlp_params; i += 64) gparams_lds[i] = 0.0f;
+      gparams = gparams_lds;
+    } else {
+      gparams = a.grad_mlp_params;
+    }
+  }
+  __syncthreads();
+
+  float act[ACT_CAP];
+  float enc[LP_MAX_WIDTH], denc[LP_MAX_WIDTH];
+  float gfeat[LP_MAX_WIDTH];
+  float dy[LP_MAX_WIDTH], dx[LP_MAX_WIDTH], dhead[LP_MAX_WIDTH];
+  const Ray ray = load_ray(a.rays, rid);
+  const int E = a.rays.encoding_dim;
+  for (int c = 0; c < E; ++c) {
+    enc[c] = a.rays.encoding[rid * E + c];
+    denc[c] = 0.0f;
+  }
+  const int Cc = a.color_chn;
+  for (int c = 0; c < Cc; ++c)
+    gfeat[c] = (valid && a.grad_feature) ? a.grad_feature[rid * Cc + c] : 0.0f;
+  const float g_len = (valid && a.grad_ray_length) ? a.grad_ray_length[rid] : 0.0f;
+  const float g_nlt = (valid && a.grad_neg_log_t) ? a.grad_neg_log_t[rid] : 0.0f;
+
+  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
+  const bool contract = a.march.contract_coords != 0;
+  const bool mask = a.march.mask_out_of_bounds != 0;
+  const bool two_grids = a.color_grid.n_grids > 0;
+  const int C = a.grid.channels;
+  const int craw = p.col[a.color.n_layers - 1];
+
+  float nlt = a.neg_log_t[rid];  // -log T after the last sample
+  float suffix = 0.0f;           // sum_{i >= k} T_i (p_i - p_{i+1})
+  float p_next = 0.0f;
+  for (int s = s_tot - 1; s >= 0; --s) {
+    const float depth = sample_depth(s, a.march, ray.near_t, ray.far_t);
+    const float delta = sample_delta(s, a.march, ray.near_t, ray.far_t, depth);
+    float x, y, z;
+    sample_point(ray, depth, contract, x, y, z);
+    float occ = 1.0f;
+    if (a.scaffold) occ = scaffold_lookup(a.scaffold, a.scaffold_shape, ray.b, x, y, z);
+    float raw = decode(ga, ray, x, y, z, enc, act);
+    if (a.noise_sigma > 0.0f)
+      raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
+    const float sp = softplus_f(raw);
+    const float opacity = a.gain * sp * occ;
+    // transmittance after (t_i) and before (t_im1) this sample
+    const float t_i = __expf(-nlt);
+    nlt = fmaxf(nlt - opacity * delta, 0.0f);
+    const float t_im1 = __expf(-nlt);
+    const float w = t_im1 - t_i;
+    // p_i = g_len * depth + sum_c g_feat_c * colour_c
+    float p_i = g_len * depth;
+    for (int c = 0; c < Cc; ++c) p_i = fmaf(gfeat[c], sigmoid_f(act[craw + c]) * occ, p_i);
+    suffix = fmaf(t_i, p_i - p_next, suffix);
+    p_next = p_i;
+    const float d_a = suffix + g_nlt;  // d loss / d (delta * opacity)
+    const bool live = valid;
+    const float d_raw_op = live ? d_a * delta * a.gain * occ * d_softplus_f(raw) : 0.0f;
+
+    // ---- colour head ----
+    for (int c = 0; c < Cc; ++c) {
+      const float sg = sigmoid_f(act[craw + c]);
+      dy[c] = live ? w * gfeat[c] * occ * sg * (1.0f - sg) : 0.0f;
+    }
+    if (LDS_ACC)
+      mlp_backward<true>(ga, a.color, Cc, p.col_in, p.col, act, dy, dx, gparams, Xs, Ys, lane, live);
+    else
+      mlp_backward<false>(ga, a.color, Cc, p.col_in, p.col, act, dy, dx, gparams, Xs, Ys, lane, live);
+    const int hw = p.head_w;
+    for (int c = 0; c < hw; ++c) {
+      dhead[c] = dx[c];
+      denc[c] += dx[c];
+    }
+    // ---- opacity head ----
+    dy[0] = d_raw_op;
+    if (LDS_ACC)
+      mlp_backward<true>(ga, a.opacity, 1, p.op_in, p.op, act, dy, dx, gparams, Xs, Ys, lane, live);
+    else
+      mlp_backward<false>(ga, a.opacity, 1, p.op_in, p.op, act, dy, dx, gparams, Xs, Ys, lane, live);
+
+    if (two_grids) {
+      // opacity input = relu(x0), colour input = relu(cx0) + enc
+      for (int c = 0; c < C; ++c) {
+        dx[c] = (act[p.x0 + c] > 0.0f) ? dx[c] : 0.0f;
+        dhead[c] = (act[p.cx0 + c] > 0.0f) ? dhead[c] : 0.0f;
+      }
+      if (a.grad_grid && live) splat_list(a.grid, a.grad_grid, ray.b, x, y, z, mask, dx);
+      if (a.grad_color_grid && live)
+        splat_list(a.color_grid, a.grad_color_grid, ray.b, x, y, z, mask, dhead);
+    } else {
+      // trunk output gradient = colour-input grad + opacity-input grad, through the ReLU
+      for (int c = 0; c < hw; ++c) {
+        const float g = dhead[c] + dx[c];
+        dy[c] = (act[p.op_in + c] > 0.0f) ? g : 0.0f;
+      }
+      if (a.trunk.n_layers > 0) {
+        // mlp_backward applies ReLU masks only to hidden outputs; the trunk's last layer
+        // is ReLU'd too and was handled just above (op_in aliases trunk[n-1]).
+        const LpMlp& m = a.trunk;
+        if (LDS_ACC)
+          mlp_backward<true>(ga, m, m.dims[m.n_layers], p.x0, p.trunk, act, dy, dx, gparams, Xs, Ys, lane, live);
+        else
+          mlp_backward<false>(ga, m, m.dims[m.n_layers], p.x0, p.trunk, act, dy, dx, gparams, Xs, Ys, lane, live);
+      } else {
+        for (int c = 0; c < C; ++c) dx[c] = dy[c];
+      }
+      if (a.grad_grid && live) splat_list(a.grid, a.grad_grid, ray.b, x, y, z, mask, dx);
+    }
+  }
+  if (valid && a.grad_encoding)
+    for (int c = 0; c < E; ++c) a.grad_encoding[ray_id * E + c] = denc[c];
+  if (LDS_ACC && a.grad_mlp_params) {
+    __syncthreads();
+    for (int64_t i = lane; i < a.n_mlp_params; i += 64) {
+      const float v = gparams_lds[i];
+      if (v != 0.0f) atomic_add_f32(a.grad_mlp_params + i, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// debug hook: integer corner rows
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) renderer_corner_rows(const LpRendererArgs a, int64_t* rows, int k_tot) {
+  const int64_t ray_id = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (ray_id >= a.rays.n_rays) return;
+  const Ray ray = load_ray(a.rays, ray_id);
+  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
+  for (int s = 0; s < s_tot; ++s) {
+    const float depth = sample_depth(s, a.march, ray.near_t, ray.far_t);
+    float x, y, z;
+    sample_point(ray, depth, a.march.contract_coords != 0, x, y, z);
+    int64_t* dst = rows + (ray_id * s_tot + s) * k_tot;
+    int pos = 0;
+    for (int g = 0; g < a.grid.n_grids; ++g) {
+      const Corners cs = grid_corners<false>(a.grid.grids[g], ray.b, x, y, z);
+      for (int k = 0; k < cs.n; ++k) {
+        // report rows relative to the start of grid g (the oracle indexes each grid separately)
+        dst[pos++] = cs.row[k] < 0 ? (int64_t)-1 : cs.row[k] - a.grid.grids[g].row_offset;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+
+static int make_plan(const LpRendererArgs& a, GenPlan& p) {
+  int pos = 0;
+  const int C = a.grid.channels;
+  const bool two = a.color_grid.n_grids > 0;
+  p.x0 = pos; pos += C;
+  p.cx0 = -1;
+  if (two) { p.cx0 = pos; pos += C; }
+  int w = C;
+  for (int l = 0; l < a.trunk.n_layers; ++l) { p.trunk[l] = pos; pos += a.trunk.dims[l + 1]; w = a.trunk.dims[l + 1]; }
+  if (!two && a.trunk.n_layers > 0) {
+    p.op_in = p.trunk[a.trunk.n_layers - 1];
+  } else {
+    p.op_in = pos; pos += C; w = C;
+  }
+  p.head_w = w;
+  p.col_in = pos; pos += w;
+  for (int l = 0; l < a.opacity.n_layers; ++l) { p.op[l] = pos; pos += a.opacity.dims[l + 1]; }
+  for (int l = 0; l < a.color.n_layers; ++l) { p.col[l] = pos; pos += a.color.dims[l + 1]; }
+  p.total = pos;
+  return pos;
+}
+
+int renderer_forward_generic(const LpRendererArgs& a, hipStream_t stream) {
+  GenArgs ga;
+  ga.a = a;
+  const int total = make_plan(a, ga.p);
+  ga.stage_ld = 0;
+  ga.lds_param_accum = 0;
+  const unsigned blocks = (unsigned)((a.rays.n_rays + 63) / 64);
+  if (blocks == 0) return LP_OK;
+  if (total <= 256)
+    hipLaunchKernelGGL(renderer_fwd_generic<256>, dim3(blocks), dim3(64), 0, stream, ga);
+  else if (total <= 1024)
+    hipLaunchKernelGGL(renderer_fwd_generic<1024>, dim3(blocks), dim3(64), 0, stream, ga);
+  else
+    return set_error(LP_EUNSUPPORTED, "generic renderer: sum of layer widths %d exceeds 1024", total);
+  return check_launch("renderer_fwd_generic");
+}
+
+int renderer_backward_generic(const LpRendererArgs& a, hipStream_t stream) {
+  GenArgs ga;
+  ga.a = a;
+  const int total = make_plan(a, ga.p);
+  int maxw = a.grid.channels;
+  const LpMlp* ms[3] = {&a.trunk, &a.opacity, &a.color};
+  for (const LpMlp* m : ms)
+    for (int l = 0; l <= m->n_layers && m->n_layers > 0; ++l) maxw = m->dims[l] > maxw ? m->dims[l] : maxw;
+  ga.stage_ld = maxw + 1;
+  const size_t stage_bytes = (size_t)128 * ga.stage_ld * sizeof(float);
+  const size_t param_bytes = (size_t)a.n_mlp_params * sizeof(float);
+  const bool lds_acc = a.grad_mlp_params && (stage_bytes + param_bytes <= 96 * 1024);
+  ga.lds_param_accum = lds_acc ? 1 : 0;
+  const size_t lds = stage_bytes + (lds_acc ? param_bytes : 0);
+  const unsigned blocks = (unsigned)((a.rays.n_rays + 63) / 64);
+  if (blocks == 0) return LP_OK;
+  if (total > 1024)
+    return set_error(LP_EUNSUPPORTED, "generic renderer: sum of layer widths %d exceeds 1024", total);
+#define LP_LAUNCH_BWD(CAP, ACC)                                                                   \
+  do {                                                                                            \
+    hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_generic<CAP, ACC>,               \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+    if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e)); \
+    hipLaunchKernelGGL((renderer_bwd_generic<CAP, ACC>), dim3(blocks), dim3(64), lds, stream, ga); \
+  } while (0)
+  if (total <= 256) {
+    if (lds_acc) LP_LAUNCH_BWD(256, true); else LP_LAUNCH_BWD(256, false);
+  } else {
+    if (lds_acc) LP_LAUNCH_BWD(1024, true); else LP_LAUNCH_BWD(1024, false);
+  }
+#undef LP_LAUNCH_BWD
+  return check_launch("renderer_bwd_generic");
+}
+
+int renderer_corner_rows_launch(const LpRendererArgs& a, int64_t* rows, hipStream_t stream) {
+  int k_tot = 0;
+  for (int g = 0; g < a.grid.n_grids; ++g) {
+    const LpGrid& gd = a.grid.grids[g];
+    k_tot += (gd.D > 1 && gd.H > 1 && gd.W > 1) ? 8 : 4;
+  }
+  const unsigned blocks = (unsigned)((a.rays.n_rays + 63) / 64);
+  if (blocks == 0) return LP_OK;
+  hipLaunchKernelGGL(renderer_corner_rows, dim3(blocks), dim3(64), 0, stream, a, rows, k_tot);
+  return check_launch("renderer_corner_rows");
+}
+
+}  // namespace lp

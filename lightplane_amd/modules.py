@@ -1,0 +1,321 @@
+"""``torch.nn.Module`` front-ends: LightplaneRenderer / LightplaneSplatter / LightplaneMLPSplatter.
+
+Constructor / forward arguments, ``state_dict`` keys (``mlp_params``,
+``harmonic_ray_embedding_linear.{weight,bias}``, buffer ``bg_color``; non-persistent
+``n_hidden_*``) and return values follow the reference's
+``lightplane/renderer_module.py`` (`LightplaneRenderer` :38-601) and
+``lightplane/splatter_module.py`` (`LightplaneSplatter` :25-161, `LightplaneMLPSplatter`
+:164-331), so checkpoints interchange.  The dense pre/post ops (harmonic embedding + Linear,
+background compositing, alpha) stay PyTorch-ROCm ops; the march is the HIP library.
+
+``use_naive_impl=True`` is rejected: the pure-PyTorch implementation is this repository's
+test oracle (``oracle/``), not part of the product path.
+"""
+from __future__ import annotations
+
+import copy
+import logging
+from dataclasses import asdict
+from typing import Optional, Tuple
+
+import torch
+
+from .grids import if_not_none_else
+from .params import DecoderParams, SplatterParams, flattened_decoder_params_to_list, init_decoder_params
+from .rays import Rays, calc_harmonic_embedding, calc_harmonic_embedding_dim, jitter_near_far
+from .renderer import lightplane_renderer
+from .splatter import lightplane_mlp_splatter, lightplane_splatter
+
+logger = logging.getLogger(__name__)
+
+_NAIVE_MSG = (
+    "use_naive_impl=True is not available in lightplane_amd: the pure-PyTorch implementation is "
+    "kept as the CPU test oracle under oracle/ and is never part of the product path."
+)
+
+
+class LightplaneRenderer(torch.nn.Module):
+    """Module wrapper of :func:`lightplane_amd.lightplane_renderer`.
+
+    Owns the decoder parameters (``mlp_params``), the optional harmonic ray-direction
+    embedding (``harmonic_ray_embedding_linear``) and the background colour.
+    """
+
+    def __init__(
+        self,
+        num_samples: int,
+        color_chn: int,
+        grid_chn: int,
+        mlp_hidden_chn: int,
+        mlp_n_layers_opacity: int = 2,
+        mlp_n_layers_trunk: int = 2,
+        mlp_n_layers_color: int = 2,
+        use_separate_color_grid: bool = False,
+        opacity_init_bias: float = -5.0,
+        gain: float = 1.0,
+        bg_color=0.0,
+        enable_direction_dependent_colors: bool = True,
+        ray_embedding_num_harmonics: Optional[int] = 3,
+        num_samples_inf: int = 0,
+        mask_out_of_bounds_samples: bool = False,
+        contract_coords: bool = False,
+        disparity_at_inf: float = 1e-5,
+        inject_noise_sigma: float = 0.0,
+        inject_noise_seed: Optional[int] = None,
+        rays_jitter_near_far: bool = False,
+        return_log_transmittance: bool = False,
+        triton_block_size: int = 16,
+        triton_num_warps: int = 4,
+        use_naive_impl: bool = False,
+    ) -> None:
+        super().__init__()
+        if use_naive_impl:
+            raise NotImplementedError(_NAIVE_MSG)
+        self.num_samples = num_samples
+        self.color_chn = color_chn
+        self.opacity_init_bias = opacity_init_bias
+        self.gain = gain
+        self.num_samples_inf = num_samples_inf
+        self.mask_out_of_bounds_samples = mask_out_of_bounds_samples
+        self.contract_coords = contract_coords
+        self.disparity_at_inf = disparity_at_inf
+        self.inject_noise_sigma = inject_noise_sigma
+        self.inject_noise_seed = inject_noise_seed
+        self.rays_jitter_near_far = rays_jitter_near_far
+        self.return_log_transmittance = return_log_transmittance
+        self.triton_block_size = triton_block_size
+        self.triton_num_warps = triton_num_warps
+        self.use_naive_impl = False
+        self.enable_direction_dependent_colors = enable_direction_dependent_colors
+        self.ray_embedding_num_harmonics = ray_embedding_num_harmonics
+
+        if use_separate_color_grid and mlp_n_layers_trunk > 0:
+            logger.warning("Auto-setting mlp_n_layers_trunk=0 because a separate feature grid"
+                           " for colors is used (use_separate_color_grid=True).")
+            mlp_n_layers_trunk = 0
+
+        dec = init_decoder_params(
+            device="cpu", n_layers_opacity=mlp_n_layers_opacity, n_layers_trunk=mlp_n_layers_trunk,
+            n_layers_color=mlp_n_layers_color, input_chn=grid_chn, hidden_chn=mlp_hidden_chn,
+            color_chn=color_chn, opacity_init_bias=opacity_init_bias,
+            pad_color_channels_to_min_block_size=True, use_separate_color_grid=use_separate_color_grid,
+        )
+        self.rays_encoding_dim = int(dec.n_hidden_color[0])
+        self.mlp_params = torch.nn.Parameter(dec.mlp_params)
+
+        if ray_embedding_num_harmonics is not None:
+            if not enable_direction_dependent_colors:
+                raise ValueError(
+                    "LightplaneRenderer's viewpoint dependent colors are disabled,"
+                    " (enable_direction_dependent_colors=False), but `ray_embedding_num_harmonics` is set."
+                    " Set LightplaneRender.ray_embedding_num_harmonics = None if you intended to disable"
+                    " viewpoint dependent colors.")
+            self.harmonic_ray_embedding_linear = torch.nn.Linear(
+                calc_harmonic_embedding_dim(ray_embedding_num_harmonics), self.rays_encoding_dim)
+            torch.nn.init.xavier_uniform_(self.harmonic_ray_embedding_linear.weight)
+            self.harmonic_ray_embedding_linear.bias.data.zero_()
+
+        for name in ("n_hidden_trunk", "n_hidden_opacity", "n_hidden_color"):
+            self.register_buffer(name, getattr(dec, name), persistent=False)
+        self.register_buffer("bg_color", self._process_bg_color(bg_color))
+
+    # -- parameter access ----------------------------------------------------------------
+    def get_decoder_params(self) -> DecoderParams:
+        return DecoderParams(self.mlp_params, self.n_hidden_trunk, self.n_hidden_opacity,
+                             self.n_hidden_color, color_chn=self.color_chn)
+
+    def get_decoder_params_list(self):
+        return flattened_decoder_params_to_list(self.mlp_params, self.n_hidden_trunk, self.n_hidden_opacity,
+                                                self.n_hidden_color)
+
+    def _process_bg_color(self, bg_color) -> torch.Tensor:
+        if bg_color is None:
+            return self.bg_color
+        if isinstance(bg_color, (float, int)):
+            bg_color = torch.full((self.color_chn,), float(bg_color))
+        elif not torch.is_tensor(bg_color):
+            bg_color = torch.tensor(bg_color, dtype=torch.float)
+        assert len(bg_color) == self.color_chn
+        return bg_color
+
+    # -- naive-only helpers of the reference ---------------------------------------------
+    def eval_decoder_at_points(self, *args, **kwargs):
+        raise NotImplementedError("eval_decoder_at_points runs the reference's naive path only; " + _NAIVE_MSG)
+
+    def eval_opacity_at_points(self, *args, **kwargs):
+        raise NotImplementedError("eval_opacity_at_points runs the reference's naive path only; " + _NAIVE_MSG)
+
+    def calculate_scaffold(self, *args, **kwargs):
+        raise NotImplementedError("calculate_scaffold runs the reference's naive path only; " + _NAIVE_MSG)
+
+    # -- ray encoding ---------------------------------------------------------------------
+    def _get_ray_embedding(self, ray_directions: torch.Tensor) -> torch.Tensor:
+        if not self.enable_direction_dependent_colors:
+            return ray_directions.new_zeros(ray_directions.shape[0], self.rays_encoding_dim)
+        assert self.ray_embedding_num_harmonics is not None
+        emb = calc_harmonic_embedding(torch.nn.functional.normalize(ray_directions, dim=-1),
+                                      self.ray_embedding_num_harmonics)
+        return self.harmonic_ray_embedding_linear(emb)
+
+    def _get_ray_encoding(self, ray_encoding, directions) -> torch.Tensor:
+        if ray_encoding is not None:
+            assert not self.enable_direction_dependent_colors or self.ray_embedding_num_harmonics is None
+            return ray_encoding
+        return self._get_ray_embedding(directions)
+
+    def forward(
+        self,
+        rays: Rays,
+        feature_grid,
+        color_feature_grid=None,
+        scaffold: Optional[torch.Tensor] = None,
+        grid_sizes=None,
+        color_grid_sizes=None,
+        bg_color=None,
+        num_samples: Optional[int] = None,
+        gain: Optional[float] = None,
+        num_samples_inf: Optional[int] = None,
+        mask_out_of_bounds_samples: Optional[bool] = None,
+        contract_coords: Optional[bool] = None,
+        disparity_at_inf: Optional[float] = None,
+        inject_noise_sigma: Optional[float] = None,
+        inject_noise_seed: Optional[int] = None,
+        rays_jitter_near_far: Optional[bool] = None,
+        return_log_transmittance: Optional[bool] = None,
+        regenerate_code: Optional[bool] = None,
+    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Render; every keyword overrides the module default for this call.
+
+        Returns ``(ray_length_render, alpha, feature_render)`` with ``alpha = 1 - T`` (or
+        ``log T`` if ``return_log_transmittance``) and ``feature_render`` composited over
+        ``bg_color`` (reference renderer_module.py:552-561).
+        """
+        device = rays.device
+        num_samples = if_not_none_else(num_samples, self.num_samples)
+        rays_jitter = if_not_none_else(rays_jitter_near_far, self.rays_jitter_near_far)
+        return_log_t = if_not_none_else(return_log_transmittance, self.return_log_transmittance)
+        bg = self._process_bg_color(if_not_none_else(bg_color, self.bg_color)).to(device)
+
+        _check_renderer_ray_encoding_input(rays.encoding, self.ray_embedding_num_harmonics,
+                                           self.rays_encoding_dim, self.enable_direction_dependent_colors)
+        r = copy.copy(rays)
+        r.encoding = self._get_ray_encoding(rays.encoding, rays.directions)
+        if rays_jitter:
+            r.near, r.far = jitter_near_far(r.near, r.far, num_samples)
+
+        ray_length, nlt, feature = lightplane_renderer(
+            r, feature_grid, self.get_decoder_params(),
+            num_samples=num_samples,
+            gain=if_not_none_else(gain, self.gain),
+            num_samples_inf=if_not_none_else(num_samples_inf, self.num_samples_inf),
+            mask_out_of_bounds_samples=if_not_none_else(mask_out_of_bounds_samples, self.mask_out_of_bounds_samples),
+            contract_coords=if_not_none_else(contract_coords, self.contract_coords),
+            disparity_at_inf=if_not_none_else(disparity_at_inf, self.disparity_at_inf),
+            inject_noise_sigma=if_not_none_else(inject_noise_sigma, self.inject_noise_sigma),
+            inject_noise_seed=if_not_none_else(inject_noise_seed, self.inject_noise_seed),
+            scaffold=scaffold, color_grid=color_feature_grid, grid_sizes=grid_sizes,
+            color_grid_sizes=color_grid_sizes,
+        )
+        transmittance = torch.exp(-nlt)
+        feature = feature + transmittance[..., None] * bg
+        alpha = -nlt if return_log_t else 1 - transmittance
+        return ray_length, alpha, feature
+
+
+def _check_renderer_ray_encoding_input(ray_encoding, ray_embedding_num_harmonics, ray_encoding_dim,
+                                       enable_direction_dependent_colors) -> None:
+    """Same decision table (and ``ValueError``s) as reference renderer_module.py:604-667."""
+    if ray_encoding is not None and ray_encoding.shape[1] != ray_encoding_dim:
+        raise ValueError(f"Ray encoding has a wrong dimension. Expected: {ray_encoding_dim},"
+                         f" got: {ray_encoding.shape[1]}")
+    if not enable_direction_dependent_colors:
+        if ray_encoding is not None:
+            raise ValueError("LightplaneRenderer's viewpoint dependent colors are disabled"
+                             " (enable_direction_dependent_colors=False), but the `encoding` field of"
+                             " `rays` is set. Set rays.encoding=None to disable viewpoint dependent colors.")
+        if ray_embedding_num_harmonics is not None:
+            raise ValueError("LightplaneRenderer's viewpoint dependent colors are disabled"
+                             " (enable_direction_dependent_colors=False), but `ray_embedding_num_harmonics`"
+                             " is set. Set it to None to disable viewpoint dependent colors.")
+        return
+    have_h, have_e = ray_embedding_num_harmonics is not None, ray_encoding is not None
+    if have_h != have_e:
+        return  # exactly one source of ray encodings: fine
+    if not have_e:
+        msg = ("rays.encoding is unset (=None), but the Lightplane module is not configured to compute"
+               " harmonic ray embeddings (self.ray_embedding_num_harmonics is unset = None).")
+    else:
+        msg = ("rays.encoding is set, but the Lightplane module is configured to also compute harmonic ray"
+               " embeddings (self.ray_embedding_num_harmonics is set).")
+    raise ValueError(msg + " Either set ray_embedding_num_harmonics to an integer and rays.encoding=None,"
+                           " or pass your own [n_rays, ray_encoding_dim] rays.encoding and set"
+                           " ray_embedding_num_harmonics=None.")
+
+
+class LightplaneSplatter(torch.nn.Module):
+    """Module wrapper of :func:`lightplane_amd.lightplane_splatter` (reference splatter_module.py:25-161)."""
+
+    def __init__(
+        self,
+        num_samples: int,
+        grid_chn: int,
+        num_samples_inf: int = 0,
+        mask_out_of_bounds_samples: bool = False,
+        contract_coords: bool = False,
+        disparity_at_inf: float = 1e-5,
+        rays_jitter_near_far: bool = False,
+        triton_block_size: int = 16,
+        triton_num_warps: int = 4,
+        use_naive_impl: bool = False,
+    ):
+        super().__init__()
+        if use_naive_impl:
+            raise NotImplementedError(_NAIVE_MSG)
+        self.num_samples = num_samples
+        self.num_samples_inf = num_samples_inf
+        self.mask_out_of_bounds_samples = mask_out_of_bounds_samples
+        self.contract_coords = contract_coords
+        self.disparity_at_inf = disparity_at_inf
+        self.rays_jitter_near_far = rays_jitter_near_far
+        self.triton_block_size = triton_block_size
+        self.triton_num_warps = triton_num_warps
+        self.use_naive_impl = False
+        self.rays_encoding_dim = grid_chn
+
+    def get_splatter_params(self) -> Optional[SplatterParams]:
+        return None
+
+    def forward(
+        self,
+        rays: Rays,
+        grid_size,
+        num_samples: Optional[int] = None,
+        num_samples_inf: Optional[int] = None,
+        mask_out_of_bounds_samples: Optional[bool] = None,
+        contract_coords: Optional[bool] = None,
+        disparity_at_inf: Optional[float] = None,
+        rays_jitter_near_far: Optional[bool] = None,
+        return_list: bool = True,
+        regenerate_code: bool = False,
+    ):
+        num_samples = if_not_none_else(num_samples, self.num_samples)
+        _check_splatter_ray_encoding_input(rays.encoding, self.rays_encoding_dim)
+        r = copy.copy(rays)
+        if if_not_none_else(rays_jitter_near_far, self.rays_jitter_near_far):
+            r.near, r.far = jitter_near_far(r.near, r.far, num_samples)
+        return lightplane_splatter(
+            r, grid_size, num_samples=num_samples,
+            num_samples_inf=if_not_none_else(num_samples_inf, self.num_samples_inf),
+            mask_out_of_bounds_samples=if_not_none_else(mask_out_of_bounds_samples, self.mask_out_of_bounds_samples),
+            contract_coords=if_not_none_else(contract_coords, self.contract_coords),
+            disparity_at_inf=if_not_none_else(disparity_at_inf, self.disparity_at_inf),
+            return_list=return_list,
+        )
+
+
+def _check_splatter_ray_encoding_input(ray_encoding, ray_encoding_dim) -> None:
+    if ray_encoding is None:
+        raise ValueError("rays.encoding has to be set: it is the feature the splatter pushes into the grid.")
+    if ray_encoding.shape[1] != ray_encoding_dim:
+        raise ValueError(f"Ray encoding has a wrong dimension. Expected: {ray_encoding_dim},"
+                         f" got: {ray_encoding.shape[1]}")

@@ -1,0 +1,279 @@
+"""Functional Lightplane Renderer on MI355X: ``lightplane_renderer`` + its autograd boundary.
+
+Drop-in for the reference's ``lightplane/lightplane_renderer.py``
+(`lightplane_renderer` :33-293, `LightplaneFunction` :296-756): same arguments, same
+returns ``(ray_length_render [N], negative_log_transmittances [N], feature_render
+[N, color_chn])``, same non-differentiable inputs (ray geometry, grid_idx, scaffold).
+The two Triton launches (:505-555 forward, :657-711 backward) are replaced by
+``lp_renderer_forward`` / ``lp_renderer_backward`` of ``liblightplane_hip.so``.
+
+Differences that are deliberate:
+* no ray padding, no power-of-two / >=16 channel restriction -- the kernels mask tails;
+* grid sizes travel by value (no ``.item()`` sync); the ``grid_idx`` range check is the only
+  device sync and can be switched off with ``lightplane_amd.config.check_inputs = False``;
+* the post-backward ``isfinite`` asserts (:719-722) are opt-in
+  (``lightplane_amd.config.check_finite_grads``);
+* ``triton_block_size`` / ``triton_num_warps`` / ``regenerate_code`` are accepted and ignored.
+"""
+from __future__ import annotations
+
+import ctypes
+import random
+import warnings
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib, config
+from .grids import (
+    GridDesc,
+    check_grid_and_color_grid,
+    make_grid_descs,
+    process_and_flatten_grid,
+)
+from .params import DecoderParams, mlp_numel
+from .rays import Rays
+
+
+@dataclass
+class _RendererCfg:
+    descs: List[GridDesc]
+    channels: int
+    n_rows: int
+    color_descs: Optional[List[GridDesc]]
+    color_n_rows: int
+    dims_trunk: List[int]
+    dims_opacity: List[int]
+    dims_color: List[int]
+    color_chn: int
+    num_samples: int
+    num_samples_inf: int
+    gain: float
+    mask_out_of_bounds_samples: bool
+    contract_coords: bool
+    disparity_at_inf: float
+    noise_sigma: float
+    noise_seed: int
+    scaffold_shape: Optional[Tuple[int, int, int, int]]
+    kernel: int
+
+
+def _fill_args(cfg: _RendererCfg, grid, color_grid, mlp_params, directions, origins, grid_idx, near, far,
+               encoding, scaffold) -> _lib.LpRendererArgs:
+    a = _lib.LpRendererArgs()
+    a.rays = _lib.make_rays(directions, origins, grid_idx, near, far, encoding)
+    a.grid = _lib.make_grid_list(grid, cfg.descs, cfg.channels, cfg.n_rows)
+    if cfg.color_descs is not None:
+        a.color_grid = _lib.make_grid_list(color_grid, cfg.color_descs, cfg.channels, cfg.color_n_rows)
+    else:
+        a.color_grid = _lib.make_grid_list(None, [], 0, 0)
+    if scaffold is not None:
+        a.scaffold = _lib.ptr(scaffold)
+        B, D, H, W = cfg.scaffold_shape
+        a.scaffold_shape = _lib.LpGrid(B, D, H, W, 0)
+    a.march = _lib.make_march(cfg.num_samples, cfg.num_samples_inf, cfg.mask_out_of_bounds_samples,
+                              cfg.contract_coords, cfg.disparity_at_inf)
+    a.mlp_params = _lib.ptr(mlp_params)
+    a.n_mlp_params = mlp_params.numel()
+    n_t, n_o = mlp_numel(cfg.dims_trunk), mlp_numel(cfg.dims_opacity)
+    a.trunk = _lib.make_mlp(cfg.dims_trunk, 0)
+    a.opacity = _lib.make_mlp(cfg.dims_opacity, n_t)
+    a.color = _lib.make_mlp(cfg.dims_color, n_t + n_o)
+    a.color_chn = cfg.color_chn
+    a.gain = float(cfg.gain)
+    a.noise_sigma = float(cfg.noise_sigma)
+    a.noise_seed = ctypes.c_int32(int(cfg.noise_seed) & 0xFFFFFFFF).value
+    a.kernel = cfg.kernel
+    return a
+
+
+class LightplaneFunction(torch.autograd.Function):
+    """Autograd boundary of the Renderer (name kept from the reference, :296)."""
+
+    @staticmethod
+    def forward(ctx, grid, mlp_params, encoding, color_grid, cfg: _RendererCfg, directions, origins,
+                grid_idx, near, far, scaffold):
+        dev = grid.device
+        stream = _lib.current_stream(dev)
+        grid, mlp_params, encoding = grid.contiguous(), mlp_params.contiguous(), encoding.contiguous()
+        color_grid = None if color_grid is None else color_grid.contiguous()
+        n = directions.shape[0]
+        ray_length = torch.empty(n, device=dev, dtype=torch.float32)
+        nlt = torch.empty(n, device=dev, dtype=torch.float32)
+        feature = torch.empty(n, cfg.color_chn, device=dev, dtype=torch.float32)
+        a = _fill_args(cfg, grid, color_grid, mlp_params, directions, origins, grid_idx, near, far, encoding,
+                       scaffold)
+        a.ray_length, a.neg_log_t, a.feature = _lib.ptr(ray_length), _lib.ptr(nlt), _lib.ptr(feature)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().lp_renderer_forward(ctypes.byref(a), stream), "lp_renderer_forward")
+        # O(N) state only: the final -log T (the reference saves the same, :558-573)
+        ctx.save_for_backward(nlt, grid, mlp_params, encoding, color_grid, directions, origins, grid_idx, near,
+                              far, scaffold)
+        ctx.cfg = cfg
+        return ray_length, nlt, feature
+
+    @staticmethod
+    def backward(ctx, g_len, g_nlt, g_feat):
+        (nlt, grid, mlp_params, encoding, color_grid, directions, origins, grid_idx, near, far,
+         scaffold) = ctx.saved_tensors
+        cfg: _RendererCfg = ctx.cfg
+        dev = grid.device
+        stream = _lib.current_stream(dev)
+        need_grid, need_params, need_enc, need_cgrid = ctx.needs_input_grad[:4]
+        a = _fill_args(cfg, grid, color_grid, mlp_params, directions, origins, grid_idx, near, far, encoding,
+                       scaffold)
+        a.neg_log_t = _lib.ptr(nlt)
+        g_len = None if g_len is None else g_len.contiguous()
+        g_nlt = None if g_nlt is None else g_nlt.contiguous()
+        g_feat = None if g_feat is None else g_feat.contiguous()
+        a.grad_ray_length, a.grad_neg_log_t, a.grad_feature = _lib.ptr(g_len), _lib.ptr(g_nlt), _lib.ptr(g_feat)
+        grad_grid = torch.zeros_like(grid) if need_grid else None
+        grad_params = torch.zeros_like(mlp_params) if need_params else None
+        grad_enc = torch.empty_like(encoding) if need_enc else None
+        grad_cgrid = torch.zeros_like(color_grid) if (need_cgrid and color_grid is not None) else None
+        a.grad_grid, a.grad_mlp_params = _lib.ptr(grad_grid), _lib.ptr(grad_params)
+        a.grad_encoding, a.grad_color_grid = _lib.ptr(grad_enc), _lib.ptr(grad_cgrid)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().lp_renderer_backward(ctypes.byref(a), stream), "lp_renderer_backward")
+        if config.check_finite_grads:
+            for name, g in (("grid", grad_grid), ("mlp_params", grad_params), ("encoding", grad_enc),
+                            ("color_grid", grad_cgrid)):
+                assert g is None or torch.isfinite(g).all(), f"non-finite gradient w.r.t. {name}"
+        return (grad_grid, grad_params, grad_enc, grad_cgrid) + (None,) * 7
+
+
+def _decoder_dims(decoder_params: DecoderParams):
+    def tolist(t):
+        return [int(v) for v in t.tolist()]
+
+    return tolist(decoder_params.n_hidden_trunk), tolist(decoder_params.n_hidden_opacity), tolist(
+        decoder_params.n_hidden_color)
+
+
+def lightplane_renderer(
+    rays: Rays,
+    grid,
+    decoder_params: DecoderParams,
+    # ------ config keys ------
+    num_samples: int,
+    gain: float,
+    num_samples_inf: int = 0,
+    mask_out_of_bounds_samples: bool = False,
+    contract_coords: bool = False,
+    disparity_at_inf: float = 1e-5,
+    inject_noise_sigma: float = 0.0,
+    inject_noise_seed: Optional[int] = None,
+    scaffold: Optional[torch.Tensor] = None,
+    color_grid=None,
+    grid_sizes=None,
+    color_grid_sizes=None,
+    regenerate_code: bool = False,  # ignored (no code generation in the HIP build)
+    triton_block_size: int = 16,  # ignored
+    triton_num_warps: int = 4,  # ignored
+    kernel: int = _lib.LP_KERNEL_AUTO,
+) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Render ``rays`` through the grid-list ``grid`` (emission-absorption ray march).
+
+    For every ray, ``num_samples`` points equispaced in ``[near, far]`` (both ends included)
+    plus ``num_samples_inf`` points beyond ``far`` (linear in disparity down to
+    ``disparity_at_inf``) are sampled; the grid-list is interpolated at each point (features
+    of all grids summed), decoded by the trunk / opacity / colour MLPs and composited:
+    ``T_i = exp(-sum_{j<=i} gain*softplus(o_j)*delta_j)``, ``w_i = T_{i-1} - T_i``,
+    ``ray_length = sum w_i depth_i``, ``feature = sum w_i sigmoid(c_i)``.
+
+    Arguments and returns are those of the reference's ``lightplane_renderer``
+    (lightplane/lightplane_renderer.py:33-212): ``grid`` is a *list* of ``[B, D, H, W, C]``
+    tensors or a flat ``[sum BDHW, C]`` tensor with ``grid_sizes``; ``color_grid`` (optional)
+    switches to the two-grid decoder without trunk MLP; ``scaffold`` ``[B, D, H, W]`` masks
+    empty space.  Gradients flow to ``grid``, ``color_grid``, ``decoder_params.mlp_params``
+    and ``rays.encoding``.
+    """
+    grid, color_grid, grid_sizes, color_grid_sizes = check_grid_and_color_grid(
+        grid, color_grid, grid_sizes, color_grid_sizes)
+    grid, color_grid, grid_sizes, color_grid_sizes = process_and_flatten_grid(
+        grid, color_grid, grid_sizes, color_grid_sizes)
+    descs, channels, n_rows = make_grid_descs(grid_sizes)
+    assert grid.ndim == 2 and grid.shape[1] == channels and grid.shape[0] == n_rows, (
+        "flat grid tensor does not match grid_sizes")
+    color_descs, color_n_rows = None, 0
+    if color_grid is not None:
+        color_descs, c_channels, color_n_rows = make_grid_descs(color_grid_sizes)
+        assert c_channels == channels and color_descs[0].B == descs[0].B
+        assert color_grid.ndim == 2 and color_grid.shape == (color_n_rows, channels)
+
+    if mask_out_of_bounds_samples and contract_coords:
+        warnings.warn(
+            "The renderer has been configured to contract the coordinates lying outside the [-1,1] cube"
+            " (contract_coords=True) and to also mask out all such points (mask_out_of_bounds_samples=True).")
+
+    dims_t, dims_o, dims_c = _decoder_dims(decoder_params)
+    use_color_grid = color_grid is not None
+    if use_color_grid:
+        assert len(dims_t) == 0, "mlp_n_layers_trunk has to be 0 when use_separate_color_grid"
+    mlp_params = decoder_params.mlp_params
+    assert mlp_params.ndim == 1 and mlp_params.dtype == torch.float32
+    expected = mlp_numel(dims_t) + mlp_numel(dims_o) + mlp_numel(dims_c)
+    assert expected == mlp_params.numel(), (
+        f"The number of elements in mlp param should be {expected}. Got {mlp_params.numel()} instead.")
+    assert rays.encoding is not None, "rays.encoding is required by the functional renderer"
+    assert rays.encoding.shape[1] == dims_c[0], "ray_encoding should have the same dimension as dim_in_color"
+    for name, t in (("grid", grid), ("encoding", rays.encoding), ("directions", rays.directions)):
+        assert t.dtype == torch.float32, f"{name} has to be float32"
+
+    if inject_noise_sigma > 0.0:
+        if inject_noise_seed is None:
+            inject_noise_seed = int(random.randint(0, 1000000))
+    else:
+        inject_noise_seed = 0
+
+    B = descs[0].B
+    grid_idx = rays.grid_idx.to(torch.int32).contiguous()
+    if config.check_inputs and grid_idx.numel() > 0:
+        lo, hi = torch.aminmax(grid_idx)
+        lo, hi = int(lo), int(hi)
+        assert lo >= 0, f"Negative grid index: {lo}"
+        assert hi <= B - 1, f"A grid index is out of bounds ({hi} >= {B})"
+
+    scaffold_shape = None
+    if scaffold is not None:
+        assert scaffold.ndim == 4 and scaffold.shape[0] == B, "scaffold has to be [B, D, H, W]"
+        scaffold_shape = tuple(int(v) for v in scaffold.shape)
+        scaffold = scaffold.to(torch.float32).contiguous()
+
+    cfg = _RendererCfg(
+        descs=descs, channels=channels, n_rows=n_rows, color_descs=color_descs, color_n_rows=color_n_rows,
+        dims_trunk=dims_t, dims_opacity=dims_o, dims_color=dims_c, color_chn=int(decoder_params.color_chn),
+        num_samples=int(num_samples), num_samples_inf=int(num_samples_inf), gain=float(gain),
+        mask_out_of_bounds_samples=bool(mask_out_of_bounds_samples), contract_coords=bool(contract_coords),
+        disparity_at_inf=float(disparity_at_inf), noise_sigma=float(inject_noise_sigma),
+        noise_seed=int(inject_noise_seed), scaffold_shape=scaffold_shape, kernel=int(kernel),
+    )
+    return LightplaneFunction.apply(
+        grid, mlp_params, rays.encoding, color_grid, cfg,
+        rays.directions.contiguous(), rays.origins.contiguous(), grid_idx, rays.near.contiguous(),
+        rays.far.contiguous(), scaffold,
+    )
+
+
+def renderer_corner_rows(rays: Rays, grid_sizes, num_samples: int, num_samples_inf: int = 0,
+                         contract_coords: bool = False, disparity_at_inf: float = 1e-5) -> torch.Tensor:
+    """Integer corner rows of the march ``[N, S_tot, K_tot]`` (int64, -1 = out of range), rows
+    relative to each grid's start.  Parity hook for the bit-exact index tests."""
+    descs, channels, n_rows = make_grid_descs(grid_sizes)
+    dev = rays.device
+    stream = _lib.current_stream(dev)
+    k_tot = sum(8 if d.kind == "voxel" else 4 for d in descs)
+    s_tot = num_samples + num_samples_inf
+    out = torch.empty(rays.n_rays, s_tot, k_tot, dtype=torch.int64, device=dev)
+    a = _lib.LpRendererArgs()
+    a.rays = _lib.make_rays(rays.directions.contiguous(), rays.origins.contiguous(),
+                            rays.grid_idx.to(torch.int32).contiguous(), rays.near.contiguous(),
+                            rays.far.contiguous(), None)
+    a.grid = _lib.make_grid_list(None, descs, channels, n_rows)
+    a.march = _lib.make_march(num_samples, num_samples_inf, False, contract_coords, disparity_at_inf)
+    keep = (a, out)  # noqa: F841  (keep tensors alive across the async launch)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().lp_renderer_corner_rows(ctypes.byref(a), out.data_ptr(), stream),
+                   "lp_renderer_corner_rows")
+    return out

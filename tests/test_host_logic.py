@@ -1,0 +1,185 @@
+"""CPU tests: host API types, the C-ABI library loads and exports every declared symbol, argument
+validation at the C boundary (no kernel is launched without a GPU), multi-process collectives on gloo."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import lightplane_amd as lp
+from lightplane_amd import _lib, grids, params
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = _lib.lib()
+    assert L.lp_version() == 100
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "lightplane_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(lp_[a-z_0-9]+)\s*\(", hdr, flags=re.M))
+    assert declared == set(_lib.EXPORTS), f"header vs binding mismatch: {declared ^ set(_lib.EXPORTS)}"
+    for name in declared:
+        assert hasattr(L, name), f"{name} not exported by liblightplane_hip.so"
+
+
+def test_abi_struct_sizes_match():
+    L = _lib.lib()
+    for which, st in enumerate((_lib.LpGrid, _lib.LpGridList, _lib.LpRays, _lib.LpMarch, _lib.LpMlp,
+                                _lib.LpRendererArgs, _lib.LpSplatterArgs)):
+        assert L.lp_abi_sizeof(which) == ctypes.sizeof(st)
+    assert L.lp_abi_sizeof(99) == -1
+
+
+def _empty_renderer_args():
+    a = _lib.LpRendererArgs()
+    a.rays.n_rays = 0
+    a.grid = _lib.make_grid_list(None, [grids.GridDesc(1, 4, 4, 4, 0)], 16, 64)
+    a.march = _lib.make_march(8, 0, False, False, 1e-5)
+    a.trunk = _lib.make_mlp([16, 32, 32], 0)
+    a.opacity = _lib.make_mlp([32, 32, 1], params.mlp_numel([16, 32, 32]))
+    a.color = _lib.make_mlp([32, 32, 16], params.mlp_numel([16, 32, 32]) + params.mlp_numel([32, 32, 1]))
+    a.n_mlp_params = sum(params.mlp_numel(d) for d in ([16, 32, 32], [32, 32, 1], [32, 32, 16]))
+    a.mlp_params = 0x1000  # never dereferenced: n_rays == 0
+    a.color_chn = 3
+    a.rays.encoding_dim = 32
+    return a
+
+
+def test_c_abi_argument_validation_without_gpu():
+    L = _lib.lib()
+    a = _empty_renderer_args()
+    assert L.lp_renderer_forward(ctypes.byref(a), None) == 0  # zero rays: validated, nothing launched
+    a.march.num_samples = 0
+    assert L.lp_renderer_forward(ctypes.byref(a), None) == -1
+    assert b"num_samples" in L.lp_last_error()
+    a = _empty_renderer_args()
+    a.n_mlp_params += 1
+    assert L.lp_renderer_forward(ctypes.byref(a), None) == -1
+    assert b"number of elements in mlp param" in L.lp_last_error()
+    a = _empty_renderer_args()
+    a.grid.grids[0].W = 1
+    a.grid.grids[0].H = 1  # a "line" grid: neither voxel nor plane
+    assert L.lp_renderer_forward(ctypes.byref(a), None) == -1
+    a = _empty_renderer_args()
+    a.rays.encoding_dim = 7
+    assert L.lp_renderer_backward(ctypes.byref(a), None) == -1
+    assert L.lp_renderer_forward(None, None) == -3
+    with pytest.raises(AssertionError):
+        _lib.check(-1, "x")
+
+
+def test_cpu_tensors_fail_loudly():
+    from tests.synth import RENDERER_CASES
+    d = RENDERER_CASES[0].build()
+    with pytest.raises(_lib.LightplaneHipError, match="GPU only"):
+        lp.lightplane_renderer(d["rays"], d["grids"], d["decoder"], **d["cfg"])
+    with pytest.raises(NotImplementedError):
+        lp.LightplaneRenderer(8, 3, 16, 32, use_naive_impl=True)
+
+
+def test_rays_container():
+    n = 21
+    r = lp.Rays(torch.randn(n, 3), torch.randn(n, 3), torch.zeros(n, dtype=torch.long), torch.zeros(n),
+                torch.ones(n), torch.randn(n, 5))
+    p, n_pad = r.pad_to_block_size(16)
+    assert n_pad == 11 and p.directions.shape == (32, 3) and p.encoding.shape == (32, 5)
+    assert (p.far[n:] == 0).all()
+    assert r[3:7].n_rays == 4 and r.to("cpu") is r and r.to("cpu", copy=True) is not r
+    assert sum(r.shard(k, 4).n_rays for k in range(4)) == n
+    with pytest.raises(AssertionError):
+        lp.Rays(torch.randn(n, 3), torch.randn(n, 3), torch.zeros(n), torch.zeros(n), torch.ones(n))
+    with pytest.raises(AssertionError):
+        lp.Rays(torch.randn(n, 3), torch.randn(n + 1, 3), torch.zeros(n, dtype=torch.long), torch.zeros(n), torch.ones(n))
+    e = lp.calc_harmonic_embedding(torch.randn(4, 3), 3)
+    assert e.shape == (4, lp.calc_harmonic_embedding_dim(3)) == (4, 21)
+    d = torch.randn(2, 3)
+    e = lp.calc_harmonic_embedding(d, 2)
+    assert torch.allclose(e[:, :6].reshape(2, 3, 2), torch.sin(d[..., None] * torch.tensor([1.0, 2.0])))
+    assert torch.allclose(e[:, 6:12].reshape(2, 3, 2), torch.cos(d[..., None] * torch.tensor([1.0, 2.0])), atol=1e-6)
+    assert torch.equal(e[:, 12:], d)
+
+
+def test_param_layout_roundtrip():
+    dec = lp.init_decoder_params("cpu", n_layers_opacity=2, n_layers_trunk=3, n_layers_color=2, input_chn=16,
+                                 hidden_chn=32, color_chn=3, opacity_init_bias=-5.0)
+    assert dec.mlp_params.numel() == (16 * 32 + 32 * 32 * 2 + 32 * 3) + (32 * 32 + 32 + 32 + 1) + (32 * 32 + 32 * 16 + 32 + 16)
+    wt, bt, wo, bo, wc, bc = lp.flattened_decoder_params_to_list(
+        dec.mlp_params, dec.n_hidden_trunk, dec.n_hidden_opacity, dec.n_hidden_color)
+    assert [tuple(w.shape) for w in wt] == [(16, 32), (32, 32), (32, 32)]
+    assert tuple(wc[-1].shape) == (32, 16) and (wc[-1][:, 3:] == 0).all() and float(bo[-1]) == -5.0
+    flat, nt, no, nc = lp.flatten_decoder_params(wt, bt, wo, bo, wc, bc)
+    assert torch.equal(flat, dec.mlp_params) and nt.dtype == torch.int32
+    assert lp.get_triton_function_input_dims(nt, no, nc) == (32, 32, 32, 3, 2, 2, 16)
+    sp = lp.init_splatter_params("cpu", 3, 32, 64, 16)
+    assert sp.n_hidden.tolist() == [32, 64, 64, 16]
+    dec2 = lp.init_decoder_params("cpu", 2, 0, 2, input_chn=16, hidden_chn=32, use_separate_color_grid=True)
+    assert dec2.n_hidden_trunk.numel() == 0 and dec2.n_hidden_opacity.tolist() == [16, 32, 1]
+    with pytest.raises(AssertionError):
+        lp.init_decoder_params("cpu", 2, 2, 2, use_separate_color_grid=True)
+
+
+def test_grid_helpers():
+    gl = [torch.randn(2, 1, 5, 7, 4), torch.randn(2, 6, 1, 7, 4), torch.randn(2, 6, 5, 1, 4)]
+    flat, sizes = lp.flatten_grid(gl)
+    assert flat.shape == (2 * (35 + 42 + 30), 4) and sizes.tolist() == [list(g.shape) for g in gl]
+    back = lp.unflatten_grid(flat, sizes)
+    assert all(torch.equal(a, b) for a, b in zip(gl, back))
+    descs, C, rows = grids.make_grid_descs(sizes)
+    assert [d.row_offset for d in descs] == [0, 70, 154] and rows == 214 and C == 4
+    assert [d.kind for d in descs] == ["plane"] * 3
+    with pytest.raises(ValueError):
+        grids.make_grid_descs([[1, 1, 1, 8, 4]])
+    with pytest.raises(NotImplementedError):
+        grids.check_grid(tuple(gl))
+    with pytest.raises(AssertionError):
+        grids.check_grid(flat, None)
+    g, cg, gs, cgs = grids.process_and_flatten_grid(gl, None)
+    assert torch.equal(g, flat) and gs == sizes.tolist()
+
+
+def test_module_state_dict_keys_match_reference():
+    m = lp.LightplaneRenderer(num_samples=8, color_chn=3, grid_chn=16, mlp_hidden_chn=32, bg_color=1.0)
+    assert sorted(m.state_dict().keys()) == ["bg_color", "harmonic_ray_embedding_linear.bias",
+                                            "harmonic_ray_embedding_linear.weight", "mlp_params"]
+    assert m.harmonic_ray_embedding_linear.weight.shape == (32, 21)
+    with pytest.raises(ValueError):
+        lp.LightplaneRenderer(8, 3, 16, 32, enable_direction_dependent_colors=False)
+    m2 = lp.LightplaneRenderer(8, 3, 16, 32, enable_direction_dependent_colors=False, ray_embedding_num_harmonics=None)
+    assert not hasattr(m2, "harmonic_ray_embedding_linear")
+    s = lp.LightplaneSplatter(8, 32)
+    assert len(s.state_dict()) == 0 and s.get_splatter_params() is None
+
+
+def _gloo_worker(rank, world_size, port, ret):
+    import torch.distributed as dist
+    from lightplane_amd import parallel
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world_size)
+    try:
+        # Splatter semantics: sum un-normalised features AND weights, then normalise
+        feat = torch.full((6, 4), float(rank + 1))
+        wgt = torch.full((6,), float(rank + 1) * 0.5)
+        parallel.allreduce_sum_([feat, wgt, None])
+        assert torch.allclose(feat, torch.full((6, 4), 3.0)) and torch.allclose(wgt, torch.full((6,), 1.5))
+        # Renderer semantics: gradients of replicated inputs are summed over ray shards
+        w = torch.ones(5, requires_grad=True)
+        (wv,) = parallel.replicate_with_grad_allreduce([w])
+        n = 10
+        lo, hi = parallel.shard_bounds(n, rank, world_size)
+        x = torch.arange(n, dtype=torch.float32)[lo:hi]
+        (wv.sum() * x.sum()).backward()
+        assert torch.allclose(w.grad, torch.full((5,), float(sum(range(n)))))
+        ret[rank] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ray_shard_allreduce_logic_on_gloo():
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs) and len(ret) == 2
