@@ -68,7 +68,7 @@ def cpu_baseline(rays, grids, dec, n_sub=1024):
 
     idx = torch.arange(0, rays.n_rays, rays.n_rays // n_sub)[:n_sub]
     r = rays[idx]
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))  # more threads only thrash on this tiny problem
 
     def one():
         rr = copy.copy(r)

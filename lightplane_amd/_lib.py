@@ -17,6 +17,13 @@ from .grids import GridDesc
 LP_MAX_GRIDS = 8
 LP_MAX_LAYERS = 8
 LP_MAX_WIDTH = 128
+LP_NLT_CKPT = 32
+
+
+def n_nlt_ckpt(num_samples: int, num_samples_inf: int) -> int:
+    """Checkpoints of the running -log T per ray (see LP_NLT_CKPT in the header)."""
+    c = LP_NLT_CKPT
+    return (num_samples + c - 1) // c + num_samples_inf
 
 LP_KERNEL_AUTO, LP_KERNEL_GENERIC, LP_KERNEL_MFMA = 0, 1, 2
 
@@ -61,6 +68,7 @@ class LpRendererArgs(C.Structure):
         ("color_chn", C.c_int32), ("gain", C.c_float), ("noise_sigma", C.c_float),
         ("noise_seed", C.c_int32), ("kernel", C.c_int32), ("_pad", C.c_int32),
         ("ray_length", C.c_void_p), ("neg_log_t", C.c_void_p), ("feature", C.c_void_p),
+        ("neg_log_t_ckpt", C.c_void_p),
         ("grad_ray_length", C.c_void_p), ("grad_neg_log_t", C.c_void_p), ("grad_feature", C.c_void_p),
         ("grad_grid", C.c_void_p), ("grad_color_grid", C.c_void_p), ("grad_mlp_params", C.c_void_p),
         ("grad_encoding", C.c_void_p),

@@ -66,6 +66,20 @@ LP_DEV float sample_delta(int i, const LpMarch& m, float near_t, float far_t, fl
   return depth_i - sample_depth(i - 1, m, near_t, far_t);
 }
 
+// -log T checkpoints: index of the checkpoint taken right after sample i, or -1.
+LP_DEV int ckpt_index(int i, const LpMarch& m) {
+  if (i < m.num_samples) {
+    if ((i + 1) % LP_NLT_CKPT == 0 || i == m.num_samples - 1) return i / LP_NLT_CKPT;
+    return -1;
+  }
+  // beyond-far samples: interval lengths grow up to far/disparity_at_inf, so -log T can jump by
+  // orders of magnitude per sample -> checkpoint every one of them
+  return (m.num_samples + LP_NLT_CKPT - 1) / LP_NLT_CKPT + (i - m.num_samples);
+}
+LP_DEV int ckpt_count(const LpMarch& m) {
+  return (m.num_samples + LP_NLT_CKPT - 1) / LP_NLT_CKPT + m.num_samples_inf;
+}
+
 LP_DEV float contract_one(float p, float n) {
   const float a = fabsf(p);
   if (fabsf(a - n) <= 1e-7f) {

@@ -197,6 +197,7 @@ __global__ void __launch_bounds__(64) renderer_fwd_generic(const GenArgs ga) {
   const int s_tot = a.march.num_samples + a.march.num_samples_inf;
   const bool contract = a.march.contract_coords != 0;
   float nlt = 0.0f, t_prev = 1.0f, len = 0.0f, depth_prev = 0.0f;
+  const int n_ckpt = ckpt_count(a.march);
   const int craw = p.col[a.color.n_layers - 1];
   for (int s = 0; s < s_tot; ++s) {
     const float depth = sample_depth(s, a.march, ray.near_t, ray.far_t);
@@ -215,6 +216,10 @@ __global__ void __launch_bounds__(64) renderer_fwd_generic(const GenArgs ga) {
       raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
     const float opacity = a.gain * softplus_f(raw) * occ;
     nlt = nlt + opacity * delta;
+    if (a.neg_log_t_ckpt && valid) {
+      const int ck = ckpt_index(s, a.march);
+      if (ck >= 0) a.neg_log_t_ckpt[ray_id * n_ckpt + ck] = nlt;
+    }
     const float t = __expf(-nlt);
     const float w = t_prev - t;
     t_prev = t;
@@ -345,6 +350,7 @@ __global__ void __launch_bounds__(64) renderer_bwd_generic(const GenArgs ga) {
   const int craw = p.col[a.color.n_layers - 1];
 
   float nlt = a.neg_log_t[rid];  // -log T after the last sample
+  const int n_ckpt = ckpt_count(a.march);
   float suffix = 0.0f;           // sum_{i >= k} T_i (p_i - p_{i+1})
   float p_next = 0.0f;
   for (int s = s_tot - 1; s >= 0; --s) {
@@ -359,7 +365,12 @@ __global__ void __launch_bounds__(64) renderer_bwd_generic(const GenArgs ga) {
       raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
     const float sp = softplus_f(raw);
     const float opacity = a.gain * sp * occ;
-    // transmittance after (t_i) and before (t_im1) this sample
+    // transmittance after (t_i) and before (t_im1) this sample; re-anchor on the exact
+    // forward value wherever a checkpoint exists (bounds the subtractive drift)
+    if (a.neg_log_t_ckpt) {
+      const int ck = ckpt_index(s, a.march);
+      if (ck >= 0) nlt = a.neg_log_t_ckpt[rid * n_ckpt + ck];
+    }
     const float t_i = __expf(-nlt);
     nlt = fmaxf(nlt - opacity * delta, 0.0f);
     const float t_im1 = __expf(-nlt);

@@ -1,13 +1,679 @@
-// lp_renderer_mfma.hip -- MFMA Renderer kernels (placeholder until the kernels land).
+// lp_renderer_mfma.hip -- Renderer forward / backward on the CDNA4 matrix cores (gfx950).
+//
+// Shape family (anything else falls back to lp_renderer_generic.hip): single grid-list with
+// C in {16, 32} channels, trunk [C,32,32], opacity [32,32,1], colour [32,32,>=Cc] with Cc <= 4.
+// That covers every BASELINE.json configuration.
+//
+// Mapping.  One wave = 32 rays.  Lane l = (h = l>>5, r = l&31) works on ray r and on the
+// feature subset F_h = { feat(q,h) = (q&3) + 8*(q>>2) + 4*h : q = 0..15 } of every 32-wide
+// activation -- exactly the rows a lane receives from v_mfma_f32_32x32x2_f32 when the product
+// is formed TRANSPOSED:  Y^T[out, ray] = W^T[out, k] * X^T[k, ray].
+//   A operand (lane l)  = W[feat(kk,h)][l&31]            (weights, pre-permuted in LDS)
+//   B operand (lane l)  = X[ray l&31][feat(kk,h)]        (= accumulator register kk of the
+//                                                          previous layer: no data movement)
+//   D register q        = Y[ray l&31][feat(q,h)]
+// so the whole trunk -> heads chain (and the dX chain of the backward) runs register to
+// register; bias + ReLU are lane-local.  K-slot kk of an MFMA pairs feature feat(kk,0) (lanes
+// 0-31) with feat(kk,1) (lanes 32-63): the contraction order is a permutation of the feature
+// index, which a sum does not care about.  fp32 MFMA is bit-for-bit an fmaf chain, so the
+// numerics are plain fp32.  (Layout algebra checked in scripts/mfma_layout_check.py.)
+//
+// The 12 (triplane) / 8 (voxel) corner gathers of a ray are split between its two lanes by
+// 16-byte channel chunks (lane h loads channels 8j+4h .. 8j+4h+3): dwordx4 loads, features land
+// directly in B-operand order.
+//
+// Backward (far -> near, recompute): weight gradients dW = X^T dY contract over RAYS, i.e. over
+// lanes; X and dY are transposed through a per-wave padded LDS tile ([ray][33]) and fed to the
+// same MFMA (A = X[ray 2kk+h][l&31], B = dY[ray 2kk+h][l&31]); the 32x32 dW tiles stay in
+// accumulator registers for the whole kernel and are flushed once per wave.  Grid gradients are
+// transposed through LDS as well so that every global_atomic_add_f32 instruction covers whole
+// contiguous C-float rows (measured on MI355X: 336 Gadd/s vs 19.6 Gadd/s lane-per-row).
 #include "lp_device.h"
 #include "lp_host.h"
 
 namespace lp {
-bool renderer_mfma_supported(const LpRendererArgs& a, const char** why) {
-  (void)a;
-  *why = "MFMA kernels not built yet";
-  return false;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+LP_DEV constexpr int featq(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
+
+#define LP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// An integer the optimiser must treat as unknown (it is always 0).  Added to LDS offsets inside
+// the sample loop it stops LICM from hoisting the ~200 loop-invariant weight / bias reads out of
+// the loop (which costs >200 VGPRs and spills); the reads stay ds_read (LDS address space kept).
+LP_DEV int opaque_zero() {
+  int z = 0;
+  asm volatile("" : "+s"(z));
+  return z;
 }
-int renderer_forward_mfma(const LpRendererArgs&, hipStream_t) { return set_error(LP_EUNSUPPORTED, "no MFMA kernel"); }
-int renderer_backward_mfma(const LpRendererArgs&, hipStream_t) { return set_error(LP_EUNSUPPORTED, "no MFMA kernel"); }
+
+constexpr int HID = 32;        // hidden width of the shape family
+constexpr int TILE_LD = 33;    // padded row stride of the per-wave transposition tiles
+constexpr int WAVES = 4;       // waves per workgroup
+constexpr int RAYS_PER_WAVE = 32;
+
+// float offsets of the parameter blocks inside mlp_params (computed on the host)
+struct MfmaParams {
+  int64_t w_t1, w_t2, b_t1, b_t2;  // trunk
+  int64_t w_o1, w_o2, b_o1, b_o2;  // opacity
+  int64_t w_c1, w_c2, b_c1, b_c2;  // colour
+  int ldc2;                        // row stride of w_c2 (padded colour width)
+};
+
+// LDS map (floats).  Forward kernels use only the first part.
+template <int C>
+struct Lds {
+  static constexpr int K0 = C / 2;  // MFMAs of the first trunk layer
+  static constexpr int WT1F = 0;
+  static constexpr int WT2F = WT1F + K0 * 64;
+  static constexpr int WO1F = WT2F + 16 * 64;
+  static constexpr int WC1F = WO1F + 16 * 64;
+  static constexpr int BIAS = WC1F + 16 * 64;   // b_t1, b_t2, b_o1, b_c1 : 4 x 32
+  static constexpr int WO2 = BIAS + 4 * 32;     // [32]
+  static constexpr int WC2 = WO2 + 32;          // [32][4]
+  static constexpr int HB = WC2 + 32 * 4;       // bo2, bc2[0..3], pad -> 8
+  static constexpr int FWD_END = HB + 8;
+  static constexpr int WT1B = FWD_END;          // backward (dX) operand forms
+  static constexpr int WT2B = WT1B + 16 * 64;
+  static constexpr int WO1B = WT2B + 16 * 64;
+  static constexpr int WC1B = WO1B + 16 * 64;
+  static constexpr int WAVE0 = WC1B + 16 * 64;  // per-wave scratch starts here
+  // per-wave scratch: two transposition tiles; the scatter stage aliases them
+  static constexpr int TX = 0;
+  static constexpr int TY = 32 * TILE_LD;
+  static constexpr int PER_WAVE = 2 * 32 * TILE_LD;
+  static constexpr int BWD_END = WAVE0 + WAVES * PER_WAVE;
+};
+
+template <int C, bool BWD>
+LP_DEV void stage_weights(const LpRendererArgs& a, const MfmaParams& mp, float* lds) {
+  using M = Lds<C>;
+  const float* P = a.mlp_params;
+  const int tid = threadIdx.x;
+  // forward operand form: slot [kk][lane] = W[feat(kk, lane>>5)][lane&31]
+  for (int i = tid; i < M::K0 * 64; i += 256) {
+    const int kk = i >> 6, l = i & 63;
+    lds[M::WT1F + i] = P[mp.w_t1 + (int64_t)featq(kk, l >> 5) * HID + (l & 31)];
+  }
+  for (int i = tid; i < 16 * 64; i += 256) {
+    const int kk = i >> 6, l = i & 63;
+    const int64_t off = (int64_t)featq(kk, l >> 5) * HID + (l & 31);
+    lds[M::WT2F + i] = P[mp.w_t2 + off];
+    lds[M::WO1F + i] = P[mp.w_o1 + off];
+    lds[M::WC1F + i] = P[mp.w_c1 + off];
+    if (BWD) {
+      // backward operand form: slot [kk][lane] = W[lane&31][feat(kk, lane>>5)]
+      const int64_t offb = (int64_t)(l & 31) * HID + featq(kk, l >> 5);
+      lds[M::WT1B + i] = ((l & 31) < C) ? P[mp.w_t1 + offb] : 0.0f;
+      lds[M::WT2B + i] = P[mp.w_t2 + offb];
+      lds[M::WO1B + i] = P[mp.w_o1 + offb];
+      lds[M::WC1B + i] = P[mp.w_c1 + offb];
+    }
+  }
+  for (int i = tid; i < 32; i += 256) {
+    lds[M::BIAS + i] = P[mp.b_t1 + i];
+    lds[M::BIAS + 32 + i] = P[mp.b_t2 + i];
+    lds[M::BIAS + 64 + i] = P[mp.b_o1 + i];
+    lds[M::BIAS + 96 + i] = P[mp.b_c1 + i];
+    lds[M::WO2 + i] = P[mp.w_o2 + i];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      lds[M::WC2 + i * 4 + c] = (c < a.color_chn) ? P[mp.w_c2 + (int64_t)i * mp.ldc2 + c] : 0.0f;
+  }
+  if (tid == 0) {
+    lds[M::HB + 0] = P[mp.b_o2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lds[M::HB + 1 + c] = (c < a.color_chn) ? P[mp.b_c2 + c] : 0.0f;
+  }
+}
+
+// bias of layer `which` (0 t1, 1 t2, 2 o1, 3 c1) in accumulator-register order for half h
+template <int C>
+LP_DEV f32x16 load_bias(const float* lds, int which, int h, int zo) {
+  const float4* b = reinterpret_cast<const float4*>(lds + Lds<C>::BIAS + which * 32 + 4 * h + zo);
+  f32x16 acc;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 v = b[2 * j];  // floats 8j + 4h .. +3
+    acc[4 * j + 0] = v.x; acc[4 * j + 1] = v.y; acc[4 * j + 2] = v.z; acc[4 * j + 3] = v.w;
+  }
+  return acc;
+}
+
+// Interpolated grid-list feature of this lane's ray, channels feat(q,h), q < C/2.
+template <int C>
+LP_DEV void gather_features(const LpRendererArgs& a, const Ray& ray, float x, float y, float z, int h,
+                            float (&x0)[C / 2]) {
+#pragma unroll
+  for (int q = 0; q < C / 2; ++q) x0[q] = 0.0f;
+  if (a.march.mask_out_of_bounds && !point_in_bounds(x, y, z)) return;
+  for (int g = 0; g < a.grid.n_grids; ++g) {
+    const Corners cs = grid_corners<false>(a.grid.grids[g], ray.b, x, y, z);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < cs.n && cs.row[k] >= 0) {
+        const float w = cs.w[k];
+        const float4* src = reinterpret_cast<const float4*>(a.grid.data + cs.row[k] * C + 4 * h);
+#pragma unroll
+        for (int j = 0; j < C / 8; ++j) {
+          const float4 v = src[2 * j];  // channels 8j + 4h .. +3
+          x0[4 * j + 0] = fmaf(w, v.x, x0[4 * j + 0]);
+          x0[4 * j + 1] = fmaf(w, v.y, x0[4 * j + 1]);
+          x0[4 * j + 2] = fmaf(w, v.z, x0[4 * j + 2]);
+          x0[4 * j + 3] = fmaf(w, v.w, x0[4 * j + 3]);
+        }
+      }
+    }
+  }
+}
+
+// One 32->32 (or C->32) layer: acc (pre-loaded with the bias) += W^T-form MFMAs over `in`.
+template <int K>
+LP_DEV f32x16 layer(const float* wop, int lane, const float* in, f32x16 acc) {
+#pragma unroll
+  for (int kk = 0; kk < K; ++kk) acc = LP_MFMA(wop[kk * 64 + lane], in[kk], acc);
+  return acc;
+}
+
+struct Heads {
+  float raw_o;
+  float raw_c[4];
+};
+
+// opacity / colour output layers on the VALU (N = 1 and N <= 4): each lane covers its 16
+// features, the partner lane (l ^ 32) the other 16.
+template <int C>
+LP_DEV Heads heads_forward(const float* lds_, int h, const float (&ho)[16], const float (&hc)[16], int zo) {
+  using M = Lds<C>;
+  const float* lds = lds_ + zo;
+  float po = 0.0f, pc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 wo = *reinterpret_cast<const float4*>(lds + M::WO2 + 8 * j + 4 * h);
+    const float wov[4] = {wo.x, wo.y, wo.z, wo.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = 4 * j + i;
+      po = fmaf(ho[q], wov[i], po);
+      const float4 wc = *reinterpret_cast<const float4*>(lds + M::WC2 + (8 * j + 4 * h + i) * 4);
+      pc[0] = fmaf(hc[q], wc.x, pc[0]);
+      pc[1] = fmaf(hc[q], wc.y, pc[1]);
+      pc[2] = fmaf(hc[q], wc.z, pc[2]);
+      pc[3] = fmaf(hc[q], wc.w, pc[3]);
+    }
+  }
+  Heads o;
+  o.raw_o = (po + __shfl_xor(po, 32)) + lds[M::HB];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) o.raw_c[c] = (pc[c] + __shfl_xor(pc[c], 32)) + lds[M::HB + 1 + c];
+  return o;
+}
+
+// Everything the decoder produces for one sample (activations in accumulator-register order).
+template <int C>
+struct Act {
+  float x0[C / 2];
+  float h1[16], e[16], ho[16], hc[16];
+};
+
+template <int C>
+LP_DEV Heads decode(const LpRendererArgs& a, const float* lds, const Ray& ray, float x, float y, float z, int lane_,
+                    const float (&enc)[16], Act<C>& t, int zo) {
+  using M = Lds<C>;
+  const int h = lane_ >> 5;
+  const int lane = lane_ + zo;  // keeps the weight-operand reads inside the sample loop
+  gather_features<C>(a, ray, x, y, z, h, t.x0);
+  f32x16 acc = layer<C / 2>(lds + M::WT1F, lane, t.x0, load_bias<C>(lds, 0, h, zo));
+#pragma unroll
+  for (int q = 0; q < 16; ++q) t.h1[q] = fmaxf(acc[q], 0.0f);
+  acc = layer<16>(lds + M::WT2F, lane, t.h1, load_bias<C>(lds, 1, h, zo));
+#pragma unroll
+  for (int q = 0; q < 16; ++q) t.e[q] = fmaxf(acc[q], 0.0f);
+  acc = layer<16>(lds + M::WO1F, lane, t.e, load_bias<C>(lds, 2, h, zo));
+#pragma unroll
+  for (int q = 0; q < 16; ++q) t.ho[q] = fmaxf(acc[q], 0.0f);
+  float ein[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) ein[q] = t.e[q] + enc[q];
+  acc = layer<16>(lds + M::WC1F, lane, ein, load_bias<C>(lds, 3, h, zo));
+#pragma unroll
+  for (int q = 0; q < 16; ++q) t.hc[q] = fmaxf(acc[q], 0.0f);
+  return heads_forward<C>(lds, h, t.ho, t.hc, zo);
+}
+
+LP_DEV void load_encoding(const LpRendererArgs& a, int64_t rid, int h, float (&enc)[16]) {
+  const float4* src = reinterpret_cast<const float4*>(a.rays.encoding + rid * HID + 4 * h);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 v = src[2 * j];
+    enc[4 * j + 0] = v.x; enc[4 * j + 1] = v.y; enc[4 * j + 2] = v.z; enc[4 * j + 3] = v.w;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(256, 2) renderer_fwd_mfma(const LpRendererArgs a, const MfmaParams mp) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_weights<C, false>(a, mp, lds);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, r = lane & 31;
+  const int64_t ray_id = ((int64_t)blockIdx.x * WAVES + wave) * RAYS_PER_WAVE + r;
+  const bool valid = ray_id < a.rays.n_rays;
+  const int64_t rid = valid ? ray_id : 0;
+  const Ray ray = load_ray(a.rays, rid);
+  float enc[16];
+  load_encoding(a, rid, h, enc);
+  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
+  const bool contract = a.march.contract_coords != 0;
+  const int n_ckpt = ckpt_count(a.march);
+  float nlt = 0.0f, t_prev = 1.0f, len = 0.0f, depth_prev = 0.0f;
+  float facc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  Act<C> t;
+  for (int s = 0; s < s_tot; ++s) {
+    const float depth = sample_depth(s, a.march, ray.near_t, ray.far_t);
+    const float delta = (s == 0) ? sample_delta(0, a.march, ray.near_t, ray.far_t, depth) : depth - depth_prev;
+    depth_prev = depth;
+    float x, y, z;
+    sample_point(ray, depth, contract, x, y, z);
+    float occ = 1.0f;
+    if (a.scaffold) occ = scaffold_lookup(a.scaffold, a.scaffold_shape, ray.b, x, y, z);
+    const int zo = opaque_zero();
+    const Heads hd = decode<C>(a, lds, ray, x, y, z, lane, enc, t, zo);
+    float raw = hd.raw_o;
+    if (a.noise_sigma > 0.0f) raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
+    const float opacity = a.gain * softplus_f(raw) * occ;
+    nlt = nlt + opacity * delta;
+    if (a.neg_log_t_ckpt && valid && h == 0) {
+      const int ck = ckpt_index(s, a.march);
+      if (ck >= 0) a.neg_log_t_ckpt[ray_id * n_ckpt + ck] = nlt;
+    }
+    const float tr = __expf(-nlt);
+    const float w = t_prev - tr;
+    t_prev = tr;
+    len = fmaf(w, depth, len);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) facc[c] = fmaf(w, sigmoid_f(hd.raw_c[c]) * occ, facc[c]);
+  }
+  if (valid && h == 0) {
+    a.ray_length[ray_id] = len;
+    a.neg_log_t[ray_id] = nlt;
+    for (int c = 0; c < a.color_chn; ++c) a.feature[ray_id * a.color_chn + c] = facc[c];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------
+
+// write a 16-register activation (accumulator order) into a [ray][33] tile; `keep` = false zeroes it
+LP_DEV void tile_store16(float* tile, int r, int h, const float (&v)[16], bool keep) {
+#pragma unroll
+  for (int q = 0; q < 16; ++q) tile[r * TILE_LD + featq(q, h)] = keep ? v[q] : 0.0f;
+}
+
+// dW tile (accumulators) += X^T dY with X, dY read transposed from the tiles
+LP_DEV f32x16 dw_mfma(const float* tx, const float* ty, int lane, f32x16 acc) {
+  const int h = lane >> 5, j = lane & 31;
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) acc = LP_MFMA(tx[(2 * kk + h) * TILE_LD + j], ty[(2 * kk + h) * TILE_LD + j], acc);
+  return acc;
+}
+
+// column sums of a tile over this half's 16 rays (bias gradient partial)
+LP_DEV float tile_colsum(const float* ty, int lane) {
+  const int h = lane >> 5, j = lane & 31;
+  float s = 0.0f;
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) s += ty[(16 * h + rr) * TILE_LD + j];
+  return s;
+}
+
+// flush a 32x32 dW accumulator tile: register q of lane l = dW[feat(q,h)][l&31]
+LP_DEV void flush_dw(float* g, const f32x16& acc, int lane, int n_rows) {
+  const int h = lane >> 5, j = lane & 31;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = featq(q, h);
+    if (i < n_rows && acc[q] != 0.0f) atomic_add_f32(g + (int64_t)i * HID + j, acc[q]);
+  }
+}
+
+template <int C>
+__global__ void __launch_bounds__(256, 1) renderer_bwd_mfma(const LpRendererArgs a, const MfmaParams mp) {
+  using M = Lds<C>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_weights<C, true>(a, mp, lds);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, r = lane & 31;
+  float* tx = lds + M::WAVE0 + wave * M::PER_WAVE + M::TX;
+  float* ty = lds + M::WAVE0 + wave * M::PER_WAVE + M::TY;
+  for (int i = lane; i < M::PER_WAVE; i += 64) tx[i] = 0.0f;  // also zeroes the x0 tile's pad columns
+  __syncthreads();
+
+  const int64_t ray_id = ((int64_t)blockIdx.x * WAVES + wave) * RAYS_PER_WAVE + r;
+  const bool valid = ray_id < a.rays.n_rays;
+  const int64_t rid = valid ? ray_id : 0;
+  const Ray ray = load_ray(a.rays, rid);
+  float enc[16], denc[16];
+  load_encoding(a, rid, h, enc);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) denc[q] = 0.0f;
+  float gfeat[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    gfeat[c] = (valid && a.grad_feature && c < a.color_chn) ? a.grad_feature[rid * a.color_chn + c] : 0.0f;
+  const float g_len = (valid && a.grad_ray_length) ? a.grad_ray_length[rid] : 0.0f;
+  const float g_nlt = (valid && a.grad_neg_log_t) ? a.grad_neg_log_t[rid] : 0.0f;
+
+  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
+  const bool contract = a.march.contract_coords != 0;
+  const int n_ckpt = ckpt_count(a.march);
+  const bool want_params = a.grad_mlp_params != nullptr;
+
+  // weight-gradient accumulators (whole kernel): four 32x32 tiles + lane-local head partials
+  f32x16 dw_t1 = {0}, dw_t2 = {0}, dw_o1 = {0}, dw_c1 = {0};
+  float db_t1 = 0.0f, db_t2 = 0.0f, db_o1 = 0.0f, db_c1 = 0.0f;
+  float dwo2[16], dwc2[16][4];
+  float dbo2 = 0.0f, dbc2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    dwo2[q] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dwc2[q][c] = 0.0f;
+  }
+
+  float nlt = a.neg_log_t[rid];
+  float suffix = 0.0f, p_next = 0.0f;
+  Act<C> t;
+  for (int s = s_tot - 1; s >= 0; --s) {
+    const float depth = sample_depth(s, a.march, ray.near_t, ray.far_t);
+    const float delta = sample_delta(s, a.march, ray.near_t, ray.far_t, depth);
+    float x, y, z;
+    sample_point(ray, depth, contract, x, y, z);
+    float occ = 1.0f;
+    if (a.scaffold) occ = scaffold_lookup(a.scaffold, a.scaffold_shape, ray.b, x, y, z);
+    const int zo = opaque_zero();
+    const float* ldz = lds + zo;
+    const int lanez = lane + zo;
+    const Heads hd = decode<C>(a, lds, ray, x, y, z, lane, enc, t, zo);
+    float raw = hd.raw_o;
+    if (a.noise_sigma > 0.0f) raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
+    const float opacity = a.gain * softplus_f(raw) * occ;
+    if (a.neg_log_t_ckpt) {
+      const int ck = ckpt_index(s, a.march);
+      if (ck >= 0) nlt = a.neg_log_t_ckpt[rid * n_ckpt + ck];
+    }
+    const float t_i = __expf(-nlt);
+    nlt = fmaxf(nlt - opacity * delta, 0.0f);
+    const float t_im1 = __expf(-nlt);
+    const float w = t_im1 - t_i;
+    float sg[4];
+    float p_i = g_len * depth;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      sg[c] = sigmoid_f(hd.raw_c[c]);
+      p_i = fmaf(gfeat[c], sg[c] * occ, p_i);
+    }
+    suffix = fmaf(t_i, p_i - p_next, suffix);
+    p_next = p_i;
+    const float d_a = suffix + g_nlt;
+    const float dro = valid ? d_a * delta * a.gain * occ * d_softplus_f(raw) : 0.0f;
+    float drc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) drc[c] = valid ? w * gfeat[c] * occ * sg[c] * (1.0f - sg[c]) : 0.0f;
+
+    // ---- output layers of the heads (VALU): weight-grad partials + gradient w.r.t. ho / hc ----
+    float dho[16], dhc[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 wo = *reinterpret_cast<const float4*>(ldz + M::WO2 + 8 * j + 4 * h);
+      const float wov[4] = {wo.x, wo.y, wo.z, wo.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = 4 * j + i;
+        const float4 wc = *reinterpret_cast<const float4*>(ldz + M::WC2 + (8 * j + 4 * h + i) * 4);
+        dwo2[q] = fmaf(t.ho[q], dro, dwo2[q]);
+        dwc2[q][0] = fmaf(t.hc[q], drc[0], dwc2[q][0]);
+        dwc2[q][1] = fmaf(t.hc[q], drc[1], dwc2[q][1]);
+        dwc2[q][2] = fmaf(t.hc[q], drc[2], dwc2[q][2]);
+        dwc2[q][3] = fmaf(t.hc[q], drc[3], dwc2[q][3]);
+        dho[q] = (t.ho[q] > 0.0f) ? dro * wov[i] : 0.0f;
+        float v = drc[0] * wc.x;
+        v = fmaf(drc[1], wc.y, v);
+        v = fmaf(drc[2], wc.z, v);
+        v = fmaf(drc[3], wc.w, v);
+        dhc[q] = (t.hc[q] > 0.0f) ? v : 0.0f;
+      }
+    }
+    if (h == 0) {  // per-ray scalars: count each ray once
+      dbo2 += dro;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dbc2[c] += drc[c];
+    }
+
+    // ---- colour hidden layer: dW_c1 += (e+enc)^T dhc ; d(e+enc) = Wc1 dhc ----
+    float ein[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ein[q] = t.e[q] + enc[q];
+    if (want_params) {
+      tile_store16(tx, r, h, ein, true);
+      tile_store16(ty, r, h, dhc, true);
+      dw_c1 = dw_mfma(tx, ty, lane, dw_c1);
+      db_c1 += tile_colsum(ty, lane);
+    }
+    f32x16 acc = {0};
+    acc = layer<16>(lds + M::WC1B, lanez, dhc, acc);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) denc[q] += acc[q];
+    // ---- opacity hidden layer: dW_o1 += e^T dho ; de += Wo1 dho ----
+    if (want_params) {
+      tile_store16(tx, r, h, t.e, true);
+      tile_store16(ty, r, h, dho, true);
+      dw_o1 = dw_mfma(tx, ty, lane, dw_o1);
+      db_o1 += tile_colsum(ty, lane);
+    }
+    acc = layer<16>(lds + M::WO1B, lanez, dho, acc);
+    float de[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) de[q] = (t.e[q] > 0.0f) ? acc[q] : 0.0f;
+    // ---- trunk layer 2 ----
+    if (want_params) {
+      tile_store16(tx, r, h, t.h1, true);
+      tile_store16(ty, r, h, de, true);
+      dw_t2 = dw_mfma(tx, ty, lane, dw_t2);
+      db_t2 += tile_colsum(ty, lane);
+    }
+    acc = (f32x16){0};
+    acc = layer<16>(lds + M::WT2B, lanez, de, acc);
+    float dh1[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dh1[q] = (t.h1[q] > 0.0f) ? acc[q] : 0.0f;
+    // ---- trunk layer 1 ----
+    if (want_params) {
+      // x0 tile: only the first C columns carry data, the rest must read as zero
+#pragma unroll
+      for (int q = 0; q < 16; ++q) tx[r * TILE_LD + featq(q, h)] = (q < C / 2) ? t.x0[q < C / 2 ? q : 0] : 0.0f;
+      tile_store16(ty, r, h, dh1, true);
+      dw_t1 = dw_mfma(tx, ty, lane, dw_t1);
+      db_t1 += tile_colsum(ty, lane);
+    }
+    if (a.grad_grid) {
+      acc = (f32x16){0};
+      acc = layer<16>(lds + M::WT1B, lanez, dh1, acc);  // rows >= C are zero weights
+      // ---- grid gradient: transpose dx0 through LDS, then row-contiguous atomics ----
+      // tile A (tx): dx0 [ray][C] (stride TILE_LD); tile B (ty): per grid corner table
+#pragma unroll
+      for (int q = 0; q < C / 2; ++q) tx[r * TILE_LD + featq(q, h)] = acc[q];
+      const bool oob = a.march.mask_out_of_bounds && !point_in_bounds(x, y, z);
+      int* trow = reinterpret_cast<int*>(ty);        // [32][8] corner rows (relative to grid.data rows)
+      float* tw = ty + 32 * 8;                       // [32][8] corner weights
+      constexpr int LPR = C;                         // lanes per row
+      constexpr int RPI = 64 / LPR;                  // rows per instruction
+      const int sub = lane % LPR, grp = lane / LPR;
+      for (int g = 0; g < a.grid.n_grids; ++g) {
+        const Corners cs = grid_corners<false>(a.grid.grids[g], ray.b, x, y, z);
+        if (h == 0) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const bool ok = valid && !oob && k < cs.n && cs.row[k] >= 0;
+            trow[r * 8 + k] = ok ? (int)cs.row[k] : -1;
+            tw[r * 8 + k] = ok ? cs.w[k] : 0.0f;
+          }
+        }
+        const int kshift = (cs.n == 8) ? 3 : 2;  // wave-uniform: depends on the grid shape only
+        const int n_pairs = 32 << kshift;
+        for (int p0 = 0; p0 < n_pairs; p0 += RPI) {
+          const int p = p0 + grp;
+          const int rr = p >> kshift, k = p & ((1 << kshift) - 1);
+          const int row = trow[rr * 8 + k];
+          if (row >= 0) {
+            const float v = tw[rr * 8 + k] * tx[rr * TILE_LD + sub];
+            atomic_add_f32(a.grad_grid + (int64_t)row * C + sub, v);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue ----
+  if (valid && a.grad_encoding) {
+    float4* dst = reinterpret_cast<float4*>(a.grad_encoding + ray_id * HID + 4 * h);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[2 * j] = make_float4(denc[4 * j], denc[4 * j + 1], denc[4 * j + 2], denc[4 * j + 3]);
+  }
+  if (want_params) {
+    float* G = a.grad_mlp_params;
+    flush_dw(G + mp.w_t1, dw_t1, lane, C);
+    flush_dw(G + mp.w_t2, dw_t2, lane, HID);
+    flush_dw(G + mp.w_o1, dw_o1, lane, HID);
+    flush_dw(G + mp.w_c1, dw_c1, lane, HID);
+    // hidden-layer biases: lane j (both halves hold a partial over 16 rays each)
+    const int j = lane & 31;
+    atomic_add_f32(G + mp.b_t1 + j, db_t1);
+    atomic_add_f32(G + mp.b_t2 + j, db_t2);
+    atomic_add_f32(G + mp.b_o1 + j, db_o1);
+    atomic_add_f32(G + mp.b_c1 + j, db_c1);
+    // head output layers: reduce the lane-local partials over the 32 rays of each half
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float v = dwo2[q];
+      float c0 = dwc2[q][0], c1 = dwc2[q][1], c2 = dwc2[q][2], c3 = dwc2[q][3];
+#pragma unroll
+      for (int m = 16; m >= 1; m >>= 1) {
+        v += __shfl_xor(v, m);
+        c0 += __shfl_xor(c0, m);
+        c1 += __shfl_xor(c1, m);
+        c2 += __shfl_xor(c2, m);
+        c3 += __shfl_xor(c3, m);
+      }
+      if (r == 0) {
+        const int f = featq(q, h);
+        atomic_add_f32(G + mp.w_o2 + f, v);
+        const float cv[4] = {c0, c1, c2, c3};
+        for (int c = 0; c < a.color_chn; ++c) atomic_add_f32(G + mp.w_c2 + (int64_t)f * mp.ldc2 + c, cv[c]);
+      }
+    }
+    float v = dbo2, c0 = dbc2[0], c1 = dbc2[1], c2 = dbc2[2], c3 = dbc2[3];
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) {
+      v += __shfl_xor(v, m);
+      c0 += __shfl_xor(c0, m);
+      c1 += __shfl_xor(c1, m);
+      c2 += __shfl_xor(c2, m);
+      c3 += __shfl_xor(c3, m);
+    }
+    if (lane == 0) {
+      atomic_add_f32(G + mp.b_o2, v);
+      const float cv[4] = {c0, c1, c2, c3};
+      for (int c = 0; c < a.color_chn; ++c) atomic_add_f32(G + mp.b_c2 + c, cv[c]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+
+bool renderer_mfma_supported(const LpRendererArgs& a, const char** why) {
+  *why = "";
+  const int C = a.grid.channels;
+  if (a.color_grid.n_grids > 0) { *why = "separate colour grid"; return false; }
+  if (C != 16 && C != 32) { *why = "grid channels not 16 or 32"; return false; }
+  if (a.trunk.n_layers != 2 || a.opacity.n_layers != 2 || a.color.n_layers != 2) {
+    *why = "layer counts other than trunk 2 / opacity 2 / colour 2";
+    return false;
+  }
+  if (a.trunk.dims[1] != HID || a.trunk.dims[2] != HID || a.opacity.dims[1] != HID || a.color.dims[1] != HID) {
+    *why = "hidden width other than 32";
+    return false;
+  }
+  if (a.color_chn > 4) { *why = "more than 4 colour channels"; return false; }
+  if (a.grid.n_rows >= (int64_t)1 << 31) { *why = "grid-list has 2^31 rows or more"; return false; }
+  return true;
+}
+
+static MfmaParams make_params(const LpRendererArgs& a) {
+  MfmaParams p;
+  const int C = a.grid.channels;
+  p.w_t1 = a.trunk.offset;
+  p.w_t2 = p.w_t1 + (int64_t)C * HID;
+  p.b_t1 = p.w_t2 + HID * HID;
+  p.b_t2 = p.b_t1 + HID;
+  p.w_o1 = a.opacity.offset;
+  p.w_o2 = p.w_o1 + HID * HID;
+  p.b_o1 = p.w_o2 + HID;
+  p.b_o2 = p.b_o1 + HID;
+  p.ldc2 = a.color.dims[2];
+  p.w_c1 = a.color.offset;
+  p.w_c2 = p.w_c1 + HID * HID;
+  p.b_c1 = p.w_c2 + (int64_t)HID * p.ldc2;
+  p.b_c2 = p.b_c1 + HID;
+  return p;
+}
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+  const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  return LP_OK;
+}
+
+int renderer_forward_mfma(const LpRendererArgs& a, hipStream_t stream) {
+  const MfmaParams mp = make_params(a);
+  const unsigned blocks = (unsigned)((a.rays.n_rays + WAVES * RAYS_PER_WAVE - 1) / (WAVES * RAYS_PER_WAVE));
+  if (blocks == 0) return LP_OK;
+  int rc;
+  if (a.grid.channels == 16) {
+    const size_t lds = Lds<16>::FWD_END * sizeof(float);
+    if ((rc = set_lds(renderer_fwd_mfma<16>, lds))) return rc;
+    hipLaunchKernelGGL(renderer_fwd_mfma<16>, dim3(blocks), dim3(256), lds, stream, a, mp);
+  } else {
+    const size_t lds = Lds<32>::FWD_END * sizeof(float);
+    if ((rc = set_lds(renderer_fwd_mfma<32>, lds))) return rc;
+    hipLaunchKernelGGL(renderer_fwd_mfma<32>, dim3(blocks), dim3(256), lds, stream, a, mp);
+  }
+  return check_launch("renderer_fwd_mfma");
+}
+
+int renderer_backward_mfma(const LpRendererArgs& a, hipStream_t stream) {
+  const MfmaParams mp = make_params(a);
+  const unsigned blocks = (unsigned)((a.rays.n_rays + WAVES * RAYS_PER_WAVE - 1) / (WAVES * RAYS_PER_WAVE));
+  if (blocks == 0) return LP_OK;
+  int rc;
+  if (a.grid.channels == 16) {
+    const size_t lds = Lds<16>::BWD_END * sizeof(float);
+    if ((rc = set_lds(renderer_bwd_mfma<16>, lds))) return rc;
+    hipLaunchKernelGGL(renderer_bwd_mfma<16>, dim3(blocks), dim3(256), lds, stream, a, mp);
+  } else {
+    const size_t lds = Lds<32>::BWD_END * sizeof(float);
+    if ((rc = set_lds(renderer_bwd_mfma<32>, lds))) return rc;
+    hipLaunchKernelGGL(renderer_bwd_mfma<32>, dim3(blocks), dim3(256), lds, stream, a, mp);
+  }
+  return check_launch("renderer_bwd_mfma");
+}
+
 }  // namespace lp

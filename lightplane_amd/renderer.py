@@ -11,6 +11,8 @@ Differences that are deliberate:
 * no ray padding, no power-of-two / >=16 channel restriction -- the kernels mask tails;
 * grid sizes travel by value (no ``.item()`` sync); the ``grid_idx`` range check is the only
   device sync and can be switched off with ``lightplane_amd.config.check_inputs = False``;
+* besides the final ``-log T`` the forward saves it every 32 samples (``[N, ceil(S/32)]``,
+  still O(N)) so that the backward's far->near transmittance reconstruction cannot drift;
 * the post-backward ``isfinite`` asserts (:719-722) are opt-in
   (``lightplane_amd.config.check_finite_grads``);
 * ``triton_block_size`` / ``triton_num_warps`` / ``regenerate_code`` are accepted and ignored.
@@ -105,17 +107,21 @@ class LightplaneFunction(torch.autograd.Function):
         a = _fill_args(cfg, grid, color_grid, mlp_params, directions, origins, grid_idx, near, far, encoding,
                        scaffold)
         a.ray_length, a.neg_log_t, a.feature = _lib.ptr(ray_length), _lib.ptr(nlt), _lib.ptr(feature)
+        # running -log T every LP_NLT_CKPT samples: O(N) state that keeps the backward's
+        # transmittance reconstruction exact (the reference saves only the final value, :558-573)
+        ckpt = torch.empty(n, _lib.n_nlt_ckpt(cfg.num_samples, cfg.num_samples_inf), device=dev, dtype=torch.float32)
+        a.neg_log_t_ckpt = _lib.ptr(ckpt)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().lp_renderer_forward(ctypes.byref(a), stream), "lp_renderer_forward")
         # O(N) state only: the final -log T (the reference saves the same, :558-573)
-        ctx.save_for_backward(nlt, grid, mlp_params, encoding, color_grid, directions, origins, grid_idx, near,
-                              far, scaffold)
+        ctx.save_for_backward(nlt, ckpt, grid, mlp_params, encoding, color_grid, directions, origins, grid_idx,
+                              near, far, scaffold)
         ctx.cfg = cfg
         return ray_length, nlt, feature
 
     @staticmethod
     def backward(ctx, g_len, g_nlt, g_feat):
-        (nlt, grid, mlp_params, encoding, color_grid, directions, origins, grid_idx, near, far,
+        (nlt, ckpt, grid, mlp_params, encoding, color_grid, directions, origins, grid_idx, near, far,
          scaffold) = ctx.saved_tensors
         cfg: _RendererCfg = ctx.cfg
         dev = grid.device
@@ -124,6 +130,7 @@ class LightplaneFunction(torch.autograd.Function):
         a = _fill_args(cfg, grid, color_grid, mlp_params, directions, origins, grid_idx, near, far, encoding,
                        scaffold)
         a.neg_log_t = _lib.ptr(nlt)
+        a.neg_log_t_ckpt = _lib.ptr(ckpt)
         g_len = None if g_len is None else g_len.contiguous()
         g_nlt = None if g_nlt is None else g_nlt.contiguous()
         g_feat = None if g_feat is None else g_feat.contiguous()

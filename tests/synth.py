@@ -210,6 +210,8 @@ RENDERER_CASES = [
     RendererCase("single_sample", seed=10, num_samples=1, n_rays=5),
     RendererCase("one_ray_repeated", seed=11, one_ray=True, is_triplane=True, n_rays=33),
     RendererCase("color16", seed=12, color_chn=16, n_rays=8),
+    RendererCase("triplane_c32", seed=13, is_triplane=True, grid_base=(2, 6, 5, 4, 32), n_rays=40, num_samples_inf=2),
+    RendererCase("voxel_c32_color1", seed=14, grid_base=(1, 4, 5, 6, 32), color_chn=1, n_rays=70, num_samples=37),
 ]
 
 SPLATTER_CASES = [
