@@ -188,6 +188,69 @@ LP_DEV Corners grid_corners(const LpGrid& g, int b, float x, float y, float z) {
   return c;
 }
 
+// Slim variant used by the hot kernels: int32 rows (the host guarantees < 2^31 rows), planes
+// evaluate 4 taps on their two live axes only.  Arithmetic (and therefore every integer index
+// and weight) is identical to grid_corners().
+struct Taps {
+  int row[8];   // row inside the flat grid-list tensor, -1 = out of range
+  float w[8];   // interpolation weight, 0 where out of range
+  int n;        // 8 (voxel) or 4 (plane)
+};
+
+template <bool SPLAT>
+LP_DEV void axis_taps(float c, int size, int& i0, float (&w)[2], bool (&ok)[2]) {
+  const float t = unnormalize<SPLAT>(c, size);
+  const float f = floorf(t);
+  i0 = (int)fminf(fmaxf(f, -2.0f), (float)size);  // NaN -> -2: both taps invalid
+  w[1] = t - f;
+  w[0] = (f + 1.0f) - t;
+  ok[0] = (unsigned)i0 < (unsigned)size;
+  ok[1] = (unsigned)(i0 + 1) < (unsigned)size;
+}
+
+template <bool SPLAT>
+LP_DEV void grid_taps(const LpGrid& g, int b, float x, float y, float z, Taps& t) {
+  const int base = (int)g.row_offset + b * (g.D * g.H * g.W);
+  if (g.D > 1 && g.H > 1 && g.W > 1) {
+    int ix, iy, iz;
+    float wx[2], wy[2], wz[2];
+    bool okx[2], oky[2], okz[2];
+    axis_taps<SPLAT>(x, g.W, ix, wx, okx);
+    axis_taps<SPLAT>(y, g.H, iy, wy, oky);
+    axis_taps<SPLAT>(z, g.D, iz, wz, okz);
+    t.n = 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ux = k & 1, uy = (k >> 1) & 1, uz = (k >> 2) & 1;
+      const bool ok = okx[ux] && oky[uy] && okz[uz];
+      t.row[k] = ok ? base + ((iz + uz) * g.H + (iy + uy)) * g.W + (ix + ux) : -1;
+      t.w[k] = ok ? (wx[ux] * wy[uy]) * wz[uz] : 0.0f;
+    }
+  } else {
+    // plane: (u, v) = (x, y) | (x, z) | (y, z); row = iv * U + iu in all three cases
+    float cu, cv;
+    int U, V;
+    if (g.D == 1) { cu = x; cv = y; U = g.W; V = g.H; }
+    else if (g.H == 1) { cu = x; cv = z; U = g.W; V = g.D; }
+    else { cu = y; cv = z; U = g.H; V = g.D; }
+    int iu, iv;
+    float wu[2], wv[2];
+    bool oku[2], okv[2];
+    axis_taps<SPLAT>(cu, U, iu, wu, oku);
+    axis_taps<SPLAT>(cv, V, iv, wv, okv);
+    t.n = 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int uu = k & 1, uv = (k >> 1) & 1;
+      const bool ok = oku[uu] && okv[uv];
+      t.row[k] = ok ? base + (iv + uv) * U + (iu + uu) : -1;
+      t.w[k] = ok ? wu[uu] * wv[uv] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 4; k < 8; ++k) { t.row[k] = -1; t.w[k] = 0.0f; }
+  }
+}
+
 // nearest-neighbour scaffold lookup (round-half-even like F.grid_sample(mode="nearest")),
 // zero outside the grid, times the in-bounds mask (naive_renderer.py:484-499).
 LP_DEV float scaffold_lookup(const float* scaffold, const LpGrid& s, int b, float x, float y, float z) {

@@ -28,6 +28,8 @@
 // accumulator registers for the whole kernel and are flushed once per wave.  Grid gradients are
 // transposed through LDS as well so that every global_atomic_add_f32 instruction covers whole
 // contiguous C-float rows (measured on MI355X: 336 Gadd/s vs 19.6 Gadd/s lane-per-row).
+#include <stdlib.h>
+
 #include "lp_device.h"
 #include "lp_host.h"
 
@@ -61,28 +63,28 @@ struct MfmaParams {
   int ldc2;                        // row stride of w_c2 (padded colour width)
 };
 
-// LDS map (floats).  Forward kernels use only the first part.
+// LDS map (floats).  Weight matrices are kept ONCE, row-major [in][W_LD] with a padded row
+// stride of 33: the forward operand W[feat(kk,h)][l&31] walks a row (conflict-free), the
+// backward operand W[l&31][feat(kk,h)] walks a column with stride 33 (conflict-free as well).
+constexpr int W_LD = 33;
 template <int C>
 struct Lds {
-  static constexpr int K0 = C / 2;  // MFMAs of the first trunk layer
-  static constexpr int WT1F = 0;
-  static constexpr int WT2F = WT1F + K0 * 64;
-  static constexpr int WO1F = WT2F + 16 * 64;
-  static constexpr int WC1F = WO1F + 16 * 64;
-  static constexpr int BIAS = WC1F + 16 * 64;   // b_t1, b_t2, b_o1, b_c1 : 4 x 32
-  static constexpr int WO2 = BIAS + 4 * 32;     // [32]
-  static constexpr int WC2 = WO2 + 32;          // [32][4]
-  static constexpr int HB = WC2 + 32 * 4;       // bo2, bc2[0..3], pad -> 8
-  static constexpr int FWD_END = HB + 8;
-  static constexpr int WT1B = FWD_END;          // backward (dX) operand forms
-  static constexpr int WT2B = WT1B + 16 * 64;
-  static constexpr int WO1B = WT2B + 16 * 64;
-  static constexpr int WC1B = WO1B + 16 * 64;
-  static constexpr int WAVE0 = WC1B + 16 * 64;  // per-wave scratch starts here
-  // per-wave scratch: two transposition tiles; the scatter stage aliases them
-  static constexpr int TX = 0;
+  static constexpr int WT1 = 0;                  // [C][33]
+  static constexpr int WT2 = WT1 + 32 * W_LD;    // [32][33] (WT1 is sized for C = 32: rows >= C are zero)
+  static constexpr int WO1 = WT2 + 32 * W_LD;
+  static constexpr int WC1 = WO1 + 32 * W_LD;
+  static constexpr int BIAS = WC1 + 32 * W_LD;   // b_t1, b_t2, b_o1, b_c1 : 4 x 32
+  static constexpr int WO2 = BIAS + 4 * 32;      // [32]
+  static constexpr int WC2 = WO2 + 32;           // [32][4]
+  static constexpr int HB = WC2 + 32 * 4;        // bo2, bc2[0..3], pad -> 8
+  static constexpr int FWD_END = ((HB + 8 + 3) / 4) * 4;
+  // backward only: block-wide dW accumulators (ds_add_f32), then per-wave scratch
+  static constexpr int DW = FWD_END;             // 4 x [32][32]: t1, t2, o1, c1
+  static constexpr int WAVE0 = DW + 4 * 1024;
+  static constexpr int TX = 0;                   // per-wave: two transposition tiles [32][33] ...
   static constexpr int TY = 32 * TILE_LD;
-  static constexpr int PER_WAVE = 2 * 32 * TILE_LD;
+  static constexpr int TS = 2 * 32 * TILE_LD;    // ... + [32 rays][8]: dro, drc[0..3] of the current sample
+  static constexpr int PER_WAVE = 2 * 32 * TILE_LD + 32 * 8;
   static constexpr int BWD_END = WAVE0 + WAVES * PER_WAVE;
 };
 
@@ -91,24 +93,18 @@ LP_DEV void stage_weights(const LpRendererArgs& a, const MfmaParams& mp, float* 
   using M = Lds<C>;
   const float* P = a.mlp_params;
   const int tid = threadIdx.x;
-  // forward operand form: slot [kk][lane] = W[feat(kk, lane>>5)][lane&31]
-  for (int i = tid; i < M::K0 * 64; i += 256) {
-    const int kk = i >> 6, l = i & 63;
-    lds[M::WT1F + i] = P[mp.w_t1 + (int64_t)featq(kk, l >> 5) * HID + (l & 31)];
-  }
-  for (int i = tid; i < 16 * 64; i += 256) {
-    const int kk = i >> 6, l = i & 63;
-    const int64_t off = (int64_t)featq(kk, l >> 5) * HID + (l & 31);
-    lds[M::WT2F + i] = P[mp.w_t2 + off];
-    lds[M::WO1F + i] = P[mp.w_o1 + off];
-    lds[M::WC1F + i] = P[mp.w_c1 + off];
+  for (int i = tid; i < 32 * 32; i += 256) {
+    const int row = i >> 5, col = i & 31;
+    const int d = row * W_LD + col;
+    lds[M::WT1 + d] = (row < C) ? P[mp.w_t1 + i] : 0.0f;
+    lds[M::WT2 + d] = P[mp.w_t2 + i];
+    lds[M::WO1 + d] = P[mp.w_o1 + i];
+    lds[M::WC1 + d] = P[mp.w_c1 + i];
     if (BWD) {
-      // backward operand form: slot [kk][lane] = W[lane&31][feat(kk, lane>>5)]
-      const int64_t offb = (int64_t)(l & 31) * HID + featq(kk, l >> 5);
-      lds[M::WT1B + i] = ((l & 31) < C) ? P[mp.w_t1 + offb] : 0.0f;
-      lds[M::WT2B + i] = P[mp.w_t2 + offb];
-      lds[M::WO1B + i] = P[mp.w_o1 + offb];
-      lds[M::WC1B + i] = P[mp.w_c1 + offb];
+      lds[M::DW + i] = 0.0f;
+      lds[M::DW + 1024 + i] = 0.0f;
+      lds[M::DW + 2048 + i] = 0.0f;
+      lds[M::DW + 3072 + i] = 0.0f;
     }
   }
   for (int i = tid; i < 32; i += 256) {
@@ -143,36 +139,50 @@ LP_DEV f32x16 load_bias(const float* lds, int which, int h, int zo) {
 
 // Interpolated grid-list feature of this lane's ray, channels feat(q,h), q < C/2.
 template <int C>
+LP_DEV void gather_tap(const float* data, int row, float w, int h, float (&x0)[C / 2]) {
+  if (row >= 0) {
+    const float4* src = reinterpret_cast<const float4*>(data + (int64_t)row * C + 4 * h);
+#pragma unroll
+    for (int j = 0; j < C / 8; ++j) {
+      const float4 v = src[2 * j];  // channels 8j + 4h .. +3
+      x0[4 * j + 0] = fmaf(w, v.x, x0[4 * j + 0]);
+      x0[4 * j + 1] = fmaf(w, v.y, x0[4 * j + 1]);
+      x0[4 * j + 2] = fmaf(w, v.z, x0[4 * j + 2]);
+      x0[4 * j + 3] = fmaf(w, v.w, x0[4 * j + 3]);
+    }
+  }
+}
+
+template <int C>
 LP_DEV void gather_features(const LpRendererArgs& a, const Ray& ray, float x, float y, float z, int h,
                             float (&x0)[C / 2]) {
 #pragma unroll
   for (int q = 0; q < C / 2; ++q) x0[q] = 0.0f;
   if (a.march.mask_out_of_bounds && !point_in_bounds(x, y, z)) return;
   for (int g = 0; g < a.grid.n_grids; ++g) {
-    const Corners cs = grid_corners<false>(a.grid.grids[g], ray.b, x, y, z);
+    Taps t;
+    grid_taps<false>(a.grid.grids[g], ray.b, x, y, z, t);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (k < cs.n && cs.row[k] >= 0) {
-        const float w = cs.w[k];
-        const float4* src = reinterpret_cast<const float4*>(a.grid.data + cs.row[k] * C + 4 * h);
+    for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k], h, x0);
+    if (t.n == 8) {
 #pragma unroll
-        for (int j = 0; j < C / 8; ++j) {
-          const float4 v = src[2 * j];  // channels 8j + 4h .. +3
-          x0[4 * j + 0] = fmaf(w, v.x, x0[4 * j + 0]);
-          x0[4 * j + 1] = fmaf(w, v.y, x0[4 * j + 1]);
-          x0[4 * j + 2] = fmaf(w, v.z, x0[4 * j + 2]);
-          x0[4 * j + 3] = fmaf(w, v.w, x0[4 * j + 3]);
-        }
-      }
+      for (int k = 4; k < 8; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k], h, x0);
     }
   }
 }
 
-// One 32->32 (or C->32) layer: acc (pre-loaded with the bias) += W^T-form MFMAs over `in`.
+// One layer, forward form: acc (pre-loaded with the bias) += sum_kk A(kk) * in[kk] with
+// A(kk) = W[feat(kk,h)][l&31].  `w` already points at W + (4h)*W_LD + (l&31) (+ opaque zero).
 template <int K>
-LP_DEV f32x16 layer(const float* wop, int lane, const float* in, f32x16 acc) {
+LP_DEV f32x16 layer(const float* w, const float* in, f32x16 acc) {
 #pragma unroll
-  for (int kk = 0; kk < K; ++kk) acc = LP_MFMA(wop[kk * 64 + lane], in[kk], acc);
+  for (int kk = 0; kk < K; ++kk) acc = LP_MFMA(w[featq(kk, 0) * W_LD], in[kk], acc);
+  return acc;
+}
+// Backward (dX) form: A(kk) = W[l&31][feat(kk,h)].  `w` points at W + (l&31)*W_LD + 4h.
+LP_DEV f32x16 layer_t(const float* w, const float* in, f32x16 acc) {
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) acc = LP_MFMA(w[featq(kk, 0)], in[kk], acc);
   return acc;
 }
 
@@ -222,21 +232,22 @@ LP_DEV Heads decode(const LpRendererArgs& a, const float* lds, const Ray& ray, f
                     const float (&enc)[16], Act<C>& t, int zo) {
   using M = Lds<C>;
   const int h = lane_ >> 5;
-  const int lane = lane_ + zo;  // keeps the weight-operand reads inside the sample loop
+  // operand base of this lane; `zo` (always 0) keeps the weight reads inside the sample loop
+  const float* wl = lds + (4 * h) * W_LD + (lane_ & 31) + zo;
   gather_features<C>(a, ray, x, y, z, h, t.x0);
-  f32x16 acc = layer<C / 2>(lds + M::WT1F, lane, t.x0, load_bias<C>(lds, 0, h, zo));
+  f32x16 acc = layer<C / 2>(wl + M::WT1, t.x0, load_bias<C>(lds, 0, h, zo));
 #pragma unroll
   for (int q = 0; q < 16; ++q) t.h1[q] = fmaxf(acc[q], 0.0f);
-  acc = layer<16>(lds + M::WT2F, lane, t.h1, load_bias<C>(lds, 1, h, zo));
+  acc = layer<16>(wl + M::WT2, t.h1, load_bias<C>(lds, 1, h, zo));
 #pragma unroll
   for (int q = 0; q < 16; ++q) t.e[q] = fmaxf(acc[q], 0.0f);
-  acc = layer<16>(lds + M::WO1F, lane, t.e, load_bias<C>(lds, 2, h, zo));
+  acc = layer<16>(wl + M::WO1, t.e, load_bias<C>(lds, 2, h, zo));
 #pragma unroll
   for (int q = 0; q < 16; ++q) t.ho[q] = fmaxf(acc[q], 0.0f);
   float ein[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) ein[q] = t.e[q] + enc[q];
-  acc = layer<16>(lds + M::WC1F, lane, ein, load_bias<C>(lds, 3, h, zo));
+  acc = layer<16>(wl + M::WC1, ein, load_bias<C>(lds, 3, h, zo));
 #pragma unroll
   for (int q = 0; q < 16; ++q) t.hc[q] = fmaxf(acc[q], 0.0f);
   return heads_forward<C>(lds, h, t.ho, t.hc, zo);
@@ -315,7 +326,10 @@ LP_DEV void tile_store16(float* tile, int r, int h, const float (&v)[16], bool k
   for (int q = 0; q < 16; ++q) tile[r * TILE_LD + featq(q, h)] = keep ? v[q] : 0.0f;
 }
 
-// dW tile (accumulators) += X^T dY with X, dY read transposed from the tiles
+// dW tile (16 accumulator registers, kept for the whole kernel) += X^T dY with X, dY read
+// transposed from the tiles.  Register q of lane l is dW[feat(q,h)][l&31].
+// (ds_add_f32 into a block-shared LDS copy was measured 8x slower than the whole rest of the
+// kernel: LDS float atomics retire ~0.3 lane-adds per clock per CU on gfx950.)
 LP_DEV f32x16 dw_mfma(const float* tx, const float* ty, int lane, f32x16 acc) {
   const int h = lane >> 5, j = lane & 31;
 #pragma unroll
@@ -327,23 +341,13 @@ LP_DEV f32x16 dw_mfma(const float* tx, const float* ty, int lane, f32x16 acc) {
 LP_DEV float tile_colsum(const float* ty, int lane) {
   const int h = lane >> 5, j = lane & 31;
   float s = 0.0f;
-#pragma unroll
+#pragma unroll 4
   for (int rr = 0; rr < 16; ++rr) s += ty[(16 * h + rr) * TILE_LD + j];
   return s;
 }
 
-// flush a 32x32 dW accumulator tile: register q of lane l = dW[feat(q,h)][l&31]
-LP_DEV void flush_dw(float* g, const f32x16& acc, int lane, int n_rows) {
-  const int h = lane >> 5, j = lane & 31;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int i = featq(q, h);
-    if (i < n_rows && acc[q] != 0.0f) atomic_add_f32(g + (int64_t)i * HID + j, acc[q]);
-  }
-}
-
-template <int C>
-__global__ void __launch_bounds__(256, 1) renderer_bwd_mfma(const LpRendererArgs a, const MfmaParams mp) {
+template <int C, int OCC>
+__global__ void __launch_bounds__(256, OCC) renderer_bwd_mfma(const LpRendererArgs a, const MfmaParams mp) {
   using M = Lds<C>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_weights<C, true>(a, mp, lds);
@@ -374,17 +378,13 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma(const LpRendererArgs
   const int n_ckpt = ckpt_count(a.march);
   const bool want_params = a.grad_mlp_params != nullptr;
 
-  // weight-gradient accumulators (whole kernel): four 32x32 tiles + lane-local head partials
+  // weight-gradient accumulators (whole kernel): four 32x32 MFMA tiles + small head partials
   f32x16 dw_t1 = {0}, dw_t2 = {0}, dw_o1 = {0}, dw_c1 = {0};
   float db_t1 = 0.0f, db_t2 = 0.0f, db_o1 = 0.0f, db_c1 = 0.0f;
-  float dwo2[16], dwc2[16][4];
+  // output layers of the heads: lane (f = l&31, half h) owns feature f, partial over 16 rays
+  float dwo2 = 0.0f, dwc2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   float dbo2 = 0.0f, dbc2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    dwo2[q] = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) dwc2[q][c] = 0.0f;
-  }
+  float* ts = lds + M::WAVE0 + wave * M::PER_WAVE + M::TS;
 
   float nlt = a.neg_log_t[rid];
   float suffix = 0.0f, p_next = 0.0f;
@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma(const LpRendererArgs
     if (a.scaffold) occ = scaffold_lookup(a.scaffold, a.scaffold_shape, ray.b, x, y, z);
     const int zo = opaque_zero();
     const float* ldz = lds + zo;
-    const int lanez = lane + zo;
+    const float* wt = lds + r * W_LD + 4 * h + zo;  // dX operand base of this lane
     const Heads hd = decode<C>(a, lds, ray, x, y, z, lane, enc, t, zo);
     float raw = hd.raw_o;
     if (a.noise_sigma > 0.0f) raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
@@ -436,11 +436,6 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma(const LpRendererArgs
       for (int i = 0; i < 4; ++i) {
         const int q = 4 * j + i;
         const float4 wc = *reinterpret_cast<const float4*>(ldz + M::WC2 + (8 * j + 4 * h + i) * 4);
-        dwo2[q] = fmaf(t.ho[q], dro, dwo2[q]);
-        dwc2[q][0] = fmaf(t.hc[q], drc[0], dwc2[q][0]);
-        dwc2[q][1] = fmaf(t.hc[q], drc[1], dwc2[q][1]);
-        dwc2[q][2] = fmaf(t.hc[q], drc[2], dwc2[q][2]);
-        dwc2[q][3] = fmaf(t.hc[q], drc[3], dwc2[q][3]);
         dho[q] = (t.ho[q] > 0.0f) ? dro * wov[i] : 0.0f;
         float v = drc[0] * wc.x;
         v = fmaf(drc[1], wc.y, v);
@@ -454,6 +449,28 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma(const LpRendererArgs
 #pragma unroll
       for (int c = 0; c < 4; ++c) dbc2[c] += drc[c];
     }
+    if (want_params) {
+      // weight gradients of the two output layers: dW[f] += sum_ray h[ray][f] * d_raw[ray].
+      // ho / hc go through the transposition tiles, the per-ray scalars through `ts`.
+      tile_store16(tx, r, h, t.ho, true);
+      tile_store16(ty, r, h, t.hc, true);
+      if (h == 0) {
+        *reinterpret_cast<float4*>(ts + r * 8) = make_float4(drc[0], drc[1], drc[2], drc[3]);
+        ts[r * 8 + 4] = dro;
+      }
+      const int f = lane & 31;
+#pragma unroll 2
+      for (int rr = 0; rr < 16; ++rr) {
+        const int ry = 16 * h + rr;
+        const float hov = tx[ry * TILE_LD + f], hcv = ty[ry * TILE_LD + f];
+        const float4 dc = *reinterpret_cast<const float4*>(ts + ry * 8);
+        dwo2 = fmaf(hov, ts[ry * 8 + 4], dwo2);
+        dwc2[0] = fmaf(hcv, dc.x, dwc2[0]);
+        dwc2[1] = fmaf(hcv, dc.y, dwc2[1]);
+        dwc2[2] = fmaf(hcv, dc.z, dwc2[2]);
+        dwc2[3] = fmaf(hcv, dc.w, dwc2[3]);
+      }
+    }
 
     // ---- colour hidden layer: dW_c1 += (e+enc)^T dhc ; d(e+enc) = Wc1 dhc ----
     float ein[16];
@@ -466,7 +483,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma(const LpRendererArgs
       db_c1 += tile_colsum(ty, lane);
     }
     f32x16 acc = {0};
-    acc = layer<16>(lds + M::WC1B, lanez, dhc, acc);
+    acc = layer_t(wt + M::WC1, dhc, acc);
 #pragma unroll
     for (int q = 0; q < 16; ++q) denc[q] += acc[q];
     // ---- opacity hidden layer: dW_o1 += e^T dho ; de += Wo1 dho ----
@@ -476,7 +493,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma(const LpRendererArgs
       dw_o1 = dw_mfma(tx, ty, lane, dw_o1);
       db_o1 += tile_colsum(ty, lane);
     }
-    acc = layer<16>(lds + M::WO1B, lanez, dho, acc);
+    acc = layer_t(wt + M::WO1, dho, acc);
     float de[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) de[q] = (t.e[q] > 0.0f) ? acc[q] : 0.0f;
@@ -488,7 +505,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma(const LpRendererArgs
       db_t2 += tile_colsum(ty, lane);
     }
     acc = (f32x16){0};
-    acc = layer<16>(lds + M::WT2B, lanez, de, acc);
+    acc = layer_t(wt + M::WT2, de, acc);
     float dh1[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) dh1[q] = (t.h1[q] > 0.0f) ? acc[q] : 0.0f;
@@ -503,37 +520,44 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma(const LpRendererArgs
     }
     if (a.grad_grid) {
       acc = (f32x16){0};
-      acc = layer<16>(lds + M::WT1B, lanez, dh1, acc);  // rows >= C are zero weights
+      acc = layer_t(wt + M::WT1, dh1, acc);  // rows >= C are zero weights
       // ---- grid gradient: transpose dx0 through LDS, then row-contiguous atomics ----
       // tile A (tx): dx0 [ray][C] (stride TILE_LD); tile B (ty): per grid corner table
 #pragma unroll
       for (int q = 0; q < C / 2; ++q) tx[r * TILE_LD + featq(q, h)] = acc[q];
       const bool oob = a.march.mask_out_of_bounds && !point_in_bounds(x, y, z);
-      int* trow = reinterpret_cast<int*>(ty);        // [32][8] corner rows (relative to grid.data rows)
-      float* tw = ty + 32 * 8;                       // [32][8] corner weights
-      constexpr int LPR = C;                         // lanes per row
-      constexpr int RPI = 64 / LPR;                  // rows per instruction
-      const int sub = lane % LPR, grp = lane / LPR;
+      float2* tab = reinterpret_cast<float2*>(ty);  // [32 rays][8 taps] {row bits, weight}
+      constexpr int GRPS = 64 / C;                  // rows (= taps) handled per instruction
+      const int sub = lane % C, grp = lane / C;
       for (int g = 0; g < a.grid.n_grids; ++g) {
-        const Corners cs = grid_corners<false>(a.grid.grids[g], ray.b, x, y, z);
+        Taps tp;
+        grid_taps<false>(a.grid.grids[g], ray.b, x, y, z, tp);
         if (h == 0) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            const bool ok = valid && !oob && k < cs.n && cs.row[k] >= 0;
-            trow[r * 8 + k] = ok ? (int)cs.row[k] : -1;
-            tw[r * 8 + k] = ok ? cs.w[k] : 0.0f;
+            const bool ok = valid && !oob && tp.row[k] >= 0;
+            tab[r * 8 + k] = make_float2(__int_as_float(ok ? tp.row[k] : -1), ok ? tp.w[k] : 0.0f);
           }
         }
-        const int kshift = (cs.n == 8) ? 3 : 2;  // wave-uniform: depends on the grid shape only
-        const int n_pairs = 32 << kshift;
-        for (int p0 = 0; p0 < n_pairs; p0 += RPI) {
-          const int p = p0 + grp;
-          const int rr = p >> kshift, k = p & ((1 << kshift) - 1);
-          const int row = trow[rr * 8 + k];
-          if (row >= 0) {
-            const float v = tw[rr * 8 + k] * tx[rr * TILE_LD + sub];
-            atomic_add_f32(a.grad_grid + (int64_t)row * C + sub, v);
+        // Tap slot k of all 32 rays is walked in ray order by one group of C lanes (lane = channel).
+        // Neighbouring rays mostly fall into the same cell: contributions to the same row are
+        // summed in a register and leave as ONE row-contiguous atomic per run (run-length merge).
+        for (int k0 = 0; k0 < tp.n; k0 += GRPS) {
+          const int k = k0 + grp;
+          int cur = -1;
+          float run = 0.0f;
+#pragma unroll 4
+          for (int rr = 0; rr < 32; ++rr) {
+            const float2 e = tab[rr * 8 + k];
+            const int row = __float_as_int(e.x);
+            if (row != cur) {
+              if (cur >= 0) atomic_add_f32(a.grad_grid + (int64_t)cur * C + sub, run);
+              cur = row;
+              run = 0.0f;
+            }
+            run = fmaf(e.y, tx[rr * TILE_LD + sub], run);
           }
+          if (cur >= 0) atomic_add_f32(a.grad_grid + (int64_t)cur * C + sub, run);
         }
       }
     }
@@ -547,36 +571,15 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma(const LpRendererArgs
   }
   if (want_params) {
     float* G = a.grad_mlp_params;
-    flush_dw(G + mp.w_t1, dw_t1, lane, C);
-    flush_dw(G + mp.w_t2, dw_t2, lane, HID);
-    flush_dw(G + mp.w_o1, dw_o1, lane, HID);
-    flush_dw(G + mp.w_c1, dw_c1, lane, HID);
     // hidden-layer biases: lane j (both halves hold a partial over 16 rays each)
     const int j = lane & 31;
     atomic_add_f32(G + mp.b_t1 + j, db_t1);
     atomic_add_f32(G + mp.b_t2 + j, db_t2);
     atomic_add_f32(G + mp.b_o1 + j, db_o1);
     atomic_add_f32(G + mp.b_c1 + j, db_c1);
-    // head output layers: reduce the lane-local partials over the 32 rays of each half
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      float v = dwo2[q];
-      float c0 = dwc2[q][0], c1 = dwc2[q][1], c2 = dwc2[q][2], c3 = dwc2[q][3];
-#pragma unroll
-      for (int m = 16; m >= 1; m >>= 1) {
-        v += __shfl_xor(v, m);
-        c0 += __shfl_xor(c0, m);
-        c1 += __shfl_xor(c1, m);
-        c2 += __shfl_xor(c2, m);
-        c3 += __shfl_xor(c3, m);
-      }
-      if (r == 0) {
-        const int f = featq(q, h);
-        atomic_add_f32(G + mp.w_o2 + f, v);
-        const float cv[4] = {c0, c1, c2, c3};
-        for (int c = 0; c < a.color_chn; ++c) atomic_add_f32(G + mp.w_c2 + (int64_t)f * mp.ldc2 + c, cv[c]);
-      }
-    }
+    // head output layers: lane (f, h) holds the partial over the 16 rays of its half
+    atomic_add_f32(G + mp.w_o2 + j, dwo2);
+    for (int c = 0; c < a.color_chn; ++c) atomic_add_f32(G + mp.w_c2 + (int64_t)j * mp.ldc2 + c, dwc2[c]);
     float v = dbo2, c0 = dbc2[0], c1 = dbc2[1], c2 = dbc2[2], c3 = dbc2[3];
 #pragma unroll
     for (int m = 16; m >= 1; m >>= 1) {
@@ -590,6 +593,29 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma(const LpRendererArgs
       atomic_add_f32(G + mp.b_o2, v);
       const float cv[4] = {c0, c1, c2, c3};
       for (int c = 0; c < a.color_chn; ++c) atomic_add_f32(G + mp.b_c2 + c, cv[c]);
+    }
+  }
+  // the four 32x32 tiles: summed over the waves of the block in LDS (once per kernel), then one
+  // global flush per block
+  if (want_params) {
+    const int j = lane & 31;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int o = featq(q, h) * 32 + j;
+      atomicAdd(lds + M::DW + o, dw_t1[q]);
+      atomicAdd(lds + M::DW + 1024 + o, dw_t2[q]);
+      atomicAdd(lds + M::DW + 2048 + o, dw_o1[q]);
+      atomicAdd(lds + M::DW + 3072 + o, dw_c1[q]);
+    }
+  }
+  __syncthreads();
+  if (want_params) {
+    float* G = a.grad_mlp_params;
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+      if (i < C * 32) atomic_add_f32(G + mp.w_t1 + i, lds[M::DW + i]);
+      atomic_add_f32(G + mp.w_t2 + i, lds[M::DW + 1024 + i]);
+      atomic_add_f32(G + mp.w_o1 + i, lds[M::DW + 2048 + i]);
+      atomic_add_f32(G + mp.w_c1 + i, lds[M::DW + 3072 + i]);
     }
   }
 }
@@ -659,20 +685,30 @@ int renderer_forward_mfma(const LpRendererArgs& a, hipStream_t stream) {
   return check_launch("renderer_fwd_mfma");
 }
 
+template <int C, int OCC>
+static int launch_bwd(const LpRendererArgs& a, const MfmaParams& mp, unsigned blocks, hipStream_t stream) {
+  const size_t lds = Lds<C>::BWD_END * sizeof(float);
+  int rc;
+  if ((rc = set_lds(renderer_bwd_mfma<C, OCC>, lds))) return rc;
+  hipLaunchKernelGGL((renderer_bwd_mfma<C, OCC>), dim3(blocks), dim3(256), lds, stream, a, mp);
+  return LP_OK;
+}
+
 int renderer_backward_mfma(const LpRendererArgs& a, hipStream_t stream) {
   const MfmaParams mp = make_params(a);
   const unsigned blocks = (unsigned)((a.rays.n_rays + WAVES * RAYS_PER_WAVE - 1) / (WAVES * RAYS_PER_WAVE));
   if (blocks == 0) return LP_OK;
+  // waves per SIMD the backward kernel is register-allocated for (tuning knob, default 2)
+  static const int occ = [] {
+    const char* e = getenv("LP_MFMA_BWD_OCC");
+    return (e && e[0] == '1') ? 1 : 2;
+  }();
   int rc;
-  if (a.grid.channels == 16) {
-    const size_t lds = Lds<16>::BWD_END * sizeof(float);
-    if ((rc = set_lds(renderer_bwd_mfma<16>, lds))) return rc;
-    hipLaunchKernelGGL(renderer_bwd_mfma<16>, dim3(blocks), dim3(256), lds, stream, a, mp);
-  } else {
-    const size_t lds = Lds<32>::BWD_END * sizeof(float);
-    if ((rc = set_lds(renderer_bwd_mfma<32>, lds))) return rc;
-    hipLaunchKernelGGL(renderer_bwd_mfma<32>, dim3(blocks), dim3(256), lds, stream, a, mp);
-  }
+  if (a.grid.channels == 16)
+    rc = (occ == 1) ? launch_bwd<16, 1>(a, mp, blocks, stream) : launch_bwd<16, 2>(a, mp, blocks, stream);
+  else
+    rc = (occ == 1) ? launch_bwd<32, 1>(a, mp, blocks, stream) : launch_bwd<32, 2>(a, mp, blocks, stream);
+  if (rc) return rc;
   return check_launch("renderer_bwd_mfma");
 }
 
