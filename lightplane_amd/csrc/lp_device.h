@@ -58,6 +58,20 @@ LP_DEV float sample_depth(int i, const LpMarch& m, float near_t, float far_t) {
   return far_t * (float)(1.0 / n_disp);
 }
 
+// Scale factors of the beyond-far samples, float(1 / n_disp_k) in the oracle's double arithmetic;
+// kernels tabulate them once (LDS) so that the per-sample depth is branch-free.
+LP_DEV float inf_scale(int k, const LpMarch& m) {
+  const double frac = (double)(k + 1) / (double)m.num_samples_inf;
+  const double n_disp = (m.disparity_at_inf - 1.0) * frac + 1.0;
+  return (float)(1.0 / n_disp);
+}
+LP_DEV float sample_depth_tab(int i, const LpMarch& m, float near_t, float far_t, const float* inf_tab) {
+  const int k = i - m.num_samples;
+  const float lin = near_t + lin01(i, m.num_samples) * (far_t - near_t);
+  const float inf = far_t * inf_tab[k > 0 ? k : 0];
+  return (k < 0) ? lin : inf;
+}
+
 // interval length of sample i (naive_renderer.py:252-257); depth_i must be sample_depth(i)
 LP_DEV float sample_delta(int i, const LpMarch& m, float near_t, float far_t, float depth_i) {
   if (i == 0) {
@@ -209,46 +223,54 @@ LP_DEV void axis_taps(float c, int size, int& i0, float (&w)[2], bool (&ok)[2]) 
 }
 
 template <bool SPLAT>
-LP_DEV void grid_taps(const LpGrid& g, int b, float x, float y, float z, Taps& t) {
+LP_DEV void voxel_taps(const LpGrid& g, int b, float x, float y, float z, Taps& t) {
   const int base = (int)g.row_offset + b * (g.D * g.H * g.W);
-  if (g.D > 1 && g.H > 1 && g.W > 1) {
-    int ix, iy, iz;
-    float wx[2], wy[2], wz[2];
-    bool okx[2], oky[2], okz[2];
-    axis_taps<SPLAT>(x, g.W, ix, wx, okx);
-    axis_taps<SPLAT>(y, g.H, iy, wy, oky);
-    axis_taps<SPLAT>(z, g.D, iz, wz, okz);
-    t.n = 8;
+  int ix, iy, iz;
+  float wx[2], wy[2], wz[2];
+  bool okx[2], oky[2], okz[2];
+  axis_taps<SPLAT>(x, g.W, ix, wx, okx);
+  axis_taps<SPLAT>(y, g.H, iy, wy, oky);
+  axis_taps<SPLAT>(z, g.D, iz, wz, okz);
+  t.n = 8;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int ux = k & 1, uy = (k >> 1) & 1, uz = (k >> 2) & 1;
-      const bool ok = okx[ux] && oky[uy] && okz[uz];
-      t.row[k] = ok ? base + ((iz + uz) * g.H + (iy + uy)) * g.W + (ix + ux) : -1;
-      t.w[k] = ok ? (wx[ux] * wy[uy]) * wz[uz] : 0.0f;
-    }
-  } else {
-    // plane: (u, v) = (x, y) | (x, z) | (y, z); row = iv * U + iu in all three cases
-    float cu, cv;
-    int U, V;
-    if (g.D == 1) { cu = x; cv = y; U = g.W; V = g.H; }
-    else if (g.H == 1) { cu = x; cv = z; U = g.W; V = g.D; }
-    else { cu = y; cv = z; U = g.H; V = g.D; }
-    int iu, iv;
-    float wu[2], wv[2];
-    bool oku[2], okv[2];
-    axis_taps<SPLAT>(cu, U, iu, wu, oku);
-    axis_taps<SPLAT>(cv, V, iv, wv, okv);
-    t.n = 4;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int uu = k & 1, uv = (k >> 1) & 1;
-      const bool ok = oku[uu] && okv[uv];
-      t.row[k] = ok ? base + (iv + uv) * U + (iu + uu) : -1;
-      t.w[k] = ok ? wu[uu] * wv[uv] : 0.0f;
-    }
-#pragma unroll
-    for (int k = 4; k < 8; ++k) { t.row[k] = -1; t.w[k] = 0.0f; }
+  for (int k = 0; k < 8; ++k) {
+    const int ux = k & 1, uy = (k >> 1) & 1, uz = (k >> 2) & 1;
+    const bool ok = okx[ux] && oky[uy] && okz[uz];
+    t.row[k] = ok ? base + ((iz + uz) * g.H + (iy + uy)) * g.W + (ix + ux) : -1;
+    t.w[k] = ok ? (wx[ux] * wy[uy]) * wz[uz] : 0.0f;
   }
+}
+
+// plane: (u, v) = (x, y) | (x, z) | (y, z); row = iv * U + iu in all three cases (branch-free)
+template <bool SPLAT>
+LP_DEV void plane_taps(const LpGrid& g, int b, float x, float y, float z, Taps& t) {
+  const int base = (int)g.row_offset + b * (g.D * g.H * g.W);
+  const bool xy = g.D == 1, xz = g.H == 1;
+  const float cu = (xy || xz) ? x : y;
+  const float cv = xy ? y : z;
+  const int U = (xy || xz) ? g.W : g.H;
+  const int V = xy ? g.H : g.D;
+  int iu, iv;
+  float wu[2], wv[2];
+  bool oku[2], okv[2];
+  axis_taps<SPLAT>(cu, U, iu, wu, oku);
+  axis_taps<SPLAT>(cv, V, iv, wv, okv);
+  t.n = 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int uu = k & 1, uv = (k >> 1) & 1;
+    const bool ok = oku[uu] && okv[uv];
+    t.row[k] = ok ? base + (iv + uv) * U + (iu + uu) : -1;
+    t.w[k] = ok ? wu[uu] * wv[uv] : 0.0f;
+  }
+#pragma unroll
+  for (int k = 4; k < 8; ++k) { t.row[k] = -1; t.w[k] = 0.0f; }
+}
+
+template <bool SPLAT>
+LP_DEV void grid_taps(const LpGrid& g, int b, float x, float y, float z, Taps& t) {
+  if (g.D > 1 && g.H > 1 && g.W > 1) voxel_taps<SPLAT>(g, b, x, y, z, t);
+  else plane_taps<SPLAT>(g, b, x, y, z, t);
 }
 
 // nearest-neighbour scaffold lookup (round-half-even like F.grid_sample(mode="nearest")),

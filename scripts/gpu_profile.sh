@@ -1,8 +1,16 @@
 #!/bin/bash
-# rocprofv3 kernel trace of bench.py + backward ablation. Outputs under gpurun_out/.
-mkdir -p gpurun_out/prof
+# rocprofv3 kernel trace of bench.py (+ PMC passes). Outputs under gpurun_out/prof*.
+mkdir -p gpurun_out
 export TMPDIR=/tmp
-python scripts/ablate_bwd.py > gpurun_out/ablate.txt 2>&1; tail -2 gpurun_out/ablate.txt
-cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.txt 2>&1
-cd $GRAFT_REPO_ROOT; tail -2 gpurun_out/prof_bench.txt; ls -R gpurun_out/prof | head -20
-f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); echo "== $f"; head -12 "$f"
+R=$GRAFT_REPO_ROOT
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_bench.txt 2>&1
+tail -1 $R/gpurun_out/prof_bench.txt
+find $R/gpurun_out/prof -type f | head
+f=$(find $R/gpurun_out/prof -name "*kernel_stats.csv" | head -1); echo "== $f"; head -8 "$f"
+# PMC pass 1: SQ counters for the two renderer kernels
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_ANY --output-format csv -d $R/gpurun_out/pmc1 -o pmc -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc1.txt 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_INSTS_SALU --output-format csv -d $R/gpurun_out/pmc2 -o pmc -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc2.txt 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc3 -o pmc -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc3.txt 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/pmc4 -o pmc -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc4.txt 2>&1
+find $R/gpurun_out/pmc1 -type f | head -5
