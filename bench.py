@@ -60,6 +60,24 @@ def algorithmic_bytes(n_rays):
     return fwd, bwd
 
 
+def pmc_traffic():
+    """HBM bytes per backward launch from the committed rocprofv3 PMC passes (profiles/r*_pmc_summary.json:
+    (FETCH_SIZE + WRITE_SIZE) * 1024, separate --pmc runs of this same command), or None."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        for k, v in d.items():
+            if "renderer_bwd_mfma" in k and "hbm_bytes_per_launch" in v:
+                return int(v["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+    return None
+
+
 def cpu_baseline(rays, grids, dec, n_sub=1024):
     """Oracle (kind 'port': our PyTorch restatement of the reference's naive path) fwd+bwd on CPU."""
     import copy
@@ -196,7 +214,7 @@ def main():
             "peak_bwd_mem_mb": round(peak_mb, 2),
             "fwd_ms": round(fwd_ms, 4), "bwd_ms": round(bwd_ms, 4),
             "roofline": {"bound": "hbm", "kernel": "renderer backward", "achieved": round(achieved, 2), "peak": 8000.0,
-                         "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": pmc_traffic(),
                          "algorithmic_bytes_per_launch": bwd_b,
                          "note": "effective bandwidth: the 786 KB grid is L2 resident, compulsory HBM bytes are ~0.5 KB/ray"},
             "mlp_fp32_frac_of_peak": round(flops_fwdbwd / ((fwd_ms + bwd_ms) * 1e-3) / 157.3e12, 5),
