@@ -152,6 +152,13 @@ typedef struct LpRendererArgs {
   float* grad_color_grid;  /* like color_grid.data  */
   float* grad_mlp_params;  /* [n_mlp_params]        */
   float* grad_encoding;    /* [N, encoding_dim] (written, not accumulated) */
+  /* optional de-contention workspace: n_grad_replicas extra zero-filled copies of grad_grid
+   * ([n_grad_replicas][rows*C]).  Workgroups spread their atomics over grad_grid and the
+   * replicas (same-row fp32 atomics serialise at ~25 ns each on MI355X; coherent image rays
+   * hammer the same plane rows), lp_renderer_backward then folds the replicas into grad_grid. */
+  float* grad_grid_replicas;
+  int32_t n_grad_replicas; /* 0 = none */
+  int32_t _pad2;
 } LpRendererArgs;
 
 typedef struct LpSplatterArgs {

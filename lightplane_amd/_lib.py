@@ -72,6 +72,7 @@ class LpRendererArgs(C.Structure):
         ("grad_ray_length", C.c_void_p), ("grad_neg_log_t", C.c_void_p), ("grad_feature", C.c_void_p),
         ("grad_grid", C.c_void_p), ("grad_color_grid", C.c_void_p), ("grad_mlp_params", C.c_void_p),
         ("grad_encoding", C.c_void_p),
+        ("grad_grid_replicas", C.c_void_p), ("n_grad_replicas", C.c_int32), ("_pad2", C.c_int32),
     ]
 
 

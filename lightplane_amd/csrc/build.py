@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "liblightplane_hip.so")
 SOURCES = ["lp_api.hip", "lp_renderer_generic.hip", "lp_renderer_mfma.hip", "lp_splatter.hip"]
-HEADERS = ["lp_device.h", "lp_host.h", os.path.join("..", "..", "include", "lightplane_hip.h")]
+HEADERS = ["lp_device.h", "lp_host.h", "lp_mfma_common.h", os.path.join("..", "..", "include", "lightplane_hip.h")]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
     "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",

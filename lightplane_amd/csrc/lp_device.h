@@ -273,6 +273,66 @@ LP_DEV void grid_taps(const LpGrid& g, int b, float x, float y, float z, Taps& t
   else plane_taps<SPLAT>(g, b, x, y, z, t);
 }
 
+// Tap set in "origin + strides" form (used by the run-merging gradient scatter): slot k adds
+// (k&1)*su + ((k>>1)&1)*sv + (k>>2)*st rows to the VIRTUAL row of slot 0 (which may lie outside
+// the grid; `ok` bit k says whether slot k is in range).  Weights / indices are computed by the
+// same arithmetic as voxel_taps() / plane_taps(), i.e. they are bit-identical to them.
+struct TapSet {
+  int row0;
+  int su, sv, st;
+  float w[8];   // 0 where out of range
+  unsigned ok;  // bit k set <=> slot k in range
+  int n;        // 4 (plane) or 8 (voxel)
+};
+
+template <bool SPLAT>
+LP_DEV void grid_tapset(const LpGrid& g, int b, float x, float y, float z, TapSet& t) {
+  const int base = (int)g.row_offset + b * (g.D * g.H * g.W);
+  if (g.D > 1 && g.H > 1 && g.W > 1) {
+    int ix, iy, iz;
+    float wx[2], wy[2], wz[2];
+    bool okx[2], oky[2], okz[2];
+    axis_taps<SPLAT>(x, g.W, ix, wx, okx);
+    axis_taps<SPLAT>(y, g.H, iy, wy, oky);
+    axis_taps<SPLAT>(z, g.D, iz, wz, okz);
+    t.n = 8;
+    t.su = 1; t.sv = g.W; t.st = g.H * g.W;
+    t.row0 = base + (iz * g.H + iy) * g.W + ix;
+    t.ok = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ux = k & 1, uy = (k >> 1) & 1, uz = (k >> 2) & 1;
+      const bool ok = okx[ux] && oky[uy] && okz[uz];
+      t.ok |= ok ? (1u << k) : 0u;
+      t.w[k] = ok ? (wx[ux] * wy[uy]) * wz[uz] : 0.0f;
+    }
+  } else {
+    const bool xy = g.D == 1, xz = g.H == 1;
+    const float cu = (xy || xz) ? x : y;
+    const float cv = xy ? y : z;
+    const int U = (xy || xz) ? g.W : g.H;
+    const int V = xy ? g.H : g.D;
+    int iu, iv;
+    float wu[2], wv[2];
+    bool oku[2], okv[2];
+    axis_taps<SPLAT>(cu, U, iu, wu, oku);
+    axis_taps<SPLAT>(cv, V, iv, wv, okv);
+    t.n = 4;
+    t.su = 1; t.sv = U; t.st = 0;
+    t.row0 = base + iv * U + iu;
+    t.ok = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int uu = k & 1, uv = (k >> 1) & 1;
+      const bool ok = oku[uu] && okv[uv];
+      t.ok |= ok ? (1u << k) : 0u;
+      t.w[k] = ok ? wu[uu] * wv[uv] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 4; k < 8; ++k) t.w[k] = 0.0f;
+  }
+}
+
 // nearest-neighbour scaffold lookup (round-half-even like F.grid_sample(mode="nearest")),
 // zero outside the grid, times the in-bounds mask (naive_renderer.py:484-499).
 LP_DEV float scaffold_lookup(const float* scaffold, const LpGrid& s, int b, float x, float y, float z) {

@@ -1,0 +1,421 @@
+// lp_mfma_common.h -- building blocks shared by the MFMA Renderer kernels (forward:
+// lp_renderer_mfma.hip, backward: lp_renderer_mfma_bwd.hip).  See the header comment of
+// lp_renderer_mfma.hip for the lane <-> (ray, feature) mapping.
+#pragma once
+#include <stdlib.h>
+
+#include "lp_device.h"
+#include "lp_host.h"
+
+namespace lp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+LP_DEV constexpr int featq(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
+
+#define LP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// An integer the optimiser must treat as unknown (it is always 0).  Added to LDS offsets inside
+// the sample loop it stops LICM from hoisting the ~200 loop-invariant weight / bias reads out of
+// the loop (which costs >200 VGPRs and spills); the reads stay ds_read (LDS address space kept).
+LP_DEV int opaque_zero() {
+  int z = 0;
+  asm volatile("" : "+s"(z));
+  return z;
+}
+
+constexpr int HID = 32;        // hidden width of the shape family
+constexpr int TILE_LD = 33;    // padded row stride of the per-wave transposition tiles
+constexpr int W_LD = 33;       // padded row stride of the weight matrices in LDS
+constexpr int WAVES = 4;       // waves per workgroup
+constexpr int RAYS_PER_WAVE = 32;
+constexpr int MAX_INF = 256;   // beyond-far samples tabulated in LDS
+
+// grid-list shape the kernel is specialised for
+constexpr int GM_GENERIC = 0;   // run-time loop over the grid-list
+constexpr int GM_TRIPLANE = 1;  // exactly three plane grids
+constexpr int GM_VOXEL = 2;     // exactly one voxel grid
+
+// float offsets of the parameter blocks inside mlp_params (computed on the host)
+struct MfmaParams {
+  int64_t w_t1, w_t2, b_t1, b_t2;  // trunk
+  int64_t w_o1, w_o2, b_o1, b_o2;  // opacity
+  int64_t w_c1, w_c2, b_c1, b_c2;  // colour
+  int ldc2;                        // row stride of w_c2 (padded colour width)
+  int dbg;                         // LP_MFMA_DEBUG bits (timing experiments only)
+};
+
+// LDS map (floats).  Weight matrices are kept ONCE, row-major [in][W_LD] with a padded row
+// stride of 33: the forward operand W[feat(kk,h)][l&31] walks a row (conflict-free), the
+// backward operand W[l&31][feat(kk,h)] walks a column with stride 33 (conflict-free as well).
+struct Lds {
+  static constexpr int WT1 = 0;                  // [32][33] (rows >= C are zero)
+  static constexpr int WT2 = WT1 + 32 * W_LD;
+  static constexpr int WO1 = WT2 + 32 * W_LD;
+  static constexpr int WC1 = WO1 + 32 * W_LD;
+  static constexpr int BIAS = WC1 + 32 * W_LD;   // b_t1, b_t2, b_o1, b_c1 : 4 x 32
+  static constexpr int WO2 = BIAS + 4 * 32;      // [32]
+  static constexpr int WC2 = WO2 + 32;           // [32][4]
+  static constexpr int HB = WC2 + 32 * 4;        // bo2, bc2[0..3], pad -> 8
+  static constexpr int INF = HB + 8;             // [MAX_INF] depth scale of the beyond-far samples
+  static constexpr int FWD_END = INF + MAX_INF;
+  // backward only: block-wide dW sum (epilogue), then per-wave scratch
+  static constexpr int DW = FWD_END;             // 4 x [32][32]: t1, t2, o1, c1
+  static constexpr int WAVE0 = DW + 4 * 1024;
+  static constexpr int TX = 0;                   // per-wave: two transposition tiles [32][33] ...
+  static constexpr int TY = 32 * TILE_LD;
+  static constexpr int TS = 2 * 32 * TILE_LD;    // ... + [32 rays][8]: dro, drc[0..3] of the current sample
+  static constexpr int PER_WAVE = 2 * 32 * TILE_LD + 32 * 8;
+  static constexpr int BWD_END = WAVE0 + WAVES * PER_WAVE;
+};
+
+template <int C, bool BWD>
+LP_DEV void stage_weights(const LpRendererArgs& a, const MfmaParams& mp, float* lds) {
+  using M = Lds;
+  const float* P = a.mlp_params;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 32 * 32; i += 256) {
+    const int row = i >> 5, col = i & 31;
+    const int d = row * W_LD + col;
+    lds[M::WT1 + d] = (row < C) ? P[mp.w_t1 + i] : 0.0f;
+    lds[M::WT2 + d] = P[mp.w_t2 + i];
+    lds[M::WO1 + d] = P[mp.w_o1 + i];
+    lds[M::WC1 + d] = P[mp.w_c1 + i];
+    if (BWD) {
+      lds[M::DW + i] = 0.0f;
+      lds[M::DW + 1024 + i] = 0.0f;
+      lds[M::DW + 2048 + i] = 0.0f;
+      lds[M::DW + 3072 + i] = 0.0f;
+    }
+  }
+  for (int i = tid; i < 32; i += 256) {
+    lds[M::BIAS + i] = P[mp.b_t1 + i];
+    lds[M::BIAS + 32 + i] = P[mp.b_t2 + i];
+    lds[M::BIAS + 64 + i] = P[mp.b_o1 + i];
+    lds[M::BIAS + 96 + i] = P[mp.b_c1 + i];
+    lds[M::WO2 + i] = P[mp.w_o2 + i];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      lds[M::WC2 + i * 4 + c] = (c < a.color_chn) ? P[mp.w_c2 + (int64_t)i * mp.ldc2 + c] : 0.0f;
+  }
+  for (int i = tid; i < MAX_INF; i += 256)
+    lds[M::INF + i] = (i < a.march.num_samples_inf) ? inf_scale(i, a.march) : 0.0f;
+  if (tid == 0) {
+    lds[M::HB + 0] = P[mp.b_o2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lds[M::HB + 1 + c] = (c < a.color_chn) ? P[mp.b_c2 + c] : 0.0f;
+  }
+}
+
+// bias of layer `which` (0 t1, 1 t2, 2 o1, 3 c1) in accumulator-register order for half h
+LP_DEV f32x16 load_bias(const float* lds, int which, int h, int zo) {
+  const float4* b = reinterpret_cast<const float4*>(lds + Lds::BIAS + which * 32 + 4 * h + zo);
+  f32x16 acc;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 v = b[2 * j];  // floats 8j + 4h .. +3
+    acc[4 * j + 0] = v.x; acc[4 * j + 1] = v.y; acc[4 * j + 2] = v.z; acc[4 * j + 3] = v.w;
+  }
+  return acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// grid-list gather: interpolated feature of this lane's ray, channels feat(q,h), q < C/2
+// ---------------------------------------------------------------------------------------
+template <int C>
+LP_DEV void gather_tap(const float* data, int row, float w, int h, float (&x0)[C / 2]) {
+  // out-of-range taps carry weight 0 and read row 0: no branch
+  const float4* src = reinterpret_cast<const float4*>(data + (int64_t)(row < 0 ? 0 : row) * C + 4 * h);
+#pragma unroll
+  for (int j = 0; j < C / 8; ++j) {
+    const float4 v = src[2 * j];  // channels 8j + 4h .. +3
+    x0[4 * j + 0] = fmaf(w, v.x, x0[4 * j + 0]);
+    x0[4 * j + 1] = fmaf(w, v.y, x0[4 * j + 1]);
+    x0[4 * j + 2] = fmaf(w, v.z, x0[4 * j + 2]);
+    x0[4 * j + 3] = fmaf(w, v.w, x0[4 * j + 3]);
+  }
+}
+
+template <int C, int GM>
+LP_DEV void gather_features(const LpRendererArgs& a, const Ray& ray, float x, float y, float z, int h,
+                            float (&x0)[C / 2]) {
+#pragma unroll
+  for (int q = 0; q < C / 2; ++q) x0[q] = 0.0f;
+  const float keep = (a.march.mask_out_of_bounds && !point_in_bounds(x, y, z)) ? 0.0f : 1.0f;
+  if (GM == GM_TRIPLANE) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      Taps t;
+      plane_taps<false>(a.grid.grids[g], ray.b, x, y, z, t);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
+    }
+  } else if (GM == GM_VOXEL) {
+    Taps t;
+    voxel_taps<false>(a.grid.grids[0], ray.b, x, y, z, t);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
+  } else {
+    for (int g = 0; g < a.grid.n_grids; ++g) {
+      Taps t;
+      grid_taps<false>(a.grid.grids[g], ray.b, x, y, z, t);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
+      if (t.n == 8) {
+#pragma unroll
+        for (int k = 4; k < 8; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// decoder
+// ---------------------------------------------------------------------------------------
+
+// One layer, forward form: acc (pre-loaded with the bias) += sum_kk A(kk) * in[kk] with
+// A(kk) = W[feat(kk,h)][l&31].  `w` already points at W + (4h)*W_LD + (l&31) (+ opaque zero).
+template <int K>
+LP_DEV f32x16 layer(const float* w, const float* in, f32x16 acc) {
+#pragma unroll
+  for (int kk = 0; kk < K; ++kk) acc = LP_MFMA(w[featq(kk, 0) * W_LD], in[kk], acc);
+  return acc;
+}
+// Backward (dX) form: A(kk) = W[l&31][feat(kk,h)].  `w` points at W + (l&31)*W_LD + 4h.
+LP_DEV f32x16 layer_t(const float* w, const float* in, f32x16 acc) {
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) acc = LP_MFMA(w[featq(kk, 0)], in[kk], acc);
+  return acc;
+}
+
+struct Heads {
+  float raw_o;
+  float raw_c[4];
+};
+
+// opacity / colour output layers on the VALU (N = 1 and N <= 4): each lane covers its 16
+// features, the partner lane (l ^ 32) the other 16.
+LP_DEV Heads heads_forward(const float* lds_, int h, const float (&ho)[16], const float (&hc)[16], int zo) {
+  using M = Lds;
+  const float* lds = lds_ + zo;
+  float po = 0.0f, pc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 wo = *reinterpret_cast<const float4*>(lds + M::WO2 + 8 * j + 4 * h);
+    const float wov[4] = {wo.x, wo.y, wo.z, wo.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = 4 * j + i;
+      po = fmaf(ho[q], wov[i], po);
+      const float4 wc = *reinterpret_cast<const float4*>(lds + M::WC2 + (8 * j + 4 * h + i) * 4);
+      pc[0] = fmaf(hc[q], wc.x, pc[0]);
+      pc[1] = fmaf(hc[q], wc.y, pc[1]);
+      pc[2] = fmaf(hc[q], wc.z, pc[2]);
+      pc[3] = fmaf(hc[q], wc.w, pc[3]);
+    }
+  }
+  Heads o;
+  o.raw_o = (po + __shfl_xor(po, 32)) + lds[M::HB];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) o.raw_c[c] = (pc[c] + __shfl_xor(pc[c], 32)) + lds[M::HB + 1 + c];
+  return o;
+}
+
+// Activations of one sample (accumulator-register order).
+template <int C>
+struct Act {
+  float x0[C / 2];
+  float h1[16], e[16], ho[16], hc[16];
+};
+
+// Nothing may be scheduled across this point.  Used to cut the sample loop body into groups of
+// "one layer's MFMAs + one plane's gather": inside a group the scheduler interleaves freely, but it
+// can no longer hoist all 24 dwordx4 loads of a sample to the top (96 live VGPRs).
+#define LP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// Ask the scheduler for the issue order "1 MFMA, a few VALU, (1 global load), (1 LDS read)" N times:
+// a dependent v_mfma_f32_32x32x2_f32 chain stalls its wave 64 cycles per link (in-order issue), so
+// every instruction placed between two links is free.
+template <int N, int VALU_PER, int VMEM_EVERY>
+LP_DEV void interleave_hint() {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // MFMA
+    if (VMEM_EVERY > 0 && (i % VMEM_EVERY) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // DS read (next operand)
+    __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER, 0);                // VALU
+  }
+}
+
+LP_DEV void load_encoding(const LpRendererArgs& a, int64_t rid, int h, float (&enc)[16]) {
+  const float4* src = reinterpret_cast<const float4*>(a.rays.encoding + rid * HID + 4 * h);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 v = src[2 * j];
+    enc[4 * j + 0] = v.x; enc[4 * j + 1] = v.y; enc[4 * j + 2] = v.z; enc[4 * j + 3] = v.w;
+  }
+}
+
+// geometry of one sample + its (prefetched) grid feature
+template <int C>
+struct Sample {
+  float depth, occ, x, y, z;
+  float x0[C / 2];
+};
+
+template <int C>
+LP_DEV void sample_geometry(const LpRendererArgs& a, const float* lds, const Ray& ray, int s, Sample<C>& o) {
+  o.depth = sample_depth_tab(s, a.march, ray.near_t, ray.far_t, lds + Lds::INF);
+  sample_point(ray, o.depth, a.march.contract_coords != 0, o.x, o.y, o.z);
+  o.occ = 1.0f;
+  if (a.scaffold) o.occ = scaffold_lookup(a.scaffold, a.scaffold_shape, ray.b, o.x, o.y, o.z);
+}
+
+template <int C, int GM>
+LP_DEV void fetch_sample(const LpRendererArgs& a, const float* lds, const Ray& ray, int s, int h, Sample<C>& o) {
+  sample_geometry<C>(a, lds, ray, s, o);
+  gather_features<C, GM>(a, ray, o.x, o.y, o.z, h, o.x0);
+}
+
+// Decoder of the CURRENT sample (input t.x0; fills t.h1 / t.e / t.ho / t.hc) interleaved with the
+// gather of sample `s_next` into `nx` (software pipeline).  Triplane: plane g is gathered next to
+// hidden layer g+1; voxel: taps 0-3 / 4-7 next to layers 2 / 3; generic grid-lists: whole gather
+// first.
+template <int C, int GM_, bool PREFETCH = true>
+LP_DEV Heads decode_prefetch(const LpRendererArgs& a, const float* lds, const Ray& ray, int lane,
+                             const float (&enc)[16], Act<C>& t, int s_next, Sample<C>& nx, int zo) {
+  using M = Lds;
+  // without prefetch this is the plain decoder (GM = -1 disables every gather below)
+  constexpr int GM = PREFETCH ? GM_ : -1;
+  const int h = lane >> 5;
+  // operand base of this lane; `zo` (always 0) keeps the weight reads inside the sample loop
+  const float* wl = lds + (4 * h) * W_LD + (lane & 31) + zo;
+  float keep = 1.0f;
+  if (PREFETCH) {
+    sample_geometry<C>(a, lds, ray, s_next, nx);
+    keep = (a.march.mask_out_of_bounds && !point_in_bounds(nx.x, nx.y, nx.z)) ? 0.0f : 1.0f;
+  }
+  Taps tp[GM == GM_TRIPLANE ? 3 : 1];
+  if (GM == GM_TRIPLANE) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) plane_taps<false>(a.grid.grids[g], ray.b, nx.x, nx.y, nx.z, tp[g]);
+  } else if (GM == GM_VOXEL) {
+    voxel_taps<false>(a.grid.grids[0], ray.b, nx.x, nx.y, nx.z, tp[0]);
+  } else if (GM == GM_GENERIC) {
+    gather_features<C, GM_GENERIC>(a, ray, nx.x, nx.y, nx.z, h, nx.x0);
+  }
+  if (GM == GM_TRIPLANE || GM == GM_VOXEL) {
+#pragma unroll
+    for (int q = 0; q < C / 2; ++q) nx.x0[q] = 0.0f;
+  }
+  LP_SCHED_FENCE();
+  f32x16 acc = layer<C / 2>(wl + M::WT1, t.x0, load_bias(lds, 0, h, zo));
+#pragma unroll
+  for (int q = 0; q < 16; ++q) t.h1[q] = fmaxf(acc[q], 0.0f);
+  LP_SCHED_FENCE();
+  // ---- group 1: trunk layer 2  ||  plane 0 / voxel taps 0-3 ----
+  if (GM == GM_TRIPLANE || GM == GM_VOXEL) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, tp[0].row[k], tp[0].w[k] * keep, h, nx.x0);
+  }
+  acc = layer<16>(wl + M::WT2, t.h1, load_bias(lds, 1, h, zo));
+#pragma unroll
+  for (int q = 0; q < 16; ++q) t.e[q] = fmaxf(acc[q], 0.0f);
+  if (GM == GM_TRIPLANE || GM == GM_VOXEL) interleave_hint<16, 5, 2>();
+  LP_SCHED_FENCE();
+  // ---- group 2: opacity hidden layer  ||  plane 1 / voxel taps 4-7 ----
+  if (GM == GM_TRIPLANE) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, tp[1].row[k], tp[1].w[k] * keep, h, nx.x0);
+  } else if (GM == GM_VOXEL) {
+#pragma unroll
+    for (int k = 4; k < 8; ++k) gather_tap<C>(a.grid.data, tp[0].row[k], tp[0].w[k] * keep, h, nx.x0);
+  }
+  acc = layer<16>(wl + M::WO1, t.e, load_bias(lds, 2, h, zo));
+#pragma unroll
+  for (int q = 0; q < 16; ++q) t.ho[q] = fmaxf(acc[q], 0.0f);
+  if (GM == GM_TRIPLANE || GM == GM_VOXEL) interleave_hint<16, 5, 2>();
+  LP_SCHED_FENCE();
+  // ---- group 3: colour hidden layer  ||  plane 2 ----
+  if (GM == GM_TRIPLANE) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, tp[2].row[k], tp[2].w[k] * keep, h, nx.x0);
+  }
+  float ein[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) ein[q] = t.e[q] + enc[q];
+  acc = layer<16>(wl + M::WC1, ein, load_bias(lds, 3, h, zo));
+#pragma unroll
+  for (int q = 0; q < 16; ++q) t.hc[q] = fmaxf(acc[q], 0.0f);
+  if (GM == GM_TRIPLANE) interleave_hint<16, 6, 2>();
+  LP_SCHED_FENCE();
+  return heads_forward(lds, h, t.ho, t.hc, zo);
+}
+
+// Gradient scatter of one grid, row-contiguous and run-length merged.
+// dx0 of the wave's 32 rays has been transposed through LDS: every lane holds ONE channel (`sub`) of
+// all 32 rays in registers (dx[]), lane group `grp` (C lanes) works on tap slot k.  Rays are walked
+// in order; consecutive rays that fall into the same cell (the common case for image-coherent rays)
+// are summed in a register and leave as ONE atomic per row whose C lanes cover the C contiguous
+// floats of the row.  All slots of a grid change cell together, so the run boundaries are a
+// wave-uniform bit mask (ballot in the lane = ray layout): the walk is scalar-branched, the tap rows
+// come from v_readlane, and the only LDS traffic is the bulk (b128) load of the weights.
+constexpr int DX_LD = 36;  // row stride of the transposed dx0 tile [channel][ray]
+
+template <int C>
+LP_DEV void flush_run(float* gg, int s_row, unsigned s_ok, int koff, unsigned kbit, int sub, float run, int dbg) {
+  if ((s_ok & kbit) && !(dbg & 1)) atomic_add_f32(gg + ((int64_t)(s_row + koff) * C + sub), run);
+}
+
+template <int C>
+LP_DEV void scatter_grid(float* gg, const LpGrid& g, int b, float x, float y, float z, bool live, int lane,
+                         const float (&dx)[32], float* wT, int dbg) {
+  constexpr int GRPS = 64 / C;  // tap slots per pass
+  const int h = lane >> 5, r = lane & 31, sub = lane % C, grp = lane / C;
+  TapSet tp;
+  grid_tapset<false>(g, b, x, y, z, tp);
+  if (!live) {
+    tp.ok = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tp.w[k] = 0.0f;
+  }
+  // weights -> wT[slot][ray]; the two lanes of a ray write four slots each
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wT[(4 * h + i) * 32 + r] = h ? tp.w[4 + i] : tp.w[i];
+  const int row0 = tp.row0;
+  const int ok = (int)tp.ok;
+  const int prow = __shfl_up(row0, 1);
+  const int pok = __shfl_up(ok, 1);
+  const bool head = (r == 0) || row0 != prow || ok != pok;
+  const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head));
+  const bool voxel = g.D > 1 && g.H > 1 && g.W > 1;
+  const int n_pass = (voxel ? 8 : 4) / GRPS;
+  for (int p = 0; p < n_pass; ++p) {
+    const int k = p * GRPS + grp;
+    const int koff = (k & 1) * tp.su + ((k >> 1) & 1) * tp.sv + (k >> 2) * tp.st;
+    const unsigned kbit = 1u << k;
+    float w[32];
+    const float4* wsrc = reinterpret_cast<const float4*>(wT + k * 32);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 v = wsrc[j];
+      w[4 * j + 0] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+    }
+    float run = 0.0f;
+    int s_row = __builtin_amdgcn_readlane(row0, 0);
+    unsigned s_ok = (unsigned)__builtin_amdgcn_readlane(ok, 0);
+#pragma unroll
+    for (int rr = 0; rr < 32; ++rr) {
+      if (rr > 0 && ((mask >> rr) & 1u)) {
+        flush_run<C>(gg, s_row, s_ok, koff, kbit, sub, run, dbg);
+        run = 0.0f;
+        s_row = __builtin_amdgcn_readlane(row0, rr);
+        s_ok = (unsigned)__builtin_amdgcn_readlane(ok, rr);
+      }
+      run = fmaf(w[rr], dx[rr], run);
+    }
+    flush_run<C>(gg, s_row, s_ok, koff, kbit, sub, run, dbg);
+  }
+}
+
+}  // namespace lp

@@ -34,354 +34,9 @@
 // so that every global_atomic_add_f32 instruction covers whole contiguous C-float rows (measured
 // on MI355X: 336 Gadd/s vs 19.6 Gadd/s lane-per-row), and contributions of neighbouring rays to
 // the same cell are merged in a register first (run-length merge).
-#include <stdlib.h>
-
-#include "lp_device.h"
-#include "lp_host.h"
+#include "lp_mfma_common.h"
 
 namespace lp {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-LP_DEV constexpr int featq(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
-
-#define LP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-
-// An integer the optimiser must treat as unknown (it is always 0).  Added to LDS offsets inside
-// the sample loop it stops LICM from hoisting the ~200 loop-invariant weight / bias reads out of
-// the loop (which costs >200 VGPRs and spills); the reads stay ds_read (LDS address space kept).
-LP_DEV int opaque_zero() {
-  int z = 0;
-  asm volatile("" : "+s"(z));
-  return z;
-}
-
-constexpr int HID = 32;        // hidden width of the shape family
-constexpr int TILE_LD = 33;    // padded row stride of the per-wave transposition tiles
-constexpr int W_LD = 33;       // padded row stride of the weight matrices in LDS
-constexpr int WAVES = 4;       // waves per workgroup
-constexpr int RAYS_PER_WAVE = 32;
-constexpr int MAX_INF = 256;   // beyond-far samples tabulated in LDS
-
-// grid-list shape the kernel is specialised for
-constexpr int GM_GENERIC = 0;   // run-time loop over the grid-list
-constexpr int GM_TRIPLANE = 1;  // exactly three plane grids
-constexpr int GM_VOXEL = 2;     // exactly one voxel grid
-
-// float offsets of the parameter blocks inside mlp_params (computed on the host)
-struct MfmaParams {
-  int64_t w_t1, w_t2, b_t1, b_t2;  // trunk
-  int64_t w_o1, w_o2, b_o1, b_o2;  // opacity
-  int64_t w_c1, w_c2, b_c1, b_c2;  // colour
-  int ldc2;                        // row stride of w_c2 (padded colour width)
-};
-
-// LDS map (floats).  Weight matrices are kept ONCE, row-major [in][W_LD] with a padded row
-// stride of 33: the forward operand W[feat(kk,h)][l&31] walks a row (conflict-free), the
-// backward operand W[l&31][feat(kk,h)] walks a column with stride 33 (conflict-free as well).
-struct Lds {
-  static constexpr int WT1 = 0;                  // [32][33] (rows >= C are zero)
-  static constexpr int WT2 = WT1 + 32 * W_LD;
-  static constexpr int WO1 = WT2 + 32 * W_LD;
-  static constexpr int WC1 = WO1 + 32 * W_LD;
-  static constexpr int BIAS = WC1 + 32 * W_LD;   // b_t1, b_t2, b_o1, b_c1 : 4 x 32
-  static constexpr int WO2 = BIAS + 4 * 32;      // [32]
-  static constexpr int WC2 = WO2 + 32;           // [32][4]
-  static constexpr int HB = WC2 + 32 * 4;        // bo2, bc2[0..3], pad -> 8
-  static constexpr int INF = HB + 8;             // [MAX_INF] depth scale of the beyond-far samples
-  static constexpr int FWD_END = INF + MAX_INF;
-  // backward only: block-wide dW sum (epilogue), then per-wave scratch
-  static constexpr int DW = FWD_END;             // 4 x [32][32]: t1, t2, o1, c1
-  static constexpr int WAVE0 = DW + 4 * 1024;
-  static constexpr int TX = 0;                   // per-wave: two transposition tiles [32][33] ...
-  static constexpr int TY = 32 * TILE_LD;
-  static constexpr int TS = 2 * 32 * TILE_LD;    // ... + [32 rays][8]: dro, drc[0..3] of the current sample
-  static constexpr int PER_WAVE = 2 * 32 * TILE_LD + 32 * 8;
-  static constexpr int BWD_END = WAVE0 + WAVES * PER_WAVE;
-};
-
-template <int C, bool BWD>
-LP_DEV void stage_weights(const LpRendererArgs& a, const MfmaParams& mp, float* lds) {
-  using M = Lds;
-  const float* P = a.mlp_params;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 32 * 32; i += 256) {
-    const int row = i >> 5, col = i & 31;
-    const int d = row * W_LD + col;
-    lds[M::WT1 + d] = (row < C) ? P[mp.w_t1 + i] : 0.0f;
-    lds[M::WT2 + d] = P[mp.w_t2 + i];
-    lds[M::WO1 + d] = P[mp.w_o1 + i];
-    lds[M::WC1 + d] = P[mp.w_c1 + i];
-    if (BWD) {
-      lds[M::DW + i] = 0.0f;
-      lds[M::DW + 1024 + i] = 0.0f;
-      lds[M::DW + 2048 + i] = 0.0f;
-      lds[M::DW + 3072 + i] = 0.0f;
-    }
-  }
-  for (int i = tid; i < 32; i += 256) {
-    lds[M::BIAS + i] = P[mp.b_t1 + i];
-    lds[M::BIAS + 32 + i] = P[mp.b_t2 + i];
-    lds[M::BIAS + 64 + i] = P[mp.b_o1 + i];
-    lds[M::BIAS + 96 + i] = P[mp.b_c1 + i];
-    lds[M::WO2 + i] = P[mp.w_o2 + i];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      lds[M::WC2 + i * 4 + c] = (c < a.color_chn) ? P[mp.w_c2 + (int64_t)i * mp.ldc2 + c] : 0.0f;
-  }
-  for (int i = tid; i < MAX_INF; i += 256)
-    lds[M::INF + i] = (i < a.march.num_samples_inf) ? inf_scale(i, a.march) : 0.0f;
-  if (tid == 0) {
-    lds[M::HB + 0] = P[mp.b_o2];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) lds[M::HB + 1 + c] = (c < a.color_chn) ? P[mp.b_c2 + c] : 0.0f;
-  }
-}
-
-// bias of layer `which` (0 t1, 1 t2, 2 o1, 3 c1) in accumulator-register order for half h
-LP_DEV f32x16 load_bias(const float* lds, int which, int h, int zo) {
-  const float4* b = reinterpret_cast<const float4*>(lds + Lds::BIAS + which * 32 + 4 * h + zo);
-  f32x16 acc;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float4 v = b[2 * j];  // floats 8j + 4h .. +3
-    acc[4 * j + 0] = v.x; acc[4 * j + 1] = v.y; acc[4 * j + 2] = v.z; acc[4 * j + 3] = v.w;
-  }
-  return acc;
-}
-
-// ---------------------------------------------------------------------------------------
-// grid-list gather: interpolated feature of this lane's ray, channels feat(q,h), q < C/2
-// ---------------------------------------------------------------------------------------
-template <int C>
-LP_DEV void gather_tap(const float* data, int row, float w, int h, float (&x0)[C / 2]) {
-  // out-of-range taps carry weight 0 and read row 0: no branch
-  const float4* src = reinterpret_cast<const float4*>(data + (int64_t)(row < 0 ? 0 : row) * C + 4 * h);
-#pragma unroll
-  for (int j = 0; j < C / 8; ++j) {
-    const float4 v = src[2 * j];  // channels 8j + 4h .. +3
-    x0[4 * j + 0] = fmaf(w, v.x, x0[4 * j + 0]);
-    x0[4 * j + 1] = fmaf(w, v.y, x0[4 * j + 1]);
-    x0[4 * j + 2] = fmaf(w, v.z, x0[4 * j + 2]);
-    x0[4 * j + 3] = fmaf(w, v.w, x0[4 * j + 3]);
-  }
-}
-
-template <int C, int GM>
-LP_DEV void gather_features(const LpRendererArgs& a, const Ray& ray, float x, float y, float z, int h,
-                            float (&x0)[C / 2]) {
-#pragma unroll
-  for (int q = 0; q < C / 2; ++q) x0[q] = 0.0f;
-  const float keep = (a.march.mask_out_of_bounds && !point_in_bounds(x, y, z)) ? 0.0f : 1.0f;
-  if (GM == GM_TRIPLANE) {
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-      Taps t;
-      plane_taps<false>(a.grid.grids[g], ray.b, x, y, z, t);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
-    }
-  } else if (GM == GM_VOXEL) {
-    Taps t;
-    voxel_taps<false>(a.grid.grids[0], ray.b, x, y, z, t);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
-  } else {
-    for (int g = 0; g < a.grid.n_grids; ++g) {
-      Taps t;
-      grid_taps<false>(a.grid.grids[g], ray.b, x, y, z, t);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
-      if (t.n == 8) {
-#pragma unroll
-        for (int k = 4; k < 8; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// decoder
-// ---------------------------------------------------------------------------------------
-
-// One layer, forward form: acc (pre-loaded with the bias) += sum_kk A(kk) * in[kk] with
-// A(kk) = W[feat(kk,h)][l&31].  `w` already points at W + (4h)*W_LD + (l&31) (+ opaque zero).
-template <int K>
-LP_DEV f32x16 layer(const float* w, const float* in, f32x16 acc) {
-#pragma unroll
-  for (int kk = 0; kk < K; ++kk) acc = LP_MFMA(w[featq(kk, 0) * W_LD], in[kk], acc);
-  return acc;
-}
-// Backward (dX) form: A(kk) = W[l&31][feat(kk,h)].  `w` points at W + (l&31)*W_LD + 4h.
-LP_DEV f32x16 layer_t(const float* w, const float* in, f32x16 acc) {
-#pragma unroll
-  for (int kk = 0; kk < 16; ++kk) acc = LP_MFMA(w[featq(kk, 0)], in[kk], acc);
-  return acc;
-}
-
-struct Heads {
-  float raw_o;
-  float raw_c[4];
-};
-
-// opacity / colour output layers on the VALU (N = 1 and N <= 4): each lane covers its 16
-// features, the partner lane (l ^ 32) the other 16.
-LP_DEV Heads heads_forward(const float* lds_, int h, const float (&ho)[16], const float (&hc)[16], int zo) {
-  using M = Lds;
-  const float* lds = lds_ + zo;
-  float po = 0.0f, pc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float4 wo = *reinterpret_cast<const float4*>(lds + M::WO2 + 8 * j + 4 * h);
-    const float wov[4] = {wo.x, wo.y, wo.z, wo.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int q = 4 * j + i;
-      po = fmaf(ho[q], wov[i], po);
-      const float4 wc = *reinterpret_cast<const float4*>(lds + M::WC2 + (8 * j + 4 * h + i) * 4);
-      pc[0] = fmaf(hc[q], wc.x, pc[0]);
-      pc[1] = fmaf(hc[q], wc.y, pc[1]);
-      pc[2] = fmaf(hc[q], wc.z, pc[2]);
-      pc[3] = fmaf(hc[q], wc.w, pc[3]);
-    }
-  }
-  Heads o;
-  o.raw_o = (po + __shfl_xor(po, 32)) + lds[M::HB];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) o.raw_c[c] = (pc[c] + __shfl_xor(pc[c], 32)) + lds[M::HB + 1 + c];
-  return o;
-}
-
-// Activations of one sample (accumulator-register order).
-template <int C>
-struct Act {
-  float x0[C / 2];
-  float h1[16], e[16], ho[16], hc[16];
-};
-
-// Nothing may be scheduled across this point.  Used to cut the sample loop body into groups of
-// "one layer's MFMAs + one plane's gather": inside a group the scheduler interleaves freely, but it
-// can no longer hoist all 24 dwordx4 loads of a sample to the top (96 live VGPRs).
-#define LP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-
-// Ask the scheduler for the issue order "1 MFMA, a few VALU, (1 global load), (1 LDS read)" N times:
-// a dependent v_mfma_f32_32x32x2_f32 chain stalls its wave 64 cycles per link (in-order issue), so
-// every instruction placed between two links is free.
-template <int N, int VALU_PER, int VMEM_EVERY>
-LP_DEV void interleave_hint() {
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // MFMA
-    if (VMEM_EVERY > 0 && (i % VMEM_EVERY) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // DS read (next operand)
-    __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER, 0);                // VALU
-  }
-}
-
-LP_DEV void load_encoding(const LpRendererArgs& a, int64_t rid, int h, float (&enc)[16]) {
-  const float4* src = reinterpret_cast<const float4*>(a.rays.encoding + rid * HID + 4 * h);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float4 v = src[2 * j];
-    enc[4 * j + 0] = v.x; enc[4 * j + 1] = v.y; enc[4 * j + 2] = v.z; enc[4 * j + 3] = v.w;
-  }
-}
-
-// geometry of one sample + its (prefetched) grid feature
-template <int C>
-struct Sample {
-  float depth, occ, x, y, z;
-  float x0[C / 2];
-};
-
-template <int C>
-LP_DEV void sample_geometry(const LpRendererArgs& a, const float* lds, const Ray& ray, int s, Sample<C>& o) {
-  o.depth = sample_depth_tab(s, a.march, ray.near_t, ray.far_t, lds + Lds::INF);
-  sample_point(ray, o.depth, a.march.contract_coords != 0, o.x, o.y, o.z);
-  o.occ = 1.0f;
-  if (a.scaffold) o.occ = scaffold_lookup(a.scaffold, a.scaffold_shape, ray.b, o.x, o.y, o.z);
-}
-
-template <int C, int GM>
-LP_DEV void fetch_sample(const LpRendererArgs& a, const float* lds, const Ray& ray, int s, int h, Sample<C>& o) {
-  sample_geometry<C>(a, lds, ray, s, o);
-  gather_features<C, GM>(a, ray, o.x, o.y, o.z, h, o.x0);
-}
-
-// Decoder of the CURRENT sample (input t.x0; fills t.h1 / t.e / t.ho / t.hc) interleaved with the
-// gather of sample `s_next` into `nx` (software pipeline).  Triplane: plane g is gathered next to
-// hidden layer g+1; voxel: taps 0-3 / 4-7 next to layers 2 / 3; generic grid-lists: whole gather
-// first.
-template <int C, int GM_, bool PREFETCH = true>
-LP_DEV Heads decode_prefetch(const LpRendererArgs& a, const float* lds, const Ray& ray, int lane,
-                             const float (&enc)[16], Act<C>& t, int s_next, Sample<C>& nx, int zo) {
-  using M = Lds;
-  // without prefetch this is the plain decoder (GM = -1 disables every gather below)
-  constexpr int GM = PREFETCH ? GM_ : -1;
-  const int h = lane >> 5;
-  // operand base of this lane; `zo` (always 0) keeps the weight reads inside the sample loop
-  const float* wl = lds + (4 * h) * W_LD + (lane & 31) + zo;
-  float keep = 1.0f;
-  if (PREFETCH) {
-    sample_geometry<C>(a, lds, ray, s_next, nx);
-    keep = (a.march.mask_out_of_bounds && !point_in_bounds(nx.x, nx.y, nx.z)) ? 0.0f : 1.0f;
-  }
-  Taps tp[GM == GM_TRIPLANE ? 3 : 1];
-  if (GM == GM_TRIPLANE) {
-#pragma unroll
-    for (int g = 0; g < 3; ++g) plane_taps<false>(a.grid.grids[g], ray.b, nx.x, nx.y, nx.z, tp[g]);
-  } else if (GM == GM_VOXEL) {
-    voxel_taps<false>(a.grid.grids[0], ray.b, nx.x, nx.y, nx.z, tp[0]);
-  } else if (GM == GM_GENERIC) {
-    gather_features<C, GM_GENERIC>(a, ray, nx.x, nx.y, nx.z, h, nx.x0);
-  }
-  if (GM == GM_TRIPLANE || GM == GM_VOXEL) {
-#pragma unroll
-    for (int q = 0; q < C / 2; ++q) nx.x0[q] = 0.0f;
-  }
-  LP_SCHED_FENCE();
-  f32x16 acc = layer<C / 2>(wl + M::WT1, t.x0, load_bias(lds, 0, h, zo));
-#pragma unroll
-  for (int q = 0; q < 16; ++q) t.h1[q] = fmaxf(acc[q], 0.0f);
-  LP_SCHED_FENCE();
-  // ---- group 1: trunk layer 2  ||  plane 0 / voxel taps 0-3 ----
-  if (GM == GM_TRIPLANE || GM == GM_VOXEL) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, tp[0].row[k], tp[0].w[k] * keep, h, nx.x0);
-  }
-  acc = layer<16>(wl + M::WT2, t.h1, load_bias(lds, 1, h, zo));
-#pragma unroll
-  for (int q = 0; q < 16; ++q) t.e[q] = fmaxf(acc[q], 0.0f);
-  if (GM == GM_TRIPLANE || GM == GM_VOXEL) interleave_hint<16, 5, 2>();
-  LP_SCHED_FENCE();
-  // ---- group 2: opacity hidden layer  ||  plane 1 / voxel taps 4-7 ----
-  if (GM == GM_TRIPLANE) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, tp[1].row[k], tp[1].w[k] * keep, h, nx.x0);
-  } else if (GM == GM_VOXEL) {
-#pragma unroll
-    for (int k = 4; k < 8; ++k) gather_tap<C>(a.grid.data, tp[0].row[k], tp[0].w[k] * keep, h, nx.x0);
-  }
-  acc = layer<16>(wl + M::WO1, t.e, load_bias(lds, 2, h, zo));
-#pragma unroll
-  for (int q = 0; q < 16; ++q) t.ho[q] = fmaxf(acc[q], 0.0f);
-  if (GM == GM_TRIPLANE || GM == GM_VOXEL) interleave_hint<16, 5, 2>();
-  LP_SCHED_FENCE();
-  // ---- group 3: colour hidden layer  ||  plane 2 ----
-  if (GM == GM_TRIPLANE) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, tp[2].row[k], tp[2].w[k] * keep, h, nx.x0);
-  }
-  float ein[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) ein[q] = t.e[q] + enc[q];
-  acc = layer<16>(wl + M::WC1, ein, load_bias(lds, 3, h, zo));
-#pragma unroll
-  for (int q = 0; q < 16; ++q) t.hc[q] = fmaxf(acc[q], 0.0f);
-  if (GM == GM_TRIPLANE) interleave_hint<16, 6, 2>();
-  LP_SCHED_FENCE();
-  return heads_forward(lds, h, t.ho, t.hc, zo);
-}
 
 // ---------------------------------------------------------------------------------------
 // forward
@@ -466,33 +121,6 @@ LP_DEV float tile_colsum(const float* ty, int lane) {
 #pragma unroll 4
   for (int rr = 0; rr < 16; ++rr) s += ty[(16 * h + rr) * TILE_LD + j];
   return s;
-}
-
-// Row-contiguous, run-length merged scatter of one grid's taps (table already in LDS).
-// Tap slot k of all 32 rays is walked in ray order by one group of C lanes (lane = channel);
-// neighbouring rays mostly fall into the same cell: contributions to the same row are summed in a
-// register and leave as ONE row-contiguous atomic per run.
-template <int C>
-LP_DEV void scatter_taps(float* grad, const float2* tab, const float* tx, int n_taps, int lane) {
-  constexpr int GRPS = 64 / C;  // rows (= taps) handled per instruction
-  const int sub = lane % C, grp = lane / C;
-  for (int k0 = 0; k0 < n_taps; k0 += GRPS) {
-    const int k = k0 + grp;
-    int cur = -1;
-    float run = 0.0f;
-#pragma unroll 4
-    for (int rr = 0; rr < 32; ++rr) {
-      const float2 e = tab[rr * 8 + k];
-      const int row = __float_as_int(e.x);
-      if (row != cur) {
-        if (cur >= 0) atomic_add_f32(grad + (int64_t)cur * C + sub, run);
-        cur = row;
-        run = 0.0f;
-      }
-      run = fmaf(e.y, tx[rr * TILE_LD + sub], run);
-    }
-    if (cur >= 0) atomic_add_f32(grad + (int64_t)cur * C + sub, run);
-  }
 }
 
 template <int C, int GM, int OCC, bool PIPE>
@@ -681,25 +309,28 @@ __global__ void __launch_bounds__(256, OCC) renderer_bwd_mfma(const LpRendererAr
     if (a.grad_grid) {
       acc = (f32x16){0};
       acc = layer_t(wt + M::WT1, dh1, acc);  // rows >= C are zero weights
-      // ---- grid gradient: transpose dx0 through LDS (tile tx), taps through the table in ty ----
+      const int rep = (int)(blockIdx.x % (unsigned)(a.n_grad_replicas + 1));
+      float* gg = rep == 0 ? a.grad_grid : a.grad_grid_replicas + (int64_t)(rep - 1) * a.grid.n_rows * C;
+      // ---- grid gradient: dx0 transposed through LDS to [channel][ray]; every lane then holds one
+      //      channel of all 32 rays (tiles tx/ty are free here and serve as scratch) ----
+      float* dxT = tx;
+      float* wT = tx + C * DX_LD;
 #pragma unroll
-      for (int q = 0; q < C / 2; ++q) tx[r * TILE_LD + featq(q, h)] = acc[q];
-      const bool live = valid && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
-      float2* tab = reinterpret_cast<float2*>(ty);  // [32 rays][8 taps] {row bits, weight}
-      const int ng = (GM == GM_TRIPLANE) ? 3 : (GM == GM_VOXEL) ? 1 : a.grid.n_grids;
-      for (int g = 0; g < ng; ++g) {
-        Taps tp;
-        if (GM == GM_TRIPLANE) plane_taps<false>(a.grid.grids[g], ray.b, x, y, z, tp);
-        else if (GM == GM_VOXEL) voxel_taps<false>(a.grid.grids[g], ray.b, x, y, z, tp);
-        else grid_taps<false>(a.grid.grids[g], ray.b, x, y, z, tp);
-        if (h == 0) {
+      for (int q = 0; q < C / 2; ++q) dxT[featq(q, h) * DX_LD + r] = acc[q];
+      float dxr[32];
+      {
+        const float4* dsrc = reinterpret_cast<const float4*>(dxT + (lane % C) * DX_LD);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const bool ok = live && tp.row[k] >= 0;
-            tab[r * 8 + k] = make_float2(__int_as_float(ok ? tp.row[k] : -1), ok ? tp.w[k] : 0.0f);
-          }
+        for (int j = 0; j < 8; ++j) {
+          const float4 v = dsrc[j];
+          dxr[4 * j + 0] = v.x; dxr[4 * j + 1] = v.y; dxr[4 * j + 2] = v.z; dxr[4 * j + 3] = v.w;
         }
-        scatter_taps<C>(a.grad_grid, tab, tx, (GM == GM_TRIPLANE) ? 4 : (GM == GM_VOXEL) ? 8 : tp.n, lane);
+      }
+      const bool live = valid && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
+      const int ng = (GM == GM_TRIPLANE) ? 3 : (GM == GM_VOXEL) ? 1 : a.grid.n_grids;
+      if (!(mp.dbg & 2)) {
+#pragma unroll 1
+        for (int g = 0; g < ng; ++g) scatter_grid<C>(gg, a.grid.grids[g], ray.b, x, y, z, live, lane, dxr, wT, mp.dbg);
       }
     }
   }
@@ -797,6 +428,8 @@ static MfmaParams make_params(const LpRendererArgs& a) {
   p.w_c2 = p.w_c1 + HID * HID;
   p.b_c1 = p.w_c2 + (int64_t)HID * p.ldc2;
   p.b_c2 = p.b_c1 + HID;
+  static const int dbg = getenv("LP_MFMA_DEBUG") ? atoi(getenv("LP_MFMA_DEBUG")) : 0;
+  p.dbg = dbg;
   return p;
 }
 
@@ -865,6 +498,28 @@ int renderer_forward_mfma(const LpRendererArgs& a, hipStream_t stream) {
   return check_launch("renderer_fwd_mfma");
 }
 
+// grad_grid[i] += sum_r replicas[r][i]  (float4 lanes; n is a multiple of 4 because C is)
+__global__ void fold_replicas_kernel(float* __restrict__ dst, const float* __restrict__ rep, int64_t n4, int n_rep) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 s = reinterpret_cast<float4*>(dst)[i];
+  for (int r = 0; r < n_rep; ++r) {
+    const float4 v = reinterpret_cast<const float4*>(rep)[(int64_t)r * n4 + i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  reinterpret_cast<float4*>(dst)[i] = s;
+}
+
+int fold_grad_replicas(const LpRendererArgs& a, hipStream_t stream) {
+  if (!a.grad_grid || !a.grad_grid_replicas || a.n_grad_replicas <= 0) return LP_OK;
+  const int64_t n = a.grid.n_rows * a.grid.channels;
+  if (n % 4 != 0) return set_error(LP_EINVAL, "grad replicas need rows*C divisible by 4");
+  const int64_t n4 = n / 4;
+  hipLaunchKernelGGL(fold_replicas_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, a.grad_grid,
+                     a.grad_grid_replicas, n4, a.n_grad_replicas);
+  return check_launch("fold_replicas_kernel");
+}
+
 int renderer_backward_mfma(const LpRendererArgs& a, hipStream_t stream) {
   const MfmaParams mp = make_params(a);
   if (n_blocks(a) == 0) return LP_OK;
@@ -885,7 +540,8 @@ int renderer_backward_mfma(const LpRendererArgs& a, hipStream_t stream) {
 #undef LP_BWD1
 #undef LP_BWD2
   if (rc) return rc;
-  return check_launch("renderer_bwd_mfma");
+  if ((rc = check_launch("renderer_bwd_mfma"))) return rc;
+  return fold_grad_replicas(a, stream);
 }
 
 }  // namespace lp

@@ -141,6 +141,14 @@ class LightplaneFunction(torch.autograd.Function):
         grad_cgrid = torch.zeros_like(color_grid) if (need_cgrid and color_grid is not None) else None
         a.grad_grid, a.grad_mlp_params = _lib.ptr(grad_grid), _lib.ptr(grad_params)
         a.grad_encoding, a.grad_color_grid = _lib.ptr(grad_enc), _lib.ptr(grad_cgrid)
+        replicas = None
+        if need_grid:
+            n_rep = config.grad_replicas
+            if n_rep is None:
+                n_rep = min(31, config.grad_replica_bytes // max(grid.numel() * 4, 1))
+            if n_rep > 0:
+                replicas = torch.zeros(n_rep, grid.numel(), device=dev, dtype=torch.float32)
+                a.grad_grid_replicas, a.n_grad_replicas = _lib.ptr(replicas), n_rep
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().lp_renderer_backward(ctypes.byref(a), stream), "lp_renderer_backward")
         if config.check_finite_grads:

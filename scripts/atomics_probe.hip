@@ -32,6 +32,18 @@ __global__ void k_atomic_coalesced(float* buf, uint32_t n_rows, int iters) {
     unsafeAtomicAdd(buf + (size_t)((h >> 8) % n_rows) * 16 + (tid & 15), 1.0f);
   }
 }
+// channel-parallel, drained (s_waitcnt vmcnt(0)) after every batch of 16 instructions: exposed latency
+__global__ void k_atomic_drain(float* buf, uint32_t n_rows, int iters) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t h = (tid / 16) * 2654435761u + 12345u;
+  for (int i = 0; i < iters; ++i) {
+    for (int j = 0; j < 16; ++j) {
+      h = h * 1664525u + 1013904223u;
+      unsafeAtomicAdd(buf + (size_t)((h >> 8) % n_rows) * 16 + (tid & 15), 1.0f);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
 // plain (non-atomic) scattered float4 stores for reference
 __global__ void k_store(float* buf, uint32_t n_rows, int iters) {
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -68,10 +80,10 @@ int main() {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const double total = (double)blocks * threads * iters * 16;
-  uint32_t rows_list[] = {12288, 196608, 1u << 22};
+  uint32_t rows_list[] = {64, 256, 1024, 4096, 12288, 196608, 1u << 22};
   printf("float atomics: %d blocks x %d thr x %d iters x 16 ch = %.3g adds\n", blocks, threads, iters, total);
   for (uint32_t rows : rows_list) {
-    for (int variant = 0; variant < 6; ++variant) {
+    for (int variant = 0; variant < 7; ++variant) {
       float ms = 0;
       for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0));
@@ -81,13 +93,14 @@ int main() {
           case 2: hipLaunchKernelGGL(k_atomic<0>, dim3(blocks), dim3(threads), 0, 0, buf, rows, iters, 8); break;
           case 3: hipLaunchKernelGGL(k_atomic_coalesced, dim3(blocks), dim3(threads), 0, 0, buf, rows, iters); break;
           case 4: hipLaunchKernelGGL(k_store, dim3(blocks), dim3(threads), 0, 0, buf, rows, iters); break;
+          case 6: hipLaunchKernelGGL(k_atomic_drain, dim3(blocks), dim3(threads), 0, 0, buf, rows, iters); break;
           case 5: hipLaunchKernelGGL(k_lds_atomic, dim3(blocks), dim3(threads), 0, 0, buf, iters, rows > 1024 ? 1024u : rows); break;
         }
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float t; CK(hipEventElapsedTime(&t, e0, e1));
         if (rep == 0 || t < ms) ms = t;
       }
-      const char* names[] = {"agent-scope lane-per-row", "wg-scope lane-per-row", "agent 8 lanes same row", "agent channel-parallel(16 lanes/row)", "plain float4 stores", "LDS ds_add_f32 (1024 rows)"};
+      const char* names[] = {"agent-scope lane-per-row", "wg-scope lane-per-row", "agent 8 lanes same row", "agent channel-parallel(16 lanes/row)", "plain float4 stores", "LDS ds_add_f32 (1024 rows)", "channel-parallel, drained every 16"};
       printf("rows=%8u  %-38s %8.3f ms  %8.2f Gadds/s  %8.1f GB/s payload\n", rows, names[variant], ms, total / ms / 1e6, total * 4 / ms / 1e6);
     }
   }
