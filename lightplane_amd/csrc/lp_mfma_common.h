@@ -136,7 +136,7 @@ LP_DEV void gather_tap(const float* data, int row, float w, int h, float (&x0)[C
   }
 }
 
-template <int C, int GM>
+template <int C, int GM, bool FENCED = false>
 LP_DEV void gather_features(const LpRendererArgs& a, const Ray& ray, float x, float y, float z, int h,
                             float (&x0)[C / 2]) {
 #pragma unroll
@@ -149,12 +149,16 @@ LP_DEV void gather_features(const LpRendererArgs& a, const Ray& ray, float x, fl
       plane_taps<false>(a.grid.grids[g], ray.b, x, y, z, t);
 #pragma unroll
       for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
+      if (FENCED) __builtin_amdgcn_sched_barrier(0);  // one plane's loads in flight at a time
     }
   } else if (GM == GM_VOXEL) {
     Taps t;
     voxel_taps<false>(a.grid.grids[0], ray.b, x, y, z, t);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
+    for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
+    if (FENCED) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 4; k < 8; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
   } else {
     for (int g = 0; g < a.grid.n_grids; ++g) {
       Taps t;
@@ -271,10 +275,10 @@ LP_DEV void sample_geometry(const LpRendererArgs& a, const float* lds, const Ray
   if (a.scaffold) o.occ = scaffold_lookup(a.scaffold, a.scaffold_shape, ray.b, o.x, o.y, o.z);
 }
 
-template <int C, int GM>
+template <int C, int GM, bool FENCED = false>
 LP_DEV void fetch_sample(const LpRendererArgs& a, const float* lds, const Ray& ray, int s, int h, Sample<C>& o) {
   sample_geometry<C>(a, lds, ray, s, o);
-  gather_features<C, GM>(a, ray, o.x, o.y, o.z, h, o.x0);
+  gather_features<C, GM, FENCED>(a, ray, o.x, o.y, o.z, h, o.x0);
 }
 
 // Decoder of the CURRENT sample (input t.x0; fills t.h1 / t.e / t.ho / t.hc) interleaved with the
@@ -417,5 +421,9 @@ LP_DEV void scatter_grid(float* gg, const LpGrid& g, int b, float x, float y, fl
     flush_run<C>(gg, s_row, s_ok, koff, kbit, sub, run, dbg);
   }
 }
+
+// second-generation backward (lp_renderer_mfma_bwd.hip); gm = GM_* grid-list shape
+int renderer_backward_mfma2(const LpRendererArgs& a, const MfmaParams& mp, int gm, hipStream_t stream);
+int fold_grad_replicas(const LpRendererArgs& a, hipStream_t stream);
 
 }  // namespace lp

@@ -524,6 +524,11 @@ int renderer_backward_mfma(const LpRendererArgs& a, hipStream_t stream) {
   const MfmaParams mp = make_params(a);
   if (n_blocks(a) == 0) return LP_OK;
   const int gm = grid_mode(a);
+  static const bool v1 = getenv("LP_MFMA_BWD_V1") != nullptr;  // first-generation kernel (A/B timing)
+  if (!v1) {
+    const int rc2 = renderer_backward_mfma2(a, mp, gm, stream);
+    return rc2 ? rc2 : fold_grad_replicas(a, stream);
+  }
   // waves per SIMD the backward kernel is register-allocated for (tuning knob)
   static const int occ = [] {
     const char* e = getenv("LP_MFMA_BWD_OCC");

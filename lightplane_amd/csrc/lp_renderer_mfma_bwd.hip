@@ -1,0 +1,460 @@
+// lp_renderer_mfma_bwd.hip -- Renderer backward on the CDNA4 matrix cores, second generation.
+//
+// Same maths and the same lane <-> (ray, feature) mapping as the forward kernel
+// (lp_renderer_mfma.hip): far -> near sweep that recomputes the decoder of every sample, then
+// back-propagates through it.  What is different from the first-generation backward is where the
+// WEIGHT gradients live.  dW = X^T dY contracts over rays; a wave that keeps the four 32x32 tiles
+// of its own 32 rays needs 64 accumulator registers for the whole kernel, which (with the
+// activations of the recompute) does not fit the 256-register budget of two waves per SIMD: the
+// compiler spilled ~200 registers and the kernel ran at a quarter of the MFMA rate.  Here the four
+// waves of a workgroup SHARE the contraction: every wave publishes its X / dY tiles of the current
+// layer in LDS (feature-major, [feature][ray]), the workgroup synchronises, and wave w accumulates
+// ONE 16x16 quadrant of the layer's dW over all 128 rays with v_mfma_f32_16x16x4_f32 (4
+// accumulator registers per layer, 16 in total).  Operands arrive as ds_read_b128 (8 rays per
+// lane), the bias gradient is a by-product of the B operand, nothing is summed across waves at
+// the end.  The ray encoding lives in LDS as well; the kernel has no scratch.
+//
+// LDS tiles are feature-major with a row stride of 36 floats: the transposing writes are 32
+// consecutive lanes per row (conflict-free), the quadrant reads are conflict-free once the 16
+// features of a quadrant are dealt to the MFMA lanes as even | odd | even (pi() below).
+#include "lp_mfma_common.h"
+
+namespace lp {
+
+#ifdef LP_ASM_MARKS
+#define LP_MARK(n) asm volatile("; LPMARK " n)
+#else
+#define LP_MARK(n)
+#endif
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define LP_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int T_LD = 36;  // row stride of the feature-major tiles [32 features][32 rays + 4]
+
+// per-wave LDS area behind the weights (floats)
+struct LdsB {
+  static constexpr int WAVE0 = Lds::FWD_END;
+  static constexpr int XT = 0;                  // X  tile [32][36] (also: dx0 tile of the scatter)
+  static constexpr int YT = 32 * T_LD;          // dY tile [32][36]
+  static constexpr int ENC = 2 * 32 * T_LD;     // ray encoding [32 rays][36]
+  static constexpr int TS = 3 * 32 * T_LD;      // [5][32]: d raw_o, d raw_c[0..3] by ray
+  static constexpr int WTAB = TS + 5 * 32;      // [8][32] tap weights of the scatter
+  static constexpr int PER_WAVE = WTAB + 8 * 32;
+  static constexpr int END = WAVE0 + WAVES * PER_WAVE;
+};
+static_assert(2 * LdsB::END * 4 <= 160 * 1024, "two workgroups per CU must fit the 160 KB LDS");
+
+// feature of a 16-wide quadrant handled by MFMA lane index m (bank-conflict-free b128 reads)
+LP_DEV constexpr int pi16(int m) { return m < 4 ? 2 * m : (m < 12 ? 2 * (m - 4) + 1 : 2 * (m - 8)); }
+
+// workgroup barrier that only drains LDS traffic (a __syncthreads() would also wait for the
+// outstanding global atomics of the gradient scatter)
+LP_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// 16-register activation (accumulator order) -> feature-major tile
+LP_DEV void tile_store_fm(float* tile, int r, int h, const float (&v)[16]) {
+#pragma unroll
+  for (int q = 0; q < 16; ++q) tile[featq(q, h) * T_LD + r] = v[q];
+}
+
+// ein = e + ray encoding (this lane's 16 features; `enc` points at the lane's first chunk)
+LP_DEV void add_encoding(const float* enc, const float (&e)[16], float (&ein)[16]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 v = *reinterpret_cast<const float4*>(enc + 8 * j);
+    ein[4 * j + 0] = e[4 * j + 0] + v.x;
+    ein[4 * j + 1] = e[4 * j + 1] + v.y;
+    ein[4 * j + 2] = e[4 * j + 2] + v.z;
+    ein[4 * j + 3] = e[4 * j + 3] + v.w;
+  }
+}
+
+// dW quadrant of one layer over the rays of the source waves [v0, v1): acc += X^T dY.
+// a_off / b_off: float offsets of this lane's rows inside a wave area (tile + feature*T_LD + 8*(lane>>4)).
+LP_DEV f32x4 dw_quadrant(const float* wave0, int a_off, int b_off, int v0, int v1, f32x4 acc, float& db) {
+  float s = 0.0f;
+  for (int v = v0; v < v1; ++v) {
+    const float* base = wave0 + v * LdsB::PER_WAVE;
+    const float4 a0 = *reinterpret_cast<const float4*>(base + a_off);
+    const float4 a1 = *reinterpret_cast<const float4*>(base + a_off + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(base + b_off);
+    const float4 b1 = *reinterpret_cast<const float4*>(base + b_off + 4);
+    acc = LP_MFMA16(a0.x, b0.x, acc);
+    acc = LP_MFMA16(a0.y, b0.y, acc);
+    acc = LP_MFMA16(a0.z, b0.z, acc);
+    acc = LP_MFMA16(a0.w, b0.w, acc);
+    acc = LP_MFMA16(a1.x, b1.x, acc);
+    acc = LP_MFMA16(a1.y, b1.y, acc);
+    acc = LP_MFMA16(a1.z, b1.z, acc);
+    acc = LP_MFMA16(a1.w, b1.w, acc);
+    s += ((b0.x + b0.y) + (b0.z + b0.w)) + ((b1.x + b1.y) + (b1.z + b1.w));
+  }
+  db += s;
+  return acc;
+}
+
+template <int C, int GM>
+__global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArgs a, const MfmaParams mp) {
+  using M = Lds;
+  using B = LdsB;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_weights<C, false>(a, mp, lds);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, r = lane & 31;
+  float* const wave0 = lds + B::WAVE0;
+  float* const wv = wave0 + wave * B::PER_WAVE;
+  float* const xt = wv + B::XT;
+  float* const yt = wv + B::YT;
+  float* const enct = wv + B::ENC;
+  float* const ts = wv + B::TS;
+  float* const wtab = wv + B::WTAB;
+
+  const int64_t ray_id = ((int64_t)blockIdx.x * WAVES + wave) * RAYS_PER_WAVE + r;
+  const bool valid = ray_id < a.rays.n_rays;
+  const int64_t rid = valid ? ray_id : 0;
+  const Ray ray = load_ray(a.rays, rid);
+  {  // ray encoding -> LDS, [ray][36]
+    const float4* src = reinterpret_cast<const float4*>(a.rays.encoding + rid * HID + 4 * h);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(enct + r * T_LD + 8 * j + 4 * h) = src[2 * j];
+  }
+  __syncthreads();
+
+  float denc[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) denc[q] = 0.0f;
+  float gfeat[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    gfeat[c] = (valid && a.grad_feature && c < a.color_chn) ? a.grad_feature[rid * a.color_chn + c] : 0.0f;
+  const float g_len = (valid && a.grad_ray_length) ? a.grad_ray_length[rid] : 0.0f;
+  const float g_nlt = (valid && a.grad_neg_log_t) ? a.grad_neg_log_t[rid] : 0.0f;
+
+  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
+  const int n_ckpt = ckpt_count(a.march);
+  const bool want_params = a.grad_mlp_params != nullptr;
+  const float delta0 = (a.march.num_samples > 1) ? (ray.far_t - ray.near_t) / (float)(a.march.num_samples - 1) : 1.0f;
+
+  // dW quadrant of this wave: rows 16*mi.., columns 16*ni..; MFMA lane (m16, ka)
+  const int mi = wave >> 1, ni = wave & 1;
+  const int m16 = lane & 15, ka = lane >> 4;
+  const int a_off = B::XT + (16 * mi + pi16(m16)) * T_LD + 8 * ka;
+  const int b_off = B::YT + (16 * ni + pi16(m16)) * T_LD + 8 * ka;
+  // trunk layer 1 has only C input rows: with C == 16 its two quadrants are split over the rays instead
+  const int a_off_t1 = (C == 16) ? B::XT + pi16(m16) * T_LD + 8 * ka : a_off;
+  const int t1_v0 = (C == 16) ? 2 * mi : 0, t1_v1 = (C == 16) ? 2 * mi + 2 : WAVES;
+  f32x4 dq_t1 = {0, 0, 0, 0}, dq_t2 = {0, 0, 0, 0}, dq_o1 = {0, 0, 0, 0}, dq_c1 = {0, 0, 0, 0};
+  float db_t1 = 0.0f, db_t2 = 0.0f, db_o1 = 0.0f, db_c1 = 0.0f;
+  // output layers of the heads: lane (f = l&31, half h) owns feature f, partial over 16 rays
+  float dwo2 = 0.0f, dwc2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float dbo2 = 0.0f, dbc2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+  const int rep = (int)(blockIdx.x % (unsigned)(a.n_grad_replicas + 1));
+  float* const gg = !a.grad_grid ? nullptr
+                    : (rep == 0 ? a.grad_grid : a.grad_grid_replicas + (int64_t)(rep - 1) * a.grid.n_rows * C);
+
+  float nlt = a.neg_log_t[rid];
+  float suffix = 0.0f, p_next = 0.0f;
+  Sample<C> nx;
+  fetch_sample<C, GM>(a, lds, ray, s_tot - 1, h, nx);
+  for (int s = s_tot - 1; s >= 0; --s) {
+    const float depth = nx.depth, occ = nx.occ, x = nx.x, y = nx.y, z = nx.z;
+    float x0[C / 2];
+#pragma unroll
+    for (int q = 0; q < C / 2; ++q) x0[q] = nx.x0[q];
+    const int zo = opaque_zero();
+    const float* ldz = lds + zo;
+    const float* wl = lds + (4 * h) * W_LD + r + zo;   // forward operand base of this lane
+    const float* wt = lds + r * W_LD + 4 * h + zo;     // dX operand base of this lane
+
+    // ---------------- forward recompute ----------------
+    LP_MARK("fwd");
+    float h1[16], e[16], ho[16], hc[16];
+    f32x16 acc = layer<C / 2>(wl + M::WT1, x0, load_bias(lds, 0, h, zo));
+#pragma unroll
+    for (int q = 0; q < 16; ++q) h1[q] = fmaxf(acc[q], 0.0f);
+    acc = layer<16>(wl + M::WT2, h1, load_bias(lds, 1, h, zo));
+#pragma unroll
+    for (int q = 0; q < 16; ++q) e[q] = fmaxf(acc[q], 0.0f);
+    acc = layer<16>(wl + M::WO1, e, load_bias(lds, 2, h, zo));
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ho[q] = fmaxf(acc[q], 0.0f);
+    {
+      float ein[16];
+      add_encoding(enct + zo + r * T_LD + 4 * h, e, ein);
+      acc = layer<16>(wl + M::WC1, ein, load_bias(lds, 3, h, zo));
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) hc[q] = fmaxf(acc[q], 0.0f);
+    const Heads hd = heads_forward(lds, h, ho, hc, zo);
+    LP_SCHED_FENCE();
+    // ho / hc go to the (wave-private) tiles now: their registers turn into d ho / d hc below
+    if (want_params) {
+      tile_store_fm(xt, r, h, ho);
+      tile_store_fm(yt, r, h, hc);
+    }
+    LP_SCHED_FENCE();
+
+    // ---------------- compositing, backward ----------------
+    LP_MARK("compositing");
+    const float depth_prev = sample_depth_tab((s > 0) ? s - 1 : 0, a.march, ray.near_t, ray.far_t, lds + M::INF);
+    const float delta = (s == 0) ? delta0 : depth - depth_prev;
+    float raw = hd.raw_o;
+    if (a.noise_sigma > 0.0f) raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
+    const float opacity = a.gain * softplus_f(raw) * occ;
+    if (a.neg_log_t_ckpt) {
+      const int ck = ckpt_index(s, a.march);
+      if (ck >= 0) nlt = a.neg_log_t_ckpt[rid * n_ckpt + ck];
+    }
+    const float t_i = __expf(-nlt);
+    nlt = fmaxf(nlt - opacity * delta, 0.0f);
+    const float t_im1 = __expf(-nlt);
+    const float w = t_im1 - t_i;
+    float sg[4];
+    float p_i = g_len * depth;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      sg[c] = sigmoid_f(hd.raw_c[c]);
+      p_i = fmaf(gfeat[c], sg[c] * occ, p_i);
+    }
+    suffix = fmaf(t_i, p_i - p_next, suffix);
+    p_next = p_i;
+    const float d_a = suffix + g_nlt;
+    const float dro = valid ? d_a * delta * a.gain * occ * d_softplus_f(raw) : 0.0f;
+    float drc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) drc[c] = valid ? w * gfeat[c] * occ * sg[c] * (1.0f - sg[c]) : 0.0f;
+
+    // ---------------- output layers of the heads (VALU) ----------------
+    LP_MARK("heads_bwd");
+    float dho[16], dhc[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 wo = *reinterpret_cast<const float4*>(ldz + M::WO2 + 8 * j + 4 * h);
+      const float wov[4] = {wo.x, wo.y, wo.z, wo.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = 4 * j + i;
+        const float4 wc = *reinterpret_cast<const float4*>(ldz + M::WC2 + (8 * j + 4 * h + i) * 4);
+        dho[q] = (ho[q] > 0.0f) ? dro * wov[i] : 0.0f;
+        float v = drc[0] * wc.x;
+        v = fmaf(drc[1], wc.y, v);
+        v = fmaf(drc[2], wc.z, v);
+        v = fmaf(drc[3], wc.w, v);
+        dhc[q] = (hc[q] > 0.0f) ? v : 0.0f;
+      }
+    }
+    LP_SCHED_FENCE();
+    if (h == 0) {  // per-ray scalars: count each ray once
+      dbo2 += dro;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dbc2[c] += drc[c];
+    }
+#ifndef X_NOHEADDW
+    if (want_params) {
+      // dW of the two output layers: dW[f] += sum_ray h[ray][f] * d_raw[ray] (wave-private tiles)
+      if (h == 0) {
+        ts[r] = dro;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ts[(1 + c) * 32 + r] = drc[c];
+      }
+      const float* xf = xt + r * T_LD + 16 * h;  // lane (f = r, half h): rays 16h .. 16h+15 of feature f
+      const float* yf = yt + r * T_LD + 16 * h;
+      const float* tf = ts + 16 * h;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 hov = *reinterpret_cast<const float4*>(xf + 4 * i);
+        const float4 hcv = *reinterpret_cast<const float4*>(yf + 4 * i);
+        const float4 d0 = *reinterpret_cast<const float4*>(tf + 4 * i);
+        dwo2 = fmaf(hov.x, d0.x, dwo2); dwo2 = fmaf(hov.y, d0.y, dwo2);
+        dwo2 = fmaf(hov.z, d0.z, dwo2); dwo2 = fmaf(hov.w, d0.w, dwo2);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 dc = *reinterpret_cast<const float4*>(tf + (1 + c) * 32 + 4 * i);
+          dwc2[c] = fmaf(hcv.x, dc.x, dwc2[c]); dwc2[c] = fmaf(hcv.y, dc.y, dwc2[c]);
+          dwc2[c] = fmaf(hcv.z, dc.z, dwc2[c]); dwc2[c] = fmaf(hcv.w, dc.w, dwc2[c]);
+        }
+        LP_SCHED_FENCE();  // keeps the 28 b128 reads from being hoisted together (112 registers)
+      }
+    }
+#endif
+    LP_SCHED_FENCE();
+
+    // ---------------- colour hidden layer ----------------
+    LP_MARK("c1");
+    if (want_params) {
+      float ein[16];
+      add_encoding(enct + zo + r * T_LD + 4 * h, e, ein);
+      tile_store_fm(xt, r, h, ein);
+      tile_store_fm(yt, r, h, dhc);
+      lds_barrier();
+      dq_c1 = dw_quadrant(wave0, a_off, b_off, 0, WAVES, dq_c1, db_c1);
+    }
+    acc = (f32x16){0};
+    acc = layer_t(wt + M::WC1, dhc, acc);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) denc[q] += acc[q];
+    if (want_params) lds_barrier();
+    LP_SCHED_FENCE();
+    // ---------------- opacity hidden layer ----------------
+    LP_MARK("o1");
+    if (want_params) {
+      tile_store_fm(xt, r, h, e);
+      tile_store_fm(yt, r, h, dho);
+      lds_barrier();
+      dq_o1 = dw_quadrant(wave0, a_off, b_off, 0, WAVES, dq_o1, db_o1);
+    }
+    acc = layer_t(wt + M::WO1, dho, acc);
+    float de[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) de[q] = (e[q] > 0.0f) ? acc[q] : 0.0f;
+    if (want_params) lds_barrier();
+    LP_SCHED_FENCE();
+    // ---------------- trunk layer 2 ----------------
+    LP_MARK("t2");
+    if (want_params) {
+      tile_store_fm(xt, r, h, h1);
+      tile_store_fm(yt, r, h, de);
+      lds_barrier();
+      dq_t2 = dw_quadrant(wave0, a_off, b_off, 0, WAVES, dq_t2, db_t2);
+    }
+    acc = (f32x16){0};
+    acc = layer_t(wt + M::WT2, de, acc);
+    float dh1[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dh1[q] = (h1[q] > 0.0f) ? acc[q] : 0.0f;
+    if (want_params) lds_barrier();
+    LP_SCHED_FENCE();
+    // ---------------- trunk layer 1 ----------------
+    LP_MARK("t1");
+    if (want_params) {
+#pragma unroll
+      for (int q = 0; q < C / 2; ++q) xt[featq(q, h) * T_LD + r] = x0[q];
+      tile_store_fm(yt, r, h, dh1);
+      lds_barrier();
+      dq_t1 = dw_quadrant(wave0, a_off_t1, b_off, t1_v0, t1_v1, dq_t1, db_t1);
+    }
+    if (gg) {
+      acc = (f32x16){0};
+      acc = layer_t(wt + M::WT1, dh1, acc);  // rows >= C are zero weights
+    }
+    if (want_params) lds_barrier();
+    LP_SCHED_FENCE();
+    // ---------------- next (nearer) sample: gather before this sample's atomics ----------------
+    LP_MARK("fetch");
+#ifndef X_NOFETCH
+    if (s > 0) fetch_sample<C, GM, true>(a, lds, ray, s - 1, h, nx);
+#endif
+    LP_SCHED_FENCE();
+    // ---------------- grid gradient ----------------
+    LP_MARK("scatter");
+    if (gg) {
+      float* dxT = xt;
+#pragma unroll
+      for (int q = 0; q < C / 2; ++q) dxT[featq(q, h) * DX_LD + r] = acc[q];
+      float dxr[32];
+      {
+        const float4* dsrc = reinterpret_cast<const float4*>(dxT + (lane % C) * DX_LD);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float4 v = dsrc[j];
+          dxr[4 * j + 0] = v.x; dxr[4 * j + 1] = v.y; dxr[4 * j + 2] = v.z; dxr[4 * j + 3] = v.w;
+        }
+      }
+      const bool live = valid && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
+      const int ng = (GM == GM_TRIPLANE) ? 3 : (GM == GM_VOXEL) ? 1 : a.grid.n_grids;
+#ifndef X_NOSCATTER
+      if (!(mp.dbg & 2)) {
+#pragma unroll 1
+        for (int g = 0; g < ng; ++g) scatter_grid<C>(gg, a.grid.grids[g], ray.b, x, y, z, live, lane, dxr, wtab, mp.dbg);
+      }
+#endif
+      // the dx0 tile shares LDS with the X tile other waves' quadrants read: done before they rewrite
+    }
+  }
+
+  // ---------------- epilogue ----------------
+    LP_MARK("epilogue");
+  if (valid && a.grad_encoding) {
+    float4* dst = reinterpret_cast<float4*>(a.grad_encoding + ray_id * HID + 4 * h);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[2 * j] = make_float4(denc[4 * j], denc[4 * j + 1], denc[4 * j + 2], denc[4 * j + 3]);
+  }
+  if (want_params) {
+    float* G = a.grad_mlp_params;
+    const int j = lane & 31;
+    // head output layers: lane (f, h) holds the partial over the 16 rays of its half
+    atomic_add_f32(G + mp.w_o2 + j, dwo2);
+    for (int c = 0; c < a.color_chn; ++c) atomic_add_f32(G + mp.w_c2 + (int64_t)j * mp.ldc2 + c, dwc2[c]);
+    float v = dbo2, c0 = dbc2[0], c1 = dbc2[1], c2 = dbc2[2], c3 = dbc2[3];
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) {
+      v += __shfl_xor(v, m);
+      c0 += __shfl_xor(c0, m);
+      c1 += __shfl_xor(c1, m);
+      c2 += __shfl_xor(c2, m);
+      c3 += __shfl_xor(c3, m);
+    }
+    if (lane == 0) {
+      atomic_add_f32(G + mp.b_o2, v);
+      const float cv[4] = {c0, c1, c2, c3};
+      for (int c = 0; c < a.color_chn; ++c) atomic_add_f32(G + mp.b_c2 + c, cv[c]);
+    }
+    // dW quadrants: register i of lane (n16 = l&15, ka = l>>4) is dW[m0 + pi(4ka+i)][n0 + pi(n16)]
+    const int col = 16 * ni + pi16(m16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int prow = pi16(4 * ka + i);
+      const int row = 16 * mi + prow;
+      atomic_add_f32(G + mp.w_t2 + row * 32 + col, dq_t2[i]);
+      atomic_add_f32(G + mp.w_o1 + row * 32 + col, dq_o1[i]);
+      atomic_add_f32(G + mp.w_c1 + row * 32 + col, dq_c1[i]);
+      const int row1 = (C == 16) ? prow : row;
+      if (row1 < C) atomic_add_f32(G + mp.w_t1 + row1 * 32 + col, dq_t1[i]);
+    }
+    // bias gradients: partial over the rays 8ka.. of every source wave -> sum over ka
+    db_t1 += __shfl_xor(db_t1, 16); db_t1 += __shfl_xor(db_t1, 32);
+    db_t2 += __shfl_xor(db_t2, 16); db_t2 += __shfl_xor(db_t2, 32);
+    db_o1 += __shfl_xor(db_o1, 16); db_o1 += __shfl_xor(db_o1, 32);
+    db_c1 += __shfl_xor(db_c1, 16); db_c1 += __shfl_xor(db_c1, 32);
+    if (ka == 0) {
+      if (mi == 0) {  // both quadrant rows see the same dY columns: count them once
+        atomic_add_f32(G + mp.b_t2 + col, db_t2);
+        atomic_add_f32(G + mp.b_o1 + col, db_o1);
+        atomic_add_f32(G + mp.b_c1 + col, db_c1);
+      }
+      if (C == 16 || mi == 0) atomic_add_f32(G + mp.b_t1 + col, db_t1);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+
+template <int C, int GM>
+static int launch_bwd2(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
+  const size_t lds = LdsB::END * sizeof(float);
+  const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_mfma2<C, GM>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  const unsigned nb = (unsigned)((a.rays.n_rays + WAVES * RAYS_PER_WAVE - 1) / (WAVES * RAYS_PER_WAVE));
+  hipLaunchKernelGGL((renderer_bwd_mfma2<C, GM>), dim3(nb), dim3(256), lds, stream, a, mp);
+  return LP_OK;
+}
+
+int renderer_backward_mfma2(const LpRendererArgs& a, const MfmaParams& mp, int gm, hipStream_t stream) {
+  int rc;
+#define LP_B2(CV)                                                       \
+  switch (gm) {                                                         \
+    case GM_TRIPLANE: rc = launch_bwd2<CV, GM_TRIPLANE>(a, mp, stream); break; \
+    case GM_VOXEL: rc = launch_bwd2<CV, GM_VOXEL>(a, mp, stream); break;       \
+    default: rc = launch_bwd2<CV, GM_GENERIC>(a, mp, stream); break;           \
+  }
+  if (a.grid.channels == 16) { LP_B2(16) } else { LP_B2(32) }
+#undef LP_B2
+  if (rc) return rc;
+  return check_launch("renderer_bwd_mfma2");
+}
+
+}  // namespace lp
