@@ -18,7 +18,7 @@ SOURCES = ["lp_api.hip", "lp_renderer_generic.hip", "lp_renderer_mfma.hip", "lp_
 HEADERS = ["lp_device.h", "lp_host.h", "lp_mfma_common.h", os.path.join("..", "..", "include", "lightplane_hip.h")]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-    "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+    "-fno-gpu-rdc", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
 ]
 
 

@@ -351,7 +351,15 @@ LP_DEV float scaffold_lookup(const float* scaffold, const LpGrid& s, int b, floa
 // activations
 // ---------------------------------------------------------------------------------------
 
-LP_DEV float softplus_f(float x) { return (x > 20.0f) ? x : log1pf(__expf(x)); }
+// softplus (torch: beta 1, linear above 20).  log1p(e) through the hardware log for e >= 2^-6 and
+// through its series below (|error| < 3e-8 there): a handful of VALU ops instead of libm's log1pf.
+LP_DEV float softplus_f(float x) {
+  const float e = __expf(x);
+  const float series = e * fmaf(e, fmaf(e, 0.333333343f, -0.5f), 1.0f);
+  const float lg = __logf(1.0f + e);
+  const float sp = (e < 0.015625f) ? series : lg;
+  return (x > 20.0f) ? x : sp;
+}
 LP_DEV float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 // d softplus / dx (torch: threshold 20 -> 1)
 LP_DEV float d_softplus_f(float x) { return (x > 20.0f) ? 1.0f : sigmoid_f(x); }

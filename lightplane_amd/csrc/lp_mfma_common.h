@@ -25,7 +25,6 @@ LP_DEV int opaque_zero() {
 }
 
 constexpr int HID = 32;        // hidden width of the shape family
-constexpr int TILE_LD = 33;    // padded row stride of the per-wave transposition tiles
 constexpr int W_LD = 33;       // padded row stride of the weight matrices in LDS
 constexpr int WAVES = 4;       // waves per workgroup
 constexpr int RAYS_PER_WAVE = 32;
@@ -59,17 +58,9 @@ struct Lds {
   static constexpr int HB = WC2 + 32 * 4;        // bo2, bc2[0..3], pad -> 8
   static constexpr int INF = HB + 8;             // [MAX_INF] depth scale of the beyond-far samples
   static constexpr int FWD_END = INF + MAX_INF;
-  // backward only: block-wide dW sum (epilogue), then per-wave scratch
-  static constexpr int DW = FWD_END;             // 4 x [32][32]: t1, t2, o1, c1
-  static constexpr int WAVE0 = DW + 4 * 1024;
-  static constexpr int TX = 0;                   // per-wave: two transposition tiles [32][33] ...
-  static constexpr int TY = 32 * TILE_LD;
-  static constexpr int TS = 2 * 32 * TILE_LD;    // ... + [32 rays][8]: dro, drc[0..3] of the current sample
-  static constexpr int PER_WAVE = 2 * 32 * TILE_LD + 32 * 8;
-  static constexpr int BWD_END = WAVE0 + WAVES * PER_WAVE;
 };
 
-template <int C, bool BWD>
+template <int C>
 LP_DEV void stage_weights(const LpRendererArgs& a, const MfmaParams& mp, float* lds) {
   using M = Lds;
   const float* P = a.mlp_params;
@@ -81,12 +72,6 @@ LP_DEV void stage_weights(const LpRendererArgs& a, const MfmaParams& mp, float* 
     lds[M::WT2 + d] = P[mp.w_t2 + i];
     lds[M::WO1 + d] = P[mp.w_o1 + i];
     lds[M::WC1 + d] = P[mp.w_c1 + i];
-    if (BWD) {
-      lds[M::DW + i] = 0.0f;
-      lds[M::DW + 1024 + i] = 0.0f;
-      lds[M::DW + 2048 + i] = 0.0f;
-      lds[M::DW + 3072 + i] = 0.0f;
-    }
   }
   for (int i = tid; i < 32; i += 256) {
     lds[M::BIAS + i] = P[mp.b_t1 + i];
@@ -267,17 +252,24 @@ struct Sample {
   float x0[C / 2];
 };
 
-template <int C>
+// PLAIN: no beyond-far samples, no contraction, no scaffold (the kernels are specialised on it)
+template <int C, bool PLAIN = false>
 LP_DEV void sample_geometry(const LpRendererArgs& a, const float* lds, const Ray& ray, int s, Sample<C>& o) {
+  if (PLAIN) {
+    o.depth = ray.near_t + lin01(s, a.march.num_samples) * (ray.far_t - ray.near_t);
+    sample_point(ray, o.depth, false, o.x, o.y, o.z);
+    o.occ = 1.0f;
+    return;
+  }
   o.depth = sample_depth_tab(s, a.march, ray.near_t, ray.far_t, lds + Lds::INF);
   sample_point(ray, o.depth, a.march.contract_coords != 0, o.x, o.y, o.z);
   o.occ = 1.0f;
   if (a.scaffold) o.occ = scaffold_lookup(a.scaffold, a.scaffold_shape, ray.b, o.x, o.y, o.z);
 }
 
-template <int C, int GM, bool FENCED = false>
+template <int C, int GM, bool FENCED = false, bool PLAIN = false>
 LP_DEV void fetch_sample(const LpRendererArgs& a, const float* lds, const Ray& ray, int s, int h, Sample<C>& o) {
-  sample_geometry<C>(a, lds, ray, s, o);
+  sample_geometry<C, PLAIN>(a, lds, ray, s, o);
   gather_features<C, GM, FENCED>(a, ray, o.x, o.y, o.z, h, o.x0);
 }
 
@@ -357,8 +349,9 @@ LP_DEV Heads decode_prefetch(const LpRendererArgs& a, const float* lds, const Ra
 }
 
 // Gradient scatter of one grid, row-contiguous and run-length merged.
-// dx0 of the wave's 32 rays has been transposed through LDS: every lane holds ONE channel (`sub`) of
-// all 32 rays in registers (dx[]), lane group `grp` (C lanes) works on tap slot k.  Rays are walked
+// dx0 of the wave's 32 rays has been transposed through LDS ([channel][ray], row stride DX_LD):
+// every lane reads ONE channel (`sub`, row `dxrow`) of the rays, lane group `grp` (C lanes) works on
+// tap slot k.  Rays are walked
 // in order; consecutive rays that fall into the same cell (the common case for image-coherent rays)
 // are summed in a register and leave as ONE atomic per row whose C lanes cover the C contiguous
 // floats of the row.  All slots of a grid change cell together, so the run boundaries are a
@@ -373,7 +366,7 @@ LP_DEV void flush_run(float* gg, int s_row, unsigned s_ok, int koff, unsigned kb
 
 template <int C>
 LP_DEV void scatter_grid(float* gg, const LpGrid& g, int b, float x, float y, float z, bool live, int lane,
-                         const float (&dx)[32], float* wT, int dbg) {
+                         const float* dxrow, float* wT, int dbg) {
   constexpr int GRPS = 64 / C;  // tap slots per pass
   const int h = lane >> 5, r = lane & 31, sub = lane % C, grp = lane / C;
   TapSet tp;
@@ -398,25 +391,29 @@ LP_DEV void scatter_grid(float* gg, const LpGrid& g, int b, float x, float y, fl
     const int k = p * GRPS + grp;
     const int koff = (k & 1) * tp.su + ((k >> 1) & 1) * tp.sv + (k >> 2) * tp.st;
     const unsigned kbit = 1u << k;
-    float w[32];
     const float4* wsrc = reinterpret_cast<const float4*>(wT + k * 32);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float4 v = wsrc[j];
-      w[4 * j + 0] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
-    }
+    const float4* dsrc = reinterpret_cast<const float4*>(dxrow);
     float run = 0.0f;
     int s_row = __builtin_amdgcn_readlane(row0, 0);
     unsigned s_ok = (unsigned)__builtin_amdgcn_readlane(ok, 0);
 #pragma unroll
-    for (int rr = 0; rr < 32; ++rr) {
-      if (rr > 0 && ((mask >> rr) & 1u)) {
-        flush_run<C>(gg, s_row, s_ok, koff, kbit, sub, run, dbg);
-        run = 0.0f;
-        s_row = __builtin_amdgcn_readlane(row0, rr);
-        s_ok = (unsigned)__builtin_amdgcn_readlane(ok, rr);
+    for (int c8 = 0; c8 < 4; ++c8) {  // 8 rays at a time: 16 live operand registers
+      const float4 w0 = wsrc[2 * c8], w1 = wsrc[2 * c8 + 1];
+      const float4 d0 = dsrc[2 * c8], d1 = dsrc[2 * c8 + 1];
+      const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+      const float dx[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rr = 8 * c8 + i;
+        if (rr > 0 && ((mask >> rr) & 1u)) {
+          flush_run<C>(gg, s_row, s_ok, koff, kbit, sub, run, dbg);
+          run = 0.0f;
+          s_row = __builtin_amdgcn_readlane(row0, rr);
+          s_ok = (unsigned)__builtin_amdgcn_readlane(ok, rr);
+        }
+        run = fmaf(w[i], dx[i], run);
       }
-      run = fmaf(w[rr], dx[rr], run);
+      __builtin_amdgcn_sched_barrier(0);
     }
     flush_run<C>(gg, s_row, s_ok, koff, kbit, sub, run, dbg);
   }

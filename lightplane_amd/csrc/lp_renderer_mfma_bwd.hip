@@ -93,12 +93,12 @@ LP_DEV f32x4 dw_quadrant(const float* wave0, int a_off, int b_off, int v0, int v
   return acc;
 }
 
-template <int C, int GM>
+template <int C, int GM, bool PLAIN>
 __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArgs a, const MfmaParams mp) {
   using M = Lds;
   using B = LdsB;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_weights<C, false>(a, mp, lds);
+  stage_weights<C>(a, mp, lds);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, r = lane & 31;
   float* const wave0 = lds + B::WAVE0;
@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
   float nlt = a.neg_log_t[rid];
   float suffix = 0.0f, p_next = 0.0f;
   Sample<C> nx;
-  fetch_sample<C, GM>(a, lds, ray, s_tot - 1, h, nx);
+  fetch_sample<C, GM, false, PLAIN>(a, lds, ray, s_tot - 1, h, nx);
   for (int s = s_tot - 1; s >= 0; --s) {
     const float depth = nx.depth, occ = nx.occ, x = nx.x, y = nx.y, z = nx.z;
     float x0[C / 2];
@@ -197,13 +197,17 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
 
     // ---------------- compositing, backward ----------------
     LP_MARK("compositing");
-    const float depth_prev = sample_depth_tab((s > 0) ? s - 1 : 0, a.march, ray.near_t, ray.far_t, lds + M::INF);
+    const float depth_prev =
+        PLAIN ? ray.near_t + lin01((s > 0) ? s - 1 : 0, a.march.num_samples) * (ray.far_t - ray.near_t)
+              : sample_depth_tab((s > 0) ? s - 1 : 0, a.march, ray.near_t, ray.far_t, lds + M::INF);
     const float delta = (s == 0) ? delta0 : depth - depth_prev;
     float raw = hd.raw_o;
-    if (a.noise_sigma > 0.0f) raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
+    if (!PLAIN && a.noise_sigma > 0.0f)
+      raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
     const float opacity = a.gain * softplus_f(raw) * occ;
     if (a.neg_log_t_ckpt) {
-      const int ck = ckpt_index(s, a.march);
+      const int ck = PLAIN ? ((((s + 1) % LP_NLT_CKPT) == 0 || s == s_tot - 1) ? s / LP_NLT_CKPT : -1)
+                           : ckpt_index(s, a.march);
       if (ck >= 0) nlt = a.neg_log_t_ckpt[rid * n_ckpt + ck];
     }
     const float t_i = __expf(-nlt);
@@ -227,21 +231,28 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
 
     // ---------------- output layers of the heads (VALU) ----------------
     LP_MARK("heads_bwd");
-    float dho[16], dhc[16];
+    // d ho is formed where it is needed (opacity hidden layer): keep only the ReLU mask of ho
+    unsigned ho_mask = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float4 wo = *reinterpret_cast<const float4*>(ldz + M::WO2 + 8 * j + 4 * h);
-      const float wov[4] = {wo.x, wo.y, wo.z, wo.w};
+    for (int q = 0; q < 16; ++q) ho_mask |= (ho[q] > 0.0f) ? (1u << q) : 0u;
+    float dhc[16];
+    {
+      // a fresh opaque offset: the colour output weights are re-read here instead of being kept in
+      // 64 registers since the forward heads
+      const float* wc2 = lds + M::WC2 + 16 * h + opaque_zero();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int q = 4 * j + i;
-        const float4 wc = *reinterpret_cast<const float4*>(ldz + M::WC2 + (8 * j + 4 * h + i) * 4);
-        dho[q] = (ho[q] > 0.0f) ? dro * wov[i] : 0.0f;
-        float v = drc[0] * wc.x;
-        v = fmaf(drc[1], wc.y, v);
-        v = fmaf(drc[2], wc.z, v);
-        v = fmaf(drc[3], wc.w, v);
-        dhc[q] = (hc[q] > 0.0f) ? v : 0.0f;
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int q = 4 * j + i;
+          const float4 wc = *reinterpret_cast<const float4*>(wc2 + (8 * j + i) * 4);
+          float v = drc[0] * wc.x;
+          v = fmaf(drc[1], wc.y, v);
+          v = fmaf(drc[2], wc.z, v);
+          v = fmaf(drc[3], wc.w, v);
+          dhc[q] = (hc[q] > 0.0f) ? v : 0.0f;
+        }
+        LP_SCHED_FENCE();
       }
     }
     LP_SCHED_FENCE();
@@ -298,6 +309,15 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     LP_SCHED_FENCE();
     // ---------------- opacity hidden layer ----------------
     LP_MARK("o1");
+    float dho[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 wo = *reinterpret_cast<const float4*>(ldz + M::WO2 + 8 * j + 4 * h);
+      dho[4 * j + 0] = (ho_mask & (1u << (4 * j + 0))) ? dro * wo.x : 0.0f;
+      dho[4 * j + 1] = (ho_mask & (1u << (4 * j + 1))) ? dro * wo.y : 0.0f;
+      dho[4 * j + 2] = (ho_mask & (1u << (4 * j + 2))) ? dro * wo.z : 0.0f;
+      dho[4 * j + 3] = (ho_mask & (1u << (4 * j + 3))) ? dro * wo.w : 0.0f;
+    }
     if (want_params) {
       tile_store_fm(xt, r, h, e);
       tile_store_fm(yt, r, h, dho);
@@ -339,37 +359,30 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
       acc = layer_t(wt + M::WT1, dh1, acc);  // rows >= C are zero weights
     }
     if (want_params) lds_barrier();
+    // dx0 -> LDS right away ([channel][ray]; the X tile is free after the barrier): frees the accumulator
+    if (gg) {
+#pragma unroll
+      for (int q = 0; q < C / 2; ++q) xt[featq(q, h) * DX_LD + r] = acc[q];
+    }
     LP_SCHED_FENCE();
     // ---------------- next (nearer) sample: gather before this sample's atomics ----------------
     LP_MARK("fetch");
 #ifndef X_NOFETCH
-    if (s > 0) fetch_sample<C, GM, true>(a, lds, ray, s - 1, h, nx);
+    if (s > 0) fetch_sample<C, GM, true, PLAIN>(a, lds, ray, s - 1, h, nx);
 #endif
     LP_SCHED_FENCE();
     // ---------------- grid gradient ----------------
     LP_MARK("scatter");
     if (gg) {
-      float* dxT = xt;
-#pragma unroll
-      for (int q = 0; q < C / 2; ++q) dxT[featq(q, h) * DX_LD + r] = acc[q];
-      float dxr[32];
-      {
-        const float4* dsrc = reinterpret_cast<const float4*>(dxT + (lane % C) * DX_LD);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float4 v = dsrc[j];
-          dxr[4 * j + 0] = v.x; dxr[4 * j + 1] = v.y; dxr[4 * j + 2] = v.z; dxr[4 * j + 3] = v.w;
-        }
-      }
       const bool live = valid && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
       const int ng = (GM == GM_TRIPLANE) ? 3 : (GM == GM_VOXEL) ? 1 : a.grid.n_grids;
 #ifndef X_NOSCATTER
       if (!(mp.dbg & 2)) {
 #pragma unroll 1
-        for (int g = 0; g < ng; ++g) scatter_grid<C>(gg, a.grid.grids[g], ray.b, x, y, z, live, lane, dxr, wtab, mp.dbg);
+        for (int g = 0; g < ng; ++g)
+          scatter_grid<C>(gg, a.grid.grids[g], ray.b, x, y, z, live, lane, xt + (lane % C) * DX_LD, wtab, mp.dbg);
       }
 #endif
-      // the dx0 tile shares LDS with the X tile other waves' quadrants read: done before they rewrite
     }
   }
 
@@ -432,15 +445,23 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
 // host side
 // ---------------------------------------------------------------------------------------
 
-template <int C, int GM>
-static int launch_bwd2(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
+template <int C, int GM, bool PLAIN>
+static int launch_bwd2p(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
   const size_t lds = LdsB::END * sizeof(float);
-  const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_mfma2<C, GM>,
+  const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_mfma2<C, GM, PLAIN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   const unsigned nb = (unsigned)((a.rays.n_rays + WAVES * RAYS_PER_WAVE - 1) / (WAVES * RAYS_PER_WAVE));
-  hipLaunchKernelGGL((renderer_bwd_mfma2<C, GM>), dim3(nb), dim3(256), lds, stream, a, mp);
+  hipLaunchKernelGGL((renderer_bwd_mfma2<C, GM, PLAIN>), dim3(nb), dim3(256), lds, stream, a, mp);
   return LP_OK;
+}
+
+// PLAIN = the common configuration (no opacity noise, no contraction, no scaffold, no beyond-far
+// samples): a leaner instantiation of the same kernel
+template <int C, int GM>
+static int launch_bwd2(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
+  const bool plain = !(a.noise_sigma > 0.0f) && !a.march.contract_coords && !a.scaffold && a.march.num_samples_inf == 0;
+  return plain ? launch_bwd2p<C, GM, true>(a, mp, stream) : launch_bwd2p<C, GM, false>(a, mp, stream);
 }
 
 int renderer_backward_mfma2(const LpRendererArgs& a, const MfmaParams& mp, int gm, hipStream_t stream) {
