@@ -22,6 +22,9 @@ FLAGS = [
 ]
 
 
+FLAGS += os.environ.get("LP_BUILD_FLAGS", "").split()
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True

@@ -4,6 +4,7 @@
 #include <stdio.h>
 
 #include "lp_host.h"
+#include "lp_mfma_common.h"
 
 namespace lp {
 
@@ -230,6 +231,10 @@ int lp_splatter_backward(const LpSplatterArgs* args, void* stream) {
   if (rc) return rc;
   return splatter_backward_launch(*args, (hipStream_t)stream);
 }
+
+/* developer hook (not part of include/lightplane_hip.h): per-phase cycle totals of the MFMA backward,
+ * only in builds with -DLP_PHASE_TIMING (returns -1 otherwise) */
+int lp_debug_phase_cycles(unsigned long long* out16) { return debug_phase_cycles(out16); }
 
 int lp_hash_randn(const int32_t* x1, const int32_t* x2, float* out, int64_t n, int32_t seed, void* stream) {
   if (n < 0) return set_error(LP_EINVAL, "n < 0");

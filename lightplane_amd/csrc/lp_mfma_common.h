@@ -348,7 +348,7 @@ LP_DEV Heads decode_prefetch(const LpRendererArgs& a, const float* lds, const Ra
   return heads_forward(lds, h, t.ho, t.hc, zo);
 }
 
-// Gradient scatter of one grid, row-contiguous and run-length merged.
+// Gradient scatter, row-contiguous and run-length merged.
 // dx0 of the wave's 32 rays has been transposed through LDS ([channel][ray], row stride DX_LD):
 // every lane reads ONE channel (`sub`, row `dxrow`) of the rays, lane group `grp` (C lanes) works on
 // tap slot k.  Rays are walked
@@ -422,5 +422,6 @@ LP_DEV void scatter_grid(float* gg, const LpGrid& g, int b, float x, float y, fl
 // second-generation backward (lp_renderer_mfma_bwd.hip); gm = GM_* grid-list shape
 int renderer_backward_mfma2(const LpRendererArgs& a, const MfmaParams& mp, int gm, hipStream_t stream);
 int fold_grad_replicas(const LpRendererArgs& a, hipStream_t stream);
+int debug_phase_cycles(unsigned long long* out);  // developer builds with -DLP_PHASE_TIMING, else -1
 
 }  // namespace lp

@@ -23,6 +23,23 @@ namespace lp {
 
 #ifdef LP_ASM_MARKS
 #define LP_MARK(n) asm volatile("; LPMARK " n)
+#elif defined(LP_PHASE_TIMING)
+// developer build (-DLP_PHASE_TIMING): per-phase shader-clock totals of the sample loop, summed over
+// all waves into g_phase[] (read with lp_debug_phase_cycles)
+__device__ unsigned long long g_phase[16];
+__device__ constexpr int phase_id(const char* n) {
+  return n[0] == 'f' && n[1] == 'w' ? 0 : n[0] == 'c' && n[1] == 'o' ? 1 : n[0] == 'h' ? 2 : n[0] == 'c' ? 3
+       : n[0] == 'o' ? 4 : n[0] == 't' && n[1] == '2' ? 5 : n[0] == 't' ? 6 : n[0] == 'f' ? 7 : n[0] == 's' ? 8 : 9;
+}
+#define LP_MARK(n)                                                     \
+  {                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    const unsigned long long t_now = __builtin_readcyclecounter();     \
+    ph[ph_cur] += t_now - t_last;                                      \
+    t_last = t_now;                                                    \
+    ph_cur = phase_id(n);                                              \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+  }
 #else
 #define LP_MARK(n)
 #endif
@@ -38,8 +55,7 @@ struct LdsB {
   static constexpr int YT = 32 * T_LD;          // dY tile [32][36]
   static constexpr int ENC = 2 * 32 * T_LD;     // ray encoding [32 rays][36]
   static constexpr int TS = 3 * 32 * T_LD;      // [5][32]: d raw_o, d raw_c[0..3] by ray
-  static constexpr int WTAB = TS + 5 * 32;      // [8][32] tap weights of the scatter
-  static constexpr int PER_WAVE = WTAB + 8 * 32;
+  static constexpr int PER_WAVE = TS + 5 * 32;    // (the scatter's weight table lives in the dY tile)
   static constexpr int END = WAVE0 + WAVES * PER_WAVE;
 };
 static_assert(2 * LdsB::END * 4 <= 160 * 1024, "two workgroups per CU must fit the 160 KB LDS");
@@ -107,7 +123,6 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
   float* const yt = wv + B::YT;
   float* const enct = wv + B::ENC;
   float* const ts = wv + B::TS;
-  float* const wtab = wv + B::WTAB;
 
   const int64_t ray_id = ((int64_t)blockIdx.x * WAVES + wave) * RAYS_PER_WAVE + r;
   const bool valid = ray_id < a.rays.n_rays;
@@ -153,6 +168,11 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
   float* const gg = !a.grad_grid ? nullptr
                     : (rep == 0 ? a.grad_grid : a.grad_grid_replicas + (int64_t)(rep - 1) * a.grid.n_rows * C);
 
+#ifdef LP_PHASE_TIMING
+  unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = __builtin_readcyclecounter();
+  int ph_cur = 9;
+#endif
   float nlt = a.neg_log_t[rid];
   float suffix = 0.0f, p_next = 0.0f;
   Sample<C> nx;
@@ -365,29 +385,29 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
       for (int q = 0; q < C / 2; ++q) xt[featq(q, h) * DX_LD + r] = acc[q];
     }
     LP_SCHED_FENCE();
-    // ---------------- next (nearer) sample: gather before this sample's atomics ----------------
+    // ---------------- next (nearer) sample + grid gradient ----------------
     LP_MARK("fetch");
-#ifndef X_NOFETCH
+    const bool live = valid && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
+    // gather with one plane's loads in flight at a time (registers), consumed before the atomics
+    // below are issued: no wait ever has to drain the atomics
     if (s > 0) fetch_sample<C, GM, true, PLAIN>(a, lds, ray, s - 1, h, nx);
-#endif
     LP_SCHED_FENCE();
-    // ---------------- grid gradient ----------------
     LP_MARK("scatter");
-    if (gg) {
-      const bool live = valid && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
+    if (gg && !(mp.dbg & 2)) {
+      const float* dxrow = xt + (lane % C) * DX_LD;
       const int ng = (GM == GM_TRIPLANE) ? 3 : (GM == GM_VOXEL) ? 1 : a.grid.n_grids;
-#ifndef X_NOSCATTER
-      if (!(mp.dbg & 2)) {
 #pragma unroll 1
-        for (int g = 0; g < ng; ++g)
-          scatter_grid<C>(gg, a.grid.grids[g], ray.b, x, y, z, live, lane, xt + (lane % C) * DX_LD, wtab, mp.dbg);
-      }
-#endif
+      for (int g = 0; g < ng; ++g) scatter_grid<C>(gg, a.grid.grids[g], ray.b, x, y, z, live, lane, dxrow, yt, mp.dbg);
     }
   }
 
   // ---------------- epilogue ----------------
-    LP_MARK("epilogue");
+  LP_MARK("epilogue");
+#ifdef LP_PHASE_TIMING
+  if (lane == 0) {
+    for (int i = 0; i < 10; ++i) atomicAdd(&g_phase[i], ph[i]);
+  }
+#endif
   if (valid && a.grad_encoding) {
     float4* dst = reinterpret_cast<float4*>(a.grad_encoding + ray_id * HID + 4 * h);
 #pragma unroll
@@ -477,5 +497,20 @@ int renderer_backward_mfma2(const LpRendererArgs& a, const MfmaParams& mp, int g
   if (rc) return rc;
   return check_launch("renderer_bwd_mfma2");
 }
+
+#ifdef LP_PHASE_TIMING
+int debug_phase_cycles(unsigned long long* out) {
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return set_error((int)e, "sync: %s", hipGetErrorString(e));
+  e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 16);
+  if (e != hipSuccess) return set_error((int)e, "from symbol: %s", hipGetErrorString(e));
+  unsigned long long z[16] = {0};
+  e = hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
+  if (e != hipSuccess) return set_error((int)e, "to symbol: %s", hipGetErrorString(e));
+  return 0;
+}
+#else
+int debug_phase_cycles(unsigned long long*) { return -1; }
+#endif
 
 }  // namespace lp
