@@ -88,7 +88,7 @@ class LpSplatterArgs(C.Structure):
 
 
 _LIB = None
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblightplane_hip.so")
+LIB_PATH = os.environ.get("LIGHTPLANE_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblightplane_hip.so")
 
 #: every symbol include/lightplane_hip.h declares
 EXPORTS = (

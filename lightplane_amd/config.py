@@ -6,14 +6,14 @@
 ``check_finite_grads`` run the reference's post-backward ``isfinite`` asserts
                        (lightplane_renderer.py:719-722; a device sync each).  Default off.
 ``grad_replicas``      extra zero-filled copies of ``grad_grid`` the Renderer backward spreads its
-                       atomics over (None = automatic: as many as fit in ``grad_replica_bytes``,
-                       at most 31).  Same-row fp32 atomics serialise on MI355X; image-coherent
-                       rays hit the same plane rows from every workgroup at the same time.
+                       atomics over (folded into ``grad_grid`` after the kernel).  Same-row fp32
+                       atomics serialise on MI355X (~25 ns each) and image-coherent rays hit the
+                       same plane rows from every workgroup; with the run-merged scatter the effect
+                       measured on the 256x256 triplane benchmark is nil, so the default is 0.
 """
 import os
 
 check_inputs: bool = os.environ.get("LIGHTPLANE_AMD_CHECK_INPUTS", "1") != "0"
 check_finite_grads: bool = os.environ.get("LIGHTPLANE_AMD_CHECK_FINITE", "0") == "1"
 _gr = os.environ.get("LIGHTPLANE_AMD_GRAD_REPLICAS")
-grad_replicas = int(_gr) if _gr is not None else None
-grad_replica_bytes: int = 64 << 20
+grad_replicas: int = int(_gr) if _gr is not None else 0

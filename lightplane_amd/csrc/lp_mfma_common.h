@@ -361,7 +361,9 @@ constexpr int DX_LD = 36;  // row stride of the transposed dx0 tile [channel][ra
 
 template <int C>
 LP_DEV void flush_run(float* gg, int s_row, unsigned s_ok, int koff, unsigned kbit, int sub, float run, int dbg) {
-  if ((s_ok & kbit) && !(dbg & 1)) atomic_add_f32(gg + ((int64_t)(s_row + koff) * C + sub), run);
+  // 32-bit byte offset from the uniform base (grid-lists below 4 GB only, see renderer_mfma_supported)
+  const unsigned off = (unsigned)(s_row + koff) * (unsigned)(C * 4) + (unsigned)(sub * 4);
+  if ((s_ok & kbit) && !(dbg & 1)) atomic_add_f32(reinterpret_cast<float*>(reinterpret_cast<char*>(gg) + off), run);
 }
 
 template <int C>

@@ -105,7 +105,7 @@ bool renderer_mfma_supported(const LpRendererArgs& a, const char** why) {
     return false;
   }
   if (a.color_chn > 4) { *why = "more than 4 colour channels"; return false; }
-  if (a.grid.n_rows >= (int64_t)1 << 31) { *why = "grid-list has 2^31 rows or more"; return false; }
+  if (a.grid.n_rows * C * 4 >= (int64_t)1 << 32) { *why = "grid-list of 4 GB or more"; return false; }
   if (a.march.num_samples_inf > MAX_INF) { *why = "more than 256 beyond-far samples"; return false; }
   return true;
 }

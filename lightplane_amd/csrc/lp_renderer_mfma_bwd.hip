@@ -311,6 +311,8 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
 #endif
     LP_SCHED_FENCE();
 
+    // Every layer below: publish the X / dY tiles, run the dX chain (MFMA) while the LDS writes land
+    // and the other waves arrive, barrier, dW quadrant (LDS reads + MFMA), barrier.
     // ---------------- colour hidden layer ----------------
     LP_MARK("c1");
     if (want_params) {
@@ -318,17 +320,16 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
       add_encoding(enct + zo + r * T_LD + 4 * h, e, ein);
       tile_store_fm(xt, r, h, ein);
       tile_store_fm(yt, r, h, dhc);
-      lds_barrier();
-      dq_c1 = dw_quadrant(wave0, a_off, b_off, 0, WAVES, dq_c1, db_c1);
     }
     acc = (f32x16){0};
     acc = layer_t(wt + M::WC1, dhc, acc);
+    if (want_params) {
+      lds_barrier();
+      dq_c1 = dw_quadrant(wave0, a_off, b_off, 0, WAVES, dq_c1, db_c1);
+    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) denc[q] += acc[q];
-    if (want_params) lds_barrier();
-    LP_SCHED_FENCE();
-    // ---------------- opacity hidden layer ----------------
-    LP_MARK("o1");
+    // d ho from the ReLU mask of ho
     float dho[16];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -338,13 +339,19 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
       dho[4 * j + 2] = (ho_mask & (1u << (4 * j + 2))) ? dro * wo.z : 0.0f;
       dho[4 * j + 3] = (ho_mask & (1u << (4 * j + 3))) ? dro * wo.w : 0.0f;
     }
+    if (want_params) lds_barrier();
+    LP_SCHED_FENCE();
+    // ---------------- opacity hidden layer ----------------
+    LP_MARK("o1");
     if (want_params) {
       tile_store_fm(xt, r, h, e);
       tile_store_fm(yt, r, h, dho);
+    }
+    acc = layer_t(wt + M::WO1, dho, acc);
+    if (want_params) {
       lds_barrier();
       dq_o1 = dw_quadrant(wave0, a_off, b_off, 0, WAVES, dq_o1, db_o1);
     }
-    acc = layer_t(wt + M::WO1, dho, acc);
     float de[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) de[q] = (e[q] > 0.0f) ? acc[q] : 0.0f;
@@ -355,11 +362,13 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     if (want_params) {
       tile_store_fm(xt, r, h, h1);
       tile_store_fm(yt, r, h, de);
-      lds_barrier();
-      dq_t2 = dw_quadrant(wave0, a_off, b_off, 0, WAVES, dq_t2, db_t2);
     }
     acc = (f32x16){0};
     acc = layer_t(wt + M::WT2, de, acc);
+    if (want_params) {
+      lds_barrier();
+      dq_t2 = dw_quadrant(wave0, a_off, b_off, 0, WAVES, dq_t2, db_t2);
+    }
     float dh1[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) dh1[q] = (h1[q] > 0.0f) ? acc[q] : 0.0f;
@@ -371,14 +380,16 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
 #pragma unroll
       for (int q = 0; q < C / 2; ++q) xt[featq(q, h) * T_LD + r] = x0[q];
       tile_store_fm(yt, r, h, dh1);
-      lds_barrier();
-      dq_t1 = dw_quadrant(wave0, a_off_t1, b_off, t1_v0, t1_v1, dq_t1, db_t1);
     }
     if (gg) {
       acc = (f32x16){0};
       acc = layer_t(wt + M::WT1, dh1, acc);  // rows >= C are zero weights
     }
-    if (want_params) lds_barrier();
+    if (want_params) {
+      lds_barrier();
+      dq_t1 = dw_quadrant(wave0, a_off_t1, b_off, t1_v0, t1_v1, dq_t1, db_t1);
+      lds_barrier();
+    }
     // dx0 -> LDS right away ([channel][ray]; the X tile is free after the barrier): frees the accumulator
     if (gg) {
 #pragma unroll
@@ -467,7 +478,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
 
 template <int C, int GM, bool PLAIN>
 static int launch_bwd2p(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
-  const size_t lds = LdsB::END * sizeof(float);
+  const size_t lds = (mp.dbg & 16) ? 100 * 1024 : LdsB::END * sizeof(float);  // dbg 16: one workgroup per CU
   const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_mfma2<C, GM, PLAIN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));

@@ -143,9 +143,7 @@ class LightplaneFunction(torch.autograd.Function):
         a.grad_encoding, a.grad_color_grid = _lib.ptr(grad_enc), _lib.ptr(grad_cgrid)
         replicas = None
         if need_grid:
-            n_rep = config.grad_replicas
-            if n_rep is None:
-                n_rep = min(31, config.grad_replica_bytes // max(grid.numel() * 4, 1))
+            n_rep = int(config.grad_replicas)
             if n_rep > 0:
                 replicas = torch.zeros(n_rep, grid.numel(), device=dev, dtype=torch.float32)
                 a.grad_grid_replicas, a.n_grad_replicas = _lib.ptr(replicas), n_rep
