@@ -143,15 +143,35 @@ static int check_splatter(const LpSplatterArgs& a, bool backward) {
   if ((rc = check_rays(a.rays, true))) return rc;
   if ((rc = check_march(a.march))) return rc;
   if ((rc = check_grid_list("out", a.out, true))) return rc;
-  if (a.mlp.n_layers > 0) return set_error(LP_EUNSUPPORTED, "MLP splatter: not built into this library yet");
-  if (a.rays.encoding_dim != a.out.channels)
+  const bool use_mlp = a.mlp.n_layers > 0;
+  if (use_mlp) {
+    // MLP-Splatter: MLP(sample(input_grid) + encoding) is splatted (reference lightplane_splatter.py:167-338)
+    if ((rc = check_mlp("splatter", a.mlp, false))) return rc;
+    if ((rc = check_grid_list("input_grid", a.input_grid, true))) return rc;
+    if (a.rays.n_rays > 0 && !a.input_grid.data) return set_error(LP_ENULL, "input_grid.data is NULL");
+    if (a.input_grid.grids[0].B != a.out.grids[0].B)
+      return set_error(LP_EINVAL, "input_grid batch %d != output grid batch %d", a.input_grid.grids[0].B,
+                       a.out.grids[0].B);
+    if (a.mlp.dims[0] != a.input_grid.channels || a.mlp.dims[0] != a.rays.encoding_dim)
+      return set_error(LP_EINVAL, "MLP input width %d must equal input_grid channels %d and encoding width %d",
+                       a.mlp.dims[0], a.input_grid.channels, a.rays.encoding_dim);
+    if (a.mlp.dims[a.mlp.n_layers] != a.out.channels)
+      return set_error(LP_EINVAL, "MLP output width %d != output grid channels %d", a.mlp.dims[a.mlp.n_layers],
+                       a.out.channels);
+    if (a.mlp.offset != 0 || mlp_numel(a.mlp) != a.n_mlp_params)
+      return set_error(LP_EINVAL, "The number of elements in mlp param should be %lld. Got %lld instead.",
+                       (long long)mlp_numel(a.mlp), (long long)a.n_mlp_params);
+    if (!a.mlp_params) return set_error(LP_ENULL, "mlp_params is NULL");
+  } else if (a.rays.encoding_dim != a.out.channels) {
     return set_error(LP_EINVAL, "splatting feature width %d != output grid channels %d", a.rays.encoding_dim,
                      a.out.channels);
+  }
   if (a.rays.n_rays > 0) {
     if (!backward && (!a.out_feature || !a.out_weight))
       return set_error(LP_ENULL, "out_feature / out_weight must be non-NULL");
-    if (backward && (!a.grad_out || !a.weight || !a.grad_encoding))
-      return set_error(LP_ENULL, "grad_out / weight / grad_encoding must be non-NULL");
+    if (backward && (!a.grad_out || !a.weight))
+      return set_error(LP_ENULL, "grad_out / weight must be non-NULL");
+    if (backward && !use_mlp && !a.grad_encoding) return set_error(LP_ENULL, "grad_encoding must be non-NULL");
   }
   return LP_OK;
 }
@@ -216,6 +236,7 @@ int lp_splatter_forward(const LpSplatterArgs* args, void* stream) {
   if (!args) return set_error(LP_ENULL, "args is NULL");
   int rc = check_splatter(*args, false);
   if (rc) return rc;
+  if (args->mlp.n_layers > 0) return splatter_mlp_forward_launch(*args, (hipStream_t)stream);
   return splatter_forward_launch(*args, (hipStream_t)stream);
 }
 
@@ -229,6 +250,7 @@ int lp_splatter_backward(const LpSplatterArgs* args, void* stream) {
   if (!args) return set_error(LP_ENULL, "args is NULL");
   int rc = check_splatter(*args, true);
   if (rc) return rc;
+  if (args->mlp.n_layers > 0) return splatter_mlp_backward_launch(*args, (hipStream_t)stream);
   return splatter_backward_launch(*args, (hipStream_t)stream);
 }
 

@@ -24,6 +24,9 @@ int renderer_backward_mfma(const LpRendererArgs& a, hipStream_t stream);
 // splatter: lp_splatter.hip
 int splatter_forward_launch(const LpSplatterArgs& a, hipStream_t stream);
 int splatter_backward_launch(const LpSplatterArgs& a, hipStream_t stream);
+// MLP-Splatter: lp_splatter_mlp.hip
+int splatter_mlp_forward_launch(const LpSplatterArgs& a, hipStream_t stream);
+int splatter_mlp_backward_launch(const LpSplatterArgs& a, hipStream_t stream);
 int splatter_normalize_launch(float* feature, const float* weight, int64_t n_rows, int channels,
                               hipStream_t stream);
 int hash_randn_launch(const int32_t* x1, const int32_t* x2, float* out, int64_t n, int32_t seed,

@@ -21,7 +21,8 @@ from typing import Optional, Tuple
 import torch
 
 from .grids import if_not_none_else
-from .params import DecoderParams, SplatterParams, flattened_decoder_params_to_list, init_decoder_params
+from .params import (DecoderParams, SplatterParams, flattened_decoder_params_to_list, init_decoder_params,
+                     init_splatter_params)
 from .rays import Rays, calc_harmonic_embedding, calc_harmonic_embedding_dim, jitter_near_far
 from .renderer import lightplane_renderer
 from .splatter import lightplane_mlp_splatter, lightplane_splatter
@@ -310,6 +311,79 @@ class LightplaneSplatter(torch.nn.Module):
             contract_coords=if_not_none_else(contract_coords, self.contract_coords),
             disparity_at_inf=if_not_none_else(disparity_at_inf, self.disparity_at_inf),
             return_list=return_list,
+        )
+
+
+class LightplaneMLPSplatter(torch.nn.Module):
+    """Module wrapper of :func:`lightplane_amd.lightplane_mlp_splatter` (reference
+    splatter_module.py:164-331): owns the MLP (``mlp_params`` parameter, ``n_hidden`` buffer)."""
+
+    def __init__(
+        self,
+        num_samples: int,
+        grid_chn: int,
+        input_grid_chn: int = 32,
+        mlp_hidden_chn: int = 32,
+        mlp_n_layers: int = 2,
+        num_samples_inf: int = 0,
+        mask_out_of_bounds_samples: bool = False,
+        contract_coords: bool = False,
+        disparity_at_inf: float = 1e-5,
+        rays_jitter_near_far: bool = False,
+        triton_block_size: int = 16,
+        triton_num_warps: int = 4,
+        use_naive_impl: bool = False,
+    ):
+        super().__init__()
+        if use_naive_impl:
+            raise NotImplementedError(_NAIVE_MSG)
+        self.num_samples = num_samples
+        self.num_samples_inf = num_samples_inf
+        self.mask_out_of_bounds_samples = mask_out_of_bounds_samples
+        self.contract_coords = contract_coords
+        self.disparity_at_inf = disparity_at_inf
+        self.rays_jitter_near_far = rays_jitter_near_far
+        self.triton_block_size = triton_block_size
+        self.triton_num_warps = triton_num_warps
+        self.use_naive_impl = False
+        assert input_grid_chn is not None, "input_grid_chn must be provided"
+        sp = init_splatter_params(device="cpu", n_layers=mlp_n_layers, input_chn=input_grid_chn,
+                                  hidden_chn=mlp_hidden_chn, out_chn=grid_chn)
+        self.mlp_params = torch.nn.Parameter(sp.mlp_params)
+        self.register_buffer("n_hidden", sp.n_hidden, persistent=False)
+        self.rays_encoding_dim = input_grid_chn
+
+    def get_splatter_params(self) -> SplatterParams:
+        return SplatterParams(self.mlp_params, self.n_hidden)
+
+    def forward(
+        self,
+        rays: Rays,
+        grid_size,
+        input_grid,
+        num_samples: Optional[int] = None,
+        num_samples_inf: Optional[int] = None,
+        mask_out_of_bounds_samples: Optional[bool] = None,
+        contract_coords: Optional[bool] = None,
+        disparity_at_inf: Optional[float] = None,
+        input_grid_sizes=None,
+        rays_jitter_near_far: Optional[bool] = None,
+        return_list: bool = True,
+        regenerate_code: bool = False,
+    ):
+        num_samples = if_not_none_else(num_samples, self.num_samples)
+        _check_splatter_ray_encoding_input(rays.encoding, self.rays_encoding_dim)
+        assert input_grid is not None, "input_grid must be provided"
+        r = copy.copy(rays)
+        if if_not_none_else(rays_jitter_near_far, self.rays_jitter_near_far):
+            r.near, r.far = jitter_near_far(r.near, r.far, num_samples)
+        return lightplane_mlp_splatter(
+            r, grid_size, self.get_splatter_params(), input_grid, num_samples=num_samples,
+            num_samples_inf=if_not_none_else(num_samples_inf, self.num_samples_inf),
+            mask_out_of_bounds_samples=if_not_none_else(mask_out_of_bounds_samples, self.mask_out_of_bounds_samples),
+            contract_coords=if_not_none_else(contract_coords, self.contract_coords),
+            disparity_at_inf=if_not_none_else(disparity_at_inf, self.disparity_at_inf),
+            input_grid_sizes=input_grid_sizes, return_list=return_list,
         )
 
 

@@ -36,14 +36,25 @@ class _SplatterCfg:
     contract_coords: bool
     disparity_at_inf: float
     process_group: object = None
+    # MLP-Splatter only
+    in_descs: Optional[List[GridDesc]] = None
+    in_channels: int = 0
+    in_n_rows: int = 0
+    mlp_dims: Optional[List[int]] = None
 
 
-def _fill_args(cfg: _SplatterCfg, directions, origins, grid_idx, near, far, feature) -> _lib.LpSplatterArgs:
+def _fill_args(cfg: _SplatterCfg, directions, origins, grid_idx, near, far, feature, mlp_params=None,
+               input_grid=None) -> _lib.LpSplatterArgs:
     a = _lib.LpSplatterArgs()
     a.rays = _lib.make_rays(directions, origins, grid_idx, near, far, feature)
     a.march = _lib.make_march(cfg.num_samples, cfg.num_samples_inf, cfg.mask_out_of_bounds_samples,
                               cfg.contract_coords, cfg.disparity_at_inf)
     a.out = _lib.make_grid_list(None, cfg.descs, cfg.channels, cfg.n_rows)
+    if cfg.mlp_dims is not None:
+        a.input_grid = _lib.make_grid_list(input_grid, cfg.in_descs, cfg.in_channels, cfg.in_n_rows)
+        a.mlp_params = _lib.ptr(mlp_params)
+        a.n_mlp_params = mlp_params.numel()
+        a.mlp = _lib.make_mlp(cfg.mlp_dims, 0)
     return a
 
 
@@ -89,6 +100,57 @@ class LightplaneSplatterFunction(torch.autograd.Function):
         if config.check_finite_grads:
             assert torch.isfinite(grad_feature).all()
         return (grad_feature,) + (None,) * 6
+
+
+class LightplaneMLPSplatterFunction(torch.autograd.Function):
+    """Autograd boundary of the MLP-Splatter (the reference routes both variants through
+    ``LightplaneSplatterFunction``, lightplane_splatter.py:341-700; the MLP path is :440-501, :608-700)."""
+
+    @staticmethod
+    def forward(ctx, feature, mlp_params, input_grid, cfg: _SplatterCfg, directions, origins, grid_idx, near, far):
+        dev = feature.device
+        stream = _lib.current_stream(dev)
+        feature, mlp_params, input_grid = feature.contiguous(), mlp_params.contiguous(), input_grid.contiguous()
+        out = torch.zeros(cfg.n_rows, cfg.channels, device=dev, dtype=torch.float32)
+        weight = torch.zeros(cfg.n_rows, device=dev, dtype=torch.float32)
+        a = _fill_args(cfg, directions, origins, grid_idx, near, far, feature, mlp_params, input_grid)
+        a.out.data = _lib.ptr(out)
+        a.out_feature, a.out_weight = _lib.ptr(out), _lib.ptr(weight)
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            _lib.check(L.lp_splatter_forward(ctypes.byref(a), stream), "lp_splatter_forward")
+            if cfg.process_group is not None:
+                from .parallel import allreduce_sum_
+                allreduce_sum_([out, weight], cfg.process_group)
+            _lib.check(L.lp_splatter_normalize(out.data_ptr(), weight.data_ptr(), cfg.n_rows, cfg.channels, stream),
+                       "lp_splatter_normalize")
+        ctx.save_for_backward(weight, feature, mlp_params, input_grid, directions, origins, grid_idx, near, far)
+        ctx.cfg = cfg
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        weight, feature, mlp_params, input_grid, directions, origins, grid_idx, near, far = ctx.saved_tensors
+        cfg: _SplatterCfg = ctx.cfg
+        need_feat, need_params, need_grid = ctx.needs_input_grad[:3]
+        if not (need_feat or need_params or need_grid):
+            return (None,) * 9
+        dev = feature.device
+        stream = _lib.current_stream(dev)
+        grad_out = grad_out.contiguous()
+        grad_feature = torch.empty_like(feature) if need_feat else None
+        grad_params = torch.zeros_like(mlp_params) if need_params else None
+        grad_in = torch.zeros_like(input_grid) if need_grid else None
+        a = _fill_args(cfg, directions, origins, grid_idx, near, far, feature, mlp_params, input_grid)
+        a.grad_out, a.weight = _lib.ptr(grad_out), _lib.ptr(weight)
+        a.grad_encoding, a.grad_mlp_params, a.grad_input_grid = (
+            _lib.ptr(grad_feature), _lib.ptr(grad_params), _lib.ptr(grad_in))
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().lp_splatter_backward(ctypes.byref(a), stream), "lp_splatter_backward")
+        if config.check_finite_grads:
+            for g in (grad_feature, grad_params, grad_in):
+                assert g is None or torch.isfinite(g).all()
+        return (grad_feature, grad_params, grad_in) + (None,) * 6
 
 
 def _prep_rays(rays: Rays, B: int):
@@ -152,11 +214,49 @@ def lightplane_mlp_splatter(
     disparity_at_inf: float = 1e-5,
     input_grid_sizes=None,
     return_list: bool = True,
-    regenerate_code: bool = False,
-    triton_block_size: int = 16,
-    triton_num_warps: int = 4,
+    regenerate_code: bool = False,  # ignored
+    triton_block_size: int = 16,  # ignored
+    triton_num_warps: int = 4,  # ignored
+    process_group=None,
 ):
-    """MLP-Splatter: splat ``MLP(sample(input_grid, x) + rays.encoding)`` (reference
-    lightplane_splatter.py:167-338).  Listed as "next" in SURVEY.md 8(f); not built yet."""
-    raise NotImplementedError(
-        "lightplane_mlp_splatter is not implemented in the HIP library yet (SURVEY.md 8(f) item 1)")
+    """Splat ``MLP(sample(input_grid, x) + rays.encoding)`` into a zero-initialised grid-list.
+
+    For every sample point of every ray the *input* grid-list is interpolated (features of all its
+    grids summed, like the Renderer does), the ray encoding is added, the result goes through the
+    MLP (ReLU between layers, none after the last) and is splatted into the output grid-list with
+    tri/bi-linear weights; the output is normalised by the splatted weights
+    (``features / clamp(weights, 1e-5)``).  Arguments / returns follow the reference's
+    ``lightplane_mlp_splatter`` (lightplane/lightplane_splatter.py:167-338).  Gradients flow to
+    ``rays.encoding``, ``mlp_params.mlp_params`` and ``input_grid``.
+    """
+    sizes = sizes_to_list(output_grid_size)
+    descs, channels, n_rows = make_grid_descs(sizes)
+    assert mlp_params is not None and len(mlp_params.n_hidden) > 1, (
+        "mlp depth has to be bigger than 1 when using input_grid")
+    assert input_grid is not None, "input_grid cannot be None when mlp_params is not None"
+    check_grid(input_grid, input_grid_sizes)
+    input_grid, _, input_grid_sizes, _ = process_and_flatten_grid(input_grid, None, input_grid_sizes, None)
+    in_descs, in_channels, in_n_rows = make_grid_descs(input_grid_sizes)
+    assert input_grid.ndim == 2 and input_grid.shape == (in_n_rows, in_channels), (
+        "flat input grid tensor does not match input_grid_sizes")
+    dims = [int(v) for v in mlp_params.n_hidden.tolist()]
+    assert rays.encoding is not None, "rays.encoding is required"
+    assert rays.encoding.dtype == torch.float32 and input_grid.dtype == torch.float32
+    assert dims[0] == in_channels == rays.encoding.shape[1], (
+        f"MLP input width {dims[0]} must equal the input grid channels {in_channels} and the ray encoding "
+        f"width {rays.encoding.shape[1]}")
+    assert dims[-1] == channels, f"MLP output width {dims[-1]} != output grid channels {channels}"
+    assert in_descs[0].B == descs[0].B, "input and output grid-lists must share the batch size"
+    flat_params = mlp_params.mlp_params
+    assert flat_params.ndim == 1 and flat_params.dtype == torch.float32
+    from .params import mlp_numel
+    assert flat_params.numel() == mlp_numel(dims), (
+        f"The number of elements in mlp param should be {mlp_numel(dims)}. Got {flat_params.numel()} instead.")
+    cfg = _SplatterCfg(descs, channels, n_rows, int(num_samples), int(num_samples_inf),
+                       bool(mask_out_of_bounds_samples), bool(contract_coords), float(disparity_at_inf),
+                       process_group, in_descs, in_channels, in_n_rows, dims)
+    out = LightplaneMLPSplatterFunction.apply(rays.encoding, flat_params, input_grid, cfg,
+                                              *_prep_rays(rays, descs[0].B))
+    if return_list:
+        return list(unflatten_grid(out, sizes))
+    return out

@@ -183,3 +183,44 @@ def test_ray_shard_allreduce_logic_on_gloo():
     for p in procs:
         p.join(120)
     assert all(p.exitcode == 0 for p in procs) and len(ret) == 2
+
+
+def test_mlp_splatter_host_checks():
+    """lightplane_mlp_splatter validates shapes like the reference (asserts) and never runs on CPU."""
+    from tests.synth import SPLATTER_CASES
+    d = SPLATTER_CASES[4].build()
+    with pytest.raises(_lib.LightplaneHipError, match="GPU only"):
+        lp.lightplane_mlp_splatter(d["rays"], d["out_sizes"], d["mlp"], d["in_grids"], **d["cfg"])
+    bad = lp.SplatterParams(d["mlp"].mlp_params[:-1], d["mlp"].n_hidden)
+    with pytest.raises(AssertionError, match="number of elements in mlp param"):
+        lp.lightplane_mlp_splatter(d["rays"], d["out_sizes"], bad, d["in_grids"], **d["cfg"])
+    with pytest.raises(AssertionError):
+        lp.lightplane_mlp_splatter(d["rays"], [[2, 6, 5, 7, 16]], d["mlp"], d["in_grids"], **d["cfg"])
+    m = lp.LightplaneMLPSplatter(num_samples=8, grid_chn=16, input_grid_chn=32, mlp_hidden_chn=64, mlp_n_layers=3)
+    assert set(m.state_dict().keys()) == {"mlp_params"}  # n_hidden is a non-persistent buffer (reference :232)
+    assert m.get_splatter_params().n_hidden.tolist() == [32, 64, 64, 16]
+    with pytest.raises(NotImplementedError):
+        lp.LightplaneMLPSplatter(8, 16, use_naive_impl=True)
+
+
+def test_mlp_splatter_c_abi_argument_errors():
+    L = _lib.lib()
+    a = _lib.LpSplatterArgs()
+    a.rays.n_rays = 0
+    a.march = _lib.make_march(4, 0, False, False, 1e-5)
+    from lightplane_amd.grids import make_grid_descs
+    descs, C, rows = make_grid_descs([[1, 4, 4, 4, 16]])
+    a.out = _lib.make_grid_list(None, descs, C, rows)
+    a.rays.encoding_dim = 32
+    a.mlp = _lib.make_mlp([32, 32, 8], 0)  # output width 8 != 16 grid channels
+    in_descs, Ci, rows_i = make_grid_descs([[1, 3, 3, 3, 32]])
+    a.input_grid = _lib.make_grid_list(None, in_descs, Ci, rows_i)
+    a.n_mlp_params = 32 * 32 + 32 * 8 + 32 + 8
+    assert L.lp_splatter_forward(ctypes.byref(a), None) == -1
+    assert b"output grid channels" in L.lp_last_error()
+    a.mlp = _lib.make_mlp([32, 32, 16], 0)
+    a.n_mlp_params = 5
+    assert L.lp_splatter_forward(ctypes.byref(a), None) == -1
+    assert b"number of elements in mlp param" in L.lp_last_error()
+    a.n_mlp_params = 32 * 32 + 32 * 16 + 32 + 16
+    assert L.lp_splatter_forward(ctypes.byref(a), None) == -3  # mlp_params NULL
