@@ -9,6 +9,8 @@
 // instruction of the group touches ONE contiguous C*4-byte row: fully coalesced 128-byte
 // segments for C=32 instead of 64 scattered dwords.  Features and unit weights are splatted
 // in the same march (the reference launches the kernel twice).
+#include <stdlib.h>
+
 #include "lp_device.h"
 #include "lp_host.h"
 
@@ -52,6 +54,148 @@ __global__ void __launch_bounds__(256) splat_fwd_kernel(const LpSplatterArgs a) 
         }
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Forward, run-merged ("walk") variant for C in {16, 32}: one wave = 32 rays.
+// The encodings of the wave's rays are transposed once (LDS) so that every lane holds ONE channel
+// of all 32 rays in registers; lane group `grp` (C lanes) works on tap slot k of the current sample.
+// Rays are walked in order and consecutive rays that fall into the same cell (neighbouring pixels
+// usually do) are summed in a register: one row-contiguous atomic (+ one weight atomic) per RUN
+// instead of per ray.  Run boundaries are the same for all slots of a grid, i.e. one wave-uniform
+// bit mask (ballot in the lane = ray layout): the walk is scalar-branched, tap rows come from
+// v_readlane.  Same scheme as the Renderer's gradient scatter (lp_mfma_common.h).
+// ---------------------------------------------------------------------------------------
+// RPW rays per wave (16: twice as many waves in flight for the same ray count -- the walk is a
+// latency-bound scalar loop, and 256x256 rays are only 2048 waves of 32).
+template <int C, int RPW>
+LP_DEV void splat_walk(float* feat, float* wgt, const LpGrid& g, int b, float x, float y, float z, bool live,
+                       int lane, const float (&enc)[RPW], float* wT, int dbg) {
+  constexpr int GRPS = 64 / C;       // tap slots per pass
+  constexpr int NQ = 64 / RPW;       // lanes per ray in the lane = ray layout
+  constexpr int SPQ = 8 / NQ;        // tap-weight slots each of them writes
+  const int q = lane / RPW, r = lane % RPW, sub = lane % C, grp = lane / C;
+  TapSet tp;
+  grid_tapset<true>(g, b, x, y, z, tp);
+  if (!live) {
+    tp.ok = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tp.w[k] = 0.0f;
+  }
+#pragma unroll
+  for (int i = 0; i < SPQ; ++i) {
+    float v = tp.w[i];
+#pragma unroll
+    for (int qq = 1; qq < NQ; ++qq) v = (q == qq) ? tp.w[qq * SPQ + i] : v;
+    wT[(q * SPQ + i) * RPW + r] = v;
+  }
+  const int row0 = tp.row0;
+  const int ok = (int)tp.ok;
+  const bool head = (r == 0) || row0 != __shfl_up(row0, 1) || ok != __shfl_up(ok, 1);
+  const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head));
+  const bool voxel = g.D > 1 && g.H > 1 && g.W > 1;
+  const int n_pass = (voxel ? 8 : 4) / GRPS;
+  for (int p = 0; p < n_pass; ++p) {
+    const int k = p * GRPS + grp;
+    const int koff = (k & 1) * tp.su + ((k >> 1) & 1) * tp.sv + (k >> 2) * tp.st;
+    const unsigned kbit = 1u << k;
+    const float4* wsrc = reinterpret_cast<const float4*>(wT + k * RPW);
+    float run = 0.0f;
+    int s_row = __builtin_amdgcn_readlane(row0, 0);
+    unsigned s_ok = (unsigned)__builtin_amdgcn_readlane(ok, 0);
+#pragma unroll
+    for (int c8 = 0; c8 < RPW / 8; ++c8) {
+      const float4 w0 = wsrc[2 * c8], w1 = wsrc[2 * c8 + 1];
+      const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rr = 8 * c8 + i;
+        if (rr > 0 && ((mask >> rr) & 1u)) {
+          if ((s_ok & kbit) && !(dbg & 1)) atomic_add_f32(feat + (int64_t)(s_row + koff) * C + sub, run);
+          run = 0.0f;
+          s_row = __builtin_amdgcn_readlane(row0, rr);
+          s_ok = (unsigned)__builtin_amdgcn_readlane(ok, rr);
+        }
+        run = fmaf(w[i], enc[rr], run);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if ((s_ok & kbit) && !(dbg & 1)) atomic_add_f32(feat + (int64_t)(s_row + koff) * C + sub, run);
+  }
+  // unit weights: ONE more walk in which lane j < 8 owns tap slot j, so that a run costs a single
+  // atomic instruction for all its slots (x-neighbours share a 128-byte line of the weight grid)
+  {
+    const int k = lane & 7;
+    const int koff = (k & 1) * tp.su + ((k >> 1) & 1) * tp.sv + (k >> 2) * tp.st;
+    const unsigned kbit = (lane < 8 && k < (voxel ? 8 : 4)) ? (1u << k) : 0u;
+    const float4* wsrc = reinterpret_cast<const float4*>(wT + k * RPW);
+    float runw = 0.0f;
+    int s_row = __builtin_amdgcn_readlane(row0, 0);
+    unsigned s_ok = (unsigned)__builtin_amdgcn_readlane(ok, 0);
+#pragma unroll
+    for (int c8 = 0; c8 < RPW / 8; ++c8) {
+      const float4 w0 = wsrc[2 * c8], w1 = wsrc[2 * c8 + 1];
+      const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rr = 8 * c8 + i;
+        if (rr > 0 && ((mask >> rr) & 1u)) {
+          if ((s_ok & kbit) && !(dbg & 2)) atomic_add_f32(wgt + (int64_t)(s_row + koff), runw);
+          runw = 0.0f;
+          s_row = __builtin_amdgcn_readlane(row0, rr);
+          s_ok = (unsigned)__builtin_amdgcn_readlane(ok, rr);
+        }
+        runw += w[i];
+      }
+    }
+    if ((s_ok & kbit) && !(dbg & 2)) atomic_add_f32(wgt + (int64_t)(s_row + koff), runw);
+  }
+}
+
+template <int C, int RPW>
+__global__ void __launch_bounds__(256) splat_fwd_walk_kernel(const LpSplatterArgs a, int dbg) {
+  constexpr int LD = RPW + 4;  // row stride of the transposed encoding tile [channel][ray]
+  constexpr int NQ = 64 / RPW;
+  __shared__ __attribute__((aligned(16))) float lds[4][C * LD > 8 * RPW ? C * LD : 8 * RPW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane / RPW, r = lane % RPW;
+  float* tile = lds[wave];
+  const int64_t ray_id = ((int64_t)blockIdx.x * 4 + wave) * RPW + r;
+  const bool valid = ray_id < a.rays.n_rays;
+  const int64_t rid = valid ? ray_id : 0;
+  const Ray ray = load_ray(a.rays, rid);
+  // encoding -> [channel][ray]; lane (q, r) moves channels q*C/NQ .. of its ray
+  constexpr int CPQ = C / NQ;
+#pragma unroll
+  for (int j = 0; j < CPQ / 4; ++j) {
+    const int c0 = q * CPQ + 4 * j;
+    const float4 v = *reinterpret_cast<const float4*>(a.rays.encoding + rid * C + c0);
+    tile[(c0 + 0) * LD + r] = valid ? v.x : 0.0f;
+    tile[(c0 + 1) * LD + r] = valid ? v.y : 0.0f;
+    tile[(c0 + 2) * LD + r] = valid ? v.z : 0.0f;
+    tile[(c0 + 3) * LD + r] = valid ? v.w : 0.0f;
+  }
+  float enc[RPW];
+  {
+    const float4* src = reinterpret_cast<const float4*>(tile + (lane % C) * LD);
+#pragma unroll
+    for (int j = 0; j < RPW / 4; ++j) {
+      const float4 v = src[j];
+      enc[4 * j + 0] = v.x; enc[4 * j + 1] = v.y; enc[4 * j + 2] = v.z; enc[4 * j + 3] = v.w;
+    }
+  }
+  float* wT = tile;  // the tile is free now: [8][RPW] tap weights of the current sample
+  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
+  const bool contract = a.march.contract_coords != 0;
+  const bool mask = a.march.mask_out_of_bounds != 0;
+  for (int s = 0; s < s_tot; ++s) {
+    const float depth = sample_depth(s, a.march, ray.near_t, ray.far_t);
+    float x, y, z;
+    sample_point(ray, depth, contract, x, y, z);
+    const bool live = valid && !(mask && !point_in_bounds(x, y, z));
+    for (int g = 0; g < a.out.n_grids; ++g)
+      splat_walk<C, RPW>(a.out_feature, a.out_weight, a.out.grids[g], ray.b, x, y, z, live, lane, enc, wT, dbg);
   }
 }
 
@@ -151,6 +295,19 @@ __global__ void __launch_bounds__(256) hash_randn_kernel(const int32_t* x1, cons
   } while (0)
 
 int splatter_forward_launch(const LpSplatterArgs& a, hipStream_t stream) {
+  const int Cw = a.out.channels;
+  static const bool no_walk = getenv("LP_SPLAT_NO_WALK") != nullptr;  // A/B timing knob
+  if ((Cw == 16 || Cw == 32) && a.out.n_rows < ((int64_t)1 << 31) && !no_walk) {
+    static const int rpw = getenv("LP_SPLAT_RPW") ? atoi(getenv("LP_SPLAT_RPW")) : 16;
+    static const int dbg = getenv("LP_SPLAT_DEBUG") ? atoi(getenv("LP_SPLAT_DEBUG")) : 0;  // timing experiments
+    const unsigned blocks = (unsigned)((a.rays.n_rays + 4 * rpw - 1) / (4 * rpw));
+    if (blocks == 0) return LP_OK;
+    if (Cw == 16 && rpw == 32) hipLaunchKernelGGL((splat_fwd_walk_kernel<16, 32>), dim3(blocks), dim3(256), 0, stream, a, dbg);
+    else if (Cw == 16) hipLaunchKernelGGL((splat_fwd_walk_kernel<16, 16>), dim3(blocks), dim3(256), 0, stream, a, dbg);
+    else if (rpw == 32) hipLaunchKernelGGL((splat_fwd_walk_kernel<32, 32>), dim3(blocks), dim3(256), 0, stream, a, dbg);
+    else hipLaunchKernelGGL((splat_fwd_walk_kernel<32, 16>), dim3(blocks), dim3(256), 0, stream, a, dbg);
+    return check_launch("splat_fwd_walk_kernel");
+  }
   LP_SPLAT_DISPATCH(splat_fwd_kernel);
   return check_launch("splat_fwd_kernel");
 }

@@ -42,8 +42,18 @@ def flatten_grid(grid: Sequence[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tens
     """Stack a grid-list into ``([sum BDHW, C] tensor, [G, 5] int32 sizes)``."""
     dev = grid[0].device
     sizes = torch.tensor([list(g.shape) for g in grid], dtype=torch.int32, device=dev)
-    flat = torch.cat([g.reshape(-1, g.shape[-1]) for g in grid], dim=0).contiguous()
-    return flat, sizes
+    return _flatten_only(grid), sizes
+
+
+def _flatten_only(grid: Sequence[torch.Tensor]) -> torch.Tensor:
+    """The flat ``[sum BDHW, C]`` tensor of a grid-list (no size tensor: no host->device copy)."""
+    if len(grid) == 1:
+        # zero-copy for single-grid lists (a 256^3 x 32 voxel grid is 2.1 GB: torch.cat would copy it,
+        # and its backward would copy the gradient again)
+        flat = grid[0].reshape(-1, grid[0].shape[-1]).contiguous()
+    else:
+        flat = torch.cat([g.reshape(-1, g.shape[-1]) for g in grid], dim=0).contiguous()
+    return flat
 
 
 def unflatten_grid(grid: torch.Tensor, grid_sizes) -> Tuple[torch.Tensor, ...]:
@@ -134,11 +144,11 @@ def process_and_flatten_grid(grid, color_grid, grid_sizes=None, color_grid_sizes
     if isinstance(grid, list):
         if color_grid is not None:
             color_grid_sizes = [list(g.shape) for g in color_grid]
-            color_grid = flatten_grid(color_grid)[0]
+            color_grid = _flatten_only(color_grid)
         else:
             color_grid_sizes = None
         grid_sizes = [list(g.shape) for g in grid]
-        grid = flatten_grid(grid)[0]
+        grid = _flatten_only(grid)
     elif isinstance(grid, torch.Tensor):
         grid_sizes = sizes_to_list(grid_sizes)
         if color_grid is not None:

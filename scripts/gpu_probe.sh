@@ -1,3 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 scripts/lds_atomic_probe.hip -o /tmp/lap && /tmp/lap | tee gpurun_out/lds_atomic_probe.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 scripts/$1.hip -o /tmp/probe_bin && /tmp/probe_bin | tee gpurun_out/$1.txt
