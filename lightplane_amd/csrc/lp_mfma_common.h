@@ -220,7 +220,11 @@ struct Act {
 // Nothing may be scheduled across this point.  Used to cut the sample loop body into groups of
 // "one layer's MFMAs + one plane's gather": inside a group the scheduler interleaves freely, but it
 // can no longer hoist all 24 dwordx4 loads of a sample to the top (96 live VGPRs).
+#ifdef LP_NO_FENCE
+#define LP_SCHED_FENCE()
+#else
 #define LP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 // Ask the scheduler for the issue order "1 MFMA, a few VALU, (1 global load), (1 LDS read)" N times:
 // a dependent v_mfma_f32_32x32x2_f32 chain stalls its wave 64 cycles per link (in-order issue), so

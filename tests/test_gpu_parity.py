@@ -222,6 +222,40 @@ def test_mlp_splatter_module_and_flat_input():
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
 
 
+def test_empty_and_single_ray_batches():
+    """N = 0 rays is legal everywhere (outputs of the right shape, zero gradients); N = 1 works."""
+    dev = _dev()
+    d = RENDERER_CASES[1].build()
+    dec = d["decoder"]
+    for n in (0, 1):
+        rays = _rays_to(d["rays"][:n], dev, True)
+        params = dec.mlp_params.to(dev).clone().requires_grad_(True)
+        hdec = lp.DecoderParams(params, dec.n_hidden_trunk, dec.n_hidden_opacity, dec.n_hidden_color, dec.color_chn)
+        grids = [g.to(dev).clone().requires_grad_(True) for g in d["grids"]]
+        for kernel in KERNELS:
+            out = lp.lightplane_renderer(rays, grids, hdec, kernel=kernel, **d["cfg"])
+            assert out[0].shape == (n,) and out[1].shape == (n,) and out[2].shape == (n, dec.color_chn)
+            (out[0].sum() + out[1].sum() + out[2].sum()).backward()
+            assert torch.isfinite(params.grad).all() and all(torch.isfinite(g.grad).all() for g in grids)
+            if n == 0:
+                assert float(params.grad.abs().max()) == 0.0 and all(float(g.grad.abs().max()) == 0.0 for g in grids)
+            params.grad = None
+            for g in grids:
+                g.grad = None
+    ds = SPLATTER_CASES[0].build()
+    rays = _rays_to(ds["rays"][:0], dev, True)
+    out = lp.lightplane_splatter(rays, ds["out_sizes"], **ds["cfg"])
+    assert all(float(o.detach().abs().max()) == 0.0 for o in out)
+    sum(o.sum() for o in out).backward()
+    assert rays.encoding.grad.shape == (0, 32)
+    dm = SPLATTER_CASES[4].build()
+    rays = _rays_to(dm["rays"][:0], dev, True)
+    mlp = lp.SplatterParams(dm["mlp"].mlp_params.to(dev).clone().requires_grad_(True), dm["mlp"].n_hidden)
+    out = lp.lightplane_mlp_splatter(rays, dm["out_sizes"], mlp, [g.to(dev) for g in dm["in_grids"]], **dm["cfg"])
+    sum(o.sum() for o in out).backward()
+    assert float(mlp.mlp_params.grad.abs().max()) == 0.0
+
+
 def test_hash_rng(golden_dir):
     dev = _dev()
     z = np.load(os.path.join(golden_dir, "randn.npz"))
