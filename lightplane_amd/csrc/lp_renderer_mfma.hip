@@ -87,6 +87,61 @@ __global__ void __launch_bounds__(256, 2) renderer_fwd_mfma(const LpRendererArgs
   }
 }
 
+// Variant without the software-pipelined gather, register-allocated for OCC waves per SIMD: with
+// C = 32 the pipelined kernel needs >256 registers (94 spilled) and is 2.3x slower than this one at
+// three waves/SIMD; with C = 16 it wins once there are more than two waves of rays per SIMD.
+template <int C, int GM, int OCC>
+__global__ void __launch_bounds__(256, OCC) renderer_fwd_mfma_np(const LpRendererArgs a, const MfmaParams mp) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_weights<C>(a, mp, lds);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, r = lane & 31;
+  const int64_t ray_id = ((int64_t)blockIdx.x * WAVES + wave) * RAYS_PER_WAVE + r;
+  const bool valid = ray_id < a.rays.n_rays;
+  const int64_t rid = valid ? ray_id : 0;
+  const Ray ray = load_ray(a.rays, rid);
+  float enc[16];
+  load_encoding(a, rid, h, enc);
+  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
+  const int n_ckpt = ckpt_count(a.march);
+  const float delta0 = (a.march.num_samples > 1) ? (ray.far_t - ray.near_t) / (float)(a.march.num_samples - 1) : 1.0f;
+  float nlt = 0.0f, t_prev = 1.0f, len = 0.0f, depth_prev = 0.0f;
+  float facc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  Sample<C> nx;
+  Act<C> t;
+  for (int s = 0; s < s_tot; ++s) {
+    fetch_sample<C, GM, true>(a, lds, ray, s, h, nx);
+    const float depth = nx.depth, occ = nx.occ;
+#pragma unroll
+    for (int q = 0; q < C / 2; ++q) t.x0[q] = nx.x0[q];
+    // software pipeline: the next sample's gather is interleaved with this sample's MFMA chain
+    const int zo = opaque_zero();
+    const Heads hd = decode_prefetch<C, GM, false>(a, lds, ray, lane, enc, t, s, nx, zo);
+    const float delta = (s == 0) ? delta0 : depth - depth_prev;
+    depth_prev = depth;
+    float raw = hd.raw_o;
+    if (a.noise_sigma > 0.0f) raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
+    const float opacity = a.gain * softplus_f(raw) * occ;
+    nlt = nlt + opacity * delta;
+    if (a.neg_log_t_ckpt && valid && h == 0) {
+      const int ck = ckpt_index(s, a.march);
+      if (ck >= 0) a.neg_log_t_ckpt[ray_id * n_ckpt + ck] = nlt;
+    }
+    const float tr = __expf(-nlt);
+    const float w = t_prev - tr;
+    t_prev = tr;
+    len = fmaf(w, depth, len);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) facc[c] = fmaf(w, sigmoid_f(hd.raw_c[c]) * occ, facc[c]);
+  }
+  if (valid && h == 0) {
+    a.ray_length[ray_id] = len;
+    a.neg_log_t[ray_id] = nlt;
+    for (int c = 0; c < a.color_chn; ++c) a.feature[ray_id * a.color_chn + c] = facc[c];
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
@@ -157,7 +212,19 @@ static int launch_fwd(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t
   const size_t lds = Lds::FWD_END * sizeof(float);
   int rc;
   if ((rc = set_lds(renderer_fwd_mfma<C, GM>, lds))) return rc;
-  hipLaunchKernelGGL((renderer_fwd_mfma<C, GM>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
+  // measured on MI355X (scripts/fwd_variants.py): 1080p C=32 S=256: 110 ms pipelined vs 48 ms at 3 waves/SIMD;
+  // C=16: 256x256 rays 0.82 vs 0.86 ms, 512x512 rays 3.02 vs 2.85 ms at 4 waves/SIMD
+  static const int forced = getenv("LP_MFMA_FWD_VARIANT") ? atoi(getenv("LP_MFMA_FWD_VARIANT")) : -1;
+  const int variant = forced >= 0 ? forced : (C == 32 ? 3 : (a.rays.n_rays > 3 * 32768 ? 4 : 0));
+  if (variant == 3) {
+    if ((rc = set_lds(renderer_fwd_mfma_np<C, GM, 3>, lds))) return rc;
+    hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM, 3>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
+  } else if (variant == 4) {
+    if ((rc = set_lds(renderer_fwd_mfma_np<C, GM, 4>, lds))) return rc;
+    hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM, 4>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
+  } else {
+    hipLaunchKernelGGL((renderer_fwd_mfma<C, GM>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
+  }
   return LP_OK;
 }
 
