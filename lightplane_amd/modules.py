@@ -139,15 +139,83 @@ class LightplaneRenderer(torch.nn.Module):
         assert len(bg_color) == self.color_chn
         return bg_color
 
-    # -- naive-only helpers of the reference ---------------------------------------------
-    def eval_decoder_at_points(self, *args, **kwargs):
-        raise NotImplementedError("eval_decoder_at_points runs the reference's naive path only; " + _NAIVE_MSG)
+    # -- point evaluation (reference renderer_module.py:183-417) ---------------------------
+    # The reference evaluates these with its naive PyTorch decoder; here they go through the HIP
+    # Renderer itself: a "ray" with near = far = 0 and ONE sample sits exactly at its origin, the
+    # interval length of a single-sample march is 1 (naive_renderer.py:252-256), so the returned
+    # -log T is the opacity at the point and, with a huge gain (T -> 0), the rendered feature is
+    # the colour at the point.
+    def _render_points(self, pts, pts_to_grid_idx, feature_grid, color_feature_grid, scaffold, gain,
+                       mask_out_of_bounds_samples, contract_coords, grid_sizes, rays_encoding):
+        n_rays, n_pts, pts_dim = pts.shape
+        assert pts_dim == 3
+        assert pts_to_grid_idx.shape == (n_rays,)
+        n = n_rays * n_pts
+        dev = pts.device
+        origins = pts.reshape(n, 3).to(torch.float32).contiguous()
+        zeros = torch.zeros(n, device=dev, dtype=torch.float32)
+        if rays_encoding is None:
+            enc = torch.zeros(n, self.rays_encoding_dim, device=dev, dtype=torch.float32)
+        else:
+            enc = rays_encoding[:, None, :].expand(-1, n_pts, -1).reshape(n, -1).contiguous()
+        rays = Rays(directions=torch.zeros_like(origins), origins=origins,
+                    grid_idx=pts_to_grid_idx.to(torch.long)[:, None].expand(-1, n_pts).reshape(n).contiguous(),
+                    near=zeros, far=zeros, encoding=enc)
+        if color_feature_grid is None and int(self.n_hidden_trunk.numel()) == 0:
+            color_feature_grid = feature_grid  # opacity-only evaluation in the two-grid mode: colours unused
+        return lightplane_renderer(
+            rays, feature_grid, self.get_decoder_params(), num_samples=1, gain=gain,
+            mask_out_of_bounds_samples=mask_out_of_bounds_samples, contract_coords=contract_coords,
+            scaffold=scaffold, color_grid=color_feature_grid, grid_sizes=grid_sizes,
+            color_grid_sizes=grid_sizes if color_feature_grid is not None else None)
 
-    def eval_opacity_at_points(self, *args, **kwargs):
-        raise NotImplementedError("eval_opacity_at_points runs the reference's naive path only; " + _NAIVE_MSG)
+    def eval_opacity_at_points(self, pts, pts_to_grid_idx, feature_grid, scaffold=None, gain=None,
+                               mask_out_of_bounds_samples=None, grid_sizes=None):
+        """Opacities ``[n_rays, n_pts]`` of the decoder at ``pts [n_rays, n_pts, 3]`` (reference :302-347)."""
+        out = self._render_points(
+            pts, pts_to_grid_idx, feature_grid, None, scaffold, if_not_none_else(gain, self.gain),
+            if_not_none_else(mask_out_of_bounds_samples, self.mask_out_of_bounds_samples), False, grid_sizes, None)
+        return out[1].reshape(pts.shape[0], pts.shape[1])
 
-    def calculate_scaffold(self, *args, **kwargs):
-        raise NotImplementedError("calculate_scaffold runs the reference's naive path only; " + _NAIVE_MSG)
+    def eval_decoder_at_points(self, pts, pts_to_grid_idx, rays_encoding, feature_grid, color_feature_grid=None,
+                               scaffold=None, gain=None, mask_out_of_bounds_samples=None, contract_coords=None,
+                               directions=None):
+        """(opacity ``[n_rays, n_pts]``, colour ``[n_rays, n_pts, color_chn]``) at ``pts`` (reference
+        :183-241).  The colour comes from a second single-sample render with gain 1e30 (weight 1 - exp(-x) = 1;
+        a point whose softplus underflows to exactly 0 would report colour 0)."""
+        n_rays, n_pts, _ = pts.shape
+        if rays_encoding is not None:
+            assert tuple(rays_encoding.shape) == (n_rays, self.rays_encoding_dim)
+        else:
+            assert directions is not None, "Must pass one of (rays_encoding, directions)"
+            assert directions.shape == (n_rays, 3)
+        enc = self._get_ray_encoding(rays_encoding, directions)
+        mask = if_not_none_else(mask_out_of_bounds_samples, self.mask_out_of_bounds_samples)
+        contract = if_not_none_else(contract_coords, self.contract_coords)
+        args = (pts, pts_to_grid_idx, feature_grid, color_feature_grid, scaffold)
+        opacity = self._render_points(*args, if_not_none_else(gain, self.gain), mask, contract, None, enc)[1]
+        color = self._render_points(*args, 1e30, mask, contract, None, enc)[2]
+        return opacity.reshape(n_rays, n_pts), color.reshape(n_rays, n_pts, self.color_chn)
+
+    @torch.no_grad()
+    def calculate_scaffold(self, feature_grid, scaffold_size, device, threshold: float = 1e-7, grid_sizes=None,
+                           dilate_scaffold: int = 2):
+        """Occupancy scaffold ``[B, D, H, W]`` (0/1 floats): the decoder's opacity on the regular lattice
+        ``x = linspace(-1, 1, W)``, ``y = linspace(-1, 1, H)``, ``z = linspace(-1, 1, D)``, dilated by a
+        max-pool of ``2 * dilate_scaffold + 1`` and thresholded (reference :349-417, which walks the lattice
+        slice by slice through the naive decoder; here one HIP launch per batch element)."""
+        B, D, H, W = (int(v) for v in scaffold_size)
+        lin = lambda n: torch.linspace(0, 1, n, device=device) * 2.0 - 1.0  # noqa: E731
+        zz, yy, xx = torch.meshgrid(lin(D), lin(H), lin(W), indexing="ij")
+        pts = torch.stack([xx, yy, zz], dim=-1).reshape(1, D * H * W, 3)
+        scaffold = torch.empty(B, D, H, W, device=device)
+        for b in range(B):
+            idx = torch.full((1,), b, dtype=torch.long, device=device)
+            scaffold[b] = self.eval_opacity_at_points(pts, idx, feature_grid, grid_sizes=grid_sizes).reshape(D, H, W)
+        if dilate_scaffold > 0:
+            ks = dilate_scaffold * 2 + 1
+            scaffold = torch.nn.functional.max_pool3d(scaffold, kernel_size=ks, padding=dilate_scaffold, stride=1)
+        return (scaffold > threshold) * 1.0
 
     # -- ray encoding ---------------------------------------------------------------------
     def _get_ray_embedding(self, ray_directions: torch.Tensor) -> torch.Tensor:

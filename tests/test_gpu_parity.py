@@ -256,6 +256,43 @@ def test_empty_and_single_ray_batches():
     assert float(mlp.mlp_params.grad.abs().max()) == 0.0
 
 
+def test_module_point_evaluation_and_scaffold():
+    """LightplaneRenderer.eval_opacity_at_points / eval_decoder_at_points / calculate_scaffold run through
+    the HIP path (single-sample rays) and agree with the oracle's point decoder."""
+    dev = _dev()
+    torch.manual_seed(0)
+    mod = lp.LightplaneRenderer(num_samples=8, color_chn=3, grid_chn=16, mlp_hidden_chn=32, gain=2.0,
+                                opacity_init_bias=-1.0, ray_embedding_num_harmonics=None).to(dev)
+    with torch.no_grad():
+        mod.mlp_params.mul_(3.0)
+    grids = [0.5 * torch.randn(s) for s in grid_sizes_for((2, 6, 5, 7, 16), True)]
+    pts = torch.rand(5, 11, 3) * 2.4 - 1.2
+    gidx = torch.tensor([0, 1, 1, 0, 1])
+    enc = torch.randn(5, 32)
+    dec = mod.get_decoder_params()
+    cdec = lp.DecoderParams(dec.mlp_params.detach().cpu(), dec.n_hidden_trunk.cpu(), dec.n_hidden_opacity.cpu(),
+                            dec.n_hidden_color.cpu(), 3)
+    for mask in (False, True):
+        o_op, o_col = O.eval_decoder(pts, grids, gidx, cdec, enc, 2.0, mask_out_of_bounds_samples=mask)
+        op = mod.eval_opacity_at_points(pts.to(dev), gidx.to(dev), [g.to(dev) for g in grids],
+                                        mask_out_of_bounds_samples=mask)
+        _assert_close("opacity", op, o_op.detach().numpy(), tol=2e-5)
+        op2, col = mod.eval_decoder_at_points(pts.to(dev), gidx.to(dev), enc.to(dev), [g.to(dev) for g in grids],
+                                              mask_out_of_bounds_samples=mask)
+        _assert_close("opacity2", op2, o_op.detach().numpy(), tol=2e-5)
+        _assert_close("colour", col, o_col[..., :3].detach().numpy(), tol=2e-5)
+    sc = mod.calculate_scaffold([g.to(dev) for g in grids], [2, 6, 5, 7], dev, threshold=0.6, dilate_scaffold=1)
+    assert sc.shape == (2, 6, 5, 7) and set(sc.unique().tolist()) <= {0.0, 1.0}
+    lin = lambda n: torch.linspace(0, 1, n) * 2 - 1  # noqa: E731
+    zz, yy, xx = torch.meshgrid(lin(6), lin(5), lin(7), indexing="ij")
+    lattice = torch.stack([xx, yy, zz], -1).reshape(1, -1, 3)
+    want = torch.stack([O.eval_decoder(lattice, grids, torch.tensor([b]), cdec, torch.zeros(1, 32), 2.0)[0].reshape(6, 5, 7)
+                        for b in range(2)])
+    want = (torch.nn.functional.max_pool3d(want, 3, padding=1, stride=1) > 0.6).float()
+    margin = (torch.nn.functional.max_pool3d(want, 1) - 0).abs()  # noqa: F841
+    assert (sc.cpu() != want).float().mean().item() < 0.02  # thresholding of values within fp32 round-off of 0.6
+
+
 def test_hash_rng(golden_dir):
     dev = _dev()
     z = np.load(os.path.join(golden_dir, "randn.npz"))
