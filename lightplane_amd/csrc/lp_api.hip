@@ -199,15 +199,26 @@ int lp_abi_sizeof(int which) {
   }
 }
 
+// kernel selection: width-32 MFMA family, width-64 MFMA family, else the shape-generic kernel
+static int select_renderer(const LpRendererArgs& a, const char** why) {
+  const char* w32 = "";
+  const char* w64 = "";
+  if (renderer_mfma_supported(a, &w32)) return 1;
+  if (renderer_mfma_wide_supported(a, &w64)) return 2;
+  *why = w32;
+  return 0;
+}
+
 int lp_renderer_forward(const LpRendererArgs* args, void* stream) {
   if (!args) return set_error(LP_ENULL, "args is NULL");
   int rc = check_renderer(*args, false);
   if (rc) return rc;
   const char* why = "";
-  const bool mfma_ok = renderer_mfma_supported(*args, &why);
-  if (args->kernel == LP_KERNEL_MFMA && !mfma_ok)
+  const int fam = select_renderer(*args, &why);
+  if (args->kernel == LP_KERNEL_MFMA && fam == 0)
     return set_error(LP_EUNSUPPORTED, "MFMA renderer kernel unavailable for this shape: %s", why);
-  if (mfma_ok && args->kernel != LP_KERNEL_GENERIC) return renderer_forward_mfma(*args, (hipStream_t)stream);
+  if (fam == 1 && args->kernel != LP_KERNEL_GENERIC) return renderer_forward_mfma(*args, (hipStream_t)stream);
+  if (fam == 2 && args->kernel != LP_KERNEL_GENERIC) return renderer_forward_mfma_wide(*args, (hipStream_t)stream);
   return renderer_forward_generic(*args, (hipStream_t)stream);
 }
 
@@ -216,10 +227,11 @@ int lp_renderer_backward(const LpRendererArgs* args, void* stream) {
   int rc = check_renderer(*args, true);
   if (rc) return rc;
   const char* why = "";
-  const bool mfma_ok = renderer_mfma_supported(*args, &why);
-  if (args->kernel == LP_KERNEL_MFMA && !mfma_ok)
+  const int fam = select_renderer(*args, &why);
+  if (args->kernel == LP_KERNEL_MFMA && fam == 0)
     return set_error(LP_EUNSUPPORTED, "MFMA renderer kernel unavailable for this shape: %s", why);
-  if (mfma_ok && args->kernel != LP_KERNEL_GENERIC) return renderer_backward_mfma(*args, (hipStream_t)stream);
+  if (fam == 1 && args->kernel != LP_KERNEL_GENERIC) return renderer_backward_mfma(*args, (hipStream_t)stream);
+  if (fam == 2 && args->kernel != LP_KERNEL_GENERIC) return renderer_backward_mfma_wide(*args, (hipStream_t)stream);
   return renderer_backward_generic(*args, (hipStream_t)stream);
 }
 

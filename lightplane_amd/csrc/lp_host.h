@@ -20,6 +20,10 @@ int renderer_corner_rows_launch(const LpRendererArgs& a, int64_t* rows, hipStrea
 bool renderer_mfma_supported(const LpRendererArgs& a, const char** why);
 int renderer_forward_mfma(const LpRendererArgs& a, hipStream_t stream);
 int renderer_backward_mfma(const LpRendererArgs& a, hipStream_t stream);
+// MFMA kernels, hidden width 64: lp_renderer_mfma_wide.hip
+bool renderer_mfma_wide_supported(const LpRendererArgs& a, const char** why);
+int renderer_forward_mfma_wide(const LpRendererArgs& a, hipStream_t stream);
+int renderer_backward_mfma_wide(const LpRendererArgs& a, hipStream_t stream);
 
 // splatter: lp_splatter.hip
 int splatter_forward_launch(const LpSplatterArgs& a, hipStream_t stream);

@@ -118,6 +118,17 @@ def make_randn():
 
 def main():
     torch.manual_seed(0)
+    only = set(sys.argv[1:])  # optional: case names to (re)generate; default = all
+    if only:
+        for case in RENDERER_CASES:
+            if case.name in only:
+                np.savez_compressed(os.path.join(HERE, f"renderer__{case.name}.npz"), **make_renderer(case))
+                print("renderer", case.name)
+        for case in SPLATTER_CASES:
+            if case.name in only:
+                np.savez_compressed(os.path.join(HERE, f"splatter__{case.name}.npz"), **make_splatter(case))
+                print("splatter", case.name)
+        return
     for case in RENDERER_CASES:
         rec = make_renderer(case)
         np.savez_compressed(os.path.join(HERE, f"renderer__{case.name}.npz"), **rec)
