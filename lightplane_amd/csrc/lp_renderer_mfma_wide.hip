@@ -267,25 +267,36 @@ LP_DEV void dw_slab(const float* wave0, int a_off, int b_off, f32x4w (&acc)[NQ],
     const float* base = wave0 + v * PER_WAVE;
     const float4 b0 = *reinterpret_cast<const float4*>(base + b_off);
     const float4 b1 = *reinterpret_cast<const float4*>(base + b_off + 4);
+    float4 a0[NQ], a1[NQ];
 #pragma unroll
     for (int mi = 0; mi < NQ; ++mi) {
-      const float4 a0 = *reinterpret_cast<const float4*>(base + a_off + 16 * mi * TW_LD);
-      const float4 a1 = *reinterpret_cast<const float4*>(base + a_off + 16 * mi * TW_LD + 4);
-      acc[mi] = LP_MFMA16W(a0.x, b0.x, acc[mi]);
-      acc[mi] = LP_MFMA16W(a0.y, b0.y, acc[mi]);
-      acc[mi] = LP_MFMA16W(a0.z, b0.z, acc[mi]);
-      acc[mi] = LP_MFMA16W(a0.w, b0.w, acc[mi]);
-      acc[mi] = LP_MFMA16W(a1.x, b1.x, acc[mi]);
-      acc[mi] = LP_MFMA16W(a1.y, b1.y, acc[mi]);
-      acc[mi] = LP_MFMA16W(a1.z, b1.z, acc[mi]);
-      acc[mi] = LP_MFMA16W(a1.w, b1.w, acc[mi]);
+      a0[mi] = *reinterpret_cast<const float4*>(base + a_off + 16 * mi * TW_LD);
+      a1[mi] = *reinterpret_cast<const float4*>(base + a_off + 16 * mi * TW_LD + 4);
     }
+    // the NQ accumulators are independent: interleave them so that no MFMA waits for its predecessor
+    // (v_mfma_f32_16x16x4_f32: 32 cycles issue, 40 cycles dependent)
+#pragma unroll
+    for (int mi = 0; mi < NQ; ++mi) acc[mi] = LP_MFMA16W(a0[mi].x, b0.x, acc[mi]);
+#pragma unroll
+    for (int mi = 0; mi < NQ; ++mi) acc[mi] = LP_MFMA16W(a0[mi].y, b0.y, acc[mi]);
+#pragma unroll
+    for (int mi = 0; mi < NQ; ++mi) acc[mi] = LP_MFMA16W(a0[mi].z, b0.z, acc[mi]);
+#pragma unroll
+    for (int mi = 0; mi < NQ; ++mi) acc[mi] = LP_MFMA16W(a0[mi].w, b0.w, acc[mi]);
+#pragma unroll
+    for (int mi = 0; mi < NQ; ++mi) acc[mi] = LP_MFMA16W(a1[mi].x, b1.x, acc[mi]);
+#pragma unroll
+    for (int mi = 0; mi < NQ; ++mi) acc[mi] = LP_MFMA16W(a1[mi].y, b1.y, acc[mi]);
+#pragma unroll
+    for (int mi = 0; mi < NQ; ++mi) acc[mi] = LP_MFMA16W(a1[mi].z, b1.z, acc[mi]);
+#pragma unroll
+    for (int mi = 0; mi < NQ; ++mi) acc[mi] = LP_MFMA16W(a1[mi].w, b1.w, acc[mi]);
     s += ((b0.x + b0.y) + (b0.z + b0.w)) + ((b1.x + b1.y) + (b1.z + b1.w));
   }
   db += s;
 }
 
-template <int C, int GM, int NB>
+template <int C, int GM, int NB, bool PLAIN>
 __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererArgs a, const MfmaParams mp) {
   static_assert(NB == 2, "the dW slab assignment (wave w <-> output columns 16w..) assumes 64 output features");
   using M = LdsW<NB>;
@@ -351,7 +362,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
   float nlt = a.neg_log_t[rid];
   float suffix = 0.0f, p_next = 0.0f;
   Sample<C> nx;
-  fetch_sample<C, GM, true>(a, lds_inf, ray, s_tot - 1, h, nx);
+  fetch_sample<C, GM, true, PLAIN>(a, lds_inf, ray, s_tot - 1, h, nx);
   for (int s = s_tot - 1; s >= 0; --s) {
     const float depth = nx.depth, occ = nx.occ, x = nx.x, y = nx.y, z = nx.z;
     float x0[C / 2];
@@ -387,13 +398,17 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
     LP_SCHED_FENCE();
 
     // ---------------- compositing, backward ----------------
-    const float depth_prev = sample_depth_tab((s > 0) ? s - 1 : 0, a.march, ray.near_t, ray.far_t, lds + M::INF);
+    const float depth_prev =
+        PLAIN ? ray.near_t + lin01((s > 0) ? s - 1 : 0, a.march.num_samples) * (ray.far_t - ray.near_t)
+              : sample_depth_tab((s > 0) ? s - 1 : 0, a.march, ray.near_t, ray.far_t, lds + M::INF);
     const float delta = (s == 0) ? delta0 : depth - depth_prev;
     float raw = hd.raw_o;
-    if (a.noise_sigma > 0.0f) raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
+    if (!PLAIN && a.noise_sigma > 0.0f)
+      raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
     const float opacity = a.gain * softplus_f(raw) * occ;
     if (a.neg_log_t_ckpt) {
-      const int ck = ckpt_index(s, a.march);
+      const int ck = PLAIN ? ((((s + 1) % LP_NLT_CKPT) == 0 || s == s_tot - 1) ? s / LP_NLT_CKPT : -1)
+                           : ckpt_index(s, a.march);
       if (ck >= 0) nlt = a.neg_log_t_ckpt[rid * n_ckpt + ck];
     }
     const float t_i = __expf(-nlt);
@@ -416,21 +431,21 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
     for (int c = 0; c < 4; ++c) drc[c] = valid ? w * gfeat[c] * occ * sg[c] * (1.0f - sg[c]) : 0.0f;
 
     // ---------------- output layers of the heads (VALU) ----------------
-    float dho[16 * NB], dhc[16 * NB];
+    // d ho is formed where it is needed (opacity hidden layer): keep only the ReLU mask of ho
+    unsigned ho_mask = 0;
+#pragma unroll
+    for (int q = 0; q < 16 * NB; ++q) ho_mask |= (ho[q] > 0.0f) ? (1u << q) : 0u;
+    float dhc[16 * NB];
     {
-      const float* wo2 = lds + M::WO2 + 4 * h + opaque_zero();
       const float* wc2 = lds + M::WC2 + 16 * h + opaque_zero();
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float4 wo = *reinterpret_cast<const float4*>(wo2 + 32 * b + 8 * j);
-          const float wov[4] = {wo.x, wo.y, wo.z, wo.w};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int q = 16 * b + 4 * j + i;
             const float4 wc = *reinterpret_cast<const float4*>(wc2 + (32 * b + 8 * j + i) * 4);
-            dho[q] = (ho[q] > 0.0f) ? dro * wov[i] : 0.0f;
             float v = drc[0] * wc.x;
             v = fmaf(drc[1], wc.y, v);
             v = fmaf(drc[2], wc.z, v);
@@ -497,6 +512,22 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
     if (want_params) lds_barrier_w();
     LP_SCHED_FENCE();
     // ---------------- opacity hidden layer ----------------
+    float dho[16 * NB];
+    {
+      const float* wo2 = lds + M::WO2 + 4 * h + opaque_zero();
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 wo = *reinterpret_cast<const float4*>(wo2 + 32 * b + 8 * j);
+          const int q = 16 * b + 4 * j;
+          dho[q + 0] = (ho_mask & (1u << (q + 0))) ? dro * wo.x : 0.0f;
+          dho[q + 1] = (ho_mask & (1u << (q + 1))) ? dro * wo.y : 0.0f;
+          dho[q + 2] = (ho_mask & (1u << (q + 2))) ? dro * wo.z : 0.0f;
+          dho[q + 3] = (ho_mask & (1u << (q + 3))) ? dro * wo.w : 0.0f;
+        }
+      }
+    }
     if (want_params) {
       tile_store_w<NB>(xt, r, h, e);
       tile_store_w<NB>(yt, r, h, dho);
@@ -546,7 +577,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
     LP_SCHED_FENCE();
     // ---------------- next (nearer) sample + grid gradient ----------------
     const bool live = valid && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
-    if (s > 0) fetch_sample<C, GM, true>(a, lds_inf, ray, s - 1, h, nx);
+    if (s > 0) fetch_sample<C, GM, true, PLAIN>(a, lds_inf, ray, s - 1, h, nx);
     LP_SCHED_FENCE();
     if (gg && !(mp.dbg & 2)) {
       const float* dxrow = xt + (lane % C) * DX_LD;
@@ -706,7 +737,16 @@ int renderer_backward_mfma_wide(const LpRendererArgs& a, hipStream_t stream) {
   if (a.rays.n_rays == 0) return LP_OK;
   const MfmaParams mp = make_params_w(a, 64);
   int rc;
-  LP_DISPATCH_W(renderer_bwd_mfma_w, LdsW<2>::BWD_END * sizeof(float));
+  const bool plain = !(a.noise_sigma > 0.0f) && !a.march.contract_coords && !a.scaffold && a.march.num_samples_inf == 0;
+  const size_t lds_b = LdsW<2>::BWD_END * sizeof(float);
+#define LP_BW(CV, GMV) (plain ? launch_w(renderer_bwd_mfma_w<CV, GMV, 2, true>, lds_b, a, mp, stream) \
+                              : launch_w(renderer_bwd_mfma_w<CV, GMV, 2, false>, lds_b, a, mp, stream))
+  {
+    const int gm = grid_mode_w(a);
+    if (a.grid.channels == 16) rc = gm == GM_TRIPLANE ? LP_BW(16, GM_TRIPLANE) : gm == GM_VOXEL ? LP_BW(16, GM_VOXEL) : LP_BW(16, GM_GENERIC);
+    else rc = gm == GM_TRIPLANE ? LP_BW(32, GM_TRIPLANE) : gm == GM_VOXEL ? LP_BW(32, GM_VOXEL) : LP_BW(32, GM_GENERIC);
+  }
+#undef LP_BW
   if (rc) return rc;
   if ((rc = check_launch("renderer_bwd_mfma_w"))) return rc;
   return fold_grad_replicas(a, stream);
