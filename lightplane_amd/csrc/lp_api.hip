@@ -248,7 +248,13 @@ int lp_splatter_forward(const LpSplatterArgs* args, void* stream) {
   if (!args) return set_error(LP_ENULL, "args is NULL");
   int rc = check_splatter(*args, false);
   if (rc) return rc;
-  if (args->mlp.n_layers > 0) return splatter_mlp_forward_launch(*args, (hipStream_t)stream);
+  if (args->mlp.n_layers > 0) {
+    const bool fast = splatter_mlp_mfma_supported(*args);
+    if (args->kernel == LP_KERNEL_MFMA && !fast)
+      return set_error(LP_EUNSUPPORTED, "MFMA MLP-splatter kernel unavailable for this shape");
+    if (fast && args->kernel != LP_KERNEL_GENERIC) return splatter_mlp_forward_mfma(*args, (hipStream_t)stream);
+    return splatter_mlp_forward_launch(*args, (hipStream_t)stream);
+  }
   return splatter_forward_launch(*args, (hipStream_t)stream);
 }
 
@@ -262,7 +268,13 @@ int lp_splatter_backward(const LpSplatterArgs* args, void* stream) {
   if (!args) return set_error(LP_ENULL, "args is NULL");
   int rc = check_splatter(*args, true);
   if (rc) return rc;
-  if (args->mlp.n_layers > 0) return splatter_mlp_backward_launch(*args, (hipStream_t)stream);
+  if (args->mlp.n_layers > 0) {
+    const bool fast = splatter_mlp_mfma_supported(*args);
+    if (args->kernel == LP_KERNEL_MFMA && !fast)
+      return set_error(LP_EUNSUPPORTED, "MFMA MLP-splatter kernel unavailable for this shape");
+    if (fast && args->kernel != LP_KERNEL_GENERIC) return splatter_mlp_backward_mfma(*args, (hipStream_t)stream);
+    return splatter_mlp_backward_launch(*args, (hipStream_t)stream);
+  }
   return splatter_backward_launch(*args, (hipStream_t)stream);
 }
 

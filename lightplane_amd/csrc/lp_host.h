@@ -31,6 +31,10 @@ int splatter_backward_launch(const LpSplatterArgs& a, hipStream_t stream);
 // MLP-Splatter: lp_splatter_mlp.hip
 int splatter_mlp_forward_launch(const LpSplatterArgs& a, hipStream_t stream);
 int splatter_mlp_backward_launch(const LpSplatterArgs& a, hipStream_t stream);
+// MLP-Splatter on the matrix cores ([E,32,Cout] family): lp_splatter_mlp_mfma.hip
+bool splatter_mlp_mfma_supported(const LpSplatterArgs& a);
+int splatter_mlp_forward_mfma(const LpSplatterArgs& a, hipStream_t stream);
+int splatter_mlp_backward_mfma(const LpSplatterArgs& a, hipStream_t stream);
 int splatter_normalize_launch(float* feature, const float* weight, int64_t n_rows, int channels,
                               hipStream_t stream);
 int hash_randn_launch(const int32_t* x1, const int32_t* x2, float* out, int64_t n, int32_t seed,

@@ -41,6 +41,7 @@ class _SplatterCfg:
     in_channels: int = 0
     in_n_rows: int = 0
     mlp_dims: Optional[List[int]] = None
+    kernel: int = 0
 
 
 def _fill_args(cfg: _SplatterCfg, directions, origins, grid_idx, near, far, feature, mlp_params=None,
@@ -55,6 +56,7 @@ def _fill_args(cfg: _SplatterCfg, directions, origins, grid_idx, near, far, feat
         a.mlp_params = _lib.ptr(mlp_params)
         a.n_mlp_params = mlp_params.numel()
         a.mlp = _lib.make_mlp(cfg.mlp_dims, 0)
+        a.kernel = int(cfg.kernel)
     return a
 
 
@@ -218,6 +220,7 @@ def lightplane_mlp_splatter(
     triton_block_size: int = 16,  # ignored
     triton_num_warps: int = 4,  # ignored
     process_group=None,
+    kernel: int = _lib.LP_KERNEL_AUTO,
 ):
     """Splat ``MLP(sample(input_grid, x) + rays.encoding)`` into a zero-initialised grid-list.
 
@@ -254,7 +257,7 @@ def lightplane_mlp_splatter(
         f"The number of elements in mlp param should be {mlp_numel(dims)}. Got {flat_params.numel()} instead.")
     cfg = _SplatterCfg(descs, channels, n_rows, int(num_samples), int(num_samples_inf),
                        bool(mask_out_of_bounds_samples), bool(contract_coords), float(disparity_at_inf),
-                       process_group, in_descs, in_channels, in_n_rows, dims)
+                       process_group, in_descs, in_channels, in_n_rows, dims, int(kernel))
     out = LightplaneMLPSplatterFunction.apply(rays.encoding, flat_params, input_grid, cfg,
                                               *_prep_rays(rays, descs[0].B))
     if return_list:

@@ -230,4 +230,10 @@ SPLATTER_CASES = [
     SplatterCase("mlp_triplane_in_triplane", seed=5, use_mlp=True, is_triplane=True, in_triplane=True, n_layers=4,
                  hidden=64, feat_dim=64, mask_oob=True),
     SplatterCase("single_ray", seed=6, n_rays=1),
+    # two-layer hidden-32 MLPs (LightplaneMLPSplatter's default shape): MFMA MLP-Splatter family
+    SplatterCase("mlp2_voxel", seed=7, use_mlp=True, n_layers=2, n_rays=70, num_samples=11),
+    SplatterCase("mlp2_triplane_c16", seed=8, use_mlp=True, n_layers=2, feat_dim=16, out_base=(2, 6, 5, 7, 16),
+                 is_triplane=True, in_triplane=True, mask_oob=True, num_samples_inf=2, n_rays=40),
+    SplatterCase("mlp2_voxel_in16_out32", seed=9, use_mlp=True, n_layers=2, feat_dim=16, in_base=(2, 4, 6, 5, 16),
+                 contract=True, num_samples_inf=3, n_rays=33),
 ]

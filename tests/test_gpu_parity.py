@@ -162,23 +162,24 @@ def test_splatter_matches_oracle_and_golden(case, golden_dir):
     _assert_close("grad_encoding/oracle", ge, rays.encoding.grad.numpy())
 
 
-def run_hip_mlp_splatter(d, dev, flat_input=False):
+def run_hip_mlp_splatter(d, dev, kernel=_lib.LP_KERNEL_AUTO):
     rays = _rays_to(d["rays"], dev, True)
     mlp = d["mlp"]
     params = mlp.mlp_params.to(dev).clone().requires_grad_(True)
     hmlp = lp.SplatterParams(params, mlp.n_hidden)
     in_grids = [g.to(dev).clone().requires_grad_(True) for g in d["in_grids"]]
-    out = lp.lightplane_mlp_splatter(rays, d["out_sizes"], hmlp, in_grids, **d["cfg"])
+    out = lp.lightplane_mlp_splatter(rays, d["out_sizes"], hmlp, in_grids, kernel=kernel, **d["cfg"])
     sum((o * u.to(dev)).sum() for o, u in zip(out, d["upstream"])).backward()
     return out, rays.encoding.grad, params.grad, [g.grad for g in in_grids]
 
 
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
 @pytest.mark.parametrize("case", [c for c in SPLATTER_CASES if c.use_mlp], ids=lambda c: c.name)
-def test_mlp_splatter_matches_oracle_and_golden(case, golden_dir):
+def test_mlp_splatter_matches_oracle_and_golden(case, kernel, golden_dir):
     dev = _dev()
     d = case.build()
     z = np.load(os.path.join(golden_dir, f"splatter__{case.name}.npz"))
-    out, ge, gp, gin = run_hip_mlp_splatter(d, dev)
+    out, ge, gp, gin = run_hip_mlp_splatter(d, dev, kernel)
     import copy
     rays = copy.copy(d["rays"])
     rays.encoding = rays.encoding.clone().requires_grad_(True)
