@@ -402,6 +402,19 @@ LP_DEV void scatter_grid(float* gg, const LpGrid& g, int b, float x, float y, fl
     float run = 0.0f;
     int s_row = __builtin_amdgcn_readlane(row0, 0);
     unsigned s_ok = (unsigned)__builtin_amdgcn_readlane(ok, 0);
+    if (mask == 1u) {
+      // all 32 rays in one cell (e.g. the plane an image row projects onto as a line): no run logic at all
+#pragma unroll
+      for (int c4 = 0; c4 < 8; ++c4) {
+        const float4 w = wsrc[c4], d = dsrc[c4];
+        run = fmaf(w.x, d.x, run);
+        run = fmaf(w.y, d.y, run);
+        run = fmaf(w.z, d.z, run);
+        run = fmaf(w.w, d.w, run);
+      }
+      flush_run<C>(gg, s_row, s_ok, koff, kbit, sub, run, dbg);
+      continue;
+    }
 #pragma unroll
     for (int c8 = 0; c8 < 4; ++c8) {  // 8 rays at a time: 16 live operand registers
       const float4 w0 = wsrc[2 * c8], w1 = wsrc[2 * c8 + 1];
