@@ -192,6 +192,14 @@ const char* lp_last_error(void);
  * 6 LpSplatterArgs; anything else returns -1. */
 int lp_abi_sizeof(int which);
 
+/* Which kernel family LP_KERNEL_AUTO selects for these arguments (no launch; shapes only):
+ *   lp_renderer_kernel_family: 0 shape-generic VALU kernels, 1 MFMA hidden-32 family, 2 MFMA hidden-64 family
+ *   lp_splatter_kernel_family: 0 shape-generic kernels, 1 run-merged walk (plain Splatter, C in {16,32}),
+ *                              2 MFMA MLP-Splatter ([E,32,Cout] family)
+ * The generic kernels are correctness anchors, one to two orders of magnitude slower. */
+int lp_renderer_kernel_family(const LpRendererArgs* args);
+int lp_splatter_kernel_family(const LpSplatterArgs* args);
+
 int lp_renderer_forward(const LpRendererArgs* args, void* stream);
 int lp_renderer_backward(const LpRendererArgs* args, void* stream);
 

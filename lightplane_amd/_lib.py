@@ -94,7 +94,7 @@ LIB_PATH = os.environ.get("LIGHTPLANE_AMD_LIB") or os.path.join(os.path.dirname(
 EXPORTS = (
     "lp_version", "lp_last_error", "lp_abi_sizeof", "lp_renderer_forward", "lp_renderer_backward",
     "lp_splatter_forward", "lp_splatter_normalize", "lp_splatter_backward", "lp_hash_randn",
-    "lp_renderer_corner_rows",
+    "lp_renderer_corner_rows", "lp_renderer_kernel_family", "lp_splatter_kernel_family",
 )
 
 
@@ -129,6 +129,10 @@ def lib() -> C.CDLL:
     L.lp_hash_randn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
     L.lp_renderer_corner_rows.restype = C.c_int
     L.lp_renderer_corner_rows.argtypes = [C.POINTER(LpRendererArgs), C.c_void_p, C.c_void_p]
+    L.lp_renderer_kernel_family.restype = C.c_int
+    L.lp_renderer_kernel_family.argtypes = [C.POINTER(LpRendererArgs)]
+    L.lp_splatter_kernel_family.restype = C.c_int
+    L.lp_splatter_kernel_family.argtypes = [C.POINTER(LpSplatterArgs)]
     L.lp_abi_sizeof.restype = C.c_int
     L.lp_abi_sizeof.argtypes = [C.c_int]
     for which, st in enumerate((LpGrid, LpGridList, LpRays, LpMarch, LpMlp, LpRendererArgs, LpSplatterArgs)):

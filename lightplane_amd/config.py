@@ -10,6 +10,8 @@
                        atomics serialise on MI355X (~25 ns each) and image-coherent rays hit the
                        same plane rows from every workgroup; with the run-merged scatter the effect
                        measured on the 256x256 triplane benchmark is nil, so the default is 0.
+``warn_generic_kernel`` warn (once per shape) when a call falls back to the shape-generic kernels, which
+                       are one to two orders of magnitude slower than the MFMA / walk families.  Default on.
 """
 import os
 
@@ -17,3 +19,4 @@ check_inputs: bool = os.environ.get("LIGHTPLANE_AMD_CHECK_INPUTS", "1") != "0"
 check_finite_grads: bool = os.environ.get("LIGHTPLANE_AMD_CHECK_FINITE", "0") == "1"
 _gr = os.environ.get("LIGHTPLANE_AMD_GRAD_REPLICAS")
 grad_replicas: int = int(_gr) if _gr is not None else 0
+warn_generic_kernel: bool = os.environ.get("LIGHTPLANE_AMD_WARN_GENERIC", "1") != "0"

@@ -209,6 +209,19 @@ static int select_renderer(const LpRendererArgs& a, const char** why) {
   return 0;
 }
 
+int lp_renderer_kernel_family(const LpRendererArgs* args) {
+  if (!args) return set_error(LP_ENULL, "args is NULL");
+  const char* why = "";
+  return select_renderer(*args, &why);
+}
+
+int lp_splatter_kernel_family(const LpSplatterArgs* args) {
+  if (!args) return set_error(LP_ENULL, "args is NULL");
+  if (args->mlp.n_layers > 0) return splatter_mlp_mfma_supported(*args) ? 2 : 0;
+  const int C = args->out.channels;
+  return ((C == 16 || C == 32) && args->out.n_rows < ((int64_t)1 << 31)) ? 1 : 0;
+}
+
 int lp_renderer_forward(const LpRendererArgs* args, void* stream) {
   if (!args) return set_error(LP_ENULL, "args is NULL");
   int rc = check_renderer(*args, false);

@@ -90,6 +90,48 @@ def _fill_args(cfg: _RendererCfg, grid, color_grid, mlp_params, directions, orig
     return a
 
 
+_warned_shapes = set()
+
+
+def _warn_if_generic(a, cfg: _RendererCfg) -> None:
+    if not config.warn_generic_kernel or cfg.kernel != _lib.LP_KERNEL_AUTO:
+        return
+    key = (cfg.channels, tuple(cfg.dims_trunk), tuple(cfg.dims_opacity), tuple(cfg.dims_color), cfg.color_chn,
+           cfg.color_descs is not None)
+    if key in _warned_shapes:
+        return
+    if _lib.lib().lp_renderer_kernel_family(ctypes.byref(a)) == 0:
+        _warned_shapes.add(key)
+        warnings.warn(
+            "lightplane_amd: this decoder shape runs on the shape-generic Renderer kernels (10-100x slower). The "
+            "MFMA families cover grid channels 16/32, trunk/opacity/colour MLPs of 2 layers with hidden width 32 "
+            "or 64, <= 4 colour channels, a single grid-list below 4 GB. "
+            f"Got channels={cfg.channels}, trunk={cfg.dims_trunk}, opacity={cfg.dims_opacity}, "
+            f"color={cfg.dims_color}, color_chn={cfg.color_chn}, separate colour grid={cfg.color_descs is not None}.")
+
+
+def kernel_family(rays: Rays, grid, decoder_params: DecoderParams, grid_sizes=None, color_grid=None,
+                  color_grid_sizes=None) -> int:
+    """Kernel family ``LP_KERNEL_AUTO`` selects for these shapes: 0 generic, 1 MFMA hidden-32, 2 MFMA hidden-64
+    (``lp_renderer_kernel_family``; needs no GPU)."""
+    if isinstance(grid, (list, tuple)):
+        grid_sizes = [list(g.shape) for g in grid]
+    descs, channels, n_rows = make_grid_descs(grid_sizes)
+    color_descs, color_n_rows = None, 0
+    if color_grid is not None:
+        if isinstance(color_grid, (list, tuple)):
+            color_grid_sizes = [list(g.shape) for g in color_grid]
+        color_descs, _, color_n_rows = make_grid_descs(color_grid_sizes)
+    dims_t, dims_o, dims_c = _decoder_dims(decoder_params)
+    a = _lib.LpRendererArgs()
+    a.grid = _lib.make_grid_list(None, descs, channels, n_rows)
+    a.color_grid = _lib.make_grid_list(None, color_descs or [], channels if color_descs else 0, color_n_rows)
+    n_t, n_o = mlp_numel(dims_t), mlp_numel(dims_o)
+    a.trunk, a.opacity, a.color = _lib.make_mlp(dims_t, 0), _lib.make_mlp(dims_o, n_t), _lib.make_mlp(dims_c, n_t + n_o)
+    a.color_chn = int(decoder_params.color_chn)
+    return int(_lib.lib().lp_renderer_kernel_family(ctypes.byref(a)))
+
+
 class LightplaneFunction(torch.autograd.Function):
     """Autograd boundary of the Renderer (name kept from the reference, :296)."""
 
@@ -111,6 +153,7 @@ class LightplaneFunction(torch.autograd.Function):
         # transmittance reconstruction exact (the reference saves only the final value, :558-573)
         ckpt = torch.empty(n, _lib.n_nlt_ckpt(cfg.num_samples, cfg.num_samples_inf), device=dev, dtype=torch.float32)
         a.neg_log_t_ckpt = _lib.ptr(ckpt)
+        _warn_if_generic(a, cfg)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().lp_renderer_forward(ctypes.byref(a), stream), "lp_renderer_forward")
         # O(N) state only: the final -log T (the reference saves the same, :558-573)

@@ -224,3 +224,34 @@ def test_mlp_splatter_c_abi_argument_errors():
     assert b"number of elements in mlp param" in L.lp_last_error()
     a.n_mlp_params = 32 * 32 + 32 * 16 + 32 + 16
     assert L.lp_splatter_forward(ctypes.byref(a), None) == -3  # mlp_params NULL
+
+
+def test_kernel_family_selection():
+    """LP_KERNEL_AUTO picks the MFMA families for the shapes they are built for (no GPU needed): the headline
+    configuration must never fall back to the shape-generic kernels silently."""
+    from lightplane_amd.renderer import kernel_family
+    from tests.synth import RENDERER_CASES, grid_sizes_for, random_decoder
+    want = {"voxel_basic": 1, "triplane_basic": 1, "triplane_c32": 1, "voxel_c32_color1": 1, "triplane_h64_c32": 2,
+            "voxel_h64_c16_scaffold": 2, "triplane_colorgrid": 0, "voxel_deep": 0, "triplane_h16_c32": 0, "color16": 0}
+    for c in RENDERER_CASES:
+        if c.name in want:
+            d = c.build()
+            assert kernel_family(d["rays"], d["grids"], d["decoder"], color_grid=d["color_grids"]) == want[c.name], c.name
+    # BASELINE cfg 2 and cfg 4 shapes
+    gen = torch.Generator().manual_seed(0)
+    for C, G in ((16, 64), (32, 128)):
+        dec = random_decoder(gen, 2, 2, 2, C, 32, 3)
+        assert kernel_family(None, None, dec, grid_sizes=grid_sizes_for((1, G, G, G, C), True)) == 1
+    # splatter families through the C ABI
+    L = _lib.lib()
+    from lightplane_amd.grids import make_grid_descs
+    a = _lib.LpSplatterArgs()
+    descs, C, rows = make_grid_descs([[1, 128, 128, 128, 32]])
+    a.out = _lib.make_grid_list(None, descs, C, rows)
+    assert L.lp_splatter_kernel_family(ctypes.byref(a)) == 1
+    a.mlp = _lib.make_mlp([32, 32, 32], 0)
+    in_descs, Ci, rows_i = make_grid_descs([[1, 64, 64, 64, 32]])
+    a.input_grid = _lib.make_grid_list(None, in_descs, Ci, rows_i)
+    assert L.lp_splatter_kernel_family(ctypes.byref(a)) == 2
+    a.mlp = _lib.make_mlp([32, 64, 64, 32], 0)
+    assert L.lp_splatter_kernel_family(ctypes.byref(a)) == 0
