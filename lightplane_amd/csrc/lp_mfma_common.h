@@ -354,8 +354,7 @@ LP_DEV Heads decode_prefetch(const LpRendererArgs& a, const float* lds, const Ra
 
 // Gradient scatter, row-contiguous and run-length merged.
 // dx0 of the wave's 32 rays has been transposed through LDS ([channel][ray], row stride DX_LD):
-// every lane reads ONE channel (`sub`, row `dxrow`) of the rays, lane group `grp` (C lanes) works on
-// tap slot k.  Rays are walked
+// every lane reads its channel(s) of all rays, lane group `grp` (16 lanes) works on tap slot k.  Rays are walked
 // in order; consecutive rays that fall into the same cell (the common case for image-coherent rays)
 // are summed in a register and leave as ONE atomic per row whose C lanes cover the C contiguous
 // floats of the row.  All slots of a grid change cell together, so the run boundaries are a
@@ -364,17 +363,25 @@ LP_DEV Heads decode_prefetch(const LpRendererArgs& a, const float* lds, const Ra
 constexpr int DX_LD = 36;  // row stride of the transposed dx0 tile [channel][ray]
 
 template <int C>
-LP_DEV void flush_run(float* gg, int s_row, unsigned s_ok, int koff, unsigned kbit, int sub, float run, int dbg) {
+LP_DEV void flush_run(float* gg, int s_row, unsigned s_ok, int koff, unsigned kbit, int sub, const float (&run)[C / 16],
+                      int dbg) {
   // 32-bit byte offset from the uniform base (grid-lists below 4 GB only, see renderer_mfma_supported)
   const unsigned off = (unsigned)(s_row + koff) * (unsigned)(C * 4) + (unsigned)(sub * 4);
-  if ((s_ok & kbit) && !(dbg & 1)) atomic_add_f32(reinterpret_cast<float*>(reinterpret_cast<char*>(gg) + off), run);
+  if ((s_ok & kbit) && !(dbg & 1)) {
+#pragma unroll
+    for (int j = 0; j < C / 16; ++j)
+      atomic_add_f32(reinterpret_cast<float*>(reinterpret_cast<char*>(gg) + off + 64 * j), run[j]);
+  }
 }
 
+// Lane layout of the walk: 16 lanes per tap slot (four slots per pass), lane `sub` owns channels
+// sub, sub + 16, ... (C/16 of them): every atomic instruction covers four rows x 64 contiguous bytes.
+// dxT: the transposed dx0 tile [channel][ray] (row stride DX_LD).
 template <int C>
 LP_DEV void scatter_grid(float* gg, const LpGrid& g, int b, float x, float y, float z, bool live, int lane,
-                         const float* dxrow, float* wT, int dbg) {
-  constexpr int GRPS = 64 / C;  // tap slots per pass
-  const int h = lane >> 5, r = lane & 31, sub = lane % C, grp = lane / C;
+                         const float* dxT, float* wT, int dbg) {
+  constexpr int CPL = C / 16;  // channels per lane
+  const int h = lane >> 5, r = lane & 31, sub = lane & 15, grp = lane >> 4;
   TapSet tp;
   grid_tapset<false>(g, b, x, y, z, tp);
   if (!live) {
@@ -392,45 +399,60 @@ LP_DEV void scatter_grid(float* gg, const LpGrid& g, int b, float x, float y, fl
   const bool head = (r == 0) || row0 != prow || ok != pok;
   const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head));
   const bool voxel = g.D > 1 && g.H > 1 && g.W > 1;
-  const int n_pass = (voxel ? 8 : 4) / GRPS;
+  const int n_pass = voxel ? 2 : 1;
   for (int p = 0; p < n_pass; ++p) {
-    const int k = p * GRPS + grp;
+    const int k = p * 4 + grp;
     const int koff = (k & 1) * tp.su + ((k >> 1) & 1) * tp.sv + (k >> 2) * tp.st;
     const unsigned kbit = 1u << k;
     const float4* wsrc = reinterpret_cast<const float4*>(wT + k * 32);
-    const float4* dsrc = reinterpret_cast<const float4*>(dxrow);
-    float run = 0.0f;
+    const float4* dsrc[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) dsrc[j] = reinterpret_cast<const float4*>(dxT + (sub + 16 * j) * DX_LD);
+    float run[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) run[j] = 0.0f;
     int s_row = __builtin_amdgcn_readlane(row0, 0);
     unsigned s_ok = (unsigned)__builtin_amdgcn_readlane(ok, 0);
     if (mask == 1u) {
       // all 32 rays in one cell (e.g. the plane an image row projects onto as a line): no run logic at all
 #pragma unroll
       for (int c4 = 0; c4 < 8; ++c4) {
-        const float4 w = wsrc[c4], d = dsrc[c4];
-        run = fmaf(w.x, d.x, run);
-        run = fmaf(w.y, d.y, run);
-        run = fmaf(w.z, d.z, run);
-        run = fmaf(w.w, d.w, run);
+        const float4 w = wsrc[c4];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          const float4 d = dsrc[j][c4];
+          run[j] = fmaf(w.x, d.x, run[j]);
+          run[j] = fmaf(w.y, d.y, run[j]);
+          run[j] = fmaf(w.z, d.z, run[j]);
+          run[j] = fmaf(w.w, d.w, run[j]);
+        }
       }
       flush_run<C>(gg, s_row, s_ok, koff, kbit, sub, run, dbg);
       continue;
     }
 #pragma unroll
-    for (int c8 = 0; c8 < 4; ++c8) {  // 8 rays at a time: 16 live operand registers
+    for (int c8 = 0; c8 < 4; ++c8) {  // 8 rays at a time
       const float4 w0 = wsrc[2 * c8], w1 = wsrc[2 * c8 + 1];
-      const float4 d0 = dsrc[2 * c8], d1 = dsrc[2 * c8 + 1];
       const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-      const float dx[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+      float dx[CPL][8];
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const float4 d0 = dsrc[j][2 * c8], d1 = dsrc[j][2 * c8 + 1];
+        dx[j][0] = d0.x; dx[j][1] = d0.y; dx[j][2] = d0.z; dx[j][3] = d0.w;
+        dx[j][4] = d1.x; dx[j][5] = d1.y; dx[j][6] = d1.z; dx[j][7] = d1.w;
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int rr = 8 * c8 + i;
         if (rr > 0 && ((mask >> rr) & 1u)) {
           flush_run<C>(gg, s_row, s_ok, koff, kbit, sub, run, dbg);
-          run = 0.0f;
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) run[j] = 0.0f;
           s_row = __builtin_amdgcn_readlane(row0, rr);
           s_ok = (unsigned)__builtin_amdgcn_readlane(ok, rr);
         }
-        run = fmaf(w[i], dx[i], run);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) run[j] = fmaf(w[i], dx[j][i], run[j]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }

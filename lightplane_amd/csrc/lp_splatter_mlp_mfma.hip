@@ -361,10 +361,9 @@ __global__ void __launch_bounds__(256, 2) splat_mlp_bwd_mfma(const LpSplatterArg
     if (a.grad_input_grid) {
 #pragma unroll
       for (int q = 0; q < E / 2; ++q) xt[featq(q, h) * DX_LD + r] = acc[q];
-      const float* dxrow = xt + (lane % E) * DX_LD;
 #pragma unroll 1
       for (int g = 0; g < a.input_grid.n_grids; ++g)
-        scatter_grid<E>(a.grad_input_grid, a.input_grid.grids[g], ray.b, x, y, z, live, lane, dxrow, yt, mp.dbg);
+        scatter_grid<E>(a.grad_input_grid, a.input_grid.grids[g], ray.b, x, y, z, live, lane, xt, yt, mp.dbg);
     }
   }
 
