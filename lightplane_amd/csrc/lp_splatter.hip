@@ -71,11 +71,11 @@ __global__ void __launch_bounds__(256) splat_fwd_kernel(const LpSplatterArgs a) 
 // latency-bound scalar loop, and 256x256 rays are only 2048 waves of 32).
 template <int C, int RPW>
 LP_DEV void splat_walk(float* feat, float* wgt, const LpGrid& g, int b, float x, float y, float z, bool live,
-                       int lane, const float (&enc)[RPW], float* wT, int dbg) {
-  constexpr int GRPS = 64 / C;       // tap slots per pass
+                       int lane, const float (&enc)[C / 16][RPW], float* wT, int dbg) {
+  constexpr int CPL = C / 16;        // channels per lane: 16 lanes per tap slot, four slots per pass
   constexpr int NQ = 64 / RPW;       // lanes per ray in the lane = ray layout
   constexpr int SPQ = 8 / NQ;        // tap-weight slots each of them writes
-  const int q = lane / RPW, r = lane % RPW, sub = lane % C, grp = lane / C;
+  const int q = lane / RPW, r = lane % RPW, sub = lane & 15, grp = lane >> 4;
   TapSet tp;
   grid_tapset<true>(g, b, x, y, z, tp);
   if (!live) {
@@ -95,13 +95,15 @@ LP_DEV void splat_walk(float* feat, float* wgt, const LpGrid& g, int b, float x,
   const bool head = (r == 0) || row0 != __shfl_up(row0, 1) || ok != __shfl_up(ok, 1);
   const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head));
   const bool voxel = g.D > 1 && g.H > 1 && g.W > 1;
-  const int n_pass = (voxel ? 8 : 4) / GRPS;
+  const int n_pass = voxel ? 2 : 1;
   for (int p = 0; p < n_pass; ++p) {
-    const int k = p * GRPS + grp;
+    const int k = p * 4 + grp;
     const int koff = (k & 1) * tp.su + ((k >> 1) & 1) * tp.sv + (k >> 2) * tp.st;
     const unsigned kbit = 1u << k;
     const float4* wsrc = reinterpret_cast<const float4*>(wT + k * RPW);
-    float run = 0.0f;
+    float run[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) run[j] = 0.0f;
     int s_row = __builtin_amdgcn_readlane(row0, 0);
     unsigned s_ok = (unsigned)__builtin_amdgcn_readlane(ok, 0);
 #pragma unroll
@@ -112,19 +114,27 @@ LP_DEV void splat_walk(float* feat, float* wgt, const LpGrid& g, int b, float x,
       for (int i = 0; i < 8; ++i) {
         const int rr = 8 * c8 + i;
         if (rr > 0 && ((mask >> rr) & 1u)) {
-          if ((s_ok & kbit) && !(dbg & 1)) atomic_add_f32(feat + (int64_t)(s_row + koff) * C + sub, run);
-          run = 0.0f;
+          if ((s_ok & kbit) && !(dbg & 1)) {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) atomic_add_f32(feat + (int64_t)(s_row + koff) * C + sub + 16 * j, run[j]);
+          }
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) run[j] = 0.0f;
           s_row = __builtin_amdgcn_readlane(row0, rr);
           s_ok = (unsigned)__builtin_amdgcn_readlane(ok, rr);
         }
-        run = fmaf(w[i], enc[rr], run);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) run[j] = fmaf(w[i], enc[j][rr], run[j]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if ((s_ok & kbit) && !(dbg & 1)) atomic_add_f32(feat + (int64_t)(s_row + koff) * C + sub, run);
+    if ((s_ok & kbit) && !(dbg & 1)) {
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) atomic_add_f32(feat + (int64_t)(s_row + koff) * C + sub + 16 * j, run[j]);
+    }
   }
   // unit weights: ONE more walk in which lane j < 8 owns tap slot j, so that a run costs a single
-  // atomic instruction for all its slots (x-neighbours share a 128-byte line of the weight grid)
+  // atomic instruction for all its slots (x-neighbours share a 64-byte segment of the weight grid)
   {
     const int k = lane & 7;
     const int koff = (k & 1) * tp.su + ((k >> 1) & 1) * tp.sv + (k >> 2) * tp.st;
@@ -157,6 +167,7 @@ template <int C, int RPW>
 __global__ void __launch_bounds__(256) splat_fwd_walk_kernel(const LpSplatterArgs a, int dbg) {
   constexpr int LD = RPW + 4;  // row stride of the transposed encoding tile [channel][ray]
   constexpr int NQ = 64 / RPW;
+  constexpr int CPL = C / 16;
   __shared__ __attribute__((aligned(16))) float lds[4][C * LD > 8 * RPW ? C * LD : 8 * RPW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane / RPW, r = lane % RPW;
@@ -176,13 +187,14 @@ __global__ void __launch_bounds__(256) splat_fwd_walk_kernel(const LpSplatterArg
     tile[(c0 + 2) * LD + r] = valid ? v.z : 0.0f;
     tile[(c0 + 3) * LD + r] = valid ? v.w : 0.0f;
   }
-  float enc[RPW];
-  {
-    const float4* src = reinterpret_cast<const float4*>(tile + (lane % C) * LD);
+  float enc[CPL][RPW];  // channels (lane & 15) + 16 j of all rays
+#pragma unroll
+  for (int jc = 0; jc < CPL; ++jc) {
+    const float4* src = reinterpret_cast<const float4*>(tile + ((lane & 15) + 16 * jc) * LD);
 #pragma unroll
     for (int j = 0; j < RPW / 4; ++j) {
       const float4 v = src[j];
-      enc[4 * j + 0] = v.x; enc[4 * j + 1] = v.y; enc[4 * j + 2] = v.z; enc[4 * j + 3] = v.w;
+      enc[jc][4 * j + 0] = v.x; enc[jc][4 * j + 1] = v.y; enc[jc][4 * j + 2] = v.z; enc[jc][4 * j + 3] = v.w;
     }
   }
   float* wT = tile;  // the tile is free now: [8][RPW] tap weights of the current sample

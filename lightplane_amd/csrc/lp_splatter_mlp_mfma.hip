@@ -68,13 +68,13 @@ LP_DEV f32x16 bias16(const float* b /* vector + 4h */) {
   return acc;
 }
 
-// Splatter-side walk of one output grid: the vector to splat sits in LDS as [channel][ray] (row `vrow`
-// of this lane's channel); features per run and slot, then the unit weights eight slots at a time.
+// Splatter-side walk of one output grid: the vector to splat sits in LDS as [channel][ray] (tile `vT`);
+// features per run and slot, then the unit weights eight slots at a time.
 template <int C>
 LP_DEV void splat_walk_lds(float* feat, float* wgt, const LpGrid& g, int b, float x, float y, float z, bool live,
-                           int lane, const float* vrow, float* wT) {
-  constexpr int GRPS = 64 / C;
-  const int h = lane >> 5, r = lane & 31, sub = lane % C, grp = lane / C;
+                           int lane, const float* vT, float* wT) {
+  constexpr int CPL = C / 16;  // channels per lane: 16 lanes per tap slot, four slots per pass
+  const int h = lane >> 5, r = lane & 31, sub = lane & 15, grp = lane >> 4;
   TapSet tp;
   grid_tapset<true>(g, b, x, y, z, tp);
   if (!live) {
@@ -89,36 +89,51 @@ LP_DEV void splat_walk_lds(float* feat, float* wgt, const LpGrid& g, int b, floa
   const bool head = (r == 0) || row0 != __shfl_up(row0, 1) || ok != __shfl_up(ok, 1);
   const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head));
   const bool voxel = g.D > 1 && g.H > 1 && g.W > 1;
-  const int n_pass = (voxel ? 8 : 4) / GRPS;
+  const int n_pass = voxel ? 2 : 1;
   for (int p = 0; p < n_pass; ++p) {
-    const int k = p * GRPS + grp;
+    const int k = p * 4 + grp;
     const int koff = (k & 1) * tp.su + ((k >> 1) & 1) * tp.sv + (k >> 2) * tp.st;
     const unsigned kbit = 1u << k;
     const float4* wsrc = reinterpret_cast<const float4*>(wT + k * 32);
-    const float4* dsrc = reinterpret_cast<const float4*>(vrow);
-    float run = 0.0f;
+    float run[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) run[j] = 0.0f;
     int s_row = __builtin_amdgcn_readlane(row0, 0);
     unsigned s_ok = (unsigned)__builtin_amdgcn_readlane(ok, 0);
 #pragma unroll
     for (int c8 = 0; c8 < 4; ++c8) {
       const float4 w0 = wsrc[2 * c8], w1 = wsrc[2 * c8 + 1];
-      const float4 d0 = dsrc[2 * c8], d1 = dsrc[2 * c8 + 1];
       const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-      const float dx[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+      float dx[CPL][8];
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const float4* dsrc = reinterpret_cast<const float4*>(vT + (sub + 16 * j) * TM_LD);
+        const float4 d0 = dsrc[2 * c8], d1 = dsrc[2 * c8 + 1];
+        dx[j][0] = d0.x; dx[j][1] = d0.y; dx[j][2] = d0.z; dx[j][3] = d0.w;
+        dx[j][4] = d1.x; dx[j][5] = d1.y; dx[j][6] = d1.z; dx[j][7] = d1.w;
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int rr = 8 * c8 + i;
         if (rr > 0 && ((mask >> rr) & 1u)) {
-          if (s_ok & kbit) atomic_add_f32(feat + (int64_t)(s_row + koff) * C + sub, run);
-          run = 0.0f;
+          if (s_ok & kbit) {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) atomic_add_f32(feat + (int64_t)(s_row + koff) * C + sub + 16 * j, run[j]);
+          }
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) run[j] = 0.0f;
           s_row = __builtin_amdgcn_readlane(row0, rr);
           s_ok = (unsigned)__builtin_amdgcn_readlane(ok, rr);
         }
-        run = fmaf(w[i], dx[i], run);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) run[j] = fmaf(w[i], dx[j][i], run[j]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (s_ok & kbit) atomic_add_f32(feat + (int64_t)(s_row + koff) * C + sub, run);
+    if (s_ok & kbit) {
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) atomic_add_f32(feat + (int64_t)(s_row + koff) * C + sub + 16 * j, run[j]);
+    }
   }
   {
     const int k = lane & 7;
@@ -195,10 +210,9 @@ __global__ void __launch_bounds__(256, 2) splat_mlp_fwd_mfma(const LpSplatterArg
     // output vector -> [channel][ray]
 #pragma unroll
     for (int q = 0; q < CO / 2; ++q) vt[featq(q, h) * TM_LD + r] = acc[q];
-    const float* vrow = vt + (lane % CO) * TM_LD;
 #pragma unroll 1
     for (int g = 0; g < a.out.n_grids; ++g)
-      splat_walk_lds<CO>(a.out_feature, a.out_weight, a.out.grids[g], ray.b, sm.x, sm.y, sm.z, live, lane, vrow, wT);
+      splat_walk_lds<CO>(a.out_feature, a.out_weight, a.out.grids[g], ray.b, sm.x, sm.y, sm.z, live, lane, vt, wT);
   }
 }
 
