@@ -59,7 +59,9 @@ extern "C" {
 /* The forward pass saves the running -log T every LP_NLT_CKPT regular samples (and at the
  * last regular sample) and after EVERY beyond-far sample, so that the backward sweep
  * (far -> near) never reconstructs the transmittance across more than LP_NLT_CKPT
- * subtractions.  O(N) memory: n_ckpt = ceil(S/LP_NLT_CKPT) + S_inf floats per ray. */
+ * subtractions.  Every checkpoint is a float PAIR (hi, lo): -log T is accumulated as an unevaluated sum so
+ * that the backward's subtraction of the same products recovers the intermediate values exactly.
+ * O(N) memory: 2 * (ceil(S/LP_NLT_CKPT) + S_inf) floats per ray. */
 #define LP_NLT_CKPT 32
 
 /* error codes (negative; positive values are hipError_t) */
@@ -141,7 +143,7 @@ typedef struct LpRendererArgs {
   float* ray_length;      /* [N]                                                 */
   float* neg_log_t;       /* [N]  negative log transmittance after the last sample */
   float* feature;         /* [N, color_chn]                                      */
-  float* neg_log_t_ckpt;  /* [N, n_ckpt] written by forward, read by backward; NULL:
+  float* neg_log_t_ckpt;  /* [N, n_ckpt, 2] written by forward, read by backward; NULL:
                              backward reconstructs from neg_log_t alone (less accurate) */
   /* backward inputs: upstream gradients (NULL = zeros) + neg_log_t from forward */
   const float* grad_ray_length; /* [N]            */

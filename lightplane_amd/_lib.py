@@ -21,9 +21,10 @@ LP_NLT_CKPT = 32
 
 
 def n_nlt_ckpt(num_samples: int, num_samples_inf: int) -> int:
-    """Checkpoints of the running -log T per ray (see LP_NLT_CKPT in the header)."""
+    """Floats per ray of the -log T checkpoint buffer: one (hi, lo) float pair per checkpoint (see
+    LP_NLT_CKPT in the header)."""
     c = LP_NLT_CKPT
-    return (num_samples + c - 1) // c + num_samples_inf
+    return 2 * ((num_samples + c - 1) // c + num_samples_inf)
 
 LP_KERNEL_AUTO, LP_KERNEL_GENERIC, LP_KERNEL_MFMA = 0, 1, 2
 

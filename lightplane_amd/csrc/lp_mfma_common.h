@@ -42,6 +42,9 @@ struct MfmaParams {
   int64_t w_c1, w_c2, b_c1, b_c2;  // colour
   int ldc2;                        // row stride of w_c2 (padded colour width)
   int dbg;                         // LP_MFMA_DEBUG bits (timing experiments only)
+  // shape flexibility of the width-32 family: actual hidden width (16 or 32; staged zero-padded to 32),
+  // second trunk layer present, hidden layer of the opacity / colour head present
+  int hid, t2, oh, ch;
 };
 
 // LDS map (floats).  Weight matrices are kept ONCE, row-major [in][W_LD] with a padded row
@@ -60,28 +63,33 @@ struct Lds {
   static constexpr int FWD_END = INF + MAX_INF;
 };
 
-template <int C>
+template <int C, bool FLEX = false>
 LP_DEV void stage_weights(const LpRendererArgs& a, const MfmaParams& mp, float* lds) {
   using M = Lds;
   const float* P = a.mlp_params;
   const int tid = threadIdx.x;
+  const int H = FLEX ? mp.hid : HID;
+  const bool t2 = FLEX ? (mp.t2 != 0) : true, oh = FLEX ? (mp.oh != 0) : true, ch = FLEX ? (mp.ch != 0) : true;
+  // matrices are staged zero-padded to 32 x 32; absent layers (mp.t2 / oh / ch == 0) are staged as zeros
   for (int i = tid; i < 32 * 32; i += 256) {
     const int row = i >> 5, col = i & 31;
     const int d = row * W_LD + col;
-    lds[M::WT1 + d] = (row < C) ? P[mp.w_t1 + i] : 0.0f;
-    lds[M::WT2 + d] = P[mp.w_t2 + i];
-    lds[M::WO1 + d] = P[mp.w_o1 + i];
-    lds[M::WC1 + d] = P[mp.w_c1 + i];
+    const bool in_h = row < H && col < H;
+    lds[M::WT1 + d] = (row < C && col < H) ? P[mp.w_t1 + row * H + col] : 0.0f;
+    lds[M::WT2 + d] = (t2 && in_h) ? P[mp.w_t2 + row * H + col] : 0.0f;
+    lds[M::WO1 + d] = (oh && in_h) ? P[mp.w_o1 + row * H + col] : 0.0f;
+    lds[M::WC1 + d] = (ch && in_h) ? P[mp.w_c1 + row * H + col] : 0.0f;
   }
   for (int i = tid; i < 32; i += 256) {
-    lds[M::BIAS + i] = P[mp.b_t1 + i];
-    lds[M::BIAS + 32 + i] = P[mp.b_t2 + i];
-    lds[M::BIAS + 64 + i] = P[mp.b_o1 + i];
-    lds[M::BIAS + 96 + i] = P[mp.b_c1 + i];
-    lds[M::WO2 + i] = P[mp.w_o2 + i];
+    const bool in_h = i < H;
+    lds[M::BIAS + i] = in_h ? P[mp.b_t1 + i] : 0.0f;
+    lds[M::BIAS + 32 + i] = (t2 && in_h) ? P[mp.b_t2 + i] : 0.0f;
+    lds[M::BIAS + 64 + i] = (oh && in_h) ? P[mp.b_o1 + i] : 0.0f;
+    lds[M::BIAS + 96 + i] = (ch && in_h) ? P[mp.b_c1 + i] : 0.0f;
+    lds[M::WO2 + i] = in_h ? P[mp.w_o2 + i] : 0.0f;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-      lds[M::WC2 + i * 4 + c] = (c < a.color_chn) ? P[mp.w_c2 + (int64_t)i * mp.ldc2 + c] : 0.0f;
+      lds[M::WC2 + i * 4 + c] = (in_h && c < a.color_chn) ? P[mp.w_c2 + (int64_t)i * mp.ldc2 + c] : 0.0f;
   }
   for (int i = tid; i < MAX_INF; i += 256)
     lds[M::INF + i] = (i < a.march.num_samples_inf) ? inf_scale(i, a.march) : 0.0f;
@@ -121,6 +129,32 @@ LP_DEV void gather_tap(const float* data, int row, float w, int h, float (&x0)[C
   }
 }
 
+// Four taps at once: all their loads are issued before the first one is consumed (the scheduling fence keeps
+// the compiler from recycling one register quad for every load, which serialises 4 * C/8 memory round trips);
+// accumulation order is that of four gather_tap() calls.
+template <int C>
+LP_DEV void gather_taps4(const float* data, const int* row, const float* w, float keep, int h, float (&x0)[C / 2]) {
+  float4 v[4][C / 8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float4* src = reinterpret_cast<const float4*>(data + (int64_t)(row[k] < 0 ? 0 : row[k]) * C + 4 * h);
+#pragma unroll
+    for (int j = 0; j < C / 8; ++j) v[k][j] = src[2 * j];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float wk = w[k] * keep;
+#pragma unroll
+    for (int j = 0; j < C / 8; ++j) {
+      x0[4 * j + 0] = fmaf(wk, v[k][j].x, x0[4 * j + 0]);
+      x0[4 * j + 1] = fmaf(wk, v[k][j].y, x0[4 * j + 1]);
+      x0[4 * j + 2] = fmaf(wk, v[k][j].z, x0[4 * j + 2]);
+      x0[4 * j + 3] = fmaf(wk, v[k][j].w, x0[4 * j + 3]);
+    }
+  }
+}
+
 template <int C, int GM, bool FENCED = false>
 LP_DEV void gather_features(const LpRendererArgs& a, const Ray& ray, float x, float y, float z, int h,
                             float (&x0)[C / 2]) {
@@ -128,31 +162,58 @@ LP_DEV void gather_features(const LpRendererArgs& a, const Ray& ray, float x, fl
   for (int q = 0; q < C / 2; ++q) x0[q] = 0.0f;
   const float keep = (a.march.mask_out_of_bounds && !point_in_bounds(x, y, z)) ? 0.0f : 1.0f;
   if (GM == GM_TRIPLANE) {
+    if (FENCED) {
+      // taps of the three planes first, then one plane's loads in flight at a time
+      Taps t[3];
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
-      Taps t;
-      plane_taps<false>(a.grid.grids[g], ray.b, x, y, z, t);
+      for (int g = 0; g < 3; ++g) plane_taps<false>(a.grid.grids[g], ray.b, x, y, z, t[g]);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
-      if (FENCED) __builtin_amdgcn_sched_barrier(0);  // one plane's loads in flight at a time
+      for (int g = 0; g < 3; ++g) {
+        __builtin_amdgcn_sched_barrier(0);
+        gather_taps4<C>(a.grid.data, t[g].row, t[g].w, keep, h, x0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        Taps t;
+        plane_taps<false>(a.grid.grids[g], ray.b, x, y, z, t);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
+      }
     }
   } else if (GM == GM_VOXEL) {
     Taps t;
     voxel_taps<false>(a.grid.grids[0], ray.b, x, y, z, t);
+    if (FENCED) {
+      __builtin_amdgcn_sched_barrier(0);
+      gather_taps4<C>(a.grid.data, t.row, t.w, keep, h, x0);
+      __builtin_amdgcn_sched_barrier(0);
+      gather_taps4<C>(a.grid.data, t.row + 4, t.w + 4, keep, h, x0);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
-    if (FENCED) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int k = 4; k < 8; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
+      for (int k = 0; k < 8; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
+    }
   } else {
     for (int g = 0; g < a.grid.n_grids; ++g) {
       Taps t;
       grid_taps<false>(a.grid.grids[g], ray.b, x, y, z, t);
+      if (FENCED) {
+        __builtin_amdgcn_sched_barrier(0);
+        gather_taps4<C>(a.grid.data, t.row, t.w, keep, h, x0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t.n == 8) {
+          gather_taps4<C>(a.grid.data, t.row + 4, t.w + 4, keep, h, x0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
-      if (t.n == 8) {
+        for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
+        if (t.n == 8) {
 #pragma unroll
-        for (int k = 4; k < 8; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
+          for (int k = 4; k < 8; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
+        }
       }
     }
   }
@@ -240,11 +301,12 @@ LP_DEV void interleave_hint() {
   }
 }
 
-LP_DEV void load_encoding(const LpRendererArgs& a, int64_t rid, int h, float (&enc)[16]) {
-  const float4* src = reinterpret_cast<const float4*>(a.rays.encoding + rid * HID + 4 * h);
+// this lane's 16 encoding features feat(q,h); `hid` = actual width (features >= hid read as 0)
+LP_DEV void load_encoding(const LpRendererArgs& a, int64_t rid, int h, float (&enc)[16], int hid = HID) {
+  const float4* src = reinterpret_cast<const float4*>(a.rays.encoding + rid * hid + 4 * h);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float4 v = src[2 * j];
+    const float4 v = (8 * j + 4 * h < hid) ? src[2 * j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     enc[4 * j + 0] = v.x; enc[4 * j + 1] = v.y; enc[4 * j + 2] = v.z; enc[4 * j + 3] = v.w;
   }
 }

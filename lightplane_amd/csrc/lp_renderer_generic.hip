@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(64) renderer_fwd_generic(const GenArgs ga) {
   for (int c = 0; c < a.color_chn; ++c) facc[c] = 0.0f;
   const int s_tot = a.march.num_samples + a.march.num_samples_inf;
   const bool contract = a.march.contract_coords != 0;
-  float nlt = 0.0f, t_prev = 1.0f, len = 0.0f, depth_prev = 0.0f;
+  float nlt = 0.0f, nlt_lo = 0.0f, t_prev = 1.0f, len = 0.0f, depth_prev = 0.0f;
   const int n_ckpt = ckpt_count(a.march);
   const int craw = p.col[a.color.n_layers - 1];
   for (int s = 0; s < s_tot; ++s) {
@@ -126,10 +126,10 @@ __global__ void __launch_bounds__(64) renderer_fwd_generic(const GenArgs ga) {
     if (a.noise_sigma > 0.0f)
       raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
     const float opacity = a.gain * softplus_f(raw) * occ;
-    nlt = nlt + opacity * delta;
+    nlt_add(nlt, nlt_lo, opacity * delta);
     if (a.neg_log_t_ckpt && valid) {
       const int ck = ckpt_index(s, a.march);
-      if (ck >= 0) a.neg_log_t_ckpt[ray_id * n_ckpt + ck] = nlt;
+      if (ck >= 0) *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + ck) * 2) = make_float2(nlt, nlt_lo);
     }
     const float t = __expf(-nlt);
     const float w = t_prev - t;
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(64) renderer_bwd_generic(const GenArgs ga) {
   const int C = a.grid.channels;
   const int craw = p.col[a.color.n_layers - 1];
 
-  float nlt = a.neg_log_t[rid];  // -log T after the last sample
+  float nlt = a.neg_log_t[rid], nlt_lo = 0.0f;  // -log T after the last sample
   const int n_ckpt = ckpt_count(a.march);
   float suffix = 0.0f;           // sum_{i >= k} T_i (p_i - p_{i+1})
   float p_next = 0.0f;
@@ -216,10 +216,15 @@ __global__ void __launch_bounds__(64) renderer_bwd_generic(const GenArgs ga) {
     // forward value wherever a checkpoint exists (bounds the subtractive drift)
     if (a.neg_log_t_ckpt) {
       const int ck = ckpt_index(s, a.march);
-      if (ck >= 0) nlt = a.neg_log_t_ckpt[rid * n_ckpt + ck];
+      if (ck >= 0) {
+        const float2 c2 = *reinterpret_cast<const float2*>(a.neg_log_t_ckpt + (rid * n_ckpt + ck) * 2);
+        nlt = c2.x;
+        nlt_lo = c2.y;
+      }
     }
     const float t_i = __expf(-nlt);
-    nlt = fmaxf(nlt - opacity * delta, 0.0f);
+    nlt_add(nlt, nlt_lo, -(opacity * delta));
+    if (!(nlt > 0.0f)) { nlt = 0.0f; nlt_lo = 0.0f; }
     const float t_im1 = __expf(-nlt);
     const float w = t_im1 - t_i;
     // p_i = g_len * depth + sum_c g_feat_c * colour_c

@@ -109,12 +109,14 @@ LP_DEV f32x4 dw_quadrant(const float* wave0, int a_off, int b_off, int v0, int v
   return acc;
 }
 
-template <int C, int GM, bool PLAIN>
+// FLEX: trunk of 1-2 layers, heads with or without hidden layer, hidden width 16 (zero-padded) or 32, chosen at
+// run time through mp.{t2,oh,ch,hid}; FLEX = false is the default shape with everything folded at compile time.
+template <int C, int GM, bool PLAIN, bool FLEX = false>
 __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArgs a, const MfmaParams mp) {
   using M = Lds;
   using B = LdsB;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_weights<C>(a, mp, lds);
+  stage_weights<C, FLEX>(a, mp, lds);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, r = lane & 31;
   float* const wave0 = lds + B::WAVE0;
@@ -128,10 +130,14 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
   const bool valid = ray_id < a.rays.n_rays;
   const int64_t rid = valid ? ray_id : 0;
   const Ray ray = load_ray(a.rays, rid);
-  {  // ray encoding -> LDS, [ray][36]
-    const float4* src = reinterpret_cast<const float4*>(a.rays.encoding + rid * HID + 4 * h);
+  const bool t2 = FLEX ? (mp.t2 != 0) : true, oh = FLEX ? (mp.oh != 0) : true, ch = FLEX ? (mp.ch != 0) : true;
+  const int hid = FLEX ? mp.hid : HID;
+  {  // ray encoding -> LDS, [ray][36] (features >= hid are zero)
+    const float4* src = reinterpret_cast<const float4*>(a.rays.encoding + rid * hid + 4 * h);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(enct + r * T_LD + 8 * j + 4 * h) = src[2 * j];
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<float4*>(enct + r * T_LD + 8 * j + 4 * h) =
+          (!FLEX || 8 * j + 4 * h < hid) ? src[2 * j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
   __syncthreads();
 
@@ -173,7 +179,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
   unsigned long long t_last = __builtin_readcyclecounter();
   int ph_cur = 9;
 #endif
-  float nlt = a.neg_log_t[rid];
+  float nlt = a.neg_log_t[rid], nlt_lo = 0.0f;
   float suffix = 0.0f, p_next = 0.0f;
   Sample<C> nx;
   fetch_sample<C, GM, false, PLAIN>(a, lds, ray, s_tot - 1, h, nx);
@@ -193,19 +199,34 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     f32x16 acc = layer<C / 2>(wl + M::WT1, x0, load_bias(lds, 0, h, zo));
 #pragma unroll
     for (int q = 0; q < 16; ++q) h1[q] = fmaxf(acc[q], 0.0f);
-    acc = layer<16>(wl + M::WT2, h1, load_bias(lds, 1, h, zo));
+    if (t2) {
+      acc = layer<16>(wl + M::WT2, h1, load_bias(lds, 1, h, zo));
 #pragma unroll
-    for (int q = 0; q < 16; ++q) e[q] = fmaxf(acc[q], 0.0f);
-    acc = layer<16>(wl + M::WO1, e, load_bias(lds, 2, h, zo));
+      for (int q = 0; q < 16; ++q) e[q] = fmaxf(acc[q], 0.0f);
+    } else {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) ho[q] = fmaxf(acc[q], 0.0f);
+      for (int q = 0; q < 16; ++q) e[q] = h1[q];
+    }
+    if (oh) {
+      acc = layer<16>(wl + M::WO1, e, load_bias(lds, 2, h, zo));
+#pragma unroll
+      for (int q = 0; q < 16; ++q) ho[q] = fmaxf(acc[q], 0.0f);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) ho[q] = e[q];
+    }
     {
       float ein[16];
       add_encoding(enct + zo + r * T_LD + 4 * h, e, ein);
-      acc = layer<16>(wl + M::WC1, ein, load_bias(lds, 3, h, zo));
-    }
+      if (ch) {
+        acc = layer<16>(wl + M::WC1, ein, load_bias(lds, 3, h, zo));
 #pragma unroll
-    for (int q = 0; q < 16; ++q) hc[q] = fmaxf(acc[q], 0.0f);
+        for (int q = 0; q < 16; ++q) hc[q] = fmaxf(acc[q], 0.0f);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) hc[q] = ein[q];
+      }
+    }
     const Heads hd = heads_forward(lds, h, ho, hc, zo);
     LP_SCHED_FENCE();
     // ho / hc go to the (wave-private) tiles now: their registers turn into d ho / d hc below
@@ -228,10 +249,15 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     if (a.neg_log_t_ckpt) {
       const int ck = PLAIN ? ((((s + 1) % LP_NLT_CKPT) == 0 || s == s_tot - 1) ? s / LP_NLT_CKPT : -1)
                            : ckpt_index(s, a.march);
-      if (ck >= 0) nlt = a.neg_log_t_ckpt[rid * n_ckpt + ck];
+      if (ck >= 0) {
+        const float2 c2 = *reinterpret_cast<const float2*>(a.neg_log_t_ckpt + (rid * n_ckpt + ck) * 2);
+        nlt = c2.x;
+        nlt_lo = c2.y;
+      }
     }
     const float t_i = __expf(-nlt);
-    nlt = fmaxf(nlt - opacity * delta, 0.0f);
+    nlt_add(nlt, nlt_lo, -(opacity * delta));
+    if (!(nlt > 0.0f)) { nlt = 0.0f; nlt_lo = 0.0f; }
     const float t_im1 = __expf(-nlt);
     const float w = t_im1 - t_i;
     float sg[4];
@@ -255,6 +281,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     unsigned ho_mask = 0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) ho_mask |= (ho[q] > 0.0f) ? (1u << q) : 0u;
+    if (!oh) ho_mask = 0xFFFFu;  // no hidden layer: ho is the trunk output, its ReLU mask is applied with d e
     float dhc[16];
     {
       // a fresh opaque offset: the colour output weights are re-read here instead of being kept in
@@ -270,7 +297,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
           v = fmaf(drc[1], wc.y, v);
           v = fmaf(drc[2], wc.z, v);
           v = fmaf(drc[3], wc.w, v);
-          dhc[q] = (hc[q] > 0.0f) ? v : 0.0f;
+          dhc[q] = (!ch || hc[q] > 0.0f) ? v : 0.0f;
         }
         LP_SCHED_FENCE();
       }
@@ -315,17 +342,22 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     // and the other waves arrive, barrier, dW quadrant (LDS reads + MFMA), barrier.
     // ---------------- colour hidden layer ----------------
     LP_MARK("c1");
-    if (want_params) {
-      float ein[16];
-      add_encoding(enct + zo + r * T_LD + 4 * h, e, ein);
-      tile_store_fm(xt, r, h, ein);
-      tile_store_fm(yt, r, h, dhc);
-    }
-    acc = (f32x16){0};
-    acc = layer_t(wt + M::WC1, dhc, acc);
-    if (want_params) {
-      lds_barrier();
-      dq_c1 = dw_quadrant(wave0, a_off, b_off, 0, WAVES, dq_c1, db_c1);
+    if (ch) {
+      if (want_params) {
+        float ein[16];
+        add_encoding(enct + zo + r * T_LD + 4 * h, e, ein);
+        tile_store_fm(xt, r, h, ein);
+        tile_store_fm(yt, r, h, dhc);
+      }
+      acc = (f32x16){0};
+      acc = layer_t(wt + M::WC1, dhc, acc);
+      if (want_params) {
+        lds_barrier();
+        dq_c1 = dw_quadrant(wave0, a_off, b_off, 0, WAVES, dq_c1, db_c1);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = dhc[q];  // the colour head is its output layer only
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) denc[q] += acc[q];
@@ -339,40 +371,50 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
       dho[4 * j + 2] = (ho_mask & (1u << (4 * j + 2))) ? dro * wo.z : 0.0f;
       dho[4 * j + 3] = (ho_mask & (1u << (4 * j + 3))) ? dro * wo.w : 0.0f;
     }
-    if (want_params) lds_barrier();
+    if (want_params && ch) lds_barrier();
     LP_SCHED_FENCE();
     // ---------------- opacity hidden layer ----------------
     LP_MARK("o1");
-    if (want_params) {
-      tile_store_fm(xt, r, h, e);
-      tile_store_fm(yt, r, h, dho);
-    }
-    acc = layer_t(wt + M::WO1, dho, acc);
-    if (want_params) {
-      lds_barrier();
-      dq_o1 = dw_quadrant(wave0, a_off, b_off, 0, WAVES, dq_o1, db_o1);
+    if (oh) {
+      if (want_params) {
+        tile_store_fm(xt, r, h, e);
+        tile_store_fm(yt, r, h, dho);
+      }
+      acc = layer_t(wt + M::WO1, dho, acc);
+      if (want_params) {
+        lds_barrier();
+        dq_o1 = dw_quadrant(wave0, a_off, b_off, 0, WAVES, dq_o1, db_o1);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] += dho[q];  // the opacity head is its output layer only
     }
     float de[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) de[q] = (e[q] > 0.0f) ? acc[q] : 0.0f;
-    if (want_params) lds_barrier();
+    if (want_params && oh) lds_barrier();
     LP_SCHED_FENCE();
     // ---------------- trunk layer 2 ----------------
     LP_MARK("t2");
-    if (want_params) {
-      tile_store_fm(xt, r, h, h1);
-      tile_store_fm(yt, r, h, de);
-    }
-    acc = (f32x16){0};
-    acc = layer_t(wt + M::WT2, de, acc);
-    if (want_params) {
-      lds_barrier();
-      dq_t2 = dw_quadrant(wave0, a_off, b_off, 0, WAVES, dq_t2, db_t2);
-    }
     float dh1[16];
+    if (t2) {
+      if (want_params) {
+        tile_store_fm(xt, r, h, h1);
+        tile_store_fm(yt, r, h, de);
+      }
+      acc = (f32x16){0};
+      acc = layer_t(wt + M::WT2, de, acc);
+      if (want_params) {
+        lds_barrier();
+        dq_t2 = dw_quadrant(wave0, a_off, b_off, 0, WAVES, dq_t2, db_t2);
+      }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) dh1[q] = (h1[q] > 0.0f) ? acc[q] : 0.0f;
-    if (want_params) lds_barrier();
+      for (int q = 0; q < 16; ++q) dh1[q] = (h1[q] > 0.0f) ? acc[q] : 0.0f;
+      if (want_params) lds_barrier();
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) dh1[q] = de[q];  // e is h1: its ReLU mask is already in d e
+    }
     LP_SCHED_FENCE();
     // ---------------- trunk layer 1 ----------------
     LP_MARK("t1");
@@ -419,16 +461,21 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
   }
 #endif
   if (valid && a.grad_encoding) {
-    float4* dst = reinterpret_cast<float4*>(a.grad_encoding + ray_id * HID + 4 * h);
+    float4* dst = reinterpret_cast<float4*>(a.grad_encoding + ray_id * hid + 4 * h);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dst[2 * j] = make_float4(denc[4 * j], denc[4 * j + 1], denc[4 * j + 2], denc[4 * j + 3]);
+    for (int j = 0; j < 4; ++j) {
+      if (!FLEX || 8 * j + 4 * h < hid)
+        dst[2 * j] = make_float4(denc[4 * j], denc[4 * j + 1], denc[4 * j + 2], denc[4 * j + 3]);
+    }
   }
   if (want_params) {
     float* G = a.grad_mlp_params;
     const int j = lane & 31;
     // head output layers: lane (f, h) holds the partial over the 16 rays of its half
-    atomic_add_f32(G + mp.w_o2 + j, dwo2);
-    for (int c = 0; c < a.color_chn; ++c) atomic_add_f32(G + mp.w_c2 + (int64_t)j * mp.ldc2 + c, dwc2[c]);
+    if (!FLEX || j < hid) {
+      atomic_add_f32(G + mp.w_o2 + j, dwo2);
+      for (int c = 0; c < a.color_chn; ++c) atomic_add_f32(G + mp.w_c2 + (int64_t)j * mp.ldc2 + c, dwc2[c]);
+    }
     float v = dbo2, c0 = dbc2[0], c1 = dbc2[1], c2 = dbc2[2], c3 = dbc2[3];
 #pragma unroll
     for (int m = 16; m >= 1; m >>= 1) {
@@ -444,27 +491,31 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
       for (int c = 0; c < a.color_chn; ++c) atomic_add_f32(G + mp.b_c2 + c, cv[c]);
     }
     // dW quadrants: register i of lane (n16 = l&15, ka = l>>4) is dW[m0 + pi(4ka+i)][n0 + pi(n16)]
+    // (matrices are [in, hid] row-major; with hid == 16 the padded rows / columns are dropped)
     const int col = 16 * ni + pi16(m16);
+    const bool col_ok = !FLEX || col < hid;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int prow = pi16(4 * ka + i);
       const int row = 16 * mi + prow;
-      atomic_add_f32(G + mp.w_t2 + row * 32 + col, dq_t2[i]);
-      atomic_add_f32(G + mp.w_o1 + row * 32 + col, dq_o1[i]);
-      atomic_add_f32(G + mp.w_c1 + row * 32 + col, dq_c1[i]);
+      if (col_ok && (!FLEX || row < hid)) {
+        if (t2) atomic_add_f32(G + mp.w_t2 + row * hid + col, dq_t2[i]);
+        if (oh) atomic_add_f32(G + mp.w_o1 + row * hid + col, dq_o1[i]);
+        if (ch) atomic_add_f32(G + mp.w_c1 + row * hid + col, dq_c1[i]);
+      }
       const int row1 = (C == 16) ? prow : row;
-      if (row1 < C) atomic_add_f32(G + mp.w_t1 + row1 * 32 + col, dq_t1[i]);
+      if (col_ok && row1 < C) atomic_add_f32(G + mp.w_t1 + row1 * hid + col, dq_t1[i]);
     }
     // bias gradients: partial over the rays 8ka.. of every source wave -> sum over ka
     db_t1 += __shfl_xor(db_t1, 16); db_t1 += __shfl_xor(db_t1, 32);
     db_t2 += __shfl_xor(db_t2, 16); db_t2 += __shfl_xor(db_t2, 32);
     db_o1 += __shfl_xor(db_o1, 16); db_o1 += __shfl_xor(db_o1, 32);
     db_c1 += __shfl_xor(db_c1, 16); db_c1 += __shfl_xor(db_c1, 32);
-    if (ka == 0) {
+    if (ka == 0 && col_ok) {
       if (mi == 0) {  // both quadrant rows see the same dY columns: count them once
-        atomic_add_f32(G + mp.b_t2 + col, db_t2);
-        atomic_add_f32(G + mp.b_o1 + col, db_o1);
-        atomic_add_f32(G + mp.b_c1 + col, db_c1);
+        if (t2) atomic_add_f32(G + mp.b_t2 + col, db_t2);
+        if (oh) atomic_add_f32(G + mp.b_o1 + col, db_o1);
+        if (ch) atomic_add_f32(G + mp.b_c1 + col, db_c1);
       }
       if (C == 16 || mi == 0) atomic_add_f32(G + mp.b_t1 + col, db_t1);
     }
@@ -475,14 +526,14 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
 // host side
 // ---------------------------------------------------------------------------------------
 
-template <int C, int GM, bool PLAIN>
+template <int C, int GM, bool PLAIN, bool FLEX>
 static int launch_bwd2p(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
   const size_t lds = (mp.dbg & 16) ? 100 * 1024 : LdsB::END * sizeof(float);  // dbg 16: one workgroup per CU
-  const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_mfma2<C, GM, PLAIN>,
+  const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_mfma2<C, GM, PLAIN, FLEX>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   const unsigned nb = (unsigned)((a.rays.n_rays + WAVES * RAYS_PER_WAVE - 1) / (WAVES * RAYS_PER_WAVE));
-  hipLaunchKernelGGL((renderer_bwd_mfma2<C, GM, PLAIN>), dim3(nb), dim3(256), lds, stream, a, mp);
+  hipLaunchKernelGGL((renderer_bwd_mfma2<C, GM, PLAIN, FLEX>), dim3(nb), dim3(256), lds, stream, a, mp);
   return LP_OK;
 }
 
@@ -491,7 +542,11 @@ static int launch_bwd2p(const LpRendererArgs& a, const MfmaParams& mp, hipStream
 template <int C, int GM>
 static int launch_bwd2(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
   const bool plain = !(a.noise_sigma > 0.0f) && !a.march.contract_coords && !a.scaffold && a.march.num_samples_inf == 0;
-  return plain ? launch_bwd2p<C, GM, true>(a, mp, stream) : launch_bwd2p<C, GM, false>(a, mp, stream);
+  const bool flex = !(mp.hid == HID && mp.t2 && mp.oh && mp.ch);
+  if (flex)  // the non-default shapes share the run-time-loop grid-list variant (fewer instantiations)
+    return plain ? launch_bwd2p<C, GM_GENERIC, true, true>(a, mp, stream)
+                 : launch_bwd2p<C, GM_GENERIC, false, true>(a, mp, stream);
+  return plain ? launch_bwd2p<C, GM, true, false>(a, mp, stream) : launch_bwd2p<C, GM, false, false>(a, mp, stream);
 }
 
 int renderer_backward_mfma2(const LpRendererArgs& a, const MfmaParams& mp, int gm, hipStream_t stream) {

@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256, 2) renderer_fwd_mfma_w(const LpRendererAr
   const int s_tot = a.march.num_samples + a.march.num_samples_inf;
   const int n_ckpt = ckpt_count(a.march);
   const float delta0 = (a.march.num_samples > 1) ? (ray.far_t - ray.near_t) / (float)(a.march.num_samples - 1) : 1.0f;
-  float nlt = 0.0f, t_prev = 1.0f, len = 0.0f, depth_prev = 0.0f;
+  float nlt = 0.0f, nlt_lo = 0.0f, t_prev = 1.0f, len = 0.0f, depth_prev = 0.0f;
   float facc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   for (int s = 0; s < s_tot; ++s) {
     Sample<C> nx;
@@ -223,10 +223,10 @@ __global__ void __launch_bounds__(256, 2) renderer_fwd_mfma_w(const LpRendererAr
     float raw = hd.raw_o;
     if (a.noise_sigma > 0.0f) raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
     const float opacity = a.gain * softplus_f(raw) * occ;
-    nlt = nlt + opacity * delta;
+    nlt_add(nlt, nlt_lo, opacity * delta);
     if (a.neg_log_t_ckpt && valid && h == 0) {
       const int ck = ckpt_index(s, a.march);
-      if (ck >= 0) a.neg_log_t_ckpt[ray_id * n_ckpt + ck] = nlt;
+      if (ck >= 0) *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + ck) * 2) = make_float2(nlt, nlt_lo);
     }
     const float tr = __expf(-nlt);
     const float w = t_prev - tr;
@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
   float* const gg = !a.grad_grid ? nullptr
                     : (rep == 0 ? a.grad_grid : a.grad_grid_replicas + (int64_t)(rep - 1) * a.grid.n_rows * C);
 
-  float nlt = a.neg_log_t[rid];
+  float nlt = a.neg_log_t[rid], nlt_lo = 0.0f;
   float suffix = 0.0f, p_next = 0.0f;
   Sample<C> nx;
   fetch_sample<C, GM, true, PLAIN>(a, lds_inf, ray, s_tot - 1, h, nx);
@@ -409,10 +409,15 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
     if (a.neg_log_t_ckpt) {
       const int ck = PLAIN ? ((((s + 1) % LP_NLT_CKPT) == 0 || s == s_tot - 1) ? s / LP_NLT_CKPT : -1)
                            : ckpt_index(s, a.march);
-      if (ck >= 0) nlt = a.neg_log_t_ckpt[rid * n_ckpt + ck];
+      if (ck >= 0) {
+        const float2 c2 = *reinterpret_cast<const float2*>(a.neg_log_t_ckpt + (rid * n_ckpt + ck) * 2);
+        nlt = c2.x;
+        nlt_lo = c2.y;
+      }
     }
     const float t_i = __expf(-nlt);
-    nlt = fmaxf(nlt - opacity * delta, 0.0f);
+    nlt_add(nlt, nlt_lo, -(opacity * delta));
+    if (!(nlt > 0.0f)) { nlt = 0.0f; nlt_lo = 0.0f; }
     const float t_im1 = __expf(-nlt);
     const float w = t_im1 - t_i;
     float sg[4];

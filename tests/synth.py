@@ -219,6 +219,13 @@ RENDERER_CASES = [
                  gain=3.0, n_rays=70, num_samples=21, param_std=0.15),
     RendererCase("triplane_plus_voxel_h64", seed=17, is_triplane=True, extra_voxel=True, hidden=64, mask_oob=True,
                  param_std=0.15),
+    # the shapes of the reference's notebooks: heads without a hidden layer, one trunk layer, hidden width 16
+    RendererCase("nb2_like_t2_o1_c1", seed=18, is_triplane=True, n_layers=(2, 1, 1), n_rays=40),
+    RendererCase("nb1_like_h16_111", seed=19, hidden=16, n_layers=(1, 1, 1), n_rays=70, num_samples=21, param_std=0.3),
+    RendererCase("flex_121_h16_c32_noise", seed=20, is_triplane=True, grid_base=(2, 6, 5, 4, 32), hidden=16,
+                 n_layers=(1, 2, 1), noise_sigma=0.5, noise_seed=77, num_samples_inf=3, contract=True, param_std=0.3),
+    RendererCase("flex_212_c32_scaffold", seed=21, grid_base=(2, 6, 5, 7, 32), n_layers=(2, 1, 2),
+                 scaffold_size=(6, 4, 5), gain=3.0, mask_oob=True, n_rays=33),
 ]
 
 SPLATTER_CASES = [
