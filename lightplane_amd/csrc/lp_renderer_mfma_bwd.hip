@@ -342,6 +342,10 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     // and the other waves arrive, barrier, dW quadrant (LDS reads + MFMA), barrier.
     // ---------------- colour hidden layer ----------------
     LP_MARK("c1");
+    // the four layer phases are coupled to the sibling waves by two barriers each: run them at raised priority
+    // so that the co-resident wave of the other workgroup (gathering / scattering) does not stretch them for
+    // all four waves (-2.4% kernel time)
+    __builtin_amdgcn_s_setprio(1);
     if (ch) {
       if (want_params) {
         float ein[16];
@@ -440,6 +444,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     LP_SCHED_FENCE();
     // ---------------- next (nearer) sample + grid gradient ----------------
     LP_MARK("fetch");
+    __builtin_amdgcn_s_setprio(0);
     const bool live = valid && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
     // gather with one plane's loads in flight at a time (registers), consumed before the atomics
     // below are issued: no wait ever has to drain the atomics

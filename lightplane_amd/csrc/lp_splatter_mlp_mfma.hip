@@ -339,6 +339,7 @@ __global__ void __launch_bounds__(256, 2) splat_mlp_bwd_mfma(const LpSplatterArg
     }
     LP_SCHED_FENCE();
     // ---- layer 2: dW2 += h1^T dv ; dh1 = relu'(h1) (W2 dv) ----
+    __builtin_amdgcn_s_setprio(1);  // barrier-coupled layer phases at raised priority (see lp_renderer_mfma_bwd.hip)
     if (want_params) {
       tile_store_m(xt, r, h, h1);
       tile_store_m(yt, r, h, dv);
@@ -372,6 +373,7 @@ __global__ void __launch_bounds__(256, 2) splat_mlp_bwd_mfma(const LpSplatterArg
     }
     LP_SCHED_FENCE();
     // ---- input-grid gradient: the Renderer's run-merged scatter of dxin ----
+    __builtin_amdgcn_s_setprio(0);
     if (a.grad_input_grid) {
 #pragma unroll
       for (int q = 0; q < E / 2; ++q) xt[featq(q, h) * DX_LD + r] = acc[q];
