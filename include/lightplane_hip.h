@@ -61,7 +61,9 @@ extern "C" {
  * (far -> near) never reconstructs the transmittance across more than LP_NLT_CKPT
  * subtractions.  Every checkpoint is a float PAIR (hi, lo): -log T is accumulated as an unevaluated sum so
  * that the backward's subtraction of the same products recovers the intermediate values exactly.
- * O(N) memory: 2 * (ceil(S/LP_NLT_CKPT) + S_inf) floats per ray. */
+ * One more pair per ray closes the list: (index of the last sample the forward marched, low word of
+ * the final -log T) -- the backward starts there (see stop_neg_log_t).
+ * O(N) memory: 2 * (ceil(S/LP_NLT_CKPT) + S_inf + 1) floats per ray. */
 #define LP_NLT_CKPT 32
 
 /* error codes (negative; positive values are hipError_t) */
@@ -160,7 +162,12 @@ typedef struct LpRendererArgs {
    * hammer the same plane rows), lp_renderer_backward then folds the replicas into grad_grid. */
   float* grad_grid_replicas;
   int32_t n_grad_replicas; /* 0 = none */
-  int32_t _pad2;
+  /* early ray termination (extension; the reference always marches every sample): > 0 = a wavefront stops
+   * marching once -log T of all its rays has reached this value (their transmittance is below
+   * exp(-stop_neg_log_t)); the backward skips the same samples.  ray_length / feature then miss
+   * contributions of at most exp(-stop_neg_log_t) per unit of depth / colour, and neg_log_t is the value
+   * reached at the stop (>= stop_neg_log_t) instead of the value after the last sample.  0 = exact. */
+  float stop_neg_log_t;
 } LpRendererArgs;
 
 typedef struct LpSplatterArgs {

@@ -21,10 +21,10 @@ LP_NLT_CKPT = 32
 
 
 def n_nlt_ckpt(num_samples: int, num_samples_inf: int) -> int:
-    """Floats per ray of the -log T checkpoint buffer: one (hi, lo) float pair per checkpoint (see
-    LP_NLT_CKPT in the header)."""
+    """Floats per ray of the -log T checkpoint buffer: one (hi, lo) float pair per checkpoint plus the
+    closing pair (see LP_NLT_CKPT in the header)."""
     c = LP_NLT_CKPT
-    return 2 * ((num_samples + c - 1) // c + num_samples_inf)
+    return 2 * ((num_samples + c - 1) // c + num_samples_inf + 1)
 
 LP_KERNEL_AUTO, LP_KERNEL_GENERIC, LP_KERNEL_MFMA = 0, 1, 2
 
@@ -73,7 +73,7 @@ class LpRendererArgs(C.Structure):
         ("grad_ray_length", C.c_void_p), ("grad_neg_log_t", C.c_void_p), ("grad_feature", C.c_void_p),
         ("grad_grid", C.c_void_p), ("grad_color_grid", C.c_void_p), ("grad_mlp_params", C.c_void_p),
         ("grad_encoding", C.c_void_p),
-        ("grad_grid_replicas", C.c_void_p), ("n_grad_replicas", C.c_int32), ("_pad2", C.c_int32),
+        ("grad_grid_replicas", C.c_void_p), ("n_grad_replicas", C.c_int32), ("stop_neg_log_t", C.c_float),
     ]
 
 

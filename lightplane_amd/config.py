@@ -12,6 +12,8 @@
                        measured on the 256x256 triplane benchmark is nil, so the default is 0.
 ``warn_generic_kernel`` warn (once per shape) when a call falls back to the shape-generic kernels, which
                        are one to two orders of magnitude slower than the MFMA / walk families.  Default on.
+``stop_transmittance`` early ray termination of the Renderer (extension, see ``lightplane_renderer``): a wavefront stops
+                       marching once every ray's transmittance is below this value.  0 (default) = off, exact.
 """
 import os
 
@@ -20,3 +22,4 @@ check_finite_grads: bool = os.environ.get("LIGHTPLANE_AMD_CHECK_FINITE", "0") ==
 _gr = os.environ.get("LIGHTPLANE_AMD_GRAD_REPLICAS")
 grad_replicas: int = int(_gr) if _gr is not None else 0
 warn_generic_kernel: bool = os.environ.get("LIGHTPLANE_AMD_WARN_GENERIC", "1") != "0"
+stop_transmittance: float = float(os.environ.get("LIGHTPLANE_AMD_STOP_TRANSMITTANCE", "0"))

@@ -96,6 +96,9 @@ static int check_renderer(const LpRendererArgs& a, bool backward) {
     if (a.trunk.n_layers != 0)
       return set_error(LP_EINVAL, "mlp_n_layers_trunk has to be 0 when use_separate_color_grid");
   }
+  if (!(a.stop_neg_log_t >= 0.0f)) return set_error(LP_EINVAL, "stop_neg_log_t must be >= 0 (0 = no early termination)");
+  if (backward && a.stop_neg_log_t > 0.0f && !a.neg_log_t_ckpt)
+    return set_error(LP_ENULL, "early termination needs neg_log_t_ckpt in the backward (it records where the forward stopped)");
   if ((rc = check_mlp("trunk", a.trunk, true))) return rc;
   if ((rc = check_mlp("opacity", a.opacity, false))) return rc;
   if ((rc = check_mlp("color", a.color, false))) return rc;

@@ -104,9 +104,11 @@ LP_DEV void nlt_add(float& hi, float& lo, float x) {
   lo = l - (t - s);
   hi = t;
 }
-LP_DEV int ckpt_count(const LpMarch& m) {
+// pairs per ray in the checkpoint buffer: the checkpoints + the closing pair (last marched sample, low word)
+LP_DEV int ckpt_end_index(const LpMarch& m) {
   return (m.num_samples + LP_NLT_CKPT - 1) / LP_NLT_CKPT + m.num_samples_inf;
 }
+LP_DEV int ckpt_count(const LpMarch& m) { return ckpt_end_index(m) + 1; }
 
 LP_DEV float contract_one(float p, float n) {
   const float a = fabsf(p);

@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(64) renderer_fwd_generic(const GenArgs ga) {
   float nlt = 0.0f, nlt_lo = 0.0f, t_prev = 1.0f, len = 0.0f, depth_prev = 0.0f;
   const int n_ckpt = ckpt_count(a.march);
   const int craw = p.col[a.color.n_layers - 1];
+  int s_last = s_tot - 1;  // last sample marched
   for (int s = 0; s < s_tot; ++s) {
     const float depth = sample_depth(s, a.march, ray.near_t, ray.far_t);
     float delta;
@@ -137,11 +138,17 @@ __global__ void __launch_bounds__(64) renderer_fwd_generic(const GenArgs ga) {
     len = fmaf(w, depth, len);
     for (int c = 0; c < a.color_chn; ++c)
       facc[c] = fmaf(w, sigmoid_f(act[craw + c]) * occ, facc[c]);
+    if (a.stop_neg_log_t > 0.0f && __ballot(valid && nlt < a.stop_neg_log_t) == 0) {  // early termination
+      s_last = s;
+      break;
+    }
   }
   if (valid) {
     a.ray_length[ray_id] = len;
     a.neg_log_t[ray_id] = nlt;
     for (int c = 0; c < a.color_chn; ++c) a.feature[ray_id * a.color_chn + c] = facc[c];
+    if (a.neg_log_t_ckpt)
+      *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + n_ckpt - 1) * 2) = make_float2((float)s_last, nlt_lo);
   }
 }
 
@@ -196,11 +203,20 @@ __global__ void __launch_bounds__(64) renderer_bwd_generic(const GenArgs ga) {
   const int C = a.grid.channels;
   const int craw = p.col[a.color.n_layers - 1];
 
-  float nlt = a.neg_log_t[rid], nlt_lo = 0.0f;  // -log T after the last sample
+  float nlt = a.neg_log_t[rid], nlt_lo = 0.0f;  // -log T after the last marched sample
   const int n_ckpt = ckpt_count(a.march);
+  // closing pair of the checkpoint list: last sample the forward marched for this wave (early termination,
+  // wave-uniform) and the low word of the final -log T
+  int s_begin = s_tot - 1;
+  if (a.neg_log_t_ckpt) {
+    const float2 e2 = *reinterpret_cast<const float2*>(a.neg_log_t_ckpt + (rid * n_ckpt + n_ckpt - 1) * 2);
+    s_begin = __builtin_amdgcn_readfirstlane((int)e2.x);
+    s_begin = s_begin < 0 ? 0 : (s_begin > s_tot - 1 ? s_tot - 1 : s_begin);
+    nlt_lo = e2.y;
+  }
   float suffix = 0.0f;           // sum_{i >= k} T_i (p_i - p_{i+1})
   float p_next = 0.0f;
-  for (int s = s_tot - 1; s >= 0; --s) {
+  for (int s = s_begin; s >= 0; --s) {
     const float depth = sample_depth(s, a.march, ray.near_t, ray.far_t);
     const float delta = sample_delta(s, a.march, ray.near_t, ray.far_t, depth);
     float x, y, z;

@@ -52,6 +52,7 @@ __global__ void __launch_bounds__(256, 2) renderer_fwd_mfma(const LpRendererArgs
   const int n_ckpt = ckpt_count(a.march);
   const float delta0 = (a.march.num_samples > 1) ? (ray.far_t - ray.near_t) / (float)(a.march.num_samples - 1) : 1.0f;
   float nlt = 0.0f, nlt_lo = 0.0f, t_prev = 1.0f, len = 0.0f, depth_prev = 0.0f;
+  int s_last = s_tot - 1;  // last sample marched
   float facc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   Sample<C> nx;
   fetch_sample<C, GM>(a, lds, ray, 0, h, nx);
@@ -79,11 +80,18 @@ __global__ void __launch_bounds__(256, 2) renderer_fwd_mfma(const LpRendererArgs
     len = fmaf(w, depth, len);
 #pragma unroll
     for (int c = 0; c < 4; ++c) facc[c] = fmaf(w, sigmoid_f(hd.raw_c[c]) * occ, facc[c]);
+    // early termination (off unless stop_neg_log_t > 0): every ray of this wave is opaque
+    if (a.stop_neg_log_t > 0.0f && __ballot(valid && nlt < a.stop_neg_log_t) == 0) {
+      s_last = s;
+      break;
+    }
   }
   if (valid && h == 0) {
     a.ray_length[ray_id] = len;
     a.neg_log_t[ray_id] = nlt;
     for (int c = 0; c < a.color_chn; ++c) a.feature[ray_id * a.color_chn + c] = facc[c];
+    if (a.neg_log_t_ckpt)
+      *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + n_ckpt - 1) * 2) = make_float2((float)s_last, nlt_lo);
   }
 }
 
@@ -146,6 +154,7 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_mfma_np(const LpRendere
   const int n_ckpt = ckpt_count(a.march);
   const float delta0 = (a.march.num_samples > 1) ? (ray.far_t - ray.near_t) / (float)(a.march.num_samples - 1) : 1.0f;
   float nlt = 0.0f, nlt_lo = 0.0f, t_prev = 1.0f, len = 0.0f, depth_prev = 0.0f;
+  int s_last = s_tot - 1;  // last sample marched
   float facc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   Sample<C> nx;
   Act<C> t;
@@ -174,11 +183,18 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_mfma_np(const LpRendere
     len = fmaf(w, depth, len);
 #pragma unroll
     for (int c = 0; c < 4; ++c) facc[c] = fmaf(w, sigmoid_f(hd.raw_c[c]) * occ, facc[c]);
+    // early termination (off unless stop_neg_log_t > 0): every ray of this wave is opaque
+    if (a.stop_neg_log_t > 0.0f && __ballot(valid && nlt < a.stop_neg_log_t) == 0) {
+      s_last = s;
+      break;
+    }
   }
   if (valid && h == 0) {
     a.ray_length[ray_id] = len;
     a.neg_log_t[ray_id] = nlt;
     for (int c = 0; c < a.color_chn; ++c) a.feature[ray_id * a.color_chn + c] = facc[c];
+    if (a.neg_log_t_ckpt)
+      *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + n_ckpt - 1) * 2) = make_float2((float)s_last, nlt_lo);
   }
 }
 

@@ -139,7 +139,33 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
       *reinterpret_cast<float4*>(enct + r * T_LD + 8 * j + 4 * h) =
           (!FLEX || 8 * j + 4 * h < hid) ? src[2 * j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
-  __syncthreads();
+  // closing pair of the checkpoint list: last sample the forward marched for this wave (early termination)
+  // and the low word of the final -log T.  The sample loop is workgroup-uniform (barriers): it starts at
+  // the largest index of the four waves, a wave is `on` only up to its own.
+  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
+  const int n_ckpt = ckpt_count(a.march);
+  int s_last_w = s_tot - 1;
+  float nlt_lo = 0.0f;
+  if (a.neg_log_t_ckpt) {
+    const float2 e2 = *reinterpret_cast<const float2*>(a.neg_log_t_ckpt + (rid * n_ckpt + n_ckpt - 1) * 2);
+    s_last_w = __builtin_amdgcn_readfirstlane((int)e2.x);
+    s_last_w = s_last_w < 0 ? 0 : (s_last_w > s_tot - 1 ? s_tot - 1 : s_last_w);
+    nlt_lo = e2.y;
+  }
+  int s_begin = s_tot - 1;
+  if (PLAIN) {  // the PLAIN instantiation is only launched without early termination
+    __syncthreads();
+  } else {
+    if (lane == 0) ts[0] = (float)s_last_w;
+    __syncthreads();
+    s_begin = 0;
+#pragma unroll
+    for (int v = 0; v < WAVES; ++v) {
+      const int sv = (int)wave0[v * B::PER_WAVE + B::TS];
+      s_begin = sv > s_begin ? sv : s_begin;
+    }
+    __syncthreads();  // ts[] is reused by the sample loop
+  }
 
   float denc[16];
 #pragma unroll
@@ -151,8 +177,6 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
   const float g_len = (valid && a.grad_ray_length) ? a.grad_ray_length[rid] : 0.0f;
   const float g_nlt = (valid && a.grad_neg_log_t) ? a.grad_neg_log_t[rid] : 0.0f;
 
-  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
-  const int n_ckpt = ckpt_count(a.march);
   const bool want_params = a.grad_mlp_params != nullptr;
   const float delta0 = (a.march.num_samples > 1) ? (ray.far_t - ray.near_t) / (float)(a.march.num_samples - 1) : 1.0f;
 
@@ -179,11 +203,12 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
   unsigned long long t_last = __builtin_readcyclecounter();
   int ph_cur = 9;
 #endif
-  float nlt = a.neg_log_t[rid], nlt_lo = 0.0f;
+  float nlt = a.neg_log_t[rid];
   float suffix = 0.0f, p_next = 0.0f;
   Sample<C> nx;
-  fetch_sample<C, GM, false, PLAIN>(a, lds, ray, s_tot - 1, h, nx);
-  for (int s = s_tot - 1; s >= 0; --s) {
+  fetch_sample<C, GM, false, PLAIN>(a, lds, ray, s_begin, h, nx);
+  for (int s = s_begin; s >= 0; --s) {
+    const bool on = PLAIN || s <= s_last_w;  // wave-uniform; false only for samples a sibling wave still marches
     const float depth = nx.depth, occ = nx.occ, x = nx.x, y = nx.y, z = nx.z;
     float x0[C / 2];
 #pragma unroll
@@ -246,7 +271,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     if (!PLAIN && a.noise_sigma > 0.0f)
       raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
     const float opacity = a.gain * softplus_f(raw) * occ;
-    if (a.neg_log_t_ckpt) {
+    if (on && a.neg_log_t_ckpt) {
       const int ck = PLAIN ? ((((s + 1) % LP_NLT_CKPT) == 0 || s == s_tot - 1) ? s / LP_NLT_CKPT : -1)
                            : ckpt_index(s, a.march);
       if (ck >= 0) {
@@ -256,7 +281,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
       }
     }
     const float t_i = __expf(-nlt);
-    nlt_add(nlt, nlt_lo, -(opacity * delta));
+    nlt_add(nlt, nlt_lo, on ? -(opacity * delta) : 0.0f);
     if (!(nlt > 0.0f)) { nlt = 0.0f; nlt_lo = 0.0f; }
     const float t_im1 = __expf(-nlt);
     const float w = t_im1 - t_i;
@@ -267,13 +292,14 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
       sg[c] = sigmoid_f(hd.raw_c[c]);
       p_i = fmaf(gfeat[c], sg[c] * occ, p_i);
     }
-    suffix = fmaf(t_i, p_i - p_next, suffix);
-    p_next = p_i;
+    suffix = on ? fmaf(t_i, p_i - p_next, suffix) : suffix;
+    p_next = on ? p_i : p_next;
     const float d_a = suffix + g_nlt;
-    const float dro = valid ? d_a * delta * a.gain * occ * d_softplus_f(raw) : 0.0f;
+    const bool contrib = valid && on;
+    const float dro = contrib ? d_a * delta * a.gain * occ * d_softplus_f(raw) : 0.0f;
     float drc[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) drc[c] = valid ? w * gfeat[c] * occ * sg[c] * (1.0f - sg[c]) : 0.0f;
+    for (int c = 0; c < 4; ++c) drc[c] = contrib ? w * gfeat[c] * occ * sg[c] * (1.0f - sg[c]) : 0.0f;
 
     // ---------------- output layers of the heads (VALU) ----------------
     LP_MARK("heads_bwd");
@@ -445,7 +471,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     // ---------------- next (nearer) sample + grid gradient ----------------
     LP_MARK("fetch");
     __builtin_amdgcn_s_setprio(0);
-    const bool live = valid && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
+    const bool live = valid && on && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
     // gather with one plane's loads in flight at a time (registers), consumed before the atomics
     // below are issued: no wait ever has to drain the atomics
     if (s > 0) fetch_sample<C, GM, true, PLAIN>(a, lds, ray, s - 1, h, nx);
@@ -546,7 +572,8 @@ static int launch_bwd2p(const LpRendererArgs& a, const MfmaParams& mp, hipStream
 // samples): a leaner instantiation of the same kernel
 template <int C, int GM>
 static int launch_bwd2(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
-  const bool plain = !(a.noise_sigma > 0.0f) && !a.march.contract_coords && !a.scaffold && a.march.num_samples_inf == 0;
+  const bool plain = !(a.noise_sigma > 0.0f) && !a.march.contract_coords && !a.scaffold && a.march.num_samples_inf == 0 &&
+                     !(a.stop_neg_log_t > 0.0f);
   const bool flex = !(mp.hid == HID && mp.t2 && mp.oh && mp.ch);
   if (flex)  // the non-default shapes share the run-time-loop grid-list variant (fewer instantiations)
     return plain ? launch_bwd2p<C, GM_GENERIC, true, true>(a, mp, stream)

@@ -197,6 +197,7 @@ __global__ void __launch_bounds__(256, 2) renderer_fwd_mfma_w(const LpRendererAr
   const int n_ckpt = ckpt_count(a.march);
   const float delta0 = (a.march.num_samples > 1) ? (ray.far_t - ray.near_t) / (float)(a.march.num_samples - 1) : 1.0f;
   float nlt = 0.0f, nlt_lo = 0.0f, t_prev = 1.0f, len = 0.0f, depth_prev = 0.0f;
+  int s_last = s_tot - 1;  // last sample marched
   float facc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   for (int s = 0; s < s_tot; ++s) {
     Sample<C> nx;
@@ -234,11 +235,17 @@ __global__ void __launch_bounds__(256, 2) renderer_fwd_mfma_w(const LpRendererAr
     len = fmaf(w, depth, len);
 #pragma unroll
     for (int c = 0; c < 4; ++c) facc[c] = fmaf(w, sigmoid_f(hd.raw_c[c]) * occ, facc[c]);
+    if (a.stop_neg_log_t > 0.0f && __ballot(valid && nlt < a.stop_neg_log_t) == 0) {  // early termination
+      s_last = s;
+      break;
+    }
   }
   if (valid && h == 0) {
     a.ray_length[ray_id] = len;
     a.neg_log_t[ray_id] = nlt;
     for (int c = 0; c < a.color_chn; ++c) a.feature[ray_id * a.color_chn + c] = facc[c];
+    if (a.neg_log_t_ckpt)
+      *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + n_ckpt - 1) * 2) = make_float2((float)s_last, nlt_lo);
   }
 }
 
@@ -322,7 +329,31 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
   load_encoding_w<NB>(a, rid, h, enc);
 #pragma unroll
   for (int q = 0; q < 16 * NB; ++q) denc[q] = 0.0f;
-  __syncthreads();
+  // closing pair of the checkpoint list (see renderer_bwd_mfma2): workgroup-uniform first sample of the loop
+  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
+  const int n_ckpt = ckpt_count(a.march);
+  int s_last_w = s_tot - 1;
+  float nlt_lo = 0.0f;
+  if (a.neg_log_t_ckpt) {
+    const float2 e2 = *reinterpret_cast<const float2*>(a.neg_log_t_ckpt + (rid * n_ckpt + n_ckpt - 1) * 2);
+    s_last_w = __builtin_amdgcn_readfirstlane((int)e2.x);
+    s_last_w = s_last_w < 0 ? 0 : (s_last_w > s_tot - 1 ? s_tot - 1 : s_last_w);
+    nlt_lo = e2.y;
+  }
+  int s_begin = s_tot - 1;
+  if (PLAIN) {  // the PLAIN instantiation is only launched without early termination
+    __syncthreads();
+  } else {
+    if (lane == 0) ts[0] = (float)s_last_w;
+    __syncthreads();
+    s_begin = 0;
+#pragma unroll
+    for (int v = 0; v < WAVES; ++v) {
+      const int sv = (int)wave0[v * M::PER_WAVE + M::TS];
+      s_begin = sv > s_begin ? sv : s_begin;
+    }
+    __syncthreads();  // ts[] is reused by the sample loop
+  }
   float gfeat[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -330,8 +361,6 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
   const float g_len = (valid && a.grad_ray_length) ? a.grad_ray_length[rid] : 0.0f;
   const float g_nlt = (valid && a.grad_neg_log_t) ? a.grad_neg_log_t[rid] : 0.0f;
 
-  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
-  const int n_ckpt = ckpt_count(a.march);
   const bool want_params = a.grad_mlp_params != nullptr;
   const float delta0 = (a.march.num_samples > 1) ? (ray.far_t - ray.near_t) / (float)(a.march.num_samples - 1) : 1.0f;
 
@@ -359,11 +388,12 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
   float* const gg = !a.grad_grid ? nullptr
                     : (rep == 0 ? a.grad_grid : a.grad_grid_replicas + (int64_t)(rep - 1) * a.grid.n_rows * C);
 
-  float nlt = a.neg_log_t[rid], nlt_lo = 0.0f;
+  float nlt = a.neg_log_t[rid];
   float suffix = 0.0f, p_next = 0.0f;
   Sample<C> nx;
-  fetch_sample<C, GM, true, PLAIN>(a, lds_inf, ray, s_tot - 1, h, nx);
-  for (int s = s_tot - 1; s >= 0; --s) {
+  fetch_sample<C, GM, true, PLAIN>(a, lds_inf, ray, s_begin, h, nx);
+  for (int s = s_begin; s >= 0; --s) {
+    const bool on = PLAIN || s <= s_last_w;  // wave-uniform; false only for samples a sibling wave still marches
     const float depth = nx.depth, occ = nx.occ, x = nx.x, y = nx.y, z = nx.z;
     float x0[C / 2];
 #pragma unroll
@@ -406,7 +436,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
     if (!PLAIN && a.noise_sigma > 0.0f)
       raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
     const float opacity = a.gain * softplus_f(raw) * occ;
-    if (a.neg_log_t_ckpt) {
+    if (on && a.neg_log_t_ckpt) {
       const int ck = PLAIN ? ((((s + 1) % LP_NLT_CKPT) == 0 || s == s_tot - 1) ? s / LP_NLT_CKPT : -1)
                            : ckpt_index(s, a.march);
       if (ck >= 0) {
@@ -416,7 +446,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
       }
     }
     const float t_i = __expf(-nlt);
-    nlt_add(nlt, nlt_lo, -(opacity * delta));
+    nlt_add(nlt, nlt_lo, on ? -(opacity * delta) : 0.0f);
     if (!(nlt > 0.0f)) { nlt = 0.0f; nlt_lo = 0.0f; }
     const float t_im1 = __expf(-nlt);
     const float w = t_im1 - t_i;
@@ -427,13 +457,14 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
       sg[c] = sigmoid_f(hd.raw_c[c]);
       p_i = fmaf(gfeat[c], sg[c] * occ, p_i);
     }
-    suffix = fmaf(t_i, p_i - p_next, suffix);
-    p_next = p_i;
+    suffix = on ? fmaf(t_i, p_i - p_next, suffix) : suffix;
+    p_next = on ? p_i : p_next;
     const float d_a = suffix + g_nlt;
-    const float dro = valid ? d_a * delta * a.gain * occ * d_softplus_f(raw) : 0.0f;
+    const bool contrib = valid && on;
+    const float dro = contrib ? d_a * delta * a.gain * occ * d_softplus_f(raw) : 0.0f;
     float drc[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) drc[c] = valid ? w * gfeat[c] * occ * sg[c] * (1.0f - sg[c]) : 0.0f;
+    for (int c = 0; c < 4; ++c) drc[c] = contrib ? w * gfeat[c] * occ * sg[c] * (1.0f - sg[c]) : 0.0f;
 
     // ---------------- output layers of the heads (VALU) ----------------
     // d ho is formed where it is needed (opacity hidden layer): keep only the ReLU mask of ho
@@ -581,7 +612,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
     }
     LP_SCHED_FENCE();
     // ---------------- next (nearer) sample + grid gradient ----------------
-    const bool live = valid && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
+    const bool live = valid && on && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
     if (s > 0) fetch_sample<C, GM, true, PLAIN>(a, lds_inf, ray, s - 1, h, nx);
     LP_SCHED_FENCE();
     if (gg && !(mp.dbg & 2)) {
@@ -741,7 +772,8 @@ int renderer_backward_mfma_wide(const LpRendererArgs& a, hipStream_t stream) {
   if (a.rays.n_rays == 0) return LP_OK;
   const MfmaParams mp = make_params_w(a, 64);
   int rc;
-  const bool plain = !(a.noise_sigma > 0.0f) && !a.march.contract_coords && !a.scaffold && a.march.num_samples_inf == 0;
+  const bool plain = !(a.noise_sigma > 0.0f) && !a.march.contract_coords && !a.scaffold && a.march.num_samples_inf == 0 &&
+                     !(a.stop_neg_log_t > 0.0f);
   const size_t lds_b = LdsW<2>::BWD_END * sizeof(float);
 #define LP_BW(CV, GMV) (plain ? launch_w(renderer_bwd_mfma_w<CV, GMV, 2, true>, lds_b, a, mp, stream) \
                               : launch_w(renderer_bwd_mfma_w<CV, GMV, 2, false>, lds_b, a, mp, stream))

@@ -20,6 +20,7 @@ Differences that are deliberate:
 from __future__ import annotations
 
 import ctypes
+import math
 import random
 import warnings
 from dataclasses import dataclass
@@ -59,6 +60,7 @@ class _RendererCfg:
     noise_seed: int
     scaffold_shape: Optional[Tuple[int, int, int, int]]
     kernel: int
+    stop_neg_log_t: float = 0.0
 
 
 def _fill_args(cfg: _RendererCfg, grid, color_grid, mlp_params, directions, origins, grid_idx, near, far,
@@ -87,6 +89,7 @@ def _fill_args(cfg: _RendererCfg, grid, color_grid, mlp_params, directions, orig
     a.noise_sigma = float(cfg.noise_sigma)
     a.noise_seed = ctypes.c_int32(int(cfg.noise_seed) & 0xFFFFFFFF).value
     a.kernel = cfg.kernel
+    a.stop_neg_log_t = float(cfg.stop_neg_log_t)
     return a
 
 
@@ -229,6 +232,7 @@ def lightplane_renderer(
     triton_block_size: int = 16,  # ignored
     triton_num_warps: int = 4,  # ignored
     kernel: int = _lib.LP_KERNEL_AUTO,
+    stop_transmittance: Optional[float] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Render ``rays`` through the grid-list ``grid`` (emission-absorption ray march).
 
@@ -245,7 +249,19 @@ def lightplane_renderer(
     switches to the two-grid decoder without trunk MLP; ``scaffold`` ``[B, D, H, W]`` masks
     empty space.  Gradients flow to ``grid``, ``color_grid``, ``decoder_params.mlp_params``
     and ``rays.encoding``.
+
+    Extension (not in the reference, off by default): ``stop_transmittance`` in (0, 1) -- or
+    ``config.stop_transmittance`` when the argument is ``None`` -- enables early ray termination.  A wavefront
+    (32 or 64 consecutive rays) stops marching once the transmittance of all its rays is below that value and
+    the backward skips the same samples.  ``ray_length`` / ``feature`` then miss contributions bounded by
+    ``stop_transmittance`` (times depth / colour) and the returned negative log transmittance is the value
+    reached at the stop (``>= -log(stop_transmittance)``), i.e. alpha is exact to ``stop_transmittance``.
     """
+    if stop_transmittance is None:
+        stop_transmittance = config.stop_transmittance
+    stop_transmittance = float(stop_transmittance or 0.0)
+    assert 0.0 <= stop_transmittance < 1.0, "stop_transmittance has to be in [0, 1)"
+    stop_neg_log_t = -math.log(stop_transmittance) if stop_transmittance > 0.0 else 0.0
     grid, color_grid, grid_sizes, color_grid_sizes = check_grid_and_color_grid(
         grid, color_grid, grid_sizes, color_grid_sizes)
     grid, color_grid, grid_sizes, color_grid_sizes = process_and_flatten_grid(
@@ -305,6 +321,7 @@ def lightplane_renderer(
         mask_out_of_bounds_samples=bool(mask_out_of_bounds_samples), contract_coords=bool(contract_coords),
         disparity_at_inf=float(disparity_at_inf), noise_sigma=float(inject_noise_sigma),
         noise_seed=int(inject_noise_seed), scaffold_shape=scaffold_shape, kernel=int(kernel),
+        stop_neg_log_t=stop_neg_log_t,
     )
     return LightplaneFunction.apply(
         grid, mlp_params, rays.encoding, color_grid, cfg,

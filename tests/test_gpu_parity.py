@@ -46,7 +46,7 @@ def _rays_to(rays, dev, requires_grad=False):
     return r
 
 
-def run_hip_renderer(d, dev, kernel, flat=False):
+def run_hip_renderer(d, dev, kernel, flat=False, **extra):
     rays = _rays_to(d["rays"], dev, True)
     dec = d["decoder"]
     params = dec.mlp_params.to(dev).clone().requires_grad_(True)
@@ -54,7 +54,7 @@ def run_hip_renderer(d, dev, kernel, flat=False):
     grids = [g.to(dev).clone().requires_grad_(True) for g in d["grids"]]
     cgrids = None if d["color_grids"] is None else [g.to(dev).clone().requires_grad_(True) for g in d["color_grids"]]
     scaffold = None if d["scaffold"] is None else d["scaffold"].to(dev)
-    out = lp.lightplane_renderer(rays, grids, hdec, scaffold=scaffold, color_grid=cgrids, kernel=kernel, **d["cfg"])
+    out = lp.lightplane_renderer(rays, grids, hdec, scaffold=scaffold, color_grid=cgrids, kernel=kernel, **d["cfg"], **extra)
     g_len, g_nlt, g_feat = (t.to(dev) for t in d["upstream"])
     ((out[0] * g_len).sum() + (out[1] * g_nlt).sum() + (out[2] * g_feat).sum()).backward()
     return out, params.grad, rays.encoding.grad, [g.grad for g in grids], None if cgrids is None else [g.grad for g in cgrids]
@@ -358,3 +358,30 @@ def test_cfg2_sized_properties():
         _assert_close("cfg2-sub ggrid", a, b.grad.numpy())
     for a, b in zip(out1, sub_out):
         assert torch.allclose(a[idx.to(dev)], b, rtol=1e-5, atol=1e-6), "ray results depend on batch composition"
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
+@pytest.mark.parametrize("name", ["triplane_basic", "voxel_c32_color1", "triplane_h64_c32", "voxel_deep"])
+def test_renderer_early_termination(name, kernel):
+    """Extension: with stop_transmittance the march of a wavefront ends once all its rays are opaque.  On a dense
+    medium the outputs and gradients stay within the stated bound of the exact march, the march really stops
+    (the returned -log T is the value at the stop), and stop_transmittance = 0 is the exact path."""
+    dev = _dev()
+    case = next(c for c in RENDERER_CASES if c.name == name)
+    d = case.build()
+    d["cfg"] = dict(d["cfg"], gain=float(d["cfg"]["gain"]) * 40.0)  # dense: rays saturate within a few samples
+    d["upstream"] = (d["upstream"][0], torch.zeros_like(d["upstream"][1]), d["upstream"][2])  # no loss on -log T
+    eps = 1e-5
+    out0, gp0, ge0, gg0, _ = run_hip_renderer(d, dev, kernel)
+    out1, gp1, ge1, gg1, _ = run_hip_renderer(d, dev, kernel, stop_transmittance=eps)
+    nlt0, nlt1 = out0[1], out1[1]
+    stopped = nlt1 < nlt0 * (1 - 1e-6) - 1e-6
+    assert bool(stopped.any()), "no wavefront terminated early"
+    assert bool((nlt1[stopped] >= -np.log(eps) - 1e-4).all())
+    assert bool((nlt1 <= nlt0 * (1 + 1e-6) + 1e-6).all())
+    far = float(d["rays"].far.max())
+    assert float((out1[0] - out0[0]).detach().abs().max()) <= 2 * eps * far * 4
+    assert float((out1[2] - out0[2]).detach().abs().max()) <= 2 * eps * 4
+    for nm, a, b in [("params", gp1, gp0), ("enc", ge1, ge0)] + [(f"grid{i}", x, y) for i, (x, y) in enumerate(zip(gg1, gg0))]:
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) / scale <= 1e-3, nm
