@@ -385,3 +385,21 @@ def test_renderer_early_termination(name, kernel):
     for nm, a, b in [("params", gp1, gp0), ("enc", ge1, ge0)] + [(f"grid{i}", x, y) for i, (x, y) in enumerate(zip(gg1, gg0))]:
         scale = float(b.abs().max()) + 1e-30
         assert float((a - b).abs().max()) / scale <= 1e-3, nm
+
+
+def test_fit_synthetic_scene_converges():
+    """End-to-end: module API + autograd + Adam on random rays drive the loss of the analytic scene down
+    (the role of the reference's examples/fit_single_scene.py loop), with and without early termination."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "fit_synthetic_scene", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "fit_synthetic_scene.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    old = lp.config.stop_transmittance
+    try:
+        for stop in (0.0, 1e-4):
+            r = mod.fit(steps=150, n_rays=4096, stop_transmittance=stop)
+            assert r["last_loss"] < 0.2 * r["first_loss"], r
+            assert r["heldout_psnr_db"] > 18.0, r
+    finally:
+        lp.config.stop_transmittance = old

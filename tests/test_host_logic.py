@@ -63,6 +63,15 @@ def test_c_abi_argument_validation_without_gpu():
     a.rays.encoding_dim = 7
     assert L.lp_renderer_backward(ctypes.byref(a), None) == -1
     assert L.lp_renderer_forward(None, None) == -3
+    # early termination: negative / NaN threshold rejected; the backward needs the checkpoint buffer
+    a = _empty_renderer_args()
+    a.stop_neg_log_t = -1.0
+    assert L.lp_renderer_forward(ctypes.byref(a), None) == -1
+    assert b"stop_neg_log_t" in L.lp_last_error()
+    a.stop_neg_log_t = 9.0
+    assert L.lp_renderer_forward(ctypes.byref(a), None) == 0
+    assert L.lp_renderer_backward(ctypes.byref(a), None) == -3
+    assert b"neg_log_t_ckpt" in L.lp_last_error()
     with pytest.raises(AssertionError):
         _lib.check(-1, "x")
 
