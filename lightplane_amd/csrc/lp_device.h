@@ -295,6 +295,7 @@ LP_DEV void grid_taps(const LpGrid& g, int b, float x, float y, float z, Taps& t
 // same arithmetic as voxel_taps() / plane_taps(), i.e. they are bit-identical to them.
 struct TapSet {
   int row0;
+  int iu;       // cell index along the fastest axis (x / u), -1 .. size-1
   int su, sv, st;
   float w[8];   // 0 where out of range
   unsigned ok;  // bit k set <=> slot k in range
@@ -314,6 +315,7 @@ LP_DEV void grid_tapset(const LpGrid& g, int b, float x, float y, float z, TapSe
     t.n = 8;
     t.su = 1; t.sv = g.W; t.st = g.H * g.W;
     t.row0 = base + (iz * g.H + iy) * g.W + ix;
+    t.iu = ix;
     t.ok = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -336,6 +338,7 @@ LP_DEV void grid_tapset(const LpGrid& g, int b, float x, float y, float z, TapSe
     t.n = 4;
     t.su = 1; t.sv = U; t.st = 0;
     t.row0 = base + iv * U + iu;
+    t.iu = iu;
     t.ok = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
