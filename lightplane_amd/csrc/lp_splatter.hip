@@ -408,6 +408,121 @@ __global__ void __launch_bounds__(256) splat_bwd_kernel(const LpSplatterArgs a) 
   }
 }
 
+// Backward on voxel grids as the mirror of splat_walk_vox: a wave = 16 image-adjacent rays, lane group = (y, z)
+// corner pair, lane = channel.  The rays are walked in order; a run of rays in one cell reads the two x-columns
+// of that cell ONCE (rows of grad_out scaled by 1 / clamp(weight): 64 contiguous bytes per lane group), every
+// ray of the run accumulates w_near * column_near + w_far * column_far into its own register.  All loads of
+// eight rays are issued before the first one is used.  The four corner pairs of a ray are summed across the
+// lane groups at the end.  (The per-ray kernel below re-derives the geometry in every lane and reads eight rows
+// per ray and sample.)
+template <int C>
+__global__ void __launch_bounds__(256) splat_bwd_walk_kernel(const LpSplatterArgs a) {
+  constexpr int RPW = 16, CPL = C / 16, NQ = 4, SPQ = 2;
+  __shared__ __attribute__((aligned(16))) float lds[4][8 * RPW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane / RPW, r = lane % RPW, sub = lane & 15, grp = lane >> 4;
+  float* wT = lds[wave];
+  const int64_t ray0 = ((int64_t)blockIdx.x * 4 + wave) * RPW;
+  const int64_t ray_id = ray0 + r;
+  const bool valid = ray_id < a.rays.n_rays;
+  const int64_t rid = valid ? ray_id : 0;
+  const Ray ray = load_ray(a.rays, rid);
+  float acc[CPL][RPW];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j)
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) acc[j][i] = 0.0f;
+  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
+  const bool contract = a.march.contract_coords != 0;
+  const bool mask_oob = a.march.mask_out_of_bounds != 0;
+  for (int s = 0; s < s_tot; ++s) {
+    const float depth = sample_depth(s, a.march, ray.near_t, ray.far_t);
+    float x, y, z;
+    sample_point(ray, depth, contract, x, y, z);
+    const bool live = valid && !(mask_oob && !point_in_bounds(x, y, z));
+    for (int g = 0; g < a.out.n_grids; ++g) {
+      TapSet tp;
+      grid_tapset<true>(a.out.grids[g], ray.b, x, y, z, tp);
+      if (!live) {
+        tp.ok = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tp.w[k] = 0.0f;
+      }
+#pragma unroll
+      for (int i = 0; i < SPQ; ++i) {
+        float v = tp.w[i];
+#pragma unroll
+        for (int qq = 1; qq < NQ; ++qq) v = (q == qq) ? tp.w[qq * SPQ + i] : v;
+        wT[(q * SPQ + i) * RPW + r] = v;
+      }
+      const int row0 = tp.row0;
+      const int ok = (int)tp.ok;
+      const bool head = (r == 0) || row0 != __shfl_up(row0, 1) || ok != __shfl_up(ok, 1);
+      const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head)) | 0x101u;
+      const int koff = (grp & 1) * tp.sv + (grp >> 1) * tp.st;
+      const unsigned bit_lo = 1u << (2 * grp), bit_hi = 2u << (2 * grp);
+      const float4* wlo = reinterpret_cast<const float4*>(wT + (2 * grp) * RPW);
+      const float4* whi = reinterpret_cast<const float4*>(wT + (2 * grp + 1) * RPW);
+#pragma unroll
+      for (int c8 = 0; c8 < RPW / 8; ++c8) {
+        // columns of the runs that start in this half (bit 8 of the mask is forced: a run crossing the middle
+        // is simply read twice)
+        float glo[8][CPL], ghi[8][CPL], ilo[8], ihi[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int rr = 8 * c8 + i;
+          if ((mask >> rr) & 1u) {
+            const int s_row = __builtin_amdgcn_readlane(row0, rr);
+            const unsigned s_ok = (unsigned)__builtin_amdgcn_readlane(ok, rr);
+            const int64_t row = (int64_t)(s_row + koff);
+            const bool l_ok = (s_ok & bit_lo) != 0, h_ok = (s_ok & bit_hi) != 0;
+            ilo[i] = l_ok ? a.weight[row] : 1.0f;
+            ihi[i] = h_ok ? a.weight[row + 1] : 1.0f;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+              glo[i][j] = l_ok ? a.grad_out[row * C + sub + 16 * j] : 0.0f;
+              ghi[i][j] = h_ok ? a.grad_out[(row + 1) * C + sub + 16 * j] : 0.0f;
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 a0 = wlo[2 * c8], a1 = wlo[2 * c8 + 1], b0 = whi[2 * c8], b1 = whi[2 * c8 + 1];
+        const float w0[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const float w1[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float cl[CPL], ch[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) cl[j] = ch[j] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int rr = 8 * c8 + i;
+          if ((mask >> rr) & 1u) {
+            // gradient of out = feat / max(weight, 1e-5) w.r.t. feat (weights carry no gradient)
+            const float il = 1.0f / fmaxf(ilo[i], 1e-5f), ih = 1.0f / fmaxf(ihi[i], 1e-5f);
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+              cl[j] = glo[i][j] * il;
+              ch[j] = ghi[i][j] * ih;
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) acc[j][rr] = fmaf(w1[i], ch[j], fmaf(w0[i], cl[j], acc[j][rr]));
+        }
+      }
+    }
+  }
+  // sum the four corner pairs (lane groups), then lane group 0 writes [ray][channel]
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      float v = acc[j][i];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (grp == 0 && ray0 + i < a.rays.n_rays) a.grad_encoding[(ray0 + i) * C + sub + 16 * j] = v;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) splat_normalize_kernel(float* feature, const float* weight,
                                                               int64_t n_rows, int C) {
   const int64_t n = n_rows * C;
@@ -479,6 +594,18 @@ int splatter_forward_launch(const LpSplatterArgs& a, hipStream_t stream) {
 }
 
 int splatter_backward_launch(const LpSplatterArgs& a, hipStream_t stream) {
+  const int Cw = a.out.channels;
+  static const bool no_walk = getenv("LP_SPLAT_NO_WALK") != nullptr;  // A/B timing knob
+  bool voxels = a.out.n_grids > 0;
+  for (int g = 0; g < a.out.n_grids; ++g)
+    voxels = voxels && a.out.grids[g].D > 1 && a.out.grids[g].H > 1 && a.out.grids[g].W > 1;
+  if ((Cw == 16 || Cw == 32) && voxels && a.out.n_rows < ((int64_t)1 << 31) && !no_walk) {
+    const unsigned blocks = (unsigned)((a.rays.n_rays + 63) / 64);
+    if (blocks == 0) return LP_OK;
+    if (Cw == 16) hipLaunchKernelGGL((splat_bwd_walk_kernel<16>), dim3(blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((splat_bwd_walk_kernel<32>), dim3(blocks), dim3(256), 0, stream, a);
+    return check_launch("splat_bwd_walk_kernel");
+  }
   LP_SPLAT_DISPATCH(splat_bwd_kernel);
   return check_launch("splat_bwd_kernel");
 }
