@@ -296,6 +296,7 @@ LP_DEV void grid_taps(const LpGrid& g, int b, float x, float y, float z, Taps& t
 struct TapSet {
   int row0;
   int iu;       // cell index along the fastest axis (x / u), -1 .. size-1
+  int cell;     // voxel grids: (ix+1) | (iy+1) << 10 | (iz+1) << 20 (axis sizes <= 1022), else 0
   int su, sv, st;
   float w[8];   // 0 where out of range
   unsigned ok;  // bit k set <=> slot k in range
@@ -316,6 +317,7 @@ LP_DEV void grid_tapset(const LpGrid& g, int b, float x, float y, float z, TapSe
     t.su = 1; t.sv = g.W; t.st = g.H * g.W;
     t.row0 = base + (iz * g.H + iy) * g.W + ix;
     t.iu = ix;
+    t.cell = (ix + 1) | ((iy + 1) << 10) | ((iz + 1) << 20);
     t.ok = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -339,6 +341,7 @@ LP_DEV void grid_tapset(const LpGrid& g, int b, float x, float y, float z, TapSe
     t.su = 1; t.sv = U; t.st = 0;
     t.row0 = base + iv * U + iu;
     t.iu = iu;
+    t.cell = 0;
     t.ok = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

@@ -163,11 +163,13 @@ LP_DEV void splat_walk(float* feat, float* wgt, const LpGrid& g, int b, float x,
   }
 }
 
-// Voxel grids: the walk of splat_walk with the two x-columns of a cell kept in separate accumulators.  Lane group
-// grp = (y, z) corner pair, lane = channel.  Image-adjacent rays mostly step from a cell to its x-neighbour: the
-// far column of the old cell is the near column of the new one, so it stays in registers and only the column
-// that is left behind is flushed -- half the atomic segments of the per-slot walk (the Splatter forward is bound
-// by the rate of 64-byte atomic segments), and one pass instead of two.
+// Voxel grids: the walk of splat_walk with the two columns of a cell along one axis kept in separate accumulators.
+// Lane group grp = corner pair over the two other axes, lane = channel.  Image-adjacent rays mostly step from a
+// cell to its neighbour along one grid axis (which one depends on the camera; it is read off the first cell
+// change of the walk): the far column of the old cell is the near column of the new one, so it stays in
+// registers and only the column that is left behind is flushed -- half the atomic segments of the per-slot
+// walk (the Splatter forward is bound by the rate of 64-byte atomic segments), and one pass
+// instead of two.
 template <int C, int RPW>
 LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, float x, float y, float z, bool live,
                            int lane, const float (&enc)[C / 16][RPW], float* wT, int dbg) {
@@ -189,20 +191,35 @@ LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, floa
     for (int qq = 1; qq < NQ; ++qq) v = (q == qq) ? tp.w[qq * SPQ + i] : v;
     wT[(q * SPQ + i) * RPW + r] = v;
   }
-  const int row0 = tp.row0, iu = tp.iu;
+  const int row0 = tp.row0, iu = tp.iu, cell = tp.cell;
   const int ok = (int)tp.ok;
   const bool head = (r == 0) || row0 != __shfl_up(row0, 1) || ok != __shfl_up(ok, 1);
   const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head));
   {
-    const int koff = (grp & 1) * tp.sv + (grp >> 1) * tp.st;  // rows of this (y, z) pair relative to row0
-    const unsigned bit_lo = 1u << (2 * grp), bit_hi = 2u << (2 * grp);
-    const float4* wlo = reinterpret_cast<const float4*>(wT + (2 * grp) * RPW);
-    const float4* whi = reinterpret_cast<const float4*>(wT + (2 * grp + 1) * RPW);
+    // merge axis A (wave-uniform): the axis of the first cell change of this walk
+    int A = 0;
+    if (mask & 0xFFFEu) {
+      const int r1 = __builtin_ctz(mask & 0xFFFEu);
+      const int dc = __builtin_amdgcn_readlane(cell, r1) - __builtin_amdgcn_readlane(cell, 0);
+      A = (dc == (1 << 10) || dc == -(1 << 10)) ? 1 : ((dc == (1 << 20) || dc == -(1 << 20)) ? 2 : 0);
+    }
+    const bool packable = g.W <= 1022 && g.H <= 1022 && g.D <= 1022;
+    const int step = packable ? (1 << (10 * A)) : 0x40000000;   // cell-code step of +1 along A
+    const int sA = A == 0 ? tp.su : (A == 1 ? tp.sv : tp.st);   // row stride along A
+    const int s0 = A == 0 ? tp.sv : tp.su, s1 = A == 2 ? tp.sv : tp.st;  // row strides of the two other axes
+    const int b0 = grp & 1, b1 = grp >> 1;
+    const int k_lo = A == 0 ? 2 * b0 + 4 * b1 : (A == 1 ? b0 + 4 * b1 : b0 + 2 * b1);
+    const int k_hi = k_lo + (1 << A);
+    const int koff = b0 * s0 + b1 * s1;  // rows of this corner pair relative to row0
+    const unsigned bit_lo = 1u << k_lo, bit_hi = 1u << k_hi;
+    const float4* wlo = reinterpret_cast<const float4*>(wT + k_lo * RPW);
+    const float4* whi = reinterpret_cast<const float4*>(wT + k_hi * RPW);
+    const int64_t hi_off = (int64_t)sA * C;
     float lo[CPL], hi[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) lo[j] = hi[j] = 0.0f;
     int s_row = __builtin_amdgcn_readlane(row0, 0);
-    int s_iu = __builtin_amdgcn_readlane(iu, 0);
+    int s_cell = __builtin_amdgcn_readlane(cell, 0);
     unsigned s_ok = (unsigned)__builtin_amdgcn_readlane(ok, 0);
     const bool on = !(dbg & 1);
 #pragma unroll
@@ -215,20 +232,20 @@ LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, floa
         const int rr = 8 * c8 + i;
         if (rr > 0 && ((mask >> rr) & 1u)) {
           const int n_row = __builtin_amdgcn_readlane(row0, rr);
-          const int n_iu = __builtin_amdgcn_readlane(iu, rr);
-          const int d = n_row - s_row;
+          const int n_cell = __builtin_amdgcn_readlane(cell, rr);
+          const int d = n_cell - s_cell, dr = n_row - s_row;  // dr: also tells grids of different batch entries apart
           float* dst = feat + (int64_t)(s_row + koff) * C + sub;
-          if (d == 1 && n_iu == s_iu + 1) {         // x + 1: the far column becomes the near one
+          if (d == step && dr == sA) {              // +1 along A: the far column becomes the near one
             if ((s_ok & bit_lo) && on) {
 #pragma unroll
               for (int j = 0; j < CPL; ++j) atomic_add_f32(dst + 16 * j, lo[j]);
             }
 #pragma unroll
             for (int j = 0; j < CPL; ++j) { lo[j] = hi[j]; hi[j] = 0.0f; }
-          } else if (d == -1 && n_iu == s_iu - 1) {  // x - 1
+          } else if (d == -step && dr == -sA) {     // -1 along A
             if ((s_ok & bit_hi) && on) {
 #pragma unroll
-              for (int j = 0; j < CPL; ++j) atomic_add_f32(dst + C + 16 * j, hi[j]);
+              for (int j = 0; j < CPL; ++j) atomic_add_f32(dst + hi_off + 16 * j, hi[j]);
             }
 #pragma unroll
             for (int j = 0; j < CPL; ++j) { hi[j] = lo[j]; lo[j] = 0.0f; }
@@ -239,13 +256,13 @@ LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, floa
             }
             if ((s_ok & bit_hi) && on) {
 #pragma unroll
-              for (int j = 0; j < CPL; ++j) atomic_add_f32(dst + C + 16 * j, hi[j]);
+              for (int j = 0; j < CPL; ++j) atomic_add_f32(dst + hi_off + 16 * j, hi[j]);
             }
 #pragma unroll
             for (int j = 0; j < CPL; ++j) lo[j] = hi[j] = 0.0f;
           }
           s_row = n_row;
-          s_iu = n_iu;
+          s_cell = n_cell;
           s_ok = (unsigned)__builtin_amdgcn_readlane(ok, rr);
         }
 #pragma unroll
@@ -263,7 +280,7 @@ LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, floa
     }
     if ((s_ok & bit_hi) && on) {
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) atomic_add_f32(dst + C + 16 * j, hi[j]);
+      for (int j = 0; j < CPL; ++j) atomic_add_f32(dst + hi_off + 16 * j, hi[j]);
     }
   }
   // unit weights: x-neighbouring rows are neighbouring floats of the weight grid, so a 16-cell window of x per
@@ -415,8 +432,8 @@ __global__ void __launch_bounds__(256) splat_bwd_kernel(const LpSplatterArgs a) 
 // eight rays are issued before the first one is used.  The four corner pairs of a ray are summed across the
 // lane groups at the end.  (The per-ray kernel below re-derives the geometry in every lane and reads eight rows
 // per ray and sample.)
-template <int C>
-__global__ void __launch_bounds__(256) splat_bwd_walk_kernel(const LpSplatterArgs a) {
+template <int C, int B>
+__global__ void __launch_bounds__(256, B == 4 ? 3 : 2) splat_bwd_walk_kernel(const LpSplatterArgs a) {
   constexpr int RPW = 16, CPL = C / 16, NQ = 4, SPQ = 2;
   __shared__ __attribute__((aligned(16))) float lds[4][8 * RPW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -458,19 +475,19 @@ __global__ void __launch_bounds__(256) splat_bwd_walk_kernel(const LpSplatterArg
       const int row0 = tp.row0;
       const int ok = (int)tp.ok;
       const bool head = (r == 0) || row0 != __shfl_up(row0, 1) || ok != __shfl_up(ok, 1);
-      const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head)) | 0x101u;
+      const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head)) | (B == 8 ? 0x101u : 0x1111u);
       const int koff = (grp & 1) * tp.sv + (grp >> 1) * tp.st;
       const unsigned bit_lo = 1u << (2 * grp), bit_hi = 2u << (2 * grp);
       const float4* wlo = reinterpret_cast<const float4*>(wT + (2 * grp) * RPW);
       const float4* whi = reinterpret_cast<const float4*>(wT + (2 * grp + 1) * RPW);
 #pragma unroll
-      for (int c8 = 0; c8 < RPW / 8; ++c8) {
-        // columns of the runs that start in this half (bit 8 of the mask is forced: a run crossing the middle
-        // is simply read twice)
-        float glo[8][CPL], ghi[8][CPL], ilo[8], ihi[8];
+      for (int cb = 0; cb < RPW / B; ++cb) {
+        // columns of the runs that start in this batch of B rays (the first ray of a batch is forced to be a
+        // run head: a run crossing a batch boundary is simply read again)
+        float glo[B][CPL], ghi[B][CPL], ilo[B], ihi[B];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int rr = 8 * c8 + i;
+        for (int i = 0; i < B; ++i) {
+          const int rr = B * cb + i;
           if ((mask >> rr) & 1u) {
             const int s_row = __builtin_amdgcn_readlane(row0, rr);
             const unsigned s_ok = (unsigned)__builtin_amdgcn_readlane(ok, rr);
@@ -486,15 +503,19 @@ __global__ void __launch_bounds__(256) splat_bwd_walk_kernel(const LpSplatterArg
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        const float4 a0 = wlo[2 * c8], a1 = wlo[2 * c8 + 1], b0 = whi[2 * c8], b1 = whi[2 * c8 + 1];
-        const float w0[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-        const float w1[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float w0[B], w1[B];
+#pragma unroll
+        for (int i4 = 0; i4 < B / 4; ++i4) {
+          const float4 a4 = wlo[(B / 4) * cb + i4], b4 = whi[(B / 4) * cb + i4];
+          w0[4 * i4 + 0] = a4.x; w0[4 * i4 + 1] = a4.y; w0[4 * i4 + 2] = a4.z; w0[4 * i4 + 3] = a4.w;
+          w1[4 * i4 + 0] = b4.x; w1[4 * i4 + 1] = b4.y; w1[4 * i4 + 2] = b4.z; w1[4 * i4 + 3] = b4.w;
+        }
         float cl[CPL], ch[CPL];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) cl[j] = ch[j] = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int rr = 8 * c8 + i;
+        for (int i = 0; i < B; ++i) {
+          const int rr = B * cb + i;
           if ((mask >> rr) & 1u) {
             // gradient of out = feat / max(weight, 1e-5) w.r.t. feat (weights carry no gradient)
             const float il = 1.0f / fmaxf(ilo[i], 1e-5f), ih = 1.0f / fmaxf(ihi[i], 1e-5f);
@@ -602,8 +623,9 @@ int splatter_backward_launch(const LpSplatterArgs& a, hipStream_t stream) {
   if ((Cw == 16 || Cw == 32) && voxels && a.out.n_rows < ((int64_t)1 << 31) && !no_walk) {
     const unsigned blocks = (unsigned)((a.rays.n_rays + 63) / 64);
     if (blocks == 0) return LP_OK;
-    if (Cw == 16) hipLaunchKernelGGL((splat_bwd_walk_kernel<16>), dim3(blocks), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((splat_bwd_walk_kernel<32>), dim3(blocks), dim3(256), 0, stream, a);
+    // batches of 8 rays; batches of 4 at three waves/SIMD measured the same (cfg 3)
+    if (Cw == 16) hipLaunchKernelGGL((splat_bwd_walk_kernel<16, 8>), dim3(blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((splat_bwd_walk_kernel<32, 8>), dim3(blocks), dim3(256), 0, stream, a);
     return check_launch("splat_bwd_walk_kernel");
   }
   LP_SPLAT_DISPATCH(splat_bwd_kernel);
