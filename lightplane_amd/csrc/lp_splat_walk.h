@@ -1,0 +1,204 @@
+// lp_splat_walk.h -- the Splatter's run-merged scatter walk on voxel grids, shared by the plain Splatter
+// (lp_splatter.hip: the splatted vector sits in registers) and the MFMA MLP-Splatter (lp_splatter_mlp_mfma.hip:
+// in an LDS tile).
+#pragma once
+#include "lp_device.h"
+
+namespace lp {
+
+// value sources of splat_walk_vox: load8(j, c8, out) = channels (lane & 15) + 16 j of rays 8 c8 .. 8 c8 + 7
+template <int CPL, int RPW>
+struct SplatSrcRegs {
+  const float (&enc)[CPL][RPW];
+  LP_DEV void load8(int j, int c8, float (&out)[8]) const {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = enc[j][8 * c8 + i];
+  }
+};
+struct SplatSrcLds {  // tile [channel][ld] in LDS
+  const float* tile;
+  int ld, sub;
+  LP_DEV void load8(int j, int c8, float (&out)[8]) const {
+    const float4* p = reinterpret_cast<const float4*>(tile + (sub + 16 * j) * ld);
+    const float4 d0 = p[2 * c8], d1 = p[2 * c8 + 1];
+    out[0] = d0.x; out[1] = d0.y; out[2] = d0.z; out[3] = d0.w;
+    out[4] = d1.x; out[5] = d1.y; out[6] = d1.z; out[7] = d1.w;
+  }
+};
+
+// Voxel grids: the walk of splat_walk with the two columns of a cell along one axis kept in separate accumulators.
+// Lane group grp = corner pair over the two other axes, lane = channel.  Image-adjacent rays mostly step from a
+// cell to its neighbour along one grid axis (which one depends on the camera; it is read off the first cell
+// change of the walk): the far column of the old cell is the near column of the new one, so it stays in
+// registers and only the column that is left behind is flushed -- half the atomic segments of the per-slot
+// walk (the Splatter forward is bound by the rate of 64-byte atomic segments), and one pass
+// instead of two.
+template <int C, int RPW, class Src>
+LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, float x, float y, float z, bool live,
+                           int lane, const Src& src, float* wT, int dbg) {
+  constexpr int CPL = C / 16;
+  constexpr int NQ = 64 / RPW;
+  constexpr int SPQ = 8 / NQ;
+  const int q = lane / RPW, r = lane % RPW, sub = lane & 15, grp = lane >> 4;
+  TapSet tp;
+  grid_tapset<true>(g, b, x, y, z, tp);
+  if (!live) {
+    tp.ok = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tp.w[k] = 0.0f;
+  }
+#pragma unroll
+  for (int i = 0; i < SPQ; ++i) {
+    float v = tp.w[i];
+#pragma unroll
+    for (int qq = 1; qq < NQ; ++qq) v = (q == qq) ? tp.w[qq * SPQ + i] : v;
+    wT[(q * SPQ + i) * RPW + r] = v;
+  }
+  const int row0 = tp.row0, iu = tp.iu, cell = tp.cell;
+  const int ok = (int)tp.ok;
+  const bool head = (r == 0) || row0 != __shfl_up(row0, 1) || ok != __shfl_up(ok, 1);
+  const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head));
+  {
+    // merge axis A (wave-uniform): the axis of the first cell change of this walk
+    int A = 0;
+    if (mask & ~1u) {
+      const int r1 = __builtin_ctz(mask & ~1u);
+      const int dc = __builtin_amdgcn_readlane(cell, r1) - __builtin_amdgcn_readlane(cell, 0);
+      A = (dc == (1 << 10) || dc == -(1 << 10)) ? 1 : ((dc == (1 << 20) || dc == -(1 << 20)) ? 2 : 0);
+    }
+    const bool packable = g.W <= 1022 && g.H <= 1022 && g.D <= 1022;
+    const int step = packable ? (1 << (10 * A)) : 0x40000000;   // cell-code step of +1 along A
+    const int sA = A == 0 ? tp.su : (A == 1 ? tp.sv : tp.st);   // row stride along A
+    const int s0 = A == 0 ? tp.sv : tp.su, s1 = A == 2 ? tp.sv : tp.st;  // row strides of the two other axes
+    const int b0 = grp & 1, b1 = grp >> 1;
+    const int k_lo = A == 0 ? 2 * b0 + 4 * b1 : (A == 1 ? b0 + 4 * b1 : b0 + 2 * b1);
+    const int k_hi = k_lo + (1 << A);
+    const int koff = b0 * s0 + b1 * s1;  // rows of this corner pair relative to row0
+    const unsigned bit_lo = 1u << k_lo, bit_hi = 1u << k_hi;
+    const float4* wlo = reinterpret_cast<const float4*>(wT + k_lo * RPW);
+    const float4* whi = reinterpret_cast<const float4*>(wT + k_hi * RPW);
+    const int64_t hi_off = (int64_t)sA * C;
+    // slots on the near / far side along A (all four corner pairs): a column is only carried over if the old
+    // and the new cell agree on its validity (a masked or padding ray in the neighbouring cell has ok == 0)
+    const unsigned lo_slots = A == 0 ? 0x55u : (A == 1 ? 0x33u : 0x0Fu);
+    const int sh = 1 << A;
+    float lo[CPL], hi[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) lo[j] = hi[j] = 0.0f;
+    int s_row = __builtin_amdgcn_readlane(row0, 0);
+    int s_cell = __builtin_amdgcn_readlane(cell, 0);
+    unsigned s_ok = (unsigned)__builtin_amdgcn_readlane(ok, 0);
+    const bool on = !(dbg & 1);
+#pragma unroll
+    for (int c8 = 0; c8 < RPW / 8; ++c8) {
+      const float4 a0 = wlo[2 * c8], a1 = wlo[2 * c8 + 1], b0 = whi[2 * c8], b1 = whi[2 * c8 + 1];
+      const float w0[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      const float w1[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      float ev[CPL][8];  // the splatted vector: channels sub + 16 j of rays 8 c8 ..
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) src.load8(j, c8, ev[j]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rr = 8 * c8 + i;
+        if (rr > 0 && ((mask >> rr) & 1u)) {
+          const int n_row = __builtin_amdgcn_readlane(row0, rr);
+          const int n_cell = __builtin_amdgcn_readlane(cell, rr);
+          const int d = n_cell - s_cell, dr = n_row - s_row;  // dr: also tells grids of different batch entries apart
+          float* dst = feat + (int64_t)(s_row + koff) * C + sub;
+          const unsigned n_ok = (unsigned)__builtin_amdgcn_readlane(ok, rr);
+          if (d == step && dr == sA && ((n_ok & lo_slots) << sh) == (s_ok & (lo_slots << sh))) {
+            // +1 along A: the far column becomes the near one
+            if ((s_ok & bit_lo) && on) {
+#pragma unroll
+              for (int j = 0; j < CPL; ++j) atomic_add_f32(dst + 16 * j, lo[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) { lo[j] = hi[j]; hi[j] = 0.0f; }
+          } else if (d == -step && dr == -sA && ((s_ok & lo_slots) << sh) == (n_ok & (lo_slots << sh))) {  // -1 along A
+            if ((s_ok & bit_hi) && on) {
+#pragma unroll
+              for (int j = 0; j < CPL; ++j) atomic_add_f32(dst + hi_off + 16 * j, hi[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) { hi[j] = lo[j]; lo[j] = 0.0f; }
+          } else {
+            if ((s_ok & bit_lo) && on) {
+#pragma unroll
+              for (int j = 0; j < CPL; ++j) atomic_add_f32(dst + 16 * j, lo[j]);
+            }
+            if ((s_ok & bit_hi) && on) {
+#pragma unroll
+              for (int j = 0; j < CPL; ++j) atomic_add_f32(dst + hi_off + 16 * j, hi[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) lo[j] = hi[j] = 0.0f;
+          }
+          s_row = n_row;
+          s_cell = n_cell;
+          s_ok = n_ok;
+        }
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          lo[j] = fmaf(w0[i], ev[j][i], lo[j]);
+          hi[j] = fmaf(w1[i], ev[j][i], hi[j]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float* dst = feat + (int64_t)(s_row + koff) * C + sub;
+    if ((s_ok & bit_lo) && on) {
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) atomic_add_f32(dst + 16 * j, lo[j]);
+    }
+    if ((s_ok & bit_hi) && on) {
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) atomic_add_f32(dst + hi_off + 16 * j, hi[j]);
+    }
+  }
+  // unit weights: x-neighbouring rows are neighbouring floats of the weight grid, so a 16-cell window of x per
+  // (y, z) pair is kept in the lanes (lane = pair * 16 + x - window base) and written with ONE atomic
+  // instruction of four 64-byte segments when the walk leaves it -- the per-run version issued four segments
+  // per run (about eight runs per 16 rays).
+  {
+    const int koff = (grp & 1) * tp.sv + (grp >> 1) * tp.st;
+    const float4* wlo = reinterpret_cast<const float4*>(wT + (2 * grp) * RPW);
+    const float4* whi = reinterpret_cast<const float4*>(wT + (2 * grp + 1) * RPW);
+    const int W = g.W;
+    float acc = 0.0f;
+    int s_row = __builtin_amdgcn_readlane(row0, 0);
+    int s_iu = __builtin_amdgcn_readlane(iu, 0);
+    int wb = ((s_iu & 15) == 15) ? s_iu : (s_iu & ~15);  // window base (x of lane sub == 0)
+    int rowb = s_row - s_iu;                              // row of x = 0 in the (y0, z0) line of the window
+    bool m0 = (wb + sub) == s_iu, m1 = (wb + sub) == s_iu + 1;
+    const bool on = !(dbg & 2);
+#pragma unroll
+    for (int c8 = 0; c8 < RPW / 8; ++c8) {
+      const float4 a0 = wlo[2 * c8], a1 = wlo[2 * c8 + 1], b0 = whi[2 * c8], b1 = whi[2 * c8 + 1];
+      const float w0[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      const float w1[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rr = 8 * c8 + i;
+        if (rr > 0 && ((mask >> rr) & 1u)) {
+          const int n_row = __builtin_amdgcn_readlane(row0, rr);
+          const int n_iu = __builtin_amdgcn_readlane(iu, rr);
+          const bool same_line = (n_row - n_iu) == rowb;
+          if (!(same_line && n_iu >= wb && n_iu + 1 < wb + 16)) {
+            const int xl = wb + sub;
+            if (acc != 0.0f && xl >= 0 && xl < W && on) atomic_add_f32(wgt + (int64_t)(rowb + koff + xl), acc);
+            acc = 0.0f;
+            wb = ((n_iu & 15) == 15) ? n_iu : (n_iu & ~15);
+            rowb = n_row - n_iu;
+          }
+          m0 = (wb + sub) == n_iu;
+          m1 = (wb + sub) == n_iu + 1;
+        }
+        acc += m0 ? w0[i] : (m1 ? w1[i] : 0.0f);
+      }
+    }
+    const int xl = wb + sub;
+    if (acc != 0.0f && xl >= 0 && xl < W && on) atomic_add_f32(wgt + (int64_t)(rowb + koff + xl), acc);
+  }
+}
+
+}  // namespace lp

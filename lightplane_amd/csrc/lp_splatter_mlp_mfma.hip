@@ -14,6 +14,7 @@
 // (v_mfma_f32_16x16x4_f32 over the X / dY tiles of all four waves, see lp_renderer_mfma_bwd.hip),
 // input-grid gradient through the Renderer's run-merged scatter.
 #include "lp_mfma_common.h"
+#include "lp_splat_walk.h"
 
 namespace lp {
 
@@ -211,8 +212,14 @@ __global__ void __launch_bounds__(256, 2) splat_mlp_fwd_mfma(const LpSplatterArg
 #pragma unroll
     for (int q = 0; q < CO / 2; ++q) vt[featq(q, h) * TM_LD + r] = acc[q];
 #pragma unroll 1
-    for (int g = 0; g < a.out.n_grids; ++g)
-      splat_walk_lds<CO>(a.out_feature, a.out_weight, a.out.grids[g], ray.b, sm.x, sm.y, sm.z, live, lane, vt, wT);
+    for (int g = 0; g < a.out.n_grids; ++g) {
+      const LpGrid& og = a.out.grids[g];
+      if (og.D > 1 && og.H > 1 && og.W > 1)
+        splat_walk_vox<CO, 32>(a.out_feature, a.out_weight, og, ray.b, sm.x, sm.y, sm.z, live, lane,
+                               SplatSrcLds{vt, TM_LD, lane & 15}, wT, 0);
+      else
+        splat_walk_lds<CO>(a.out_feature, a.out_weight, og, ray.b, sm.x, sm.y, sm.z, live, lane, vt, wT);
+    }
   }
 }
 
