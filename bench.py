@@ -219,7 +219,7 @@ def main():
                          "note": "effective bandwidth: the 786 KB grid is L2 resident, compulsory HBM bytes are ~0.5 KB/ray"},
             "mlp_fp32_frac_of_peak": round(flops_fwdbwd / ((fwd_ms + bwd_ms) * 1e-3) / 157.3e12, 5),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N=1 only
             res["cpu_baseline"] = cpu_baseline(rays_c, grids_c, dec_c)
         print(json.dumps(res), flush=True)
     if world > 1:
