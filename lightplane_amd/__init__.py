@@ -36,3 +36,16 @@ __all__ = [
     "flattened_triton_decoder_to_list", "get_triton_function_input_dims", "flatten_grid",
     "unflatten_grid", "calc_harmonic_embedding", "calc_harmonic_embedding_dim", "jitter_near_far",
 ]
+
+_NOT_PROVIDED = {
+    "lightplane_renderer_naive": "the reference's pure-PyTorch path is this repository's test oracle (oracle/), not product code",
+    "lightplane_splatter_naive": "the reference's pure-PyTorch path is this repository's test oracle (oracle/), not product code",
+    "lightplane_mlp_splatter_naive": "the reference's pure-PyTorch path is this repository's test oracle (oracle/), not product code",
+    "visualize_rays_plotly": "plotting helpers are outside the scope of the MI355X hot path (DESIGN.md section 7)",
+}
+
+
+def __getattr__(name):
+    if name in _NOT_PROVIDED:
+        raise AttributeError(f"lightplane_amd.{name} is deliberately not provided: {_NOT_PROVIDED[name]}")
+    raise AttributeError(f"module 'lightplane_amd' has no attribute '{name}'")
