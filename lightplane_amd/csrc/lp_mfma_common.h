@@ -45,6 +45,9 @@ struct MfmaParams {
   // shape flexibility of the width-32 family: actual hidden width (16 or 32; staged zero-padded to 32),
   // second trunk layer present, hidden layer of the opacity / colour head present
   int hid, t2, oh, ch;
+  // two-grid decoder (separate colour grid, no trunk): t1 = trunk layer 1 present, tg = colour grid-list present,
+  // hin = input width of the heads (grid channels with tg, hid otherwise) = width of the ray encoding
+  int t1, tg, hin;
 };
 
 // LDS map (floats).  Weight matrices are kept ONCE, row-major [in][W_LD] with a padded row
@@ -70,26 +73,30 @@ LP_DEV void stage_weights(const LpRendererArgs& a, const MfmaParams& mp, float* 
   const int tid = threadIdx.x;
   const int H = FLEX ? mp.hid : HID;
   const bool t2 = FLEX ? (mp.t2 != 0) : true, oh = FLEX ? (mp.oh != 0) : true, ch = FLEX ? (mp.ch != 0) : true;
-  // matrices are staged zero-padded to 32 x 32; absent layers (mp.t2 / oh / ch == 0) are staged as zeros
+  const bool t1 = FLEX ? (mp.t1 != 0) : true;
+  const int hin = FLEX ? mp.hin : HID;                     // input width of the heads
+  const int ho_w = oh ? H : hin, hc_w = ch ? H : hin;      // input width of the heads' output layers
+  // matrices are staged zero-padded to 32 x 32; absent layers (mp.t1 / t2 / oh / ch == 0) are staged as zeros
   for (int i = tid; i < 32 * 32; i += 256) {
     const int row = i >> 5, col = i & 31;
     const int d = row * W_LD + col;
     const bool in_h = row < H && col < H;
-    lds[M::WT1 + d] = (row < C && col < H) ? P[mp.w_t1 + row * H + col] : 0.0f;
+    const bool in_head = row < hin && col < H;
+    lds[M::WT1 + d] = (t1 && row < C && col < H) ? P[mp.w_t1 + row * H + col] : 0.0f;
     lds[M::WT2 + d] = (t2 && in_h) ? P[mp.w_t2 + row * H + col] : 0.0f;
-    lds[M::WO1 + d] = (oh && in_h) ? P[mp.w_o1 + row * H + col] : 0.0f;
-    lds[M::WC1 + d] = (ch && in_h) ? P[mp.w_c1 + row * H + col] : 0.0f;
+    lds[M::WO1 + d] = (oh && in_head) ? P[mp.w_o1 + row * H + col] : 0.0f;
+    lds[M::WC1 + d] = (ch && in_head) ? P[mp.w_c1 + row * H + col] : 0.0f;
   }
   for (int i = tid; i < 32; i += 256) {
     const bool in_h = i < H;
-    lds[M::BIAS + i] = in_h ? P[mp.b_t1 + i] : 0.0f;
+    lds[M::BIAS + i] = (t1 && in_h) ? P[mp.b_t1 + i] : 0.0f;
     lds[M::BIAS + 32 + i] = (t2 && in_h) ? P[mp.b_t2 + i] : 0.0f;
     lds[M::BIAS + 64 + i] = (oh && in_h) ? P[mp.b_o1 + i] : 0.0f;
     lds[M::BIAS + 96 + i] = (ch && in_h) ? P[mp.b_c1 + i] : 0.0f;
-    lds[M::WO2 + i] = in_h ? P[mp.w_o2 + i] : 0.0f;
+    lds[M::WO2 + i] = (i < ho_w) ? P[mp.w_o2 + i] : 0.0f;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-      lds[M::WC2 + i * 4 + c] = (in_h && c < a.color_chn) ? P[mp.w_c2 + (int64_t)i * mp.ldc2 + c] : 0.0f;
+      lds[M::WC2 + i * 4 + c] = (i < hc_w && c < a.color_chn) ? P[mp.w_c2 + (int64_t)i * mp.ldc2 + c] : 0.0f;
   }
   for (int i = tid; i < MAX_INF; i += 256)
     lds[M::INF + i] = (i < a.march.num_samples_inf) ? inf_scale(i, a.march) : 0.0f;
@@ -151,6 +158,27 @@ LP_DEV void gather_taps4(const float* data, const int* row, const float* w, floa
       x0[4 * j + 1] = fmaf(wk, v[k][j].y, x0[4 * j + 1]);
       x0[4 * j + 2] = fmaf(wk, v[k][j].z, x0[4 * j + 2]);
       x0[4 * j + 3] = fmaf(wk, v[k][j].w, x0[4 * j + 3]);
+    }
+  }
+}
+
+// gather from an explicit grid-list (run-time loop over its grids): the colour grid-list of the two-grid decoder
+template <int C, bool FENCED>
+LP_DEV void gather_list(const LpGridList& gl, bool mask_oob, const Ray& ray, float x, float y, float z, int h,
+                        float (&x0)[C / 2]) {
+#pragma unroll
+  for (int q = 0; q < C / 2; ++q) x0[q] = 0.0f;
+  const float keep = (mask_oob && !point_in_bounds(x, y, z)) ? 0.0f : 1.0f;
+  const float* data = gl.data;
+  for (int g = 0; g < gl.n_grids; ++g) {
+    Taps t;
+    grid_taps<false>(gl.grids[g], ray.b, x, y, z, t);
+    if (FENCED) __builtin_amdgcn_sched_barrier(0);
+    gather_taps4<C>(data, t.row, t.w, keep, h, x0);
+    if (FENCED) __builtin_amdgcn_sched_barrier(0);
+    if (t.n == 8) {
+      gather_taps4<C>(data, t.row + 4, t.w + 4, keep, h, x0);
+      if (FENCED) __builtin_amdgcn_sched_barrier(0);
     }
   }
 }

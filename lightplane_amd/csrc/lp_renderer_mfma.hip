@@ -100,13 +100,20 @@ __global__ void __launch_bounds__(256, 2) renderer_fwd_mfma(const LpRendererArgs
 // three waves/SIMD; with C = 16 it wins once there are more than two waves of rays per SIMD.
 // flexible decoder of the width-32 family: 1-2 trunk layers, heads with or without a hidden layer
 template <int C>
-LP_DEV Heads decode_flex(const float* lds, int lane, const float (&enc)[16], Act<C>& t, int zo, bool t2, bool oh, bool ch) {
+LP_DEV Heads decode_flex(const float* lds, int lane, const float (&enc)[16], Act<C>& t, int zo, bool t1, bool t2, bool oh,
+                         bool ch, bool tg, const float (&xc0)[C / 2]) {
   using M = Lds;
   const int h = lane >> 5;
   const float* wl = lds + (4 * h) * W_LD + (lane & 31) + zo;
-  f32x16 acc = layer<C / 2>(wl + M::WT1, t.x0, load_bias(lds, 0, h, zo));
+  if (t1) {
+    const f32x16 acc = layer<C / 2>(wl + M::WT1, t.x0, load_bias(lds, 0, h, zo));
 #pragma unroll
-  for (int q = 0; q < 16; ++q) t.h1[q] = fmaxf(acc[q], 0.0f);
+    for (int q = 0; q < 16; ++q) t.h1[q] = fmaxf(acc[q], 0.0f);
+  } else {  // two-grid decoder: the opacity head sees relu(sampled feature)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t.h1[q] = (q < C / 2) ? fmaxf(t.x0[q < C / 2 ? q : 0], 0.0f) : 0.0f;
+  }
+  f32x16 acc;
   if (t2) {
     acc = layer<16>(wl + M::WT2, t.h1, load_bias(lds, 1, h, zo));
 #pragma unroll
@@ -124,8 +131,13 @@ LP_DEV Heads decode_flex(const float* lds, int lane, const float (&enc)[16], Act
     for (int q = 0; q < 16; ++q) t.ho[q] = t.e[q];
   }
   float ein[16];
+  if (tg) {  // the colour head sees relu(sampled colour feature) + ray encoding
 #pragma unroll
-  for (int q = 0; q < 16; ++q) ein[q] = t.e[q] + enc[q];
+    for (int q = 0; q < 16; ++q) ein[q] = ((q < C / 2) ? fmaxf(xc0[q < C / 2 ? q : 0], 0.0f) : 0.0f) + enc[q];
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ein[q] = t.e[q] + enc[q];
+  }
   if (ch) {
     acc = layer<16>(wl + M::WC1, ein, load_bias(lds, 3, h, zo));
 #pragma unroll
@@ -137,7 +149,7 @@ LP_DEV Heads decode_flex(const float* lds, int lane, const float (&enc)[16], Act
   return heads_forward(lds, h, t.ho, t.hc, zo);
 }
 
-template <int C, int GM, int OCC, bool FLEX = false>
+template <int C, int GM, int OCC, bool FLEX = false, bool TG = false>
 __global__ void __launch_bounds__(256, OCC) renderer_fwd_mfma_np(const LpRendererArgs a, const MfmaParams mp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_weights<C, FLEX>(a, mp, lds);
@@ -149,7 +161,7 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_mfma_np(const LpRendere
   const int64_t rid = valid ? ray_id : 0;
   const Ray ray = load_ray(a.rays, rid);
   float enc[16];
-  load_encoding(a, rid, h, enc, FLEX ? mp.hid : HID);
+  load_encoding(a, rid, h, enc, FLEX ? mp.hin : HID);
   const int s_tot = a.march.num_samples + a.march.num_samples_inf;
   const int n_ckpt = ckpt_count(a.march);
   const float delta0 = (a.march.num_samples > 1) ? (ray.far_t - ray.near_t) / (float)(a.march.num_samples - 1) : 1.0f;
@@ -165,7 +177,10 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_mfma_np(const LpRendere
     for (int q = 0; q < C / 2; ++q) t.x0[q] = nx.x0[q];
     // software pipeline: the next sample's gather is interleaved with this sample's MFMA chain
     const int zo = opaque_zero();
-    const Heads hd = FLEX ? decode_flex<C>(lds, lane, enc, t, zo, mp.t2 != 0, mp.oh != 0, mp.ch != 0)
+    float xc0[C / 2];
+    if (FLEX && TG)
+      gather_list<C, false>(a.color_grid, a.march.mask_out_of_bounds != 0, ray, nx.x, nx.y, nx.z, h, xc0);
+    const Heads hd = FLEX ? decode_flex<C>(lds, lane, enc, t, zo, !TG, mp.t2 != 0, mp.oh != 0, mp.ch != 0, TG, xc0)
                           : decode_prefetch<C, GM, false>(a, lds, ray, lane, enc, t, s, nx, zo);
     const float delta = (s == 0) ? delta0 : depth - depth_prev;
     depth_prev = depth;
@@ -202,28 +217,34 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_mfma_np(const LpRendere
 // host side
 // ---------------------------------------------------------------------------------------
 
-// Shape family of these kernels: one grid-list with C in {16, 32} channels below 4 GB; trunk of 1 or 2 layers,
-// opacity / colour heads of 1 or 2 layers, every hidden width equal to H in {16, 32}; <= 4 colour channels.
-// The default shape (2/2/2 layers, H = 32) runs the tuned kernels; the others run the same kernels with the
-// absent layers skipped and H = 16 zero-padded to 32 ("flex").
+// Shape family of these kernels: grid-list(s) with C in {16, 32} channels below 4 GB; trunk of 1 or 2 layers -- or
+// none with a separate colour grid-list (the reference's two-grid decoder: the heads read relu(sampled feature)
+// of their own grid) --, opacity / colour heads of 1 or 2 layers, every hidden width equal to H in {16, 32};
+// <= 4 colour channels.  The default shape (2/2/2 layers, H = 32, one grid-list) runs the tuned kernels; the
+// others run the same kernels with the absent layers skipped and narrow widths zero-padded to 32 ("flex").
 bool renderer_mfma_supported(const LpRendererArgs& a, const char** why) {
   *why = "";
   const int C = a.grid.channels;
-  if (a.color_grid.n_grids > 0) { *why = "separate colour grid"; return false; }
+  const bool tg = a.color_grid.n_grids > 0;  // two-grid decoder: no trunk, the heads read the two sampled features
   if (C != 16 && C != 32) { *why = "grid channels not 16 or 32"; return false; }
-  if (a.trunk.n_layers < 1 || a.trunk.n_layers > 2 || a.opacity.n_layers < 1 || a.opacity.n_layers > 2 ||
-      a.color.n_layers < 1 || a.color.n_layers > 2) {
-    *why = "layer counts outside trunk 1-2 / opacity 1-2 / colour 1-2";
+  if (a.trunk.n_layers > 2 || a.opacity.n_layers < 1 || a.opacity.n_layers > 2 || a.color.n_layers < 1 ||
+      a.color.n_layers > 2 || (!tg && a.trunk.n_layers < 1) || (tg && a.trunk.n_layers != 0)) {
+    *why = "layer counts outside trunk 1-2 (0 with a colour grid) / opacity 1-2 / colour 1-2";
     return false;
   }
-  const int H = a.trunk.dims[1];
+  // one hidden width H for every hidden layer (trunk layers, hidden layers of the heads)
+  int H = 0;
+  bool same = true;
+  auto hidden = [&](int w) { if (H == 0) H = w; else same = same && (w == H); };
+  for (int l = 1; l <= a.trunk.n_layers; ++l) hidden(a.trunk.dims[l]);
+  if (a.opacity.n_layers == 2) hidden(a.opacity.dims[1]);
+  if (a.color.n_layers == 2) hidden(a.color.dims[1]);
+  if (H == 0) H = C;  // two-grid decoder with single-layer heads: no hidden layer at all
   if (H != 16 && H != 32) { *why = "hidden width other than 16 / 32 (64: wide family)"; return false; }
-  bool same = a.trunk.dims[a.trunk.n_layers] == H;
-  if (a.opacity.n_layers == 2) same = same && a.opacity.dims[1] == H;
-  if (a.color.n_layers == 2) same = same && a.color.dims[1] == H;
   if (!same) { *why = "hidden widths differ between layers"; return false; }
   if (a.color_chn > 4) { *why = "more than 4 colour channels"; return false; }
   if (a.grid.n_rows * C * 4 >= (int64_t)1 << 32) { *why = "grid-list of 4 GB or more"; return false; }
+  if (tg && a.color_grid.n_rows * C * 4 >= (int64_t)1 << 32) { *why = "colour grid-list of 4 GB or more"; return false; }
   if (a.march.num_samples_inf > MAX_INF) { *why = "more than 256 beyond-far samples"; return false; }
   return true;
 }
@@ -231,33 +252,36 @@ bool renderer_mfma_supported(const LpRendererArgs& a, const char** why) {
 static MfmaParams make_params(const LpRendererArgs& a) {
   MfmaParams p;
   const int C = a.grid.channels;
-  const int H = a.trunk.dims[1];
-  p.hid = H;
+  p.tg = a.color_grid.n_grids > 0;
+  p.t1 = a.trunk.n_layers >= 1;
   p.t2 = a.trunk.n_layers == 2;
   p.oh = a.opacity.n_layers == 2;
   p.ch = a.color.n_layers == 2;
+  const int H = p.t1 ? a.trunk.dims[1] : (p.oh ? a.opacity.dims[1] : (p.ch ? a.color.dims[1] : C));
+  p.hid = H;
+  p.hin = p.tg ? C : H;  // input width of the heads = width of the ray encoding
   // trunk: W_1 [C,H] (, W_2 [H,H]), b_1 (, b_2)
   p.w_t1 = a.trunk.offset;
   p.w_t2 = p.w_t1 + (int64_t)C * H;
   p.b_t1 = p.w_t2 + (p.t2 ? H * H : 0);
   p.b_t2 = p.b_t1 + H;
-  // opacity: (W_1 [H,H],) W_out [H,1], (b_1,) b_out
+  // opacity: (W_1 [hin,H],) W_out [H or hin,1], (b_1,) b_out
   p.w_o1 = a.opacity.offset;
-  p.w_o2 = p.w_o1 + (p.oh ? H * H : 0);
-  p.b_o1 = p.w_o2 + H;
+  p.w_o2 = p.w_o1 + (p.oh ? p.hin * H : 0);
+  p.b_o1 = p.w_o2 + (p.oh ? H : p.hin);
   p.b_o2 = p.b_o1 + (p.oh ? H : 0);
-  // colour: (W_1 [H,H],) W_out [H,ldc2], (b_1,) b_out
+  // colour: (W_1 [hin,H],) W_out [H or hin,ldc2], (b_1,) b_out
   p.ldc2 = a.color.dims[a.color.n_layers];
   p.w_c1 = a.color.offset;
-  p.w_c2 = p.w_c1 + (p.ch ? H * H : 0);
-  p.b_c1 = p.w_c2 + (int64_t)H * p.ldc2;
+  p.w_c2 = p.w_c1 + (p.ch ? p.hin * H : 0);
+  p.b_c1 = p.w_c2 + (int64_t)(p.ch ? H : p.hin) * p.ldc2;
   p.b_c2 = p.b_c1 + (p.ch ? H : 0);
   static const int dbg = getenv("LP_MFMA_DEBUG") ? atoi(getenv("LP_MFMA_DEBUG")) : 0;
   p.dbg = dbg;
   return p;
 }
 
-static bool is_flex(const MfmaParams& p) { return !(p.hid == HID && p.t2 && p.oh && p.ch); }
+static bool is_flex(const MfmaParams& p) { return !(p.hid == HID && p.t1 && p.t2 && p.oh && p.ch && !p.tg); }
 
 static int grid_mode(const LpRendererArgs& a) {
   auto is_voxel = [](const LpGrid& g) { return g.D > 1 && g.H > 1 && g.W > 1; };
@@ -289,7 +313,10 @@ static int launch_fwd(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t
   // C=16: 256x256 rays 0.82 vs 0.86 ms, 512x512 rays 3.02 vs 2.85 ms at 4 waves/SIMD
   static const int forced = getenv("LP_MFMA_FWD_VARIANT") ? atoi(getenv("LP_MFMA_FWD_VARIANT")) : -1;
   const int variant = forced >= 0 ? forced : (C == 32 ? 3 : (a.rays.n_rays > 3 * 32768 ? 4 : 0));
-  if (is_flex(mp)) {
+  if (mp.tg) {
+    if ((rc = set_lds(renderer_fwd_mfma_np<C, GM, 3, true, true>, lds))) return rc;
+    hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM, 3, true, true>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
+  } else if (is_flex(mp)) {
     if ((rc = set_lds(renderer_fwd_mfma_np<C, GM, 3, true>, lds))) return rc;
     hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM, 3, true>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
   } else if (variant == 3) {

@@ -111,7 +111,7 @@ LP_DEV f32x4 dw_quadrant(const float* wave0, int a_off, int b_off, int v0, int v
 
 // FLEX: trunk of 1-2 layers, heads with or without hidden layer, hidden width 16 (zero-padded) or 32, chosen at
 // run time through mp.{t2,oh,ch,hid}; FLEX = false is the default shape with everything folded at compile time.
-template <int C, int GM, bool PLAIN, bool FLEX = false>
+template <int C, int GM, bool PLAIN, bool FLEX = false, bool TG = false>
 __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArgs a, const MfmaParams mp) {
   using M = Lds;
   using B = LdsB;
@@ -131,13 +131,16 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
   const int64_t rid = valid ? ray_id : 0;
   const Ray ray = load_ray(a.rays, rid);
   const bool t2 = FLEX ? (mp.t2 != 0) : true, oh = FLEX ? (mp.oh != 0) : true, ch = FLEX ? (mp.ch != 0) : true;
+  constexpr bool tg = FLEX && TG;               // separate colour grid-list (its own instantiation)
+  constexpr bool t1 = !tg;                      // false: two-grid decoder (no trunk)
   const int hid = FLEX ? mp.hid : HID;
-  {  // ray encoding -> LDS, [ray][36] (features >= hid are zero)
-    const float4* src = reinterpret_cast<const float4*>(a.rays.encoding + rid * hid + 4 * h);
+  const int hin = FLEX ? mp.hin : HID;          // input width of the heads = width of the ray encoding
+  {  // ray encoding -> LDS, [ray][36] (features >= hin are zero)
+    const float4* src = reinterpret_cast<const float4*>(a.rays.encoding + rid * hin + 4 * h);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       *reinterpret_cast<float4*>(enct + r * T_LD + 8 * j + 4 * h) =
-          (!FLEX || 8 * j + 4 * h < hid) ? src[2 * j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          (!FLEX || 8 * j + 4 * h < hin) ? src[2 * j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
   // closing pair of the checkpoint list: last sample the forward marched for this wave (early termination)
   // and the low word of the final -log T.  The sample loop is workgroup-uniform (barriers): it starts at
@@ -197,6 +200,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
   const int rep = (int)(blockIdx.x % (unsigned)(a.n_grad_replicas + 1));
   float* const gg = !a.grad_grid ? nullptr
                     : (rep == 0 ? a.grad_grid : a.grad_grid_replicas + (int64_t)(rep - 1) * a.grid.n_rows * C);
+  float* const ggc = (tg) ? a.grad_color_grid : nullptr;
 
 #ifdef LP_PHASE_TIMING
   unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -221,9 +225,17 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     // ---------------- forward recompute ----------------
     LP_MARK("fwd");
     float h1[16], e[16], ho[16], hc[16];
-    f32x16 acc = layer<C / 2>(wl + M::WT1, x0, load_bias(lds, 0, h, zo));
+    float xc[C / 2];  // two-grid decoder: sampled colour-grid feature of this sample
+    if (tg) gather_list<C, true>(a.color_grid, a.march.mask_out_of_bounds != 0, ray, x, y, z, h, xc);
+    f32x16 acc;
+    if (t1) {
+      acc = layer<C / 2>(wl + M::WT1, x0, load_bias(lds, 0, h, zo));
 #pragma unroll
-    for (int q = 0; q < 16; ++q) h1[q] = fmaxf(acc[q], 0.0f);
+      for (int q = 0; q < 16; ++q) h1[q] = fmaxf(acc[q], 0.0f);
+    } else {  // the opacity head reads relu(sampled feature)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) h1[q] = (q < C / 2) ? fmaxf(x0[q < C / 2 ? q : 0], 0.0f) : 0.0f;
+    }
     if (t2) {
       acc = layer<16>(wl + M::WT2, h1, load_bias(lds, 1, h, zo));
 #pragma unroll
@@ -242,7 +254,14 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     }
     {
       float ein[16];
-      add_encoding(enct + zo + r * T_LD + 4 * h, e, ein);
+      if (tg) {  // the colour head reads relu(sampled colour feature) + encoding
+        float ec[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ec[q] = (q < C / 2) ? fmaxf(xc[q < C / 2 ? q : 0], 0.0f) : 0.0f;
+        add_encoding(enct + zo + r * T_LD + 4 * h, ec, ein);
+      } else {
+        add_encoding(enct + zo + r * T_LD + 4 * h, e, ein);
+      }
       if (ch) {
         acc = layer<16>(wl + M::WC1, ein, load_bias(lds, 3, h, zo));
 #pragma unroll
@@ -375,7 +394,14 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     if (ch) {
       if (want_params) {
         float ein[16];
-        add_encoding(enct + zo + r * T_LD + 4 * h, e, ein);
+        if (tg) {
+          float ec[16];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) ec[q] = (q < C / 2) ? fmaxf(xc[q < C / 2 ? q : 0], 0.0f) : 0.0f;
+          add_encoding(enct + zo + r * T_LD + 4 * h, ec, ein);
+        } else {
+          add_encoding(enct + zo + r * T_LD + 4 * h, e, ein);
+        }
         tile_store_fm(xt, r, h, ein);
         tile_store_fm(yt, r, h, dhc);
       }
@@ -403,6 +429,20 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     }
     if (want_params && ch) lds_barrier();
     LP_SCHED_FENCE();
+    if (tg) {
+      // two-grid decoder: acc is d(relu(colour feature) + encoding); its scatter into the colour grid-list
+      // happens here, while the wave's tiles are idle between two layer phases; the opacity branch then
+      // starts from zero
+      if (ggc && !(mp.dbg & 2)) {
+#pragma unroll
+        for (int q = 0; q < C / 2; ++q) xt[featq(q, h) * DX_LD + r] = (xc[q] > 0.0f) ? acc[q] : 0.0f;
+        const bool live_c = valid && on && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
+#pragma unroll 1
+        for (int g = 0; g < a.color_grid.n_grids; ++g)
+          scatter_grid<C>(ggc, a.color_grid.grids[g], ray.b, x, y, z, live_c, lane, xt, yt, mp.dbg);
+      }
+      acc = (f32x16){0};
+    }
     // ---------------- opacity hidden layer ----------------
     LP_MARK("o1");
     if (oh) {
@@ -448,19 +488,24 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     LP_SCHED_FENCE();
     // ---------------- trunk layer 1 ----------------
     LP_MARK("t1");
-    if (want_params) {
+    if (t1) {
+      if (want_params) {
 #pragma unroll
-      for (int q = 0; q < C / 2; ++q) xt[featq(q, h) * T_LD + r] = x0[q];
-      tile_store_fm(yt, r, h, dh1);
-    }
-    if (gg) {
-      acc = (f32x16){0};
-      acc = layer_t(wt + M::WT1, dh1, acc);  // rows >= C are zero weights
-    }
-    if (want_params) {
-      lds_barrier();
-      dq_t1 = dw_quadrant(wave0, a_off_t1, b_off, t1_v0, t1_v1, dq_t1, db_t1);
-      lds_barrier();
+        for (int q = 0; q < C / 2; ++q) xt[featq(q, h) * T_LD + r] = x0[q];
+        tile_store_fm(yt, r, h, dh1);
+      }
+      if (gg) {
+        acc = (f32x16){0};
+        acc = layer_t(wt + M::WT1, dh1, acc);  // rows >= C are zero weights
+      }
+      if (want_params) {
+        lds_barrier();
+        dq_t1 = dw_quadrant(wave0, a_off_t1, b_off, t1_v0, t1_v1, dq_t1, db_t1);
+        lds_barrier();
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = dh1[q];  // no trunk: d e is the gradient of the sampled feature
     }
     // dx0 -> LDS right away ([channel][ray]; the X tile is free after the barrier): frees the accumulator
     if (gg) {
@@ -492,10 +537,10 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
   }
 #endif
   if (valid && a.grad_encoding) {
-    float4* dst = reinterpret_cast<float4*>(a.grad_encoding + ray_id * hid + 4 * h);
+    float4* dst = reinterpret_cast<float4*>(a.grad_encoding + ray_id * hin + 4 * h);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (!FLEX || 8 * j + 4 * h < hid)
+      if (!FLEX || 8 * j + 4 * h < hin)
         dst[2 * j] = make_float4(denc[4 * j], denc[4 * j + 1], denc[4 * j + 2], denc[4 * j + 3]);
     }
   }
@@ -503,8 +548,8 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     float* G = a.grad_mlp_params;
     const int j = lane & 31;
     // head output layers: lane (f, h) holds the partial over the 16 rays of its half
-    if (!FLEX || j < hid) {
-      atomic_add_f32(G + mp.w_o2 + j, dwo2);
+    if (!FLEX || j < (oh ? hid : hin)) atomic_add_f32(G + mp.w_o2 + j, dwo2);
+    if (!FLEX || j < (ch ? hid : hin)) {
       for (int c = 0; c < a.color_chn; ++c) atomic_add_f32(G + mp.w_c2 + (int64_t)j * mp.ldc2 + c, dwc2[c]);
     }
     float v = dbo2, c0 = dbc2[0], c1 = dbc2[1], c2 = dbc2[2], c3 = dbc2[3];
@@ -531,11 +576,13 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
       const int row = 16 * mi + prow;
       if (col_ok && (!FLEX || row < hid)) {
         if (t2) atomic_add_f32(G + mp.w_t2 + row * hid + col, dq_t2[i]);
+      }
+      if (col_ok && (!FLEX || row < hin)) {  // first layers of the heads: [hin, hid]
         if (oh) atomic_add_f32(G + mp.w_o1 + row * hid + col, dq_o1[i]);
         if (ch) atomic_add_f32(G + mp.w_c1 + row * hid + col, dq_c1[i]);
       }
       const int row1 = (C == 16) ? prow : row;
-      if (col_ok && row1 < C) atomic_add_f32(G + mp.w_t1 + row1 * hid + col, dq_t1[i]);
+      if (t1 && col_ok && row1 < C) atomic_add_f32(G + mp.w_t1 + row1 * hid + col, dq_t1[i]);
     }
     // bias gradients: partial over the rays 8ka.. of every source wave -> sum over ka
     db_t1 += __shfl_xor(db_t1, 16); db_t1 += __shfl_xor(db_t1, 32);
@@ -548,7 +595,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
         if (oh) atomic_add_f32(G + mp.b_o1 + col, db_o1);
         if (ch) atomic_add_f32(G + mp.b_c1 + col, db_c1);
       }
-      if (C == 16 || mi == 0) atomic_add_f32(G + mp.b_t1 + col, db_t1);
+      if (t1 && (C == 16 || mi == 0)) atomic_add_f32(G + mp.b_t1 + col, db_t1);
     }
   }
 }
@@ -557,14 +604,14 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
 // host side
 // ---------------------------------------------------------------------------------------
 
-template <int C, int GM, bool PLAIN, bool FLEX>
+template <int C, int GM, bool PLAIN, bool FLEX, bool TG = false>
 static int launch_bwd2p(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
   const size_t lds = (mp.dbg & 16) ? 100 * 1024 : LdsB::END * sizeof(float);  // dbg 16: one workgroup per CU
-  const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_mfma2<C, GM, PLAIN, FLEX>,
+  const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_mfma2<C, GM, PLAIN, FLEX, TG>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   const unsigned nb = (unsigned)((a.rays.n_rays + WAVES * RAYS_PER_WAVE - 1) / (WAVES * RAYS_PER_WAVE));
-  hipLaunchKernelGGL((renderer_bwd_mfma2<C, GM, PLAIN, FLEX>), dim3(nb), dim3(256), lds, stream, a, mp);
+  hipLaunchKernelGGL((renderer_bwd_mfma2<C, GM, PLAIN, FLEX, TG>), dim3(nb), dim3(256), lds, stream, a, mp);
   return LP_OK;
 }
 
@@ -574,7 +621,10 @@ template <int C, int GM>
 static int launch_bwd2(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
   const bool plain = !(a.noise_sigma > 0.0f) && !a.march.contract_coords && !a.scaffold && a.march.num_samples_inf == 0 &&
                      !(a.stop_neg_log_t > 0.0f);
-  const bool flex = !(mp.hid == HID && mp.t2 && mp.oh && mp.ch);
+  const bool flex = !(mp.hid == HID && mp.t1 && mp.t2 && mp.oh && mp.ch && !mp.tg);
+  if (mp.tg)  // two-grid decoder
+    return plain ? launch_bwd2p<C, GM_GENERIC, true, true, true>(a, mp, stream)
+                 : launch_bwd2p<C, GM_GENERIC, false, true, true>(a, mp, stream);
   if (flex)  // the non-default shapes share the run-time-loop grid-list variant (fewer instantiations)
     return plain ? launch_bwd2p<C, GM_GENERIC, true, true>(a, mp, stream)
                  : launch_bwd2p<C, GM_GENERIC, false, true>(a, mp, stream);

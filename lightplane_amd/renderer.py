@@ -107,9 +107,9 @@ def _warn_if_generic(a, cfg: _RendererCfg) -> None:
         _warned_shapes.add(key)
         warnings.warn(
             "lightplane_amd: this decoder shape runs on the shape-generic Renderer kernels (10-100x slower). The "
-            "MFMA families cover grid channels 16/32, <= 4 colour channels, a single grid-list below 4 GB and either "
-            "trunk 1-2 / opacity 1-2 / colour 1-2 layers with one hidden width of 16 or 32, or 2/2/2 layers with "
-            "hidden width 64. "
+            "MFMA families cover grid channels 16/32, <= 4 colour channels, grid-lists below 4 GB and either trunk 1-2 "
+            "(0 with a separate colour grid) / opacity 1-2 / colour 1-2 layers with one hidden width of 16 or 32, or "
+            "2/2/2 layers with hidden width 64. "
             f"Got channels={cfg.channels}, trunk={cfg.dims_trunk}, opacity={cfg.dims_opacity}, "
             f"color={cfg.dims_color}, color_chn={cfg.color_chn}, separate colour grid={cfg.color_descs is not None}.")
 

@@ -126,6 +126,8 @@ class RendererCase:
     contract: bool = False
     scaffold_size: Optional[tuple] = None  # (D, H, W)
     separate_color_grid: bool = False
+    color_grid_base: Optional[tuple] = None  # colour grid-list of another size / type (default: like the grid-list)
+    color_is_triplane: Optional[bool] = None
     noise_sigma: float = 0.0
     noise_seed: int = 0
     param_std: float = 0.2
@@ -138,7 +140,12 @@ class RendererCase:
         if self.extra_voxel:
             sizes = sizes + [[B, 4, 3, 5, C]]
         grids = random_grids(gen, sizes)
-        color_grids = random_grids(gen, sizes) if self.separate_color_grid else None
+        color_grids = None
+        if self.separate_color_grid:
+            c_base = self.color_grid_base if self.color_grid_base is not None else self.grid_base
+            c_tri = self.color_is_triplane if self.color_is_triplane is not None else self.is_triplane
+            color_grids = random_grids(gen, sizes if self.color_grid_base is None and self.color_is_triplane is None
+                                       else grid_sizes_for(c_base, c_tri))
         dec = random_decoder(gen, *self.n_layers, input_chn=C, hidden_chn=self.hidden, color_chn=self.color_chn,
                              use_separate_color_grid=self.separate_color_grid, std=self.param_std)
         enc_dim = int(dec.n_hidden_color[0])
@@ -226,6 +233,14 @@ RENDERER_CASES = [
                  n_layers=(1, 2, 1), noise_sigma=0.5, noise_seed=77, num_samples_inf=3, contract=True, param_std=0.3),
     RendererCase("flex_212_c32_scaffold", seed=21, grid_base=(2, 6, 5, 7, 32), n_layers=(2, 1, 2),
                  scaffold_size=(6, 4, 5), gain=3.0, mask_oob=True, n_rays=33),
+    # two-grid decoder (separate colour grid-list, no trunk) on the MFMA family
+    RendererCase("colorgrid_c32_h16_voxel", seed=24, grid_base=(2, 5, 6, 7, 32), separate_color_grid=True,
+                 color_grid_base=(2, 4, 3, 9, 32), n_layers=(0, 2, 2), hidden=16, scaffold_size=(6, 4, 5), n_rays=50),
+    RendererCase("colorgrid_heads1_inf", seed=25, is_triplane=True, separate_color_grid=True,
+                 color_grid_base=(2, 3, 4, 5, 16), color_is_triplane=False, n_layers=(0, 1, 1), num_samples_inf=3,
+                 contract=True, noise_sigma=0.5, noise_seed=77, n_rays=40),
+    RendererCase("colorgrid_c32_mixed", seed=26, grid_base=(1, 6, 5, 4, 32), is_triplane=True,
+                 separate_color_grid=True, n_layers=(0, 2, 1), mask_oob=True, n_rays=70, num_samples=21),
 ]
 
 SPLATTER_CASES = [
