@@ -273,6 +273,8 @@ struct Heads {
 
 // opacity / colour output layers on the VALU (N = 1 and N <= 4): each lane covers its 16
 // features, the partner lane (l ^ 32) the other 16.
+// NC = colour channels evaluated (3: the fourth column of the output layer is padding and skipped)
+template <int NC = 4>
 LP_DEV Heads heads_forward(const float* lds_, int h, const float (&ho)[16], const float (&hc)[16], int zo) {
   using M = Lds;
   const float* lds = lds_ + zo;
@@ -289,13 +291,13 @@ LP_DEV Heads heads_forward(const float* lds_, int h, const float (&ho)[16], cons
       pc[0] = fmaf(hc[q], wc.x, pc[0]);
       pc[1] = fmaf(hc[q], wc.y, pc[1]);
       pc[2] = fmaf(hc[q], wc.z, pc[2]);
-      pc[3] = fmaf(hc[q], wc.w, pc[3]);
+      if (NC > 3) pc[3] = fmaf(hc[q], wc.w, pc[3]);
     }
   }
   Heads o;
   o.raw_o = (po + __shfl_xor(po, 32)) + lds[M::HB];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) o.raw_c[c] = (pc[c] + __shfl_xor(pc[c], 32)) + lds[M::HB + 1 + c];
+  for (int c = 0; c < 4; ++c) o.raw_c[c] = (c < NC) ? (pc[c] + __shfl_xor(pc[c], 32)) + lds[M::HB + 1 + c] : 0.0f;
   return o;
 }
 
@@ -371,7 +373,7 @@ LP_DEV void fetch_sample(const LpRendererArgs& a, const float* lds, const Ray& r
 // gather of sample `s_next` into `nx` (software pipeline).  Triplane: plane g is gathered next to
 // hidden layer g+1; voxel: taps 0-3 / 4-7 next to layers 2 / 3; generic grid-lists: whole gather
 // first.
-template <int C, int GM_, bool PREFETCH = true>
+template <int C, int GM_, bool PREFETCH = true, int NC = 4>
 LP_DEV Heads decode_prefetch(const LpRendererArgs& a, const float* lds, const Ray& ray, int lane,
                              const float (&enc)[16], Act<C>& t, int s_next, Sample<C>& nx, int zo) {
   using M = Lds;
@@ -439,7 +441,7 @@ LP_DEV Heads decode_prefetch(const LpRendererArgs& a, const float* lds, const Ra
   for (int q = 0; q < 16; ++q) t.hc[q] = fmaxf(acc[q], 0.0f);
   if (GM == GM_TRIPLANE) interleave_hint<16, 6, 2>();
   LP_SCHED_FENCE();
-  return heads_forward(lds, h, t.ho, t.hc, zo);
+  return heads_forward<NC>(lds, h, t.ho, t.hc, zo);
 }
 
 // Gradient scatter, row-contiguous and run-length merged.

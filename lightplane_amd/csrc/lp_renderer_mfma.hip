@@ -35,7 +35,8 @@ namespace lp {
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
-template <int C, int GM>
+// NC = 3: at most three colour channels (RGB), the fourth lane of the colour path is compiled out
+template <int C, int GM, int NC = 4>
 __global__ void __launch_bounds__(256, 2) renderer_fwd_mfma(const LpRendererArgs a, const MfmaParams mp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_weights<C>(a, mp, lds);
@@ -63,7 +64,7 @@ __global__ void __launch_bounds__(256, 2) renderer_fwd_mfma(const LpRendererArgs
     for (int q = 0; q < C / 2; ++q) t.x0[q] = nx.x0[q];
     // software pipeline: the next sample's gather is interleaved with this sample's MFMA chain
     const int zo = opaque_zero();
-    const Heads hd = decode_prefetch<C, GM>(a, lds, ray, lane, enc, t, (s + 1 < s_tot) ? s + 1 : s, nx, zo);
+    const Heads hd = decode_prefetch<C, GM, true, NC>(a, lds, ray, lane, enc, t, (s + 1 < s_tot) ? s + 1 : s, nx, zo);
     const float delta = (s == 0) ? delta0 : depth - depth_prev;
     depth_prev = depth;
     float raw = hd.raw_o;
@@ -79,7 +80,7 @@ __global__ void __launch_bounds__(256, 2) renderer_fwd_mfma(const LpRendererArgs
     t_prev = tr;
     len = fmaf(w, depth, len);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) facc[c] = fmaf(w, sigmoid_f(hd.raw_c[c]) * occ, facc[c]);
+    for (int c = 0; c < NC; ++c) facc[c] = fmaf(w, sigmoid_f(hd.raw_c[c]) * occ, facc[c]);
     // early termination (off unless stop_neg_log_t > 0): every ray of this wave is opaque
     if (a.stop_neg_log_t > 0.0f && __ballot(valid && nlt < a.stop_neg_log_t) == 0) {
       s_last = s;
@@ -309,6 +310,8 @@ static int launch_fwd(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t
   const size_t lds = Lds::FWD_END * sizeof(float);
   int rc;
   if ((rc = set_lds(renderer_fwd_mfma<C, GM>, lds))) return rc;
+  if ((rc = set_lds(renderer_fwd_mfma<C, GM, 3>, lds))) return rc;
+  static const bool no_nc3 = getenv("LP_MFMA_NO_NC3") != nullptr;  // A/B knob
   // measured on MI355X (scripts/fwd_variants.py): 1080p C=32 S=256: 110 ms pipelined vs 48 ms at 3 waves/SIMD;
   // C=16: 256x256 rays 0.82 vs 0.86 ms, 512x512 rays 3.02 vs 2.85 ms at 4 waves/SIMD
   static const int forced = getenv("LP_MFMA_FWD_VARIANT") ? atoi(getenv("LP_MFMA_FWD_VARIANT")) : -1;
@@ -325,6 +328,8 @@ static int launch_fwd(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t
   } else if (variant == 4) {
     if ((rc = set_lds(renderer_fwd_mfma_np<C, GM, 4>, lds))) return rc;
     hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM, 4>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
+  } else if (a.color_chn <= 3 && !no_nc3) {
+    hipLaunchKernelGGL((renderer_fwd_mfma<C, GM, 3>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
   } else {
     hipLaunchKernelGGL((renderer_fwd_mfma<C, GM>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
   }

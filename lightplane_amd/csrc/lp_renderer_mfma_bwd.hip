@@ -111,7 +111,8 @@ LP_DEV f32x4 dw_quadrant(const float* wave0, int a_off, int b_off, int v0, int v
 
 // FLEX: trunk of 1-2 layers, heads with or without hidden layer, hidden width 16 (zero-padded) or 32, chosen at
 // run time through mp.{t2,oh,ch,hid}; FLEX = false is the default shape with everything folded at compile time.
-template <int C, int GM, bool PLAIN, bool FLEX = false, bool TG = false>
+// NC = colour channels evaluated (3: RGB, the padding column of the colour path is compiled out)
+template <int C, int GM, bool PLAIN, bool FLEX = false, bool TG = false, int NC = 4>
 __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArgs a, const MfmaParams mp) {
   using M = Lds;
   using B = LdsB;
@@ -271,7 +272,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
         for (int q = 0; q < 16; ++q) hc[q] = ein[q];
       }
     }
-    const Heads hd = heads_forward(lds, h, ho, hc, zo);
+    const Heads hd = heads_forward<NC>(lds, h, ho, hc, zo);
     LP_SCHED_FENCE();
     // ho / hc go to the (wave-private) tiles now: their registers turn into d ho / d hc below
     if (want_params) {
@@ -308,8 +309,8 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     float p_i = g_len * depth;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      sg[c] = sigmoid_f(hd.raw_c[c]);
-      p_i = fmaf(gfeat[c], sg[c] * occ, p_i);
+      sg[c] = (c < NC) ? sigmoid_f(hd.raw_c[c]) : 0.0f;
+      if (c < NC) p_i = fmaf(gfeat[c], sg[c] * occ, p_i);
     }
     suffix = on ? fmaf(t_i, p_i - p_next, suffix) : suffix;
     p_next = on ? p_i : p_next;
@@ -318,7 +319,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     const float dro = contrib ? d_a * delta * a.gain * occ * d_softplus_f(raw) : 0.0f;
     float drc[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) drc[c] = contrib ? w * gfeat[c] * occ * sg[c] * (1.0f - sg[c]) : 0.0f;
+    for (int c = 0; c < 4; ++c) drc[c] = (c < NC && contrib) ? w * gfeat[c] * occ * sg[c] * (1.0f - sg[c]) : 0.0f;
 
     // ---------------- output layers of the heads (VALU) ----------------
     LP_MARK("heads_bwd");
@@ -341,7 +342,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
           float v = drc[0] * wc.x;
           v = fmaf(drc[1], wc.y, v);
           v = fmaf(drc[2], wc.z, v);
-          v = fmaf(drc[3], wc.w, v);
+          if (NC > 3) v = fmaf(drc[3], wc.w, v);
           dhc[q] = (!ch || hc[q] > 0.0f) ? v : 0.0f;
         }
         LP_SCHED_FENCE();
@@ -351,7 +352,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     if (h == 0) {  // per-ray scalars: count each ray once
       dbo2 += dro;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) dbc2[c] += drc[c];
+      for (int c = 0; c < NC; ++c) dbc2[c] += drc[c];
     }
 #ifndef X_NOHEADDW
     if (want_params) {
@@ -359,7 +360,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
       if (h == 0) {
         ts[r] = dro;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) ts[(1 + c) * 32 + r] = drc[c];
+        for (int c = 0; c < NC; ++c) ts[(1 + c) * 32 + r] = drc[c];
       }
       const float* xf = xt + r * T_LD + 16 * h;  // lane (f = r, half h): rays 16h .. 16h+15 of feature f
       const float* yf = yt + r * T_LD + 16 * h;
@@ -372,7 +373,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
         dwo2 = fmaf(hov.x, d0.x, dwo2); dwo2 = fmaf(hov.y, d0.y, dwo2);
         dwo2 = fmaf(hov.z, d0.z, dwo2); dwo2 = fmaf(hov.w, d0.w, dwo2);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NC; ++c) {
           const float4 dc = *reinterpret_cast<const float4*>(tf + (1 + c) * 32 + 4 * i);
           dwc2[c] = fmaf(hcv.x, dc.x, dwc2[c]); dwc2[c] = fmaf(hcv.y, dc.y, dwc2[c]);
           dwc2[c] = fmaf(hcv.z, dc.z, dwc2[c]); dwc2[c] = fmaf(hcv.w, dc.w, dwc2[c]);
@@ -604,14 +605,14 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
 // host side
 // ---------------------------------------------------------------------------------------
 
-template <int C, int GM, bool PLAIN, bool FLEX, bool TG = false>
+template <int C, int GM, bool PLAIN, bool FLEX, bool TG = false, int NC = 4>
 static int launch_bwd2p(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
   const size_t lds = (mp.dbg & 16) ? 100 * 1024 : LdsB::END * sizeof(float);  // dbg 16: one workgroup per CU
-  const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_mfma2<C, GM, PLAIN, FLEX, TG>,
+  const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_mfma2<C, GM, PLAIN, FLEX, TG, NC>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   const unsigned nb = (unsigned)((a.rays.n_rays + WAVES * RAYS_PER_WAVE - 1) / (WAVES * RAYS_PER_WAVE));
-  hipLaunchKernelGGL((renderer_bwd_mfma2<C, GM, PLAIN, FLEX, TG>), dim3(nb), dim3(256), lds, stream, a, mp);
+  hipLaunchKernelGGL((renderer_bwd_mfma2<C, GM, PLAIN, FLEX, TG, NC>), dim3(nb), dim3(256), lds, stream, a, mp);
   return LP_OK;
 }
 
@@ -628,6 +629,10 @@ static int launch_bwd2(const LpRendererArgs& a, const MfmaParams& mp, hipStream_
   if (flex)  // the non-default shapes share the run-time-loop grid-list variant (fewer instantiations)
     return plain ? launch_bwd2p<C, GM_GENERIC, true, true>(a, mp, stream)
                  : launch_bwd2p<C, GM_GENERIC, false, true>(a, mp, stream);
+  static const bool no_nc3 = getenv("LP_MFMA_NO_NC3") != nullptr;  // A/B knob
+  if (a.color_chn <= 3 && !no_nc3)  // RGB: the padding column of the colour path is compiled out
+    return plain ? launch_bwd2p<C, GM, true, false, false, 3>(a, mp, stream)
+                 : launch_bwd2p<C, GM, false, false, false, 3>(a, mp, stream);
   return plain ? launch_bwd2p<C, GM, true, false>(a, mp, stream) : launch_bwd2p<C, GM, false, false>(a, mp, stream);
 }
 
