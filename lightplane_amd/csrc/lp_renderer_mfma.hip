@@ -150,7 +150,7 @@ LP_DEV Heads decode_flex(const float* lds, int lane, const float (&enc)[16], Act
   return heads_forward(lds, h, t.ho, t.hc, zo);
 }
 
-template <int C, int GM, int OCC, bool FLEX = false, bool TG = false>
+template <int C, int GM, int OCC, bool FLEX = false, bool TG = false, int NC = 4>
 __global__ void __launch_bounds__(256, OCC) renderer_fwd_mfma_np(const LpRendererArgs a, const MfmaParams mp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_weights<C, FLEX>(a, mp, lds);
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_mfma_np(const LpRendere
     if (FLEX && TG)
       gather_list<C, false>(a.color_grid, a.march.mask_out_of_bounds != 0, ray, nx.x, nx.y, nx.z, h, xc0);
     const Heads hd = FLEX ? decode_flex<C>(lds, lane, enc, t, zo, !TG, mp.t2 != 0, mp.oh != 0, mp.ch != 0, TG, xc0)
-                          : decode_prefetch<C, GM, false>(a, lds, ray, lane, enc, t, s, nx, zo);
+                          : decode_prefetch<C, GM, false, NC>(a, lds, ray, lane, enc, t, s, nx, zo);
     const float delta = (s == 0) ? delta0 : depth - depth_prev;
     depth_prev = depth;
     float raw = hd.raw_o;
@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_mfma_np(const LpRendere
     t_prev = tr;
     len = fmaf(w, depth, len);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) facc[c] = fmaf(w, sigmoid_f(hd.raw_c[c]) * occ, facc[c]);
+    for (int c = 0; c < NC; ++c) facc[c] = fmaf(w, sigmoid_f(hd.raw_c[c]) * occ, facc[c]);
     // early termination (off unless stop_neg_log_t > 0): every ray of this wave is opaque
     if (a.stop_neg_log_t > 0.0f && __ballot(valid && nlt < a.stop_neg_log_t) == 0) {
       s_last = s;
@@ -322,9 +322,15 @@ static int launch_fwd(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t
   } else if (is_flex(mp)) {
     if ((rc = set_lds(renderer_fwd_mfma_np<C, GM, 3, true>, lds))) return rc;
     hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM, 3, true>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
+  } else if (variant == 3 && a.color_chn <= 3 && !no_nc3) {
+    if ((rc = set_lds(renderer_fwd_mfma_np<C, GM, 3, false, false, 3>, lds))) return rc;
+    hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM, 3, false, false, 3>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
   } else if (variant == 3) {
     if ((rc = set_lds(renderer_fwd_mfma_np<C, GM, 3>, lds))) return rc;
     hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM, 3>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
+  } else if (variant == 4 && a.color_chn <= 3 && !no_nc3) {
+    if ((rc = set_lds(renderer_fwd_mfma_np<C, GM, 4, false, false, 3>, lds))) return rc;
+    hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM, 4, false, false, 3>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
   } else if (variant == 4) {
     if ((rc = set_lds(renderer_fwd_mfma_np<C, GM, 4>, lds))) return rc;
     hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM, 4>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
