@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include "lp_device.h"
+#include "lp_splat_walk.h"
 #include "lp_host.h"
 
 namespace lp {
@@ -469,10 +470,19 @@ LP_DEV void flush_run(float* gg, int s_row, unsigned s_ok, int koff, unsigned kb
 // Lane layout of the walk: 16 lanes per tap slot (four slots per pass), lane `sub` owns channels
 // sub, sub + 16, ... (C/16 of them): every atomic instruction covers four rows x 64 contiguous bytes.
 // dxT: the transposed dx0 tile [channel][ray] (row stride DX_LD).
-template <int C>
+// GMS: what is known about the grid at compile time (GM_TRIPLANE: a plane, GM_VOXEL: a voxel grid, GM_GENERIC: either)
+// COLS = false: always the per-slot walk (the MLP-Splatter backward, with a coarse input grid and a large register
+// footprint of its own, is 7 % faster with it)
+template <int C, int GMS = GM_GENERIC, bool COLS = true>
 LP_DEV void scatter_grid(float* gg, const LpGrid& g, int b, float x, float y, float z, bool live, int lane,
                          const float* dxT, float* wT, int dbg) {
   constexpr int CPL = C / 16;  // channels per lane
+  if (COLS && GMS != GM_TRIPLANE && (GMS == GM_VOXEL || (g.D > 1 && g.H > 1 && g.W > 1)) && !(dbg & 4)) {
+    // voxel grids: the column walk of lp_splat_walk.h (two columns per corner pair, one pass, half the atomics)
+    splat_walk_vox<C, 32, SplatSrcLds, false>(gg, nullptr, g, b, x, y, z, live, lane, SplatSrcLds{dxT, DX_LD, lane & 15},
+                                              wT, dbg);
+    return;
+  }
   const int h = lane >> 5, r = lane & 31, sub = lane & 15, grp = lane >> 4;
   TapSet tp;
   grid_tapset<false>(g, b, x, y, z, tp);

@@ -618,7 +618,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
     if (gg && !(mp.dbg & 2)) {
       const int ng = (GM == GM_TRIPLANE) ? 3 : (GM == GM_VOXEL) ? 1 : a.grid.n_grids;
 #pragma unroll 1
-      for (int g = 0; g < ng; ++g) scatter_grid<C>(gg, a.grid.grids[g], ray.b, x, y, z, live, lane, xt, yt, mp.dbg);
+      for (int g = 0; g < ng; ++g) scatter_grid<C, GM>(gg, a.grid.grids[g], ray.b, x, y, z, live, lane, xt, yt, mp.dbg);
     }
   }
 

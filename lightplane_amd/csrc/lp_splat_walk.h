@@ -33,7 +33,9 @@ struct SplatSrcLds {  // tile [channel][ld] in LDS
 // registers and only the column that is left behind is flushed -- half the atomic segments of the per-slot
 // walk (the Splatter forward is bound by the rate of 64-byte atomic segments), and one pass
 // instead of two.
-template <int C, int RPW, class Src>
+// SPLAT: interpolation convention (true = Splatter, false = Renderer: the gradient scatter of its backward);
+// wgt == nullptr: no unit-weight grid (Renderer).
+template <int C, int RPW, class Src, bool SPLAT = true>
 LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, float x, float y, float z, bool live,
                            int lane, const Src& src, float* wT, int dbg) {
   constexpr int CPL = C / 16;
@@ -41,7 +43,7 @@ LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, floa
   constexpr int SPQ = 8 / NQ;
   const int q = lane / RPW, r = lane % RPW, sub = lane & 15, grp = lane >> 4;
   TapSet tp;
-  grid_tapset<true>(g, b, x, y, z, tp);
+  grid_tapset<SPLAT>(g, b, x, y, z, tp);
   if (!live) {
     tp.ok = 0;
 #pragma unroll
@@ -155,6 +157,7 @@ LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, floa
       for (int j = 0; j < CPL; ++j) atomic_add_f32(dst + hi_off + 16 * j, hi[j]);
     }
   }
+  if (!SPLAT) return;  // the Renderer's gradient scatter has no weight grid
   // unit weights: x-neighbouring rows are neighbouring floats of the weight grid, so a 16-cell window of x per
   // (y, z) pair is kept in the lanes (lane = pair * 16 + x - window base) and written with ONE atomic
   // instruction of four 64-byte segments when the walk leaves it -- the per-run version issued four segments
