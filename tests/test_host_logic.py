@@ -266,3 +266,17 @@ def test_kernel_family_selection():
     assert L.lp_splatter_kernel_family(ctypes.byref(a)) == 2
     a.mlp = _lib.make_mlp([32, 64, 64, 32], 0)
     assert L.lp_splatter_kernel_family(ctypes.byref(a)) == 0
+
+
+def test_extension_and_absent_names():
+    """stop_transmittance is validated on the host; the reference names that are deliberately absent say why."""
+    from tests.synth import RENDERER_CASES
+    d = RENDERER_CASES[0].build()
+    with pytest.raises(AssertionError, match="stop_transmittance"):
+        lp.lightplane_renderer(d["rays"], d["grids"], d["decoder"], stop_transmittance=1.5, **d["cfg"])
+    assert lp.config.stop_transmittance == 0.0  # off by default: the exact march
+    for name in ("lightplane_renderer_naive", "lightplane_splatter_naive", "lightplane_mlp_splatter_naive",
+                 "visualize_rays_plotly"):
+        with pytest.raises(AttributeError, match="deliberately not provided"):
+            getattr(lp, name)
+    assert _lib.n_nlt_ckpt(128, 0) == 2 * (4 + 1) and _lib.n_nlt_ckpt(33, 5) == 2 * (2 + 5 + 1)
