@@ -129,7 +129,7 @@ LP_DEV void layer_t_w(const float* w, const float* dy, float* dx) {
 }
 
 // opacity / colour output layers on the VALU
-template <int NB>
+template <int NB, int NC = 4>
 LP_DEV Heads heads_forward_w(const float* lds, int h, const float* ho, const float* hc) {
   using M = LdsW<NB>;
   float po = 0.0f, pc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -147,7 +147,7 @@ LP_DEV Heads heads_forward_w(const float* lds, int h, const float* ho, const flo
         pc[0] = fmaf(hc[q], wc.x, pc[0]);
         pc[1] = fmaf(hc[q], wc.y, pc[1]);
         pc[2] = fmaf(hc[q], wc.z, pc[2]);
-        pc[3] = fmaf(hc[q], wc.w, pc[3]);
+        if (NC > 3) pc[3] = fmaf(hc[q], wc.w, pc[3]);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -155,7 +155,7 @@ LP_DEV Heads heads_forward_w(const float* lds, int h, const float* ho, const flo
   Heads o;
   o.raw_o = (po + __shfl_xor(po, 32)) + lds[M::HB];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) o.raw_c[c] = (pc[c] + __shfl_xor(pc[c], 32)) + lds[M::HB + 1 + c];
+  for (int c = 0; c < 4; ++c) o.raw_c[c] = (c < NC) ? (pc[c] + __shfl_xor(pc[c], 32)) + lds[M::HB + 1 + c] : 0.0f;
   return o;
 }
 
@@ -303,7 +303,8 @@ LP_DEV void dw_slab(const float* wave0, int a_off, int b_off, f32x4w (&acc)[NQ],
   db += s;
 }
 
-template <int C, int GM, int NB, bool PLAIN>
+// NC = 3: RGB, the padding column of the colour path is compiled out
+template <int C, int GM, int NB, bool PLAIN, int NC = 4>
 __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererArgs a, const MfmaParams mp) {
   static_assert(NB == 2, "the dW slab assignment (wave w <-> output columns 16w..) assumes 64 output features");
   using M = LdsW<NB>;
@@ -419,7 +420,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
       layer_w<NB, NB, 16>(wl + M::WC1, bl + 3 * H, ein, hc, true);
     }
     LP_SCHED_FENCE();
-    const Heads hd = heads_forward_w<NB>(ldz, h, ho, hc);
+    const Heads hd = heads_forward_w<NB, NC>(ldz, h, ho, hc);
     LP_SCHED_FENCE();
     if (want_params) {
       tile_store_w<NB>(xt, r, h, ho);
@@ -454,8 +455,8 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
     float p_i = g_len * depth;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      sg[c] = sigmoid_f(hd.raw_c[c]);
-      p_i = fmaf(gfeat[c], sg[c] * occ, p_i);
+      sg[c] = (c < NC) ? sigmoid_f(hd.raw_c[c]) : 0.0f;
+      if (c < NC) p_i = fmaf(gfeat[c], sg[c] * occ, p_i);
     }
     suffix = on ? fmaf(t_i, p_i - p_next, suffix) : suffix;
     p_next = on ? p_i : p_next;
@@ -464,7 +465,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
     const float dro = contrib ? d_a * delta * a.gain * occ * d_softplus_f(raw) : 0.0f;
     float drc[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) drc[c] = contrib ? w * gfeat[c] * occ * sg[c] * (1.0f - sg[c]) : 0.0f;
+    for (int c = 0; c < 4; ++c) drc[c] = (c < NC && contrib) ? w * gfeat[c] * occ * sg[c] * (1.0f - sg[c]) : 0.0f;
 
     // ---------------- output layers of the heads (VALU) ----------------
     // d ho is formed where it is needed (opacity hidden layer): keep only the ReLU mask of ho
@@ -485,7 +486,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
             float v = drc[0] * wc.x;
             v = fmaf(drc[1], wc.y, v);
             v = fmaf(drc[2], wc.z, v);
-            v = fmaf(drc[3], wc.w, v);
+            if (NC > 3) v = fmaf(drc[3], wc.w, v);
             dhc[q] = (hc[q] > 0.0f) ? v : 0.0f;
           }
           LP_SCHED_FENCE();
@@ -495,14 +496,14 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
     if (h == 0) {
       dbo2 += dro;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) dbc2[c] += drc[c];
+      for (int c = 0; c < NC; ++c) dbc2[c] += drc[c];
     }
     if (want_params) {
       // dW of the two output layers from the wave-private ho / hc tiles
       if (h == 0) {
         ts[r] = dro;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) ts[(1 + c) * 32 + r] = drc[c];
+        for (int c = 0; c < NC; ++c) ts[(1 + c) * 32 + r] = drc[c];
       }
       const float* tf = ts + 16 * h;
 #pragma unroll
@@ -517,7 +518,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
           dwo2[b] = fmaf(hov.x, d0.x, dwo2[b]); dwo2[b] = fmaf(hov.y, d0.y, dwo2[b]);
           dwo2[b] = fmaf(hov.z, d0.z, dwo2[b]); dwo2[b] = fmaf(hov.w, d0.w, dwo2[b]);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
+          for (int c = 0; c < NC; ++c) {
             const float4 dc = *reinterpret_cast<const float4*>(tf + (1 + c) * 32 + 4 * i);
             dwc2[b][c] = fmaf(hcv.x, dc.x, dwc2[b][c]); dwc2[b][c] = fmaf(hcv.y, dc.y, dwc2[b][c]);
             dwc2[b][c] = fmaf(hcv.z, dc.z, dwc2[b][c]); dwc2[b][c] = fmaf(hcv.w, dc.w, dwc2[b][c]);
@@ -775,8 +776,13 @@ int renderer_backward_mfma_wide(const LpRendererArgs& a, hipStream_t stream) {
   const bool plain = !(a.noise_sigma > 0.0f) && !a.march.contract_coords && !a.scaffold && a.march.num_samples_inf == 0 &&
                      !(a.stop_neg_log_t > 0.0f);
   const size_t lds_b = LdsW<2>::BWD_END * sizeof(float);
-#define LP_BW(CV, GMV) (plain ? launch_w(renderer_bwd_mfma_w<CV, GMV, 2, true>, lds_b, a, mp, stream) \
-                              : launch_w(renderer_bwd_mfma_w<CV, GMV, 2, false>, lds_b, a, mp, stream))
+  static const bool no_nc3 = getenv("LP_MFMA_NO_NC3") != nullptr;
+  const bool rgb = a.color_chn <= 3 && !no_nc3;
+#define LP_BW(CV, GMV)                                                                                     \
+  (rgb ? (plain ? launch_w(renderer_bwd_mfma_w<CV, GMV, 2, true, 3>, lds_b, a, mp, stream)                 \
+                : launch_w(renderer_bwd_mfma_w<CV, GMV, 2, false, 3>, lds_b, a, mp, stream))               \
+       : (plain ? launch_w(renderer_bwd_mfma_w<CV, GMV, 2, true>, lds_b, a, mp, stream)                    \
+                : launch_w(renderer_bwd_mfma_w<CV, GMV, 2, false>, lds_b, a, mp, stream)))
   {
     const int gm = grid_mode_w(a);
     if (a.grid.channels == 16) rc = gm == GM_TRIPLANE ? LP_BW(16, GM_TRIPLANE) : gm == GM_VOXEL ? LP_BW(16, GM_VOXEL) : LP_BW(16, GM_GENERIC);
