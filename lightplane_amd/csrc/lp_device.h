@@ -382,7 +382,9 @@ LP_DEV float softplus_f(float x) {
   const float sp = (e < 0.015625f) ? series : lg;
   return (x > 20.0f) ? x : sp;
 }
-LP_DEV float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// 1 / (1 + e^-x) with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division (ten instructions):
+// the forward evaluates it 3-4 times per ray and sample, the backward once more for d softplus
+LP_DEV float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // d softplus / dx (torch: threshold 20 -> 1)
 LP_DEV float d_softplus_f(float x) { return (x > 20.0f) ? 1.0f : sigmoid_f(x); }
 
