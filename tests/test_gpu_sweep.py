@@ -1,0 +1,151 @@
+"""Seeded random sweep of the HIP kernels against the CPU oracle (GPU box), in the spirit of the reference's own
+sweeps (tests/test_renderer_with_autograd.py:35-56, tests/test_splatter_with_autograd.py:38-53): random grid types
+and sizes, channels, decoder shapes, ray counts that leave partial waves, masks, contraction, beyond-far samples,
+noise, scaffold, separate colour grid.  The named golden cases pin values the reference produced; this sweep walks
+the combinations of code paths (MFMA families, flex / two-grid instantiations, column and window walks of the
+Splatter, early-termination bookkeeping with stop = 0) that no single named case covers."""
+import copy
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import lightplane_amd as lp
+from lightplane_amd import _lib
+from oracle import lightplane_oracle as O
+from tests.synth import RendererCase, SplatterCase
+from tests.test_gpu_parity import (_dev, _rel_err, run_hip_mlp_splatter, run_hip_renderer, run_hip_splatter,
+                                   run_oracle_renderer)
+
+pytestmark = pytest.mark.gpu
+
+F64 = torch.float64
+TOL = 2e-4
+
+
+def _check(name, got, want64, ref32=None):
+    """Error against the fp64 oracle: within TOL, or -- where the reference's own fp32 path is less accurate than
+    that (beyond-far samples: interval lengths ~1e5 make its gradients cancel catastrophically, 1e-3 .. 6e-3 on some
+    seeds; index arithmetic on a cell boundary) -- within 3x the fp32 oracle's own error."""
+    e = _rel_err(got, want64.detach().numpy())
+    bound = TOL
+    if ref32 is not None:
+        bound = max(TOL, 3.0 * _rel_err(ref32, want64.detach().numpy()))
+    assert e <= bound, f"{name}: max err / scale = {e:.3e} > {bound:.3e}"
+
+
+def _rays64(rays):
+    r = copy.copy(rays)
+    for f in ("directions", "origins", "near", "far", "encoding"):
+        setattr(r, f, getattr(r, f).to(F64))
+    r.encoding = r.encoding.clone().requires_grad_(True)
+    return r
+
+
+def run_oracle_renderer64(d):
+    rays = _rays64(d["rays"])
+    dec = copy.copy(d["decoder"])
+    dec.mlp_params = dec.mlp_params.to(F64).clone().requires_grad_(True)
+    grids = [g.to(F64).clone().requires_grad_(True) for g in d["grids"]]
+    cgrids = None if d["color_grids"] is None else [g.to(F64).clone().requires_grad_(True) for g in d["color_grids"]]
+    scaffold = None if d["scaffold"] is None else d["scaffold"].to(F64)
+    out = O.lightplane_renderer_naive(rays, grids, dec, scaffold=scaffold, color_grid=cgrids, **d["cfg"])
+    g_len, g_nlt, g_feat = (u.to(F64) for u in d["upstream"])
+    ((out[0] * g_len).sum() + (out[1] * g_nlt).sum() + (out[2] * g_feat).sum()).backward()
+    return out, dec.mlp_params.grad, rays.encoding.grad, [g.grad for g in grids], None if cgrids is None else [g.grad for g in cgrids]
+
+
+def _renderer_case(i):
+    rnd = random.Random(1000 + i)
+    C = rnd.choice([16, 32])
+    tri = rnd.random() < 0.5
+    sep = rnd.random() < 0.3
+    fam = rnd.choice(["default", "flex", "wide", "deep"]) if not sep else rnd.choice(["flex", "flex", "deep"])
+    if fam == "default":
+        layers, hidden = (2, 2, 2), 32
+    elif fam == "flex":
+        layers, hidden = (rnd.choice([1, 2]), rnd.choice([1, 2]), rnd.choice([1, 2])), rnd.choice([16, 32])
+    elif fam == "wide":
+        layers, hidden = (2, 2, 2), 64
+    else:
+        layers, hidden = (rnd.choice([1, 3, 4]), rnd.choice([2, 3]), rnd.choice([2, 4])), rnd.choice([16, 32])
+    if sep:
+        layers = (0, layers[1], layers[2])
+    B = rnd.choice([1, 2, 3])
+    base = (B, rnd.randint(3, 9), rnd.randint(3, 9), rnd.randint(3, 9), C)
+    contract = rnd.random() < 0.3
+    kw = dict(seed=5000 + i, n_rays=rnd.choice([1, 7, 31, 32, 33, 65, 127, 130]), grid_base=base, is_triplane=tri,
+              extra_voxel=tri and rnd.random() < 0.3 and not sep, n_layers=layers, hidden=hidden,
+              color_chn=rnd.choice([1, 3, 3, 4]), num_samples=rnd.choice([1, 2, 9, 33, 40]),
+              num_samples_inf=rnd.choice([0, 0, 3]), gain=rnd.choice([1.0, 3.0]),
+              mask_oob=(not contract) and rnd.random() < 0.4, contract=contract,
+              scaffold_size=(rnd.randint(2, 6), rnd.randint(2, 6), rnd.randint(2, 6)) if rnd.random() < 0.3 else None,
+              separate_color_grid=sep, noise_sigma=rnd.choice([0.0, 0.0, 0.7]), noise_seed=rnd.randint(0, 2 ** 20),
+              param_std=0.25)
+    if sep and rnd.random() < 0.5:
+        kw["color_grid_base"] = (B, rnd.randint(3, 8), rnd.randint(3, 8), rnd.randint(3, 8), C)
+        kw["color_is_triplane"] = rnd.random() < 0.5
+    return RendererCase(f"sweep{i}", **kw)
+
+
+@pytest.mark.parametrize("i", range(48))
+def test_renderer_sweep(i):
+    case = _renderer_case(i)
+    d = case.build()
+    dev = _dev()
+    out, gp, ge, gg, gc = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO)
+    o_out, o_gp, o_ge, o_gg, o_gc = run_oracle_renderer64(d)
+    r_out, r_gp, r_ge, r_gg, r_gc = run_oracle_renderer(d)  # the reference's fp32 arithmetic
+    for nm, a, b, c in (("ray_length", out[0], o_out[0], r_out[0]), ("neg_log_t", out[1], o_out[1], r_out[1]),
+                        ("feature", out[2], o_out[2], r_out[2]), ("grad_mlp_params", gp, o_gp, r_gp),
+                        ("grad_encoding", ge, o_ge, r_ge)):
+        _check(f"{case}: {nm}", a, b, c)
+    for k, (a, b, c) in enumerate(zip(gg, o_gg, r_gg)):
+        _check(f"{case}: grad_grid{k}", a, b, c)
+    if gc is not None:
+        for k, (a, b, c) in enumerate(zip(gc, o_gc, r_gc)):
+            _check(f"{case}: grad_color_grid{k}", a, b, c)
+
+
+def _splatter_case(i):
+    rnd = random.Random(2000 + i)
+    C = rnd.choice([16, 32, 32, 8])
+    B = rnd.choice([1, 2])
+    tri = rnd.random() < 0.3
+    use_mlp = rnd.random() < 0.4 and C in (16, 32)
+    contract = rnd.random() < 0.3
+    kw = dict(seed=7000 + i, n_rays=rnd.choice([1, 15, 16, 17, 33, 64, 70, 130]),
+              out_base=(B, rnd.randint(3, 20), rnd.randint(3, 20), rnd.randint(3, 20), C), is_triplane=tri,
+              num_samples=rnd.choice([1, 9, 24]), num_samples_inf=rnd.choice([0, 0, 3]),
+              mask_oob=(not contract) and rnd.random() < 0.4, contract=contract)
+    if use_mlp:
+        kw.update(use_mlp=True, n_layers=rnd.choice([2, 2, 3]), feat_dim=rnd.choice([16, 32]),
+                  in_base=(B, rnd.randint(3, 8), rnd.randint(3, 8), rnd.randint(3, 8), 32), in_triplane=rnd.random() < 0.4)
+    return SplatterCase(f"sweep{i}", **kw)
+
+
+@pytest.mark.parametrize("i", range(32))
+def test_splatter_sweep(i):
+    case = _splatter_case(i)
+    d = case.build()
+    dev = _dev()
+    rays = copy.copy(d["rays"])  # fp32 oracle: the cell a sample falls into is defined by the fp32 index arithmetic
+    rays.encoding = rays.encoding.clone().requires_grad_(True)
+    if case.use_mlp:
+        out, ge, gp, gin = run_hip_mlp_splatter(d, dev)
+        mlp = copy.copy(d["mlp"])
+        mlp.mlp_params = mlp.mlp_params.clone().requires_grad_(True)
+        in_grids = [g.clone().requires_grad_(True) for g in d["in_grids"]]
+        o_out = O.lightplane_mlp_splatter_naive(rays, d["out_sizes"], mlp, in_grids, **d["cfg"])
+        sum((o * u).sum() for o, u in zip(o_out, d["upstream"])).backward()
+        _check(f"{case}: grad_mlp_params", gp, mlp.mlp_params.grad)
+        for k, (a, b) in enumerate(zip(gin, in_grids)):
+            _check(f"{case}: grad_input_grid{k}", a, b.grad)
+    else:
+        out, ge = run_hip_splatter(d, dev)
+        o_out = O.lightplane_splatter_naive(rays, d["out_sizes"], **d["cfg"])
+        sum((o * u).sum() for o, u in zip(o_out, d["upstream"])).backward()
+    for k, o in enumerate(out):
+        _check(f"{case}: out{k}", o, o_out[k])
+    _check(f"{case}: grad_encoding", ge, rays.encoding.grad)
