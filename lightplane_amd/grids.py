@@ -31,7 +31,8 @@ def if_not_none_else(x: Any, y: Any) -> Any:
 def sizes_to_list(grid_sizes) -> List[List[int]]:
     """Normalise grid sizes (tensor / nested sequence) to ``List[List[int]]`` on the host."""
     if torch.is_tensor(grid_sizes):
-        grid_sizes = grid_sizes.tolist()
+        from .params import int_list_of  # cached per tensor object: a GPU-resident size tensor is read once
+        grid_sizes = int_list_of(grid_sizes)
     out = [[int(v) for v in gs] for gs in grid_sizes]
     for gs in out:
         assert len(gs) == 5, f"each grid size has to be [B, D, H, W, C], got {gs}"

@@ -54,8 +54,25 @@ class SplatterParams:
 # --------------------------------------------------------------------------------------
 
 
+def int_list_of(t):
+    """Python ints of a small integer tensor (layer widths, grid sizes).  Such tensors usually live on the GPU
+    (module buffers), where reading them is a device sync per call: the list is remembered on the tensor object
+    itself, per in-place version.  (The reference pays `.item()` / `.tolist()` syncs here on every call.)"""
+    if not torch.is_tensor(t):
+        return [int(v) for v in t]
+    cached = getattr(t, "_lp_ints", None)
+    if cached is None or cached[0] != t._version:
+        v = t.tolist()
+        cached = (t._version, v)
+        try:
+            t._lp_ints = cached
+        except AttributeError:  # pragma: no cover
+            pass
+    return [list(r) for r in cached[1]] if cached[1] and isinstance(cached[1][0], list) else list(cached[1])
+
+
 def _layer_dims(n_hidden: torch.Tensor | Sequence[int]) -> List[Tuple[int, int]]:
-    dims = [int(v) for v in (n_hidden.tolist() if torch.is_tensor(n_hidden) else n_hidden)]
+    dims = [int(v) for v in int_list_of(n_hidden)]
     return [(dims[i], dims[i + 1]) for i in range(len(dims) - 1)]
 
 

@@ -35,7 +35,7 @@ from .grids import (
     make_grid_descs,
     process_and_flatten_grid,
 )
-from .params import DecoderParams, mlp_numel
+from .params import DecoderParams, int_list_of, mlp_numel
 from .rays import Rays
 
 
@@ -204,11 +204,8 @@ class LightplaneFunction(torch.autograd.Function):
 
 
 def _decoder_dims(decoder_params: DecoderParams):
-    def tolist(t):
-        return [int(v) for v in t.tolist()]
-
-    return tolist(decoder_params.n_hidden_trunk), tolist(decoder_params.n_hidden_opacity), tolist(
-        decoder_params.n_hidden_color)
+    return (int_list_of(decoder_params.n_hidden_trunk), int_list_of(decoder_params.n_hidden_opacity),
+            int_list_of(decoder_params.n_hidden_color))
 
 
 def lightplane_renderer(

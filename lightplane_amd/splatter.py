@@ -21,7 +21,7 @@ import torch
 
 from . import _lib, config
 from .grids import GridDesc, check_grid, make_grid_descs, process_and_flatten_grid, sizes_to_list, unflatten_grid
-from .params import SplatterParams
+from .params import SplatterParams, int_list_of
 from .rays import Rays
 
 
@@ -242,7 +242,7 @@ def lightplane_mlp_splatter(
     in_descs, in_channels, in_n_rows = make_grid_descs(input_grid_sizes)
     assert input_grid.ndim == 2 and input_grid.shape == (in_n_rows, in_channels), (
         "flat input grid tensor does not match input_grid_sizes")
-    dims = [int(v) for v in mlp_params.n_hidden.tolist()]
+    dims = int_list_of(mlp_params.n_hidden)
     assert rays.encoding is not None, "rays.encoding is required"
     assert rays.encoding.dtype == torch.float32 and input_grid.dtype == torch.float32
     assert dims[0] == in_channels == rays.encoding.shape[1], (
