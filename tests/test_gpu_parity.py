@@ -417,3 +417,46 @@ def test_splatter_walk_32_rays_per_wave():
                         "-k", "test_splatter_matches", "-p", "no:cacheprovider"],
                        cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
+
+
+def test_hip_graph_capture_of_forward_backward():
+    """A Renderer forward+backward captures into a HIP graph (torch.cuda.CUDAGraph: no host syncs, launches on the
+    capturing stream) and the replay reproduces the eager gradients (atomics: summation order only)."""
+    dev = _dev()
+    old = lp.config.check_inputs
+    lp.config.check_inputs = False  # the grid_idx range check is a host sync
+    try:
+        case = next(c for c in RENDERER_CASES if c.name == "triplane_basic")
+        d = case.build()
+        rays = _rays_to(d["rays"], dev, True)
+        dec = d["decoder"]
+        params = dec.mlp_params.to(dev).clone().requires_grad_(True)
+        hdec = lp.DecoderParams(params, dec.n_hidden_trunk, dec.n_hidden_opacity, dec.n_hidden_color, dec.color_chn)
+        flat = lp.flatten_grid([g.to(dev) for g in d["grids"]])[0].requires_grad_(True)
+        sizes = d["sizes"]
+
+        def step():
+            o = lp.lightplane_renderer(rays, flat, hdec, grid_sizes=sizes, **d["cfg"])
+            (o[0].sum() + o[1].sum() + o[2].sum()).backward()
+
+        step()
+        ref = [t.grad.clone() for t in (flat, params, rays.encoding)]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                flat.grad = params.grad = rays.encoding.grad = None
+                step()
+        torch.cuda.current_stream().wait_stream(s)
+        flat.grad = params.grad = rays.encoding.grad = None
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step()
+        for t in (flat, params, rays.encoding):
+            t.grad.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        for nm, t, r in zip(("grid", "params", "encoding"), (flat, params, rays.encoding), ref):
+            _assert_close(f"graph replay grad_{nm}", t.grad, r.cpu().numpy(), 1e-5)
+    finally:
+        lp.config.check_inputs = old
