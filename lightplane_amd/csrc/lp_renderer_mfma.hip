@@ -317,8 +317,10 @@ static int launch_fwd(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t
   static const int forced = getenv("LP_MFMA_FWD_VARIANT") ? atoi(getenv("LP_MFMA_FWD_VARIANT")) : -1;
   const int variant = forced >= 0 ? forced : (C == 32 ? 3 : (a.rays.n_rays > 3 * 32768 ? 4 : 0));
   if (mp.tg) {
-    if ((rc = set_lds(renderer_fwd_mfma_np<C, GM, 3, true, true>, lds))) return rc;
-    hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM, 3, true, true>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
+    // two gathers per sample: two waves/SIMD and the run-time-loop grid-list variant (the triplane / voxel
+    // specialisations at three waves/SIMD spill 160-230 registers with C = 32)
+    if ((rc = set_lds(renderer_fwd_mfma_np<C, GM_GENERIC, 2, true, true>, lds))) return rc;
+    hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM_GENERIC, 2, true, true>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
   } else if (is_flex(mp)) {
     if ((rc = set_lds(renderer_fwd_mfma_np<C, GM, 3, true>, lds))) return rc;
     hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM, 3, true>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
