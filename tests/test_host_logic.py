@@ -280,3 +280,25 @@ def test_extension_and_absent_names():
         with pytest.raises(AttributeError, match="deliberately not provided"):
             getattr(lp, name)
     assert _lib.n_nlt_ckpt(128, 0) == 2 * (4 + 1) and _lib.n_nlt_ckpt(33, 5) == 2 * (2 + 5 + 1)
+
+
+def test_c_abi_header_is_plain_c(tmp_path):
+    """include/lightplane_hip.h is the drop-in boundary: it has to compile as C99 (and C++11) on its own, and the struct
+    sizes a C compiler sees must be the ones the library (hipcc) and the ctypes mirror use."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include "lightplane_hip.h"\nint main(void){printf("%zu %zu %zu %zu\\n", '
+                   'sizeof(LpGridList), sizeof(LpRays), sizeof(LpRendererArgs), sizeof(LpSplatterArgs)); return 0;}\n')
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                    str(src), "-o", str(exe)], check=True)
+    subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-x", "c++", "-I", os.path.join(root, "include"), str(src)], check=True)
+    sizes = [int(v) for v in subprocess.run([str(exe)], check=True, stdout=subprocess.PIPE).stdout.split()]
+    L = _lib.lib()
+    assert sizes == [L.lp_abi_sizeof(1), L.lp_abi_sizeof(2), L.lp_abi_sizeof(5), L.lp_abi_sizeof(6)]
+    assert sizes == [ctypes.sizeof(_lib.LpGridList), ctypes.sizeof(_lib.LpRays), ctypes.sizeof(_lib.LpRendererArgs),
+                     ctypes.sizeof(_lib.LpSplatterArgs)]
