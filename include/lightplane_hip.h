@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define LP_VERSION 100 /* 0.1.0 */
+#define LP_VERSION 110 /* 0.1.10: stop_neg_log_t, float-pair -log T checkpoints + closing pair */
 
 #define LP_MAX_GRIDS 8   /* grids per grid-list                         */
 #define LP_MAX_LAYERS 8  /* layers per MLP                              */
