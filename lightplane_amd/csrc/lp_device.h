@@ -283,6 +283,42 @@ LP_DEV void plane_taps(const LpGrid& g, int b, float x, float y, float z, Taps& 
   for (int k = 4; k < 8; ++k) { t.row[k] = -1; t.w[k] = 0.0f; }
 }
 
+// Canonical triplane (grids[0] = xy plane [B,1,H,W], grids[1] = xz plane [B,D,1,W], grids[2] = yz plane [B,D,H,1] with
+// ONE size per axis -- what `is_canonical_triplane` checks on the host): the three planes share three axis
+// computations instead of doing six, and nothing about the plane orientation is decided at run time.
+struct AxisTap {
+  int i0;
+  float w[2];
+  bool ok[2];
+};
+template <bool SPLAT>
+LP_DEV void triplane_axes(const LpGrid* g, float x, float y, float z, AxisTap& ax, AxisTap& ay, AxisTap& az) {
+  axis_taps<SPLAT>(x, g[0].W, ax.i0, ax.w, ax.ok);
+  axis_taps<SPLAT>(y, g[0].H, ay.i0, ay.w, ay.ok);
+  axis_taps<SPLAT>(z, g[1].D, az.i0, az.w, az.ok);
+}
+LP_DEV void plane_taps_from_axes(int base, int U, const AxisTap& u, const AxisTap& v, Taps& t) {
+  t.n = 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int uu = k & 1, uv = (k >> 1) & 1;
+    const bool ok = u.ok[uu] && v.ok[uv];
+    t.row[k] = ok ? base + (v.i0 + uv) * U + (u.i0 + uu) : -1;
+    t.w[k] = ok ? u.w[uu] * v.w[uv] : 0.0f;
+  }
+#pragma unroll
+  for (int k = 4; k < 8; ++k) { t.row[k] = -1; t.w[k] = 0.0f; }
+}
+template <bool SPLAT>
+LP_DEV void triplane_taps(const LpGrid* g, int b, float x, float y, float z, Taps (&t)[3]) {
+  AxisTap ax, ay, az;
+  triplane_axes<SPLAT>(g, x, y, z, ax, ay, az);
+  const int W = g[0].W, H = g[0].H, D = g[1].D;
+  plane_taps_from_axes((int)g[0].row_offset + b * (H * W), W, ax, ay, t[0]);  // xy: u = x, v = y
+  plane_taps_from_axes((int)g[1].row_offset + b * (D * W), W, ax, az, t[1]);  // xz: u = x, v = z
+  plane_taps_from_axes((int)g[2].row_offset + b * (D * H), H, ay, az, t[2]);  // yz: u = y, v = z
+}
+
 template <bool SPLAT>
 LP_DEV void grid_taps(const LpGrid& g, int b, float x, float y, float z, Taps& t) {
   if (g.D > 1 && g.H > 1 && g.W > 1) voxel_taps<SPLAT>(g, b, x, y, z, t);

@@ -33,7 +33,7 @@ constexpr int MAX_INF = 256;   // beyond-far samples tabulated in LDS
 
 // grid-list shape the kernel is specialised for
 constexpr int GM_GENERIC = 0;   // run-time loop over the grid-list
-constexpr int GM_TRIPLANE = 1;  // exactly three plane grids
+constexpr int GM_TRIPLANE = 1;  // a canonical triplane (is_canonical_triplane): xy, xz, yz planes, one size per axis
 constexpr int GM_VOXEL = 2;     // exactly one voxel grid
 
 // float offsets of the parameter blocks inside mlp_params (computed on the host)
@@ -194,8 +194,7 @@ LP_DEV void gather_features(const LpRendererArgs& a, const Ray& ray, float x, fl
     if (FENCED) {
       // taps of the three planes first, then one plane's loads in flight at a time
       Taps t[3];
-#pragma unroll
-      for (int g = 0; g < 3; ++g) plane_taps<false>(a.grid.grids[g], ray.b, x, y, z, t[g]);
+      triplane_taps<false>(a.grid.grids, ray.b, x, y, z, t);
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
         __builtin_amdgcn_sched_barrier(0);
@@ -203,12 +202,12 @@ LP_DEV void gather_features(const LpRendererArgs& a, const Ray& ray, float x, fl
       }
       __builtin_amdgcn_sched_barrier(0);
     } else {
+      Taps t[3];
+      triplane_taps<false>(a.grid.grids, ray.b, x, y, z, t);
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
-        Taps t;
-        plane_taps<false>(a.grid.grids[g], ray.b, x, y, z, t);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
+        for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, t[g].row[k], t[g].w[k] * keep, h, x0);
       }
     }
   } else if (GM == GM_VOXEL) {
@@ -388,10 +387,9 @@ LP_DEV Heads decode_prefetch(const LpRendererArgs& a, const float* lds, const Ra
     sample_geometry<C>(a, lds, ray, s_next, nx);
     keep = (a.march.mask_out_of_bounds && !point_in_bounds(nx.x, nx.y, nx.z)) ? 0.0f : 1.0f;
   }
-  Taps tp[GM == GM_TRIPLANE ? 3 : 1];
+  Taps tp[3];  // one entry per plane (single-voxel grid-lists use the first)
   if (GM == GM_TRIPLANE) {
-#pragma unroll
-    for (int g = 0; g < 3; ++g) plane_taps<false>(a.grid.grids[g], ray.b, nx.x, nx.y, nx.z, tp[g]);
+    triplane_taps<false>(a.grid.grids, ray.b, nx.x, nx.y, nx.z, tp);
   } else if (GM == GM_VOXEL) {
     voxel_taps<false>(a.grid.grids[0], ray.b, nx.x, nx.y, nx.z, tp[0]);
   } else if (GM == GM_GENERIC) {
@@ -479,26 +477,19 @@ LP_DEV void flush_run(float* gg, int s_row, unsigned s_ok, int koff, unsigned kb
 // VALU instructions.  (Measured: -1 % kernel time only -- the walk is bound by its scalar branches, not by its vector
 // instructions; starting a run with a multiply instead of zero + fma was 6 % SLOWER.)
 template <int C>
-LP_DEV void scatter_plane(float* gg, const LpGrid& g, int b, float x, float y, float z, bool live, int lane,
-                          const float* dxT, float* wT, int dbg) {
+LP_DEV void scatter_plane_ax(float* gg, int base, int U, AxisTap u, AxisTap v, bool live, int lane, const float* dxT,
+                             float* wT, int dbg) {
   constexpr int CPL = C / 16;
   const int h = lane >> 5, r = lane & 31, sub = lane & 15, grp = lane >> 4;
-  const bool xy = g.D == 1, xz = g.H == 1;
-  const float cu = (xy || xz) ? x : y;
-  const float cv = xy ? y : z;
-  const int U = (xy || xz) ? g.W : g.H;
-  const int V = xy ? g.H : g.D;
-  int iu, iv;
-  float wu[2], wv[2];
-  bool oku[2], okv[2];
-  axis_taps<false>(cu, U, iu, wu, oku);
-  axis_taps<false>(cv, V, iv, wv, okv);
+  int iu = u.i0, iv = v.i0;
+  float wu[2] = {u.w[0], u.w[1]}, wv[2] = {v.w[0], v.w[1]};
+  const bool oku[2] = {u.ok[0], u.ok[1]}, okv[2] = {v.ok[0], v.ok[1]};
   const bool dead = !live || !(oku[0] || oku[1]) || !(okv[0] || okv[1]);
   if (oku[0] && !oku[1]) { iu -= 1; wu[1] = wu[0]; wu[0] = 0.0f; }
   else if (!oku[0] && oku[1]) { iu += 1; wu[0] = wu[1]; wu[1] = 0.0f; }
   if (okv[0] && !okv[1]) { iv -= 1; wv[1] = wv[0]; wv[0] = 0.0f; }
   else if (!okv[0] && okv[1]) { iv += 1; wv[0] = wv[1]; wv[1] = 0.0f; }
-  const int row0 = dead ? -1 : (int)g.row_offset + b * (U * V) + iv * U + iu;
+  const int row0 = dead ? -1 : base + iv * U + iu;
   // weights -> wT[slot][ray]; the two lanes of a ray write two slots each (slot k = u-bit + 2 v-bit)
   wT[(2 * h) * 32 + r] = dead ? 0.0f : wu[0] * wv[h];
   wT[(2 * h + 1) * 32 + r] = dead ? 0.0f : wu[1] * wv[h];
@@ -566,6 +557,22 @@ LP_DEV void scatter_plane(float* gg, const LpGrid& g, int b, float x, float y, f
     __builtin_amdgcn_sched_barrier(0);
   }
   flush(s_row);
+}
+
+// one plane (orientation decided at run time).  Sharing the axis computations of a canonical triplane between the
+// three planes here as well means three inlined copies of the walk instead of a loop: measured 2.5 % slower.
+template <int C>
+LP_DEV void scatter_plane(float* gg, const LpGrid& g, int b, float x, float y, float z, bool live, int lane,
+                          const float* dxT, float* wT, int dbg) {
+  const bool xy = g.D == 1, xz = g.H == 1;
+  const float cu = (xy || xz) ? x : y;
+  const float cv = xy ? y : z;
+  const int U = (xy || xz) ? g.W : g.H;
+  const int V = xy ? g.H : g.D;
+  AxisTap u, v;
+  axis_taps<false>(cu, U, u.i0, u.w, u.ok);
+  axis_taps<false>(cv, V, v.i0, v.w, v.ok);
+  scatter_plane_ax<C>(gg, (int)g.row_offset + b * (U * V), U, u, v, live, lane, dxT, wT, dbg);
 }
 
 // COLS = false: always the per-slot walk (the MLP-Splatter backward, with a coarse input grid and a large register
@@ -661,6 +668,15 @@ LP_DEV void scatter_grid(float* gg, const LpGrid& g, int b, float x, float y, fl
     }
     flush_run<C>(gg, s_row, s_ok, koff, kbit, sub, run, dbg);
   }
+}
+
+// host: the grid-list is a canonical triplane (see triplane_taps in lp_device.h)
+inline bool is_canonical_triplane(const LpGridList& gl) {
+  if (gl.n_grids != 3) return false;
+  const LpGrid &xy = gl.grids[0], &xz = gl.grids[1], &yz = gl.grids[2];
+  if (xy.D != 1 || xz.H != 1 || yz.W != 1) return false;
+  if (xy.H < 2 || xy.W < 2 || xz.D < 2 || xz.W < 2 || yz.D < 2 || yz.H < 2) return false;
+  return xy.W == xz.W && xy.H == yz.H && xz.D == yz.D && xy.B == xz.B && xy.B == yz.B;
 }
 
 // second-generation backward (lp_renderer_mfma_bwd.hip); gm = GM_* grid-list shape

@@ -289,8 +289,7 @@ static int grid_mode(const LpRendererArgs& a) {
   static const bool force_generic = getenv("LP_MFMA_GENERIC_GRIDS") != nullptr;  // debugging aid
   if (force_generic) return GM_GENERIC;
   if (a.grid.n_grids == 1 && is_voxel(a.grid.grids[0])) return GM_VOXEL;
-  if (a.grid.n_grids == 3 && !is_voxel(a.grid.grids[0]) && !is_voxel(a.grid.grids[1]) && !is_voxel(a.grid.grids[2]))
-    return GM_TRIPLANE;
+  if (is_canonical_triplane(a.grid)) return GM_TRIPLANE;
   return GM_GENERIC;
 }
 

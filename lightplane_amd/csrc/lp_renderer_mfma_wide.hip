@@ -732,8 +732,7 @@ static MfmaParams make_params_w(const LpRendererArgs& a, int H) {
 static int grid_mode_w(const LpRendererArgs& a) {
   auto is_voxel = [](const LpGrid& g) { return g.D > 1 && g.H > 1 && g.W > 1; };
   if (a.grid.n_grids == 1 && is_voxel(a.grid.grids[0])) return GM_VOXEL;
-  if (a.grid.n_grids == 3 && !is_voxel(a.grid.grids[0]) && !is_voxel(a.grid.grids[1]) && !is_voxel(a.grid.grids[2]))
-    return GM_TRIPLANE;
+  if (is_canonical_triplane(a.grid)) return GM_TRIPLANE;
   return GM_GENERIC;
 }
 

@@ -431,7 +431,7 @@ bool splatter_mlp_mfma_supported(const LpSplatterArgs& a) {
 static int grid_mode_of(const LpGridList& gl) {
   auto is_voxel = [](const LpGrid& g) { return g.D > 1 && g.H > 1 && g.W > 1; };
   if (gl.n_grids == 1 && is_voxel(gl.grids[0])) return GM_VOXEL;
-  if (gl.n_grids == 3 && !is_voxel(gl.grids[0]) && !is_voxel(gl.grids[1]) && !is_voxel(gl.grids[2])) return GM_TRIPLANE;
+  if (is_canonical_triplane(gl)) return GM_TRIPLANE;
   return GM_GENERIC;
 }
 
