@@ -302,3 +302,19 @@ def test_c_abi_header_is_plain_c(tmp_path):
     assert sizes == [L.lp_abi_sizeof(1), L.lp_abi_sizeof(2), L.lp_abi_sizeof(5), L.lp_abi_sizeof(6)]
     assert sizes == [ctypes.sizeof(_lib.LpGridList), ctypes.sizeof(_lib.LpRays), ctypes.sizeof(_lib.LpRendererArgs),
                      ctypes.sizeof(_lib.LpSplatterArgs)]
+
+
+def test_plain_c_binding_example(tmp_path):
+    """examples/c_abi_example.c binds the library from C99 through the public header alone (dlopen), fills the
+    benchmark decoder's descriptor and gets the MFMA family + clean argument validation back -- no GPU needed."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "c_abi_example"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "examples", "c_abi_example.c"), "-o", str(exe), "-ldl"], check=True)
+    r = subprocess.run([str(exe), _lib.LIB_PATH], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()
+    assert b"kernel family 1" in r.stdout and b"rc = -1" in r.stdout
