@@ -1,23 +1,33 @@
 #!/usr/bin/env python
-"""bench.py -- Mrays/s fwd+bwd of the Lightplane Renderer hot path on MI355X.
+"""bench.py -- Mrays/s fwd+bwd of the Lightplane Renderer / Splatter hot path on MI355X.
 
-Workload (BASELINE.json configs[1], "cfg 2"): 256x256 rays per GPU (pinhole camera looking at the
-[-1,1]^3 cube), triplane 3 x [1, 64(1), 64(1), 64(1), 16], 128 samples/ray, trunk/opacity/colour
-MLPs with 2 layers x 32 hidden, 3 colour channels, 32-wide ray encoding; synthetic N(0,1) grid,
-random-init decoder.  One step = forward + backward (gradients w.r.t. grid, MLP parameters and
-ray encoding), inputs resident in HBM.  With N>1 GPUs every rank renders its own 256x256 camera
-(weak scaling), the grid / parameters are replicated and their gradients are summed with an RCCL
-all-reduce inside the timed step.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg4|1080p_s128|cfg3]
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (renderer backward):
-algorithmic bytes per launch (S*K*C*4 re-gather + S*K*C*4 atomic payload + ray I/O)
-divided by its mean launch time measured with HIP events on the launch stream.  `cpu_baseline` is the
-CPU oracle (oracle/lightplane_oracle.py, the PyTorch restatement of the reference's naive renderer)
-timed on a bounded ray subset of the same workload on the host cores of rank 0.
+Workloads (BASELINE.json `configs`); one step = forward + backward, inputs resident in HBM:
+  cfg2        (default, the headline metric) Renderer, 256x256 rays per GPU (pinhole camera looking at the [-1,1]^3
+              cube), triplane 3 x 64^2 x 16 ch, 128 samples/ray, trunk/opacity/colour MLPs 2 layers x 32 hidden,
+              3 colour channels, 32-wide ray encoding.
+  cfg4        Renderer, ONE 1920x1080 camera per GPU (cameras on a ring, elevation 30 deg, azimuth 45 deg x rank),
+              triplane 3 x 128^2 x 32 ch, 256 samples -- the 8-GPU ray-shard configuration of BASELINE.json.
+  1080p_s128  Renderer, one 1920x1080 camera per GPU on the cfg-2 scene (triplane 64^2 x 16 ch, 128 samples):
+              the batch north_star asks the Mrays/s report for.
+  cfg3        Splatter, 256x256 rays x 32 ch per GPU -> voxel grid 128^3 x 32 ch, 256 samples.
+With N > 1 GPUs (one process per GPU, RCCL) every rank works on its own camera (weak scaling), the grid / parameters
+are replicated and the Renderer's grid + MLP gradients (the Splatter's un-normalised output + weight grid) are summed
+with an all-reduce INSIDE the timed step.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the workload (Renderer: the backward
+kernel; Splatter: the forward walk): SURVEY.md 8(d)'s algorithmic bytes per launch divided by that kernel's mean
+launch time, measured with HIP events on the launch stream (torch's current stream is the stream the C ABI launches on).
+At N = 1 with the default workload the line also carries `extras`: the other configurations measured the same way
+(short runs), so that every number quoted in DESIGN.md / README.md can be recomputed from the driver's BENCH file, and
+`cpu_baseline`: the CPU oracle (oracle/lightplane_oracle.py, the PyTorch restatement of the reference's naive path)
+timed on the host cores of rank 0, on BASELINE configs[0] (cfg 1) and on a ray subsample of the benchmarked workload.
 """
 import argparse
-import ctypes
+import glob
 import json
+import math
 import os
 import sys
 import time
@@ -29,96 +39,300 @@ sys.path.insert(0, REPO)
 
 import lightplane_amd as lp  # noqa: E402
 from lightplane_amd import _lib, parallel  # noqa: E402
-from lightplane_amd import renderer as R  # noqa: E402
 
-H = W = 256
-S = 128
-C = 16
-GRID = 64
-HIDDEN = 32
-COLOR = 3
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+FP32_PEAK = 157.3e12    # fp32 vector = fp32 MFMA peak
 
 
-def make_workload(rank: int, dev):
-    from tests.synth import grid_sizes_for, pinhole_rays, random_decoder, random_grids
+# ----------------------------------------------------------------------------------------------------------------
+# workloads
+# ----------------------------------------------------------------------------------------------------------------
 
-    gen = torch.Generator().manual_seed(0)
-    sizes = grid_sizes_for((1, GRID, GRID, GRID, C), True)
-    grids = random_grids(gen, sizes)
-    dec = random_decoder(gen, 2, 2, 2, C, HIDDEN, COLOR, std=0.15)
-    gen_r = torch.Generator().manual_seed(100 + rank)
-    rays = pinhole_rays(H, W, enc_dim=HIDDEN, gen=gen_r, azimuth_deg=45.0 * rank, elevation_deg=0.0 if rank == 0 else 30.0)
-    up = (torch.randn(H * W, generator=gen_r), torch.randn(H * W, generator=gen_r), torch.randn(H * W, COLOR, generator=gen_r))
-    return rays, grids, dec, sizes, up
-
-
-def algorithmic_bytes(n_rays):
-    k = 12  # triplane: 3 planes x 4 corners
-    per_sample = k * C * 4
-    fwd = n_rays * (S * per_sample + 184)
-    bwd = n_rays * (S * per_sample * 2 + 316)
-    return fwd, bwd
+RENDER_CFGS = {
+    #              H     W     S    C   grid  description
+    "cfg2": (256, 256, 128, 16, 64, "cfg2: Renderer fwd+bwd, 256x256 rays/GPU, triplane 64^2x16ch, 128 samples, "
+                                    "2-layer/32-hidden trunk/opacity/color MLP, 3 colour ch, 32-ch ray encoding"),
+    "cfg4": (1080, 1920, 256, 32, 128, "cfg4 shard: Renderer fwd+bwd, 1920x1080 rays/GPU, triplane 128^2x32ch, 256 samples, "
+                                       "2-layer/32-hidden MLPs, 3 colour ch, grid replicated + grad all-reduce"),
+    "1080p_s128": (1080, 1920, 128, 16, 64, "1080p_s128: Renderer fwd+bwd, 1920x1080 rays/GPU, triplane 64^2x16ch, "
+                                            "128 samples, 2-layer/32-hidden MLPs, 3 colour ch"),
+}
+HIDDEN, COLOR = 32, 3
 
 
-def pmc_traffic():
-    """HBM bytes per backward launch from the committed rocprofv3 PMC passes (profiles/r*_pmc_summary.json:
-    (FETCH_SIZE + WRITE_SIZE) * 1024, separate --pmc runs of this same command), or None."""
-    import glob
+def camera_pose(name, rank):
+    if name == "cfg2":  # rank 0: the axis-aligned view of round 1's headline; other ranks from the ring
+        return 45.0 * rank, (0.0 if rank == 0 else 30.0)
+    return 45.0 * rank, 30.0  # 8 cameras on a ring, elevation 30 deg
 
+
+class RendererWorkload:
+    def __init__(self, name, rank, dev, pg, kernel):
+        from tests.synth import grid_sizes_for, pinhole_rays, random_decoder, random_grids
+
+        self.name, self.pg, self.kernel = name, pg, kernel
+        H, W, S, C, G, self.desc = RENDER_CFGS[name]
+        self.S, self.C = S, C
+        gen = torch.Generator().manual_seed(0)
+        self.sizes = grid_sizes_for((1, G, G, G, C), True)
+        self.grids_c = random_grids(gen, self.sizes)
+        self.dec_c = random_decoder(gen, 2, 2, 2, C, HIDDEN, COLOR, std=0.15)
+        gen_r = torch.Generator().manual_seed(100 + rank)
+        az, el = camera_pose(name, rank)
+        self.rays_c = pinhole_rays(H, W, enc_dim=HIDDEN, gen=gen_r, azimuth_deg=az, elevation_deg=el)
+        n = H * W
+        up = (torch.randn(n, generator=gen_r), torch.randn(n, generator=gen_r), torch.randn(n, COLOR, generator=gen_r))
+        self.n_rays = n
+        self.rays = self.rays_c.to(dev)
+        self.flat, _ = lp.flatten_grid([g.to(dev) for g in self.grids_c])
+        self.flat.requires_grad_(True)
+        self.params = self.dec_c.mlp_params.to(dev).requires_grad_(True)
+        self.rays.encoding.requires_grad_(True)
+        self.dec = lp.DecoderParams(self.params, self.dec_c.n_hidden_trunk, self.dec_c.n_hidden_opacity,
+                                    self.dec_c.n_hidden_color, COLOR)
+        self.up = [u.to(dev) for u in up]
+
+    # bytes/ray = S*K*C*4 gathered (fwd) ; the same re-gathered + the same as atomic payload (bwd) ; + ray I/O
+    def algorithmic_bytes(self):
+        per_sample = 12 * self.C * 4  # triplane: 3 planes x 4 corners
+        return self.n_rays * (self.S * per_sample + 184), self.n_rays * (self.S * per_sample * 2 + 316)
+
+    def mlp_flops_fwdbwd(self):
+        mac = self.C * HIDDEN + HIDDEN * HIDDEN + HIDDEN * HIDDEN + HIDDEN + HIDDEN * HIDDEN + HIDDEN * COLOR
+        return 2 * mac * self.S * 4 * self.n_rays  # forward + (recompute + dX + dW)
+
+    def zero_grads(self):
+        self.flat.grad = self.params.grad = self.rays.encoding.grad = None
+
+    def forward(self, replicated=True):
+        g, p = (self.flat, self.params)
+        if replicated:
+            g, p = parallel.replicate_with_grad_allreduce([self.flat, self.params], self.pg)
+        d = lp.DecoderParams(p, self.dec.n_hidden_trunk, self.dec.n_hidden_opacity, self.dec.n_hidden_color, COLOR)
+        return lp.lightplane_renderer(self.rays, g, d, num_samples=self.S, gain=1.0, grid_sizes=self.sizes, kernel=self.kernel)
+
+    def loss(self, out):
+        return (out[0] * self.up[0]).sum() + (out[1] * self.up[1]).sum() + (out[2] * self.up[2]).sum()
+
+    def step(self):
+        self.zero_grads()
+        self.loss(self.forward()).backward()
+
+    roofline_kernel = "renderer backward"
+
+    def roofline(self, fwd_ms, bwd_ms):
+        fwd_b, bwd_b = self.algorithmic_bytes()
+        ach = bwd_b / (bwd_ms * 1e-3) / 1e9
+        both = (fwd_b + bwd_b) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": self.roofline_kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": bwd_b,
+                "frac_fwd_plus_bwd": round(both / HBM_PEAK_GBS, 5)}
+
+
+class SplatterWorkload:
+    """cfg 3: 256x256 rays x 32 ch -> voxel 128^3 x 32 ch, S = 256 (atomic scatter-add path)."""
+
+    name = "cfg3"
+    desc = "cfg3: Splatter fwd+bwd, 256x256 rays/GPU x 32ch encoding -> 128^3x32ch voxel grid, 256 samples"
+    roofline_kernel = "splatter forward walk"
+
+    def __init__(self, rank, dev, pg):
+        from tests.synth import pinhole_rays
+
+        self.pg, self.S, self.C, self.G = pg, 256, 32, 128
+        gen = torch.Generator().manual_seed(100 + rank)
+        az, el = camera_pose("cfg2", rank)
+        self.rays_c = pinhole_rays(256, 256, gen=gen, azimuth_deg=az, elevation_deg=el)
+        self.rays_c.encoding = torch.rand(self.rays_c.n_rays, self.C, generator=gen)
+        self.rays = self.rays_c.to(dev)
+        self.rays.encoding.requires_grad_(True)
+        self.n_rays = self.rays.n_rays
+        self.sizes = [[1, self.G, self.G, self.G, self.C]]
+        self.up = torch.randn(self.G ** 3, self.C, generator=gen).to(dev)
+
+    # SURVEY.md 8(d): S*(K*C*4 + K*4) atomics forward, S*K*C*4 gathered backward (K = 8 corners)
+    def algorithmic_bytes(self):
+        return self.n_rays * self.S * (8 * self.C * 4 + 8 * 4), self.n_rays * self.S * 8 * self.C * 4
+
+    def zero_grads(self):
+        self.rays.encoding.grad = None
+
+    def forward(self, replicated=True):
+        return lp.lightplane_splatter(self.rays, self.sizes, num_samples=self.S, return_list=False,
+                                      process_group=self.pg if replicated else None)
+
+    def loss(self, out):
+        return (out * self.up).sum()
+
+    def step(self):
+        self.zero_grads()
+        self.loss(self.forward()).backward()
+
+    def roofline(self, fwd_ms, bwd_ms):
+        fwd_b, bwd_b = self.algorithmic_bytes()
+        ach = fwd_b / (fwd_ms * 1e-3) / 1e9
+        both = (fwd_b + bwd_b) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": self.roofline_kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": fwd_b,
+                "frac_fwd_plus_bwd": round(both / HBM_PEAK_GBS, 5),
+                "note": "fwd = splat walk + normalise + torch zero-fill of the 268 MB grid; SURVEY 8(d)'s 532 936 B/ray"}
+
+
+def make_workload(name, rank, dev, pg, kernel):
+    if name == "cfg3":
+        return SplatterWorkload(rank, dev, pg)
+    return RendererWorkload(name, rank, dev, pg, kernel)
+
+
+def event_times(wl, reps):
+    """Mean forward / backward time of the op itself (no collective): HIP events on the launch stream, the host runs
+    ahead of the GPU so the events bracket the kernels back to back (the first two iterations fill the queue)."""
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps + 2)]
+    for ev in evs:
+        wl.zero_grads()
+        ev[0].record()
+        out = wl.forward(replicated=False)
+        ev[1].record()
+        loss = wl.loss(out)
+        ev[2].record()
+        loss.backward()
+        ev[3].record()
+    torch.cuda.synchronize()
+    fwd_ms = sum(ev[0].elapsed_time(ev[1]) for ev in evs[2:]) / reps
+    bwd_ms = sum(ev[2].elapsed_time(ev[3]) for ev in evs[2:]) / reps
+    return fwd_ms, bwd_ms
+
+
+def pmc_traffic(kernel_substr):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r*_pmc_summary.json:
+    (FETCH_SIZE + WRITE_SIZE) * 1024 from separate --pmc runs of this command).  Not measured in this run."""
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_summary.json")))
-    if not files:
-        return None
-    try:
-        d = json.load(open(files[-1]))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
         for k, v in d.items():
-            if "renderer_bwd_mfma" in k and "hbm_bytes_per_launch" in v:
-                return int(v["hbm_bytes_per_launch"])
-    except Exception:
-        return None
-    return None
+            if kernel_substr in k and "hbm_bytes_per_launch" in v:
+                return int(v["hbm_bytes_per_launch"]), os.path.relpath(f, REPO)
+    return None, None
 
 
-def cpu_baseline(rays, grids, dec, n_sub=1024):
-    """Oracle (kind 'port': our PyTorch restatement of the reference's naive path) fwd+bwd on CPU."""
-    import copy
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle = 'port' of the reference's naive path; test infrastructure, never the product)
+# ----------------------------------------------------------------------------------------------------------------
 
-    from oracle import lightplane_oracle as O
 
-    idx = torch.arange(0, rays.n_rays, rays.n_rays // n_sub)[:n_sub]
-    r = rays[idx]
-    torch.set_num_threads(min(16, os.cpu_count() or 1))  # more threads only thrash on this tiny problem
-
-    def one():
-        rr = copy.copy(r)
-        rr.encoding = r.encoding.clone().requires_grad_(True)
-        d = copy.copy(dec)
-        d.mlp_params = dec.mlp_params.clone().requires_grad_(True)
-        gs = [g.clone().requires_grad_(True) for g in grids]
-        out = O.lightplane_renderer_naive(rr, gs, d, num_samples=S, gain=1.0)
-        (out[0].sum() + out[1].sum() + out[2].sum()).backward()
-
+def _time_cpu(one, budget_s, max_reps=50):
     one()
     t0 = time.perf_counter()
     reps = 0
-    while reps < 3 or (time.perf_counter() - t0 < 10.0 and reps < 50):
+    while reps < 3 or (time.perf_counter() - t0 < budget_s and reps < max_reps):
         one()
         reps += 1
-    dt = (time.perf_counter() - t0) / reps
-    return {"value": round(n_sub / dt / 1e6, 6), "unit": "Mrays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_sub} rays (every {rays.n_rays // n_sub}-th) of the same workload, fwd+bwd, {reps} reps, "
-                      f"oracle/lightplane_oracle.py on CPU"}
+    return (time.perf_counter() - t0) / reps, reps
+
+
+def cpu_baseline(wl):
+    import copy
+
+    from oracle import lightplane_oracle as O
+    from tests.synth import random_decoder, random_grids, random_rays
+
+    torch.set_num_threads(min(16, os.cpu_count() or 1))  # more threads only thrash on problems this small
+    cores = torch.get_num_threads()
+    res = {"unit": "Mrays/s", "cores": cores, "kind": "port"}
+
+    # BASELINE configs[0] ("cfg 1"): 1k random rays, 32^3 x 16 voxel grid, 64 samples, 2/2/2 x 32 decoder
+    gen = torch.Generator().manual_seed(0)
+    grids1 = random_grids(gen, [[1, 32, 32, 32, 16]])
+    dec1 = random_decoder(gen, 2, 2, 2, 16, 32, 3, std=0.15)
+    rays1 = random_rays(gen, 1000, 1, 32)
+    rays1.near = torch.full((1000,), 0.1)
+    rays1.far = torch.full((1000,), 3.0)
+
+    def one_cfg1():
+        rr = copy.copy(rays1)
+        rr.encoding = rays1.encoding.clone().requires_grad_(True)
+        d = copy.copy(dec1)
+        d.mlp_params = dec1.mlp_params.clone().requires_grad_(True)
+        gs = [g.clone().requires_grad_(True) for g in grids1]
+        out = O.lightplane_renderer_naive(rr, gs, d, num_samples=64, gain=1.0)
+        (out[0].sum() + out[1].sum() + out[2].sum()).backward()
+
+    dt, reps = _time_cpu(one_cfg1, 6.0)
+    res["cfg1"] = {"value": round(1000 / dt / 1e6, 6), "sample": f"BASELINE configs[0] exactly: 1000 random rays, 32^3x16 voxel, "
+                   f"64 samples, 2/2/2x32 MLPs, fwd+bwd, {reps} reps"}
+
+    n_sub = 1024
+    if isinstance(wl, RendererWorkload):
+        idx = torch.arange(0, wl.n_rays, wl.n_rays // n_sub)[:n_sub]
+        r = wl.rays_c[idx]
+
+        def one():
+            rr = copy.copy(r)
+            rr.encoding = r.encoding.clone().requires_grad_(True)
+            d = copy.copy(wl.dec_c)
+            d.mlp_params = wl.dec_c.mlp_params.clone().requires_grad_(True)
+            gs = [g.clone().requires_grad_(True) for g in wl.grids_c]
+            out = O.lightplane_renderer_naive(rr, gs, d, num_samples=wl.S, gain=1.0)
+            (out[0].sum() + out[1].sum() + out[2].sum()).backward()
+    else:
+        idx = torch.arange(0, wl.n_rays, wl.n_rays // n_sub)[:n_sub]
+        r = wl.rays_c[idx]
+
+        def one():
+            rr = copy.copy(r)
+            rr.encoding = r.encoding.clone().requires_grad_(True)
+            out = O.lightplane_splatter_naive(rr, wl.sizes, num_samples=wl.S)
+            out[0].sum().backward()
+
+    dt, reps = _time_cpu(one, 10.0)
+    res["value"] = round(n_sub / dt / 1e6, 6)
+    res["sample"] = (f"{wl.name}-subsample: {n_sub} rays (every {wl.n_rays // n_sub}-th) of the benchmarked workload, fwd+bwd, "
+                     f"{reps} reps, oracle/lightplane_oracle.py on CPU")
+    return res
+
+
+# ----------------------------------------------------------------------------------------------------------------
+
+
+def measure_extra(name, dev, kernel, reps):
+    """Short single-GPU measurement of another configuration (events only) for the `extras` block."""
+    wl = make_workload(name, 0, dev, None, kernel)
+    for _ in range(2):
+        wl.step()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats(dev)
+    mem0 = torch.cuda.memory_allocated(dev)
+    fwd_ms, bwd_ms = event_times(wl, reps)
+    peak_mb = (torch.cuda.max_memory_allocated(dev) - mem0) / 2**20
+    out = {"workload": wl.desc, "rays": wl.n_rays, "fwd_ms": round(fwd_ms, 4), "bwd_ms": round(bwd_ms, 4),
+           "Mrays_per_s_fwd_bwd": round(wl.n_rays / (fwd_ms + bwd_ms) / 1e3, 4), "reps": reps,
+           "peak_bwd_mem_mb": round(peak_mb, 2), "roofline": wl.roofline(fwd_ms, bwd_ms)}
+    if isinstance(wl, RendererWorkload):
+        out["mlp_fp32_frac_of_peak"] = round(wl.mlp_flops_fwdbwd() / ((fwd_ms + bwd_ms) * 1e-3) / FP32_PEAK, 5)
+    del wl
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: >= 0.5 s of work: 200 for cfg2 / cfg3, "
+                                                            "10 for the 1080p workloads)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "1080p_s128", "cfg3"])
     ap.add_argument("--kernel", type=int, default=_lib.LP_KERNEL_AUTO)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short runs of the other configurations (N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the "
                                                        "multi-rank code path with several ranks on one GPU)")
     args = ap.parse_args()
+    big = args.workload in ("cfg4", "1080p_s128")
+    steps = args.steps if args.steps is not None else (10 if big else 200)
+    warmup = args.warmup if args.warmup is not None else (2 if big else 10)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -139,38 +353,21 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     lp.config.check_inputs = False  # the grid_idx range check is a host sync, not part of the op
-    rays_c, grids_c, dec_c, sizes, up_c = make_workload(rank, dev)
-    rays = rays_c.to(dev)
-    flat, _ = lp.flatten_grid([g.to(dev) for g in grids_c])
-    flat.requires_grad_(True)
-    params = dec_c.mlp_params.to(dev).requires_grad_(True)
-    rays.encoding.requires_grad_(True)
-    dec = lp.DecoderParams(params, dec_c.n_hidden_trunk, dec_c.n_hidden_opacity, dec_c.n_hidden_color, COLOR)
-    up = [u.to(dev) for u in up_c]
-    n_rays = rays.n_rays
-
-    def step():
-        flat.grad = params.grad = rays.encoding.grad = None
-        g, p = parallel.replicate_with_grad_allreduce([flat, params], pg)
-        d = lp.DecoderParams(p, dec.n_hidden_trunk, dec.n_hidden_opacity, dec.n_hidden_color, COLOR)
-        out = lp.lightplane_renderer(rays, g, d, num_samples=S, gain=1.0, grid_sizes=sizes, kernel=args.kernel)
-        loss = (out[0] * up[0]).sum() + (out[1] * up[1]).sum() + (out[2] * up[2]).sum()
-        loss.backward()
-        return out
+    wl = make_workload(args.workload, rank, dev, pg, args.kernel)
 
     def sync():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
+    for _ in range(warmup):
+        wl.step()
     sync()
     torch.cuda.reset_peak_memory_stats(dev)
     mem0 = torch.cuda.memory_allocated(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for _ in range(steps):
+        wl.step()
     sync()
     dt = time.perf_counter() - t0
     peak_mb = (torch.cuda.max_memory_allocated(dev) - mem0) / 2**20
@@ -178,53 +375,42 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    ms_per_step = dt / args.steps * 1e3
-    value = n_rays * world / (ms_per_step * 1e-3) / 1e6
+    ms_per_step = dt / steps * 1e3
+    value = wl.n_rays * world / (ms_per_step * 1e-3) / 1e6
 
-    # --- per-kernel timing with HIP events on the launch stream (forward / backward separately) ---
-    with torch.no_grad():
-        out = lp.lightplane_renderer(rays, flat.detach(), dec, num_samples=S, gain=1.0, grid_sizes=sizes, kernel=args.kernel)
-    cfg_args = dict(num_samples=S, gain=1.0, grid_sizes=sizes, kernel=args.kernel)
-    # No host sync inside the loop: the host runs ahead of the GPU, so the events bracket the kernels back to back
-    # on the stream instead of the host's launch latency after an idle GPU.
-    reps = max(5, min(args.steps, 20))
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps + 2)]
-    for ev in evs:
-        flat.grad = params.grad = rays.encoding.grad = None
-        ev[0].record()
-        o = lp.lightplane_renderer(rays, flat, dec, **cfg_args)
-        ev[1].record()
-        loss = (o[0] * up[0]).sum() + (o[1] * up[1]).sum() + (o[2] * up[2]).sum()
-        ev[2].record()
-        loss.backward()
-        ev[3].record()
-    torch.cuda.synchronize(dev)
-    fwd_ms = sum(ev[0].elapsed_time(ev[1]) for ev in evs[2:]) / reps  # the first two iterations fill the queue
-    bwd_ms = sum(ev[2].elapsed_time(ev[3]) for ev in evs[2:]) / reps
-    fwd_b, bwd_b = algorithmic_bytes(n_rays)
-    achieved = bwd_b / (bwd_ms * 1e-3) / 1e9
-    mlp_mac = C * HIDDEN + HIDDEN * HIDDEN + HIDDEN * HIDDEN + HIDDEN + HIDDEN * HIDDEN + HIDDEN * COLOR
-    flops_fwdbwd = 2 * mlp_mac * S * 4 * n_rays
+    fwd_ms, bwd_ms = event_times(wl, max(5, min(steps, 20)))
 
     if rank == 0:
+        roof = wl.roofline(fwd_ms, bwd_ms)
+        traffic, src = pmc_traffic("renderer_bwd_mfma" if isinstance(wl, RendererWorkload) else "splat_fwd_walk")
+        roof["traffic"] = traffic if args.workload == "cfg2" else None
+        roof["traffic_source"] = (f"{src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, NOT measured in "
+                                  f"this run; L2 -> fabric requests, i.e. one 64 B write request per atomic segment") if src else None
+        if isinstance(wl, RendererWorkload) and args.workload in ("cfg2", "1080p_s128"):
+            roof["note"] = "effective bandwidth: the 786 KB grid is L2 resident, compulsory HBM bytes are ~0.5 KB/ray"
         res = {
-            "metric": "Mrays/sec fwd+bwd, 64^3x16ch triplane @128 samples; peak bwd mem (MB)",
-            "value": round(value, 4), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": ("Mrays/sec fwd+bwd, 64^3x16ch triplane @128 samples; peak bwd mem (MB)" if args.workload == "cfg2"
+                       else f"Mrays/sec fwd+bwd ({args.workload}); peak bwd mem (MB)"),
+            "value": round(value, 4), "unit": "Mrays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg2: Renderer fwd+bwd, 256x256 rays/GPU, triplane 64^2x16ch, 128 samples, "
-                                   "2-layer/32-hidden trunk/opacity/color MLP, 3 colour ch, 32-ch ray encoding",
-                       "rays_per_gpu": n_rays, "parallelism": f"ray-shard dp{world}, grid replicated, grad all-reduce"},
+            "config": {"workload": wl.desc, "rays_per_gpu": wl.n_rays,
+                       "parallelism": f"ray-shard dp{world}, grid replicated, "
+                                      + ("un-normalised splat + weights all-reduced" if args.workload == "cfg3" else "grad all-reduce")},
             "peak_bwd_mem_mb": round(peak_mb, 2),
             "fwd_ms": round(fwd_ms, 4), "bwd_ms": round(bwd_ms, 4),
-            "roofline": {"bound": "hbm", "kernel": "renderer backward", "achieved": round(achieved, 2), "peak": 8000.0,
-                         "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": pmc_traffic(),
-                         "algorithmic_bytes_per_launch": bwd_b,
-                         "note": "effective bandwidth: the 786 KB grid is L2 resident, compulsory HBM bytes are ~0.5 KB/ray"},
-            "mlp_fp32_frac_of_peak": round(flops_fwdbwd / ((fwd_ms + bwd_ms) * 1e-3) / 157.3e12, 5),
+            "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N=1 only
-            res["cpu_baseline"] = cpu_baseline(rays_c, grids_c, dec_c)
+        if isinstance(wl, RendererWorkload):
+            res["mlp_fp32_frac_of_peak"] = round(wl.mlp_flops_fwdbwd() / ((fwd_ms + bwd_ms) * 1e-3) / FP32_PEAK, 5)
+        if world == 1 and args.workload == "cfg2" and not args.no_extras:
+            res["extras"] = {
+                "splatter_cfg3": measure_extra("cfg3", dev, args.kernel, 10),
+                "renderer_1080p_s128": measure_extra("1080p_s128", dev, args.kernel, 4),
+                "renderer_cfg4_shard": measure_extra("cfg4", dev, args.kernel, 3),
+            }
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only
+            res["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -169,6 +169,23 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+def check_tensors(device: torch.device, float32: dict, any_dtype: Optional[dict] = None) -> None:
+    """Every tensor whose raw pointer goes to the HIP library has to live on ``device`` (the kernels dereference
+    the pointers on that GPU: a CPU tensor or a tensor of another GPU would be a memory fault, not an exception)
+    and -- for the ``float32`` group -- be fp32 (the kernels reinterpret the bytes).  ``None`` entries are skipped.
+    Raises ``AssertionError`` like the reference's Python-side checks (lightplane_renderer.py:402-468)."""
+    for group, need_f32 in ((float32, True), (any_dtype or {}, False)):
+        for name, t in group.items():
+            if t is None:
+                continue
+            assert torch.is_tensor(t), f"{name} has to be a tensor"
+            assert t.device == device, (
+                f"{name} is on {t.device} but the grid is on {device}: every tensor of a lightplane_amd call has to "
+                f"live on the same GPU (forgot .to(device)?)")
+            if need_f32:
+                assert t.dtype == torch.float32, f"{name} has to be float32 (got {t.dtype})"
+
+
 def current_stream(device: torch.device) -> Optional[int]:
     if device.type != "cuda":
         raise LightplaneHipError(

@@ -45,56 +45,70 @@ def shard_rays(rays, process_group=None):
 
 
 def _big_allreduce_(t: torch.Tensor, process_group) -> None:
-    """reduce-scatter + all-gather on a flat tensor (pads to a multiple of world_size)."""
+    """reduce-scatter + all-gather on a flat tensor, in place and without a padded copy: the part divisible by the
+    world size goes through the two collectives (every rank reduces 1/world of it over all its xGMI links), the
+    remainder (< world elements) through a plain all-reduce."""
     ws = dist.get_world_size(process_group)
+    rank = dist.get_rank(process_group)
     flat = t.view(-1)
     n = flat.numel()
-    per = (n + ws - 1) // ws
+    per = n // ws
+    if per > 0:
+        head = flat[: per * ws]
+        shard = head[rank * per : (rank + 1) * per]  # a view: the reduced shard lands where it belongs
+        dist.reduce_scatter_tensor(shard, head, op=dist.ReduceOp.SUM, group=process_group)
+        dist.all_gather_into_tensor(head, shard, group=process_group)
     if per * ws != n:
-        buf = flat.new_zeros(per * ws)
-        buf[:n] = flat
-    else:
-        buf = flat
-    shard = buf.new_empty(per)
-    dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=process_group)
-    dist.all_gather_into_tensor(buf, shard, group=process_group)
-    if buf.data_ptr() != flat.data_ptr():
-        flat.copy_(buf[:n])
+        dist.all_reduce(flat[per * ws :], op=dist.ReduceOp.SUM, group=process_group)
 
 
-def allreduce_sum_(tensors: Sequence[Optional[torch.Tensor]], process_group=None) -> None:
+def _coalesced_all_reduce_(tensors: List[torch.Tensor], process_group, async_op: bool = False):
+    """One launch for several all-reduces (RCCL group call), no flattening copy.  Falls back to one collective per
+    tensor where the backend has no coalescing (gloo: the CPU test path)."""
+    if len(tensors) == 1:
+        return [dist.all_reduce(tensors[0], op=dist.ReduceOp.SUM, group=process_group, async_op=async_op)]
+    backend = dist.get_backend(process_group)
+    cm = getattr(dist.distributed_c10d, "_coalescing_manager", None)
+    if backend == "nccl" and cm is not None and tensors[0].is_cuda:
+        try:
+            with cm(group=process_group, device=tensors[0].device, async_ops=async_op) as handle:
+                for t in tensors:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group)
+            return [handle] if async_op else [None]
+        except (TypeError, RuntimeError):  # private API moved: keep working, one collective per tensor
+            pass
+    return [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group, async_op=async_op) for t in tensors]
+
+
+def allreduce_sum_(tensors: Sequence[Optional[torch.Tensor]], process_group=None, async_op: bool = False):
     """In-place sum of each tensor over the ranks of ``process_group``.
 
-    Small tensors are coalesced into one bucket (one collective); very large ones go through
-    reduce-scatter + all-gather.  No-op when not distributed.
-    """
+    Tensors up to ``BUCKET_BYTES`` go out together as ONE coalesced collective launch (no flatten / copy-back: the
+    collective works on the tensors where they are); very large ones go through reduce-scatter + all-gather.
+    No-op when not distributed.  With ``async_op`` the coalesced part is returned as a list of work handles to
+    ``wait()`` on (the large tensors are reduced synchronously)."""
     if not is_distributed(process_group):
-        return
+        return []
     tensors = [t for t in tensors if t is not None and t.numel() > 0]
     small: List[torch.Tensor] = []
+    works = []
     for t in tensors:
+        assert t.is_contiguous(), "all-reduce works in place: tensors have to be contiguous"
         nbytes = t.numel() * t.element_size()
-        if nbytes >= RS_AG_BYTES and t.is_contiguous() and _supports_rs(t):
+        if nbytes >= RS_AG_BYTES and _supports_rs(t):
             _big_allreduce_(t, process_group)
         elif nbytes <= BUCKET_BYTES:
             small.append(t)
         else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group)
-    if len(small) == 1:
-        dist.all_reduce(small[0], op=dist.ReduceOp.SUM, group=process_group)
-    elif small:
-        flat = torch.cat([t.reshape(-1) for t in small])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)
-        pos = 0
-        for t in small:
-            n = t.numel()
-            t.copy_(flat[pos : pos + n].view_as(t))
-            pos += n
+            works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group, async_op=async_op))
+    if small:
+        works += _coalesced_all_reduce_(small, process_group, async_op)
+    return [w for w in works if w is not None] if async_op else []
 
 
 def _supports_rs(t: torch.Tensor) -> bool:
     # gloo has no reduce_scatter_tensor; keep the CPU test path on plain all_reduce
-    return t.is_cuda
+    return t.is_cuda and dist.get_backend() == "nccl"
 
 
 class _AllReduceGrad(torch.autograd.Function):
@@ -111,7 +125,12 @@ class _AllReduceGrad(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        grads = [None if g is None else g.contiguous() for g in grads]
+        # never reduce into the buffers autograd handed us (they may be shared with hooks / retain_grad): own copies
+        grads = [None if g is None else g.clone(memory_format=torch.contiguous_format) for g in grads]
+        # Synchronous on the STREAM only (the host does not block).  It cannot be deferred past this node: autograd
+        # accumulates the returned tensors into .grad right away, on this stream.  Overlap with the ray-embedding
+        # backward comes from the node order instead: wrap the replicated tensors BEFORE the module computes the ray
+        # embedding, then the embedding's backward nodes (created later) run before this one.
         allreduce_sum_(grads, ctx.process_group)
         return (None, *grads)
 

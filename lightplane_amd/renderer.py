@@ -184,7 +184,7 @@ class LightplaneFunction(torch.autograd.Function):
         a.grad_ray_length, a.grad_neg_log_t, a.grad_feature = _lib.ptr(g_len), _lib.ptr(g_nlt), _lib.ptr(g_feat)
         grad_grid = torch.zeros_like(grid) if need_grid else None
         grad_params = torch.zeros_like(mlp_params) if need_params else None
-        grad_enc = torch.empty_like(encoding) if need_enc else None
+        grad_enc = torch.zeros_like(encoding) if need_enc else None
         grad_cgrid = torch.zeros_like(color_grid) if (need_cgrid and color_grid is not None) else None
         a.grad_grid, a.grad_mlp_params = _lib.ptr(grad_grid), _lib.ptr(grad_params)
         a.grad_encoding, a.grad_color_grid = _lib.ptr(grad_enc), _lib.ptr(grad_cgrid)
@@ -288,8 +288,13 @@ def lightplane_renderer(
         f"The number of elements in mlp param should be {expected}. Got {mlp_params.numel()} instead.")
     assert rays.encoding is not None, "rays.encoding is required by the functional renderer"
     assert rays.encoding.shape[1] == dims_c[0], "ray_encoding should have the same dimension as dim_in_color"
-    for name, t in (("grid", grid), ("encoding", rays.encoding), ("directions", rays.directions)):
-        assert t.dtype == torch.float32, f"{name} has to be float32"
+    # every raw pointer handed to the kernels: same GPU as the grid, fp32 where the kernels read floats
+    _lib.check_tensors(
+        grid.device,
+        {"grid": grid, "color_grid": color_grid, "decoder_params.mlp_params": mlp_params,
+         "rays.directions": rays.directions, "rays.origins": rays.origins, "rays.near": rays.near,
+         "rays.far": rays.far, "rays.encoding": rays.encoding},
+        {"rays.grid_idx": rays.grid_idx, "scaffold": scaffold})
 
     if inject_noise_sigma > 0.0:
         if inject_noise_seed is None:

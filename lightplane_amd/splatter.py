@@ -9,7 +9,13 @@ normalises in place (``lp_splatter_normalize``) and the backward kernel divides 
 clamped weight while gathering (``lp_splatter_backward``).
 
 Multi-GPU: pass ``process_group`` to sum the UN-normalised feature and weight grids over
-the ray shards (RCCL all-reduce) *before* normalising -- see ``lightplane_amd.parallel``.
+the ray shards (RCCL all-reduce) *before* normalising -- see ``lightplane_amd.parallel``.  The
+output is then a REPLICATED tensor and its incoming gradient has to be the gradient of the total
+(all-rank) loss: if what follows is itself ray-sharded (cfg 5: every rank renders its own rays from
+the splatted grid), wrap the output with ``parallel.replicate_with_grad_allreduce`` so that the
+partial gradients are summed before they reach the Splatter backward.  The MLP-Splatter's
+``grad_mlp_params`` / ``grad_input_grid`` (partial sums over the local rays) are all-reduced in
+its backward.
 """
 from __future__ import annotations
 
@@ -94,7 +100,7 @@ class LightplaneSplatterFunction(torch.autograd.Function):
         dev = feature.device
         stream = _lib.current_stream(dev)
         grad_out = grad_out.contiguous()
-        grad_feature = torch.empty_like(feature)
+        grad_feature = torch.zeros_like(feature)
         a = _fill_args(cfg, directions, origins, grid_idx, near, far, feature)
         a.grad_out, a.weight, a.grad_encoding = _lib.ptr(grad_out), _lib.ptr(weight), _lib.ptr(grad_feature)
         with torch.cuda.device(dev):
@@ -140,7 +146,7 @@ class LightplaneMLPSplatterFunction(torch.autograd.Function):
         dev = feature.device
         stream = _lib.current_stream(dev)
         grad_out = grad_out.contiguous()
-        grad_feature = torch.empty_like(feature) if need_feat else None
+        grad_feature = torch.zeros_like(feature) if need_feat else None
         grad_params = torch.zeros_like(mlp_params) if need_params else None
         grad_in = torch.zeros_like(input_grid) if need_grid else None
         a = _fill_args(cfg, directions, origins, grid_idx, near, far, feature, mlp_params, input_grid)
@@ -149,6 +155,11 @@ class LightplaneMLPSplatterFunction(torch.autograd.Function):
             _lib.ptr(grad_feature), _lib.ptr(grad_params), _lib.ptr(grad_in))
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().lp_splatter_backward(ctypes.byref(a), stream), "lp_splatter_backward")
+        if cfg.process_group is not None:
+            # ray-sharded MLP-Splatter: the MLP / input-grid gradients are partial sums over this rank's rays
+            # (SURVEY.md 8(e)); grad_feature belongs to the local rays and stays local
+            from .parallel import allreduce_sum_
+            allreduce_sum_([grad_params, grad_in], cfg.process_group)
         if config.check_finite_grads:
             for g in (grad_feature, grad_params, grad_in):
                 assert g is None or torch.isfinite(g).all()
@@ -156,6 +167,11 @@ class LightplaneMLPSplatterFunction(torch.autograd.Function):
 
 
 def _prep_rays(rays: Rays, B: int):
+    _lib.check_tensors(
+        rays.encoding.device,
+        {"rays.directions": rays.directions, "rays.origins": rays.origins, "rays.near": rays.near,
+         "rays.far": rays.far, "rays.encoding": rays.encoding},
+        {"rays.grid_idx": rays.grid_idx})
     grid_idx = rays.grid_idx.to(torch.int32).contiguous()
     if config.check_inputs and grid_idx.numel() > 0:
         lo, hi = torch.aminmax(grid_idx)
@@ -255,6 +271,7 @@ def lightplane_mlp_splatter(
     from .params import mlp_numel
     assert flat_params.numel() == mlp_numel(dims), (
         f"The number of elements in mlp param should be {mlp_numel(dims)}. Got {flat_params.numel()} instead.")
+    _lib.check_tensors(rays.encoding.device, {"input_grid": input_grid, "mlp_params.mlp_params": flat_params})
     cfg = _SplatterCfg(descs, channels, n_rows, int(num_samples), int(num_samples_inf),
                        bool(mask_out_of_bounds_samples), bool(contract_coords), float(disparity_at_inf),
                        process_group, in_descs, in_channels, in_n_rows, dims, int(kernel))

@@ -106,6 +106,25 @@ def pinhole_rays(height, width, cam_dist=2.7, enc_dim=None, gen=None, grid_idx=0
                 near=near, far=far, encoding=enc)
 
 
+def cat_rays(parts) -> Rays:
+    """Concatenate ray batches (e.g. two camera images looking at two batch entries)."""
+    kw = {}
+    for f in ("directions", "origins", "grid_idx", "near", "far", "encoding"):
+        vals = [getattr(p, f) for p in parts]
+        kw[f] = None if vals[0] is None else torch.cat(vals, dim=0)
+    return Rays(**kw)
+
+
+def pinhole_crop(height, width, y0, x0, h, w, **kw) -> Rays:
+    """The ``h x w`` block of pixels at ``(y0, x0)`` of a ``height x width`` pinhole image, row-major: rays as
+    dense as in the full image (neighbouring pixels), but few enough for the CPU oracle."""
+    full = pinhole_rays(height, width, **kw)
+    ys = torch.arange(y0, y0 + h)
+    xs = torch.arange(x0, x0 + w)
+    idx = (ys[:, None] * width + xs[None, :]).reshape(-1)
+    return full[idx]
+
+
 @dataclass
 class RendererCase:
     """One seeded Renderer test case (inputs + config)."""

@@ -1,0 +1,401 @@
+"""GPU parity on IMAGE-COHERENT rays (pinhole cameras) and at BASELINE-config scale.
+
+The golden / sweep cases draw <=130 unrelated rays on grids of <=20 cells: consecutive rays almost never share a
+cell there.  The production kernels' most intricate code -- the run-merged gradient scatter of the Renderer backward
+(lp_mfma_common.h scatter_plane_ax / scatter_grid), the voxel column walk with carried columns and the 16-cell weight
+window of the Splatter (lp_splat_walk.h), splat_bwd_walk_kernel -- only does something when CONSECUTIVE rays share or
+neighbour a cell.  These tests render / splat whole pinhole images (row-major pixel order, several rays per cell, dead
+rays inside runs through mask_out_of_bounds_samples) and hold every output and every gradient family to the CPU oracle
+(reference: tests/test_renderer_with_autograd.py:134-268, tests/test_splatter_with_autograd.py:37-279 run the same
+differential on random rays).
+
+Bars: max |err| / max |ref| <= 1e-4 per tensor (north_star) against the fp32 oracle, plus for the Renderer's gradients an
+ELEMENT-WISE bound against the oracle run in fp64 (|err| <= 1e-3 |ref| + 2e-5 max|ref|), so that small entries of a sparse
+gradient cannot hide behind the tensor's largest one.
+"""
+import copy
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import lightplane_amd as lp
+from lightplane_amd import _lib
+from oracle import lightplane_oracle as O
+from tests.synth import (cat_rays, grid_sizes_for, pinhole_crop, pinhole_rays, random_decoder, random_grids,
+                         random_splatter_mlp)
+from tests.test_gpu_parity import (KERNEL_IDS, KERNELS, _assert_close, _dev, _rel_err, run_hip_mlp_splatter,
+                                   run_hip_renderer, run_hip_splatter, run_oracle_renderer)
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def assert_elementwise(name, got, want64, rtol=1e-3, atol_rel=2e-5):
+    got = got.detach().double().cpu()
+    want = want64.detach().double()
+    assert got.shape == want.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(want.shape)}"
+    scale = max(want.abs().max().item(), 1e-30)
+    excess = (got - want).abs() - (rtol * want.abs() + atol_rel * scale)
+    worst = excess.max().item() if excess.numel() else 0.0
+    assert worst <= 0.0, (f"{name}: {int((excess > 0).sum())} of {excess.numel()} entries outside "
+                          f"{rtol} |ref| + {atol_rel} max|ref| (worst excess {worst:.3e}, scale {scale:.3e})")
+    # relative L2 error: many small wrong entries show up here
+    num = (got - want).norm().item()
+    den = max(want.norm().item(), 1e-30)
+    assert num / den <= 1e-4, f"{name}: relative L2 error {num / den:.3e}"
+
+
+def oracle_renderer64(d):
+    rays = copy.copy(d["rays"])
+    for f in ("directions", "origins", "near", "far", "encoding"):
+        setattr(rays, f, getattr(rays, f).to(F64))
+    rays.encoding = rays.encoding.clone().requires_grad_(True)
+    dec = copy.copy(d["decoder"])
+    dec.mlp_params = dec.mlp_params.to(F64).clone().requires_grad_(True)
+    grids = [g.to(F64).clone().requires_grad_(True) for g in d["grids"]]
+    cgrids = None if d["color_grids"] is None else [g.to(F64).clone().requires_grad_(True) for g in d["color_grids"]]
+    scaffold = None if d["scaffold"] is None else d["scaffold"].to(F64)
+    out = O.lightplane_renderer_naive(rays, grids, dec, scaffold=scaffold, color_grid=cgrids, **d["cfg"])
+    g_len, g_nlt, g_feat = (u.to(F64) for u in d["upstream"])
+    ((out[0] * g_len).sum() + (out[1] * g_nlt).sum() + (out[2] * g_feat).sum()).backward()
+    return out, dec.mlp_params.grad, rays.encoding.grad, [g.grad for g in grids], None if cgrids is None else [g.grad for g in cgrids]
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Renderer, coherent rays
+# --------------------------------------------------------------------------------------------------------------
+
+IMAGES = {
+    # name: (height, width, azimuth, elevation)
+    "64x64_axis": (64, 64, 0.0, 0.0),
+    "48x80_az30_el45": (48, 80, 30.0, 45.0),  # 80 is not a multiple of 32: runs straddle image rows inside a wave
+}
+GRIDS = {
+    # name: (base, triplane, extra_voxel, separate colour grid, n_layers, batch)
+    "triplane24_c16": ((1, 24, 24, 24, 16), True, False, False, (2, 2, 2), 1),
+    "voxel20_c32": ((1, 20, 20, 20, 32), False, False, False, (2, 2, 2), 1),
+    "triplane_plus_voxel_c16": ((1, 24, 24, 24, 16), True, True, False, (2, 2, 2), 1),
+    "two_grid_triplane_c16": ((1, 24, 24, 24, 16), True, False, True, (0, 2, 2), 1),
+    "voxel18_c16_b2": ((2, 18, 16, 20, 16), False, False, False, (2, 2, 2), 2),
+}
+
+
+def coherent_renderer_inputs(grid_name, image_name, mask_oob=True, num_samples=24, seed=0, hidden=32, color_chn=3,
+                             scaffold=False):
+    base, tri, extra, sep, n_layers, batch = GRIDS[grid_name]
+    height, width, az, el = IMAGES[image_name]
+    gen = torch.Generator().manual_seed(seed)
+    B, C = base[0], base[-1]
+    sizes = grid_sizes_for(base, tri)
+    if extra:
+        sizes = sizes + [[B, 12, 10, 14, C]]
+    grids = random_grids(gen, sizes)
+    cgrids = random_grids(gen, sizes) if sep else None
+    dec = random_decoder(gen, *n_layers, input_chn=C, hidden_chn=hidden, color_chn=color_chn,
+                         use_separate_color_grid=sep, std=0.2)
+    enc_dim = int(dec.n_hidden_color[0])
+    parts = []
+    for b in range(batch):  # one camera image per batch entry, from different sides
+        parts.append(pinhole_rays(height, width, enc_dim=enc_dim, gen=gen, grid_idx=b, azimuth_deg=az + 70.0 * b,
+                                  elevation_deg=el - 20.0 * b))
+    rays = parts[0] if batch == 1 else cat_rays(parts)
+    n = rays.n_rays
+    sc = None
+    if scaffold:
+        sc = (torch.rand(B, 7, 6, 8, generator=gen) > 0.35).float()
+    cfg = dict(num_samples=num_samples, gain=2.0, num_samples_inf=0, mask_out_of_bounds_samples=mask_oob,
+               contract_coords=False, inject_noise_sigma=0.0, inject_noise_seed=0)
+    up = (torch.randn(n, generator=gen), torch.randn(n, generator=gen), torch.randn(n, color_chn, generator=gen))
+    return dict(rays=rays, grids=grids, color_grids=cgrids, decoder=dec, scaffold=sc, cfg=cfg, sizes=sizes, upstream=up)
+
+
+def check_renderer(d, dev, kernel, tag, **extra):
+    out, gp, ge, gg, gc = run_hip_renderer(d, dev, kernel, **extra)
+    o_out, o_gp, o_ge, o_gg, o_gc = run_oracle_renderer(d)       # the reference's arithmetic (fp32)
+    w_out, w_gp, w_ge, w_gg, w_gc = oracle_renderer64(d)          # fp64: the truth for the element-wise bound
+    for nm, a, b in (("ray_length", out[0], o_out[0]), ("neg_log_t", out[1], o_out[1]), ("feature", out[2], o_out[2]),
+                     ("grad_mlp_params", gp, o_gp), ("grad_encoding", ge, o_ge)):
+        _assert_close(f"{tag}: {nm}", a, b.detach().numpy())
+    for i, (a, b) in enumerate(zip(gg, o_gg)):
+        _assert_close(f"{tag}: grad_grid{i}", a, b.numpy())
+    if gc is not None:
+        for i, (a, b) in enumerate(zip(gc, o_gc)):
+            _assert_close(f"{tag}: grad_color_grid{i}", a, b.numpy())
+    assert_elementwise(f"{tag}: grad_mlp_params", gp, w_gp)
+    assert_elementwise(f"{tag}: grad_encoding", ge, w_ge)
+    for i, (a, b) in enumerate(zip(gg, w_gg)):
+        assert_elementwise(f"{tag}: grad_grid{i}", a, b)
+    if gc is not None:
+        for i, (a, b) in enumerate(zip(gc, w_gc)):
+            assert_elementwise(f"{tag}: grad_color_grid{i}", a, b)
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
+@pytest.mark.parametrize("image", list(IMAGES))
+@pytest.mark.parametrize("grid", list(GRIDS))
+def test_renderer_coherent_image(grid, image, kernel):
+    """Whole pinhole images (several rays per cell, masked samples inside runs): outputs + all gradient families."""
+    d = coherent_renderer_inputs(grid, image)
+    check_renderer(d, _dev(), kernel, f"{grid}/{image}")
+
+
+@pytest.mark.parametrize("grid,kw", [
+    ("triplane24_c16", dict(mask_oob=False)),                       # unmasked: border cells re-expressed in the plane walk
+    ("voxel20_c32", dict(mask_oob=False, color_chn=4)),              # 4 colour channels: NC = 4 instantiations
+    ("triplane24_c16", dict(scaffold=True)),                        # non-PLAIN instantiation, occupancy zeros inside runs
+    ("voxel20_c32", dict(hidden=16, mask_oob=True)),                 # flex family (hidden 16 padded to 32)
+    ("triplane_plus_voxel_c16", dict(hidden=64, mask_oob=True)),     # width-64 family
+], ids=["triplane_nomask", "voxel_nomask_rgba", "triplane_scaffold", "voxel_flex_h16", "mixed_h64"])
+def test_renderer_coherent_variants(grid, kw):
+    d = coherent_renderer_inputs(grid, "48x80_az30_el45", seed=3, **kw)
+    check_renderer(d, _dev(), _lib.LP_KERNEL_AUTO, f"{grid}/{kw}")
+
+
+def test_renderer_coherent_early_termination_exact_when_off():
+    """stop_transmittance = 0 on coherent rays is the exact kernel (non-PLAIN bookkeeping with on-flags)."""
+    d = coherent_renderer_inputs("triplane24_c16", "64x64_axis", seed=5)
+    d["cfg"] = dict(d["cfg"], num_samples_inf=2)  # non-PLAIN instantiation
+    check_renderer(d, _dev(), _lib.LP_KERNEL_AUTO, "triplane/inf2")
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Splatter / MLP-Splatter, coherent rays
+# --------------------------------------------------------------------------------------------------------------
+
+SPLATS = {
+    # name: (out_base, triplane, batch)
+    "voxel24_c32": ((1, 24, 24, 24, 32), False, 1),
+    "triplane32_c16": ((1, 32, 32, 32, 16), True, 1),
+    "voxel20_c32_b2": ((2, 20, 18, 22, 32), False, 2),
+    "voxel24_c16": ((1, 24, 24, 24, 16), False, 1),
+}
+
+
+def coherent_splatter_inputs(name, image_name, mask_oob=True, num_samples=24, seed=0, mlp=None):
+    base, tri, batch = SPLATS[name]
+    height, width, az, el = IMAGES[image_name]
+    gen = torch.Generator().manual_seed(seed)
+    out_sizes = grid_sizes_for(base, tri)
+    C = base[-1]
+    feat_dim = C if mlp is None else mlp["feat_dim"]
+    parts = [pinhole_rays(height, width, grid_idx=b, azimuth_deg=az + 70.0 * b, elevation_deg=el - 20.0 * b)
+             for b in range(batch)]
+    rays = parts[0] if batch == 1 else cat_rays(parts)
+    rays.encoding = torch.rand(rays.n_rays, feat_dim, generator=gen)
+    d = dict(rays=rays, out_sizes=out_sizes, mlp=None, in_grids=None, in_sizes=None,
+             cfg=dict(num_samples=num_samples, num_samples_inf=0, mask_out_of_bounds_samples=mask_oob, contract_coords=False))
+    if mlp is not None:
+        in_sizes = grid_sizes_for((base[0], 10, 12, 14, feat_dim), mlp.get("in_triplane", False))
+        d["in_sizes"] = in_sizes
+        d["in_grids"] = random_grids(gen, in_sizes)
+        d["mlp"] = random_splatter_mlp(gen, mlp.get("n_layers", 2), feat_dim, mlp.get("hidden", 32), C, std=0.2)
+    d["upstream"] = [torch.randn(*s, generator=gen) for s in out_sizes]
+    return d
+
+
+def check_splatter(d, dev, tag):
+    out, ge = run_hip_splatter(d, dev)
+    rays = copy.copy(d["rays"])
+    rays.encoding = rays.encoding.clone().requires_grad_(True)
+    o_out = O.lightplane_splatter_naive(rays, d["out_sizes"], **d["cfg"])
+    sum((o * u).sum() for o, u in zip(o_out, d["upstream"])).backward()
+    for i, o in enumerate(out):
+        _assert_close(f"{tag}: out{i}", o, o_out[i].detach().numpy())
+    _assert_close(f"{tag}: grad_encoding", ge, rays.encoding.grad.numpy())
+    num = (ge.detach().double().cpu() - rays.encoding.grad.double()).norm().item()
+    assert num / max(rays.encoding.grad.double().norm().item(), 1e-30) <= 1e-4, f"{tag}: grad_encoding relative L2"
+
+
+def check_mlp_splatter(d, dev, kernel, tag):
+    out, ge, gp, gin = run_hip_mlp_splatter(d, dev, kernel)
+    rays = copy.copy(d["rays"])
+    rays.encoding = rays.encoding.clone().requires_grad_(True)
+    mlp = copy.copy(d["mlp"])
+    mlp.mlp_params = mlp.mlp_params.clone().requires_grad_(True)
+    in_grids = [g.clone().requires_grad_(True) for g in d["in_grids"]]
+    o_out = O.lightplane_mlp_splatter_naive(rays, d["out_sizes"], mlp, in_grids, **d["cfg"])
+    sum((o * u).sum() for o, u in zip(o_out, d["upstream"])).backward()
+    for i, o in enumerate(out):
+        _assert_close(f"{tag}: out{i}", o, o_out[i].detach().numpy())
+    _assert_close(f"{tag}: grad_encoding", ge, rays.encoding.grad.numpy())
+    _assert_close(f"{tag}: grad_mlp_params", gp, mlp.mlp_params.grad.numpy())
+    for i, g in enumerate(gin):
+        _assert_close(f"{tag}: grad_input_grid{i}", g, in_grids[i].grad.numpy())
+
+
+@pytest.mark.parametrize("image", list(IMAGES))
+@pytest.mark.parametrize("name", list(SPLATS))
+@pytest.mark.parametrize("mask", [True, False], ids=["mask", "nomask"])
+def test_splatter_coherent_image(name, image, mask):
+    """Column walk with carried columns / 16-cell weight windows / per-slot plane walk on pixel-adjacent rays."""
+    d = coherent_splatter_inputs(name, image, mask_oob=mask)
+    check_splatter(d, _dev(), f"{name}/{image}/mask={mask}")
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
+@pytest.mark.parametrize("name,mlp", [
+    ("voxel24_c32", dict(feat_dim=32)),
+    ("triplane32_c16", dict(feat_dim=16, in_triplane=True)),
+    ("voxel20_c32_b2", dict(feat_dim=16)),
+], ids=["voxel_32_32", "triplane_16_16", "voxel_b2_16_32"])
+def test_mlp_splatter_coherent_image(name, mlp, kernel):
+    d = coherent_splatter_inputs(name, "48x80_az30_el45", seed=2, mlp=mlp)
+    check_mlp_splatter(d, _dev(), kernel, f"{name}/mlp")
+
+
+def test_splatter_coherent_32_rays_per_wave():
+    """The same coherent Splatter cases with 32 rays per wave (LP_SPLAT_RPW is read once per process)."""
+    env = dict(os.environ, LP_SPLAT_RPW="32")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_coherent.py"), "-m", "gpu",
+                        "-q", "-x", "-k", "test_splatter_coherent_image or test_mlp_splatter_coherent_image",
+                        "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+
+
+# --------------------------------------------------------------------------------------------------------------
+# BASELINE-config scale
+# --------------------------------------------------------------------------------------------------------------
+
+
+def test_cfg3_scale_splatter_subimage():
+    """BASELINE cfg 3 geometry (256x256 camera, 128^3 x 32 voxel grid, S = 256): the FULL GPU splat of the central 64x64
+    block of pixels (ray density of the full image) against the oracle of the same rays, plus grad_encoding."""
+    gen = torch.Generator().manual_seed(0)
+    rays = pinhole_crop(256, 256, 96, 96, 64, 64)
+    rays.encoding = torch.rand(rays.n_rays, 32, generator=gen)
+    out_sizes = [[1, 128, 128, 128, 32]]
+    d = dict(rays=rays, out_sizes=out_sizes,
+             cfg=dict(num_samples=256, num_samples_inf=0, mask_out_of_bounds_samples=False, contract_coords=False))
+    # upstream gradient only where the splat lands would be the realistic case; a dense one also checks the empty cells
+    d["upstream"] = [torch.randn(*out_sizes[0], generator=gen)]
+    check_splatter(d, _dev(), "cfg3-subimage")
+
+
+def test_cfg4_shape_renderer_block():
+    """BASELINE cfg 4 shape (1920x1080 camera at elevation 30 deg, triplane 128^2 x 32 ch, S = 256 -> 8 checkpoint
+    intervals): a 16 x 32 block of neighbouring pixels vs the oracle, all gradient families."""
+    gen = torch.Generator().manual_seed(1)
+    sizes = grid_sizes_for((1, 128, 128, 128, 32), True)
+    grids = random_grids(gen, sizes)
+    dec = random_decoder(gen, 2, 2, 2, 32, 32, 3, std=0.15)
+    rays = pinhole_crop(1080, 1920, 532, 944, 16, 32, enc_dim=32, gen=gen, azimuth_deg=45.0, elevation_deg=30.0)
+    n = rays.n_rays
+    d = dict(rays=rays, grids=grids, color_grids=None, decoder=dec, scaffold=None, sizes=sizes,
+             cfg=dict(num_samples=256, gain=1.0, num_samples_inf=0, mask_out_of_bounds_samples=False,
+                      contract_coords=False, inject_noise_sigma=0.0, inject_noise_seed=0),
+             upstream=(torch.randn(n, generator=gen), torch.randn(n, generator=gen), torch.randn(n, 3, generator=gen)))
+    for kernel in (_lib.LP_KERNEL_AUTO,):
+        check_renderer(d, _dev(), kernel, "cfg4-block")
+
+
+def _chain_hip(rays_s, rays_r, dec, out_sizes, S, dev):
+    rs = rays_s.to(dev)
+    rs.encoding = rs.encoding.clone().requires_grad_(True)
+    rr = rays_r.to(dev)
+    rr.encoding = rr.encoding.clone().requires_grad_(True)
+    params = dec.mlp_params.to(dev).clone().requires_grad_(True)
+    hdec = lp.DecoderParams(params, dec.n_hidden_trunk, dec.n_hidden_opacity, dec.n_hidden_color, dec.color_chn)
+    grid = lp.lightplane_splatter(rs, out_sizes, num_samples=S)
+    out = lp.lightplane_renderer(rr, grid, hdec, num_samples=S, gain=1.0)
+    return rs, rr, params, grid, out
+
+
+def test_cfg5_chain_splatter_into_renderer():
+    """BASELINE cfg 5 in miniature: several views are splatted into a voxel grid, the normalised grid is rendered from a
+    new view, and the loss back-propagates through the render, the normalisation and the splat into the splatted
+    features.  Oracle: naive_splatter -> naive_renderer chained the same way."""
+    dev = _dev()
+    gen = torch.Generator().manual_seed(2)
+    S = 48
+    out_sizes = [[1, 32, 32, 32, 32]]
+    views = [pinhole_rays(40, 40, azimuth_deg=a, elevation_deg=e) for a, e in ((0.0, 0.0), (120.0, 25.0), (240.0, -30.0))]
+    rays_s = cat_rays(views)
+    rays_s.encoding = torch.rand(rays_s.n_rays, 32, generator=gen)
+    rays_r = pinhole_rays(36, 60, enc_dim=32, gen=gen, azimuth_deg=60.0, elevation_deg=15.0)
+    dec = random_decoder(gen, 2, 2, 2, 32, 32, 3, std=0.2)
+    n = rays_r.n_rays
+    up = (torch.randn(n, generator=gen), torch.randn(n, generator=gen), torch.randn(n, 3, generator=gen))
+
+    rs, rr, params, grid, out = _chain_hip(rays_s, rays_r, dec, out_sizes, S, dev)
+    for g in grid:
+        g.retain_grad()
+    sum((o * u.to(dev)).sum() for o, u in zip(out, up)).backward()
+
+    o_rs = copy.copy(rays_s)
+    o_rs.encoding = rays_s.encoding.clone().requires_grad_(True)
+    o_rr = copy.copy(rays_r)
+    o_rr.encoding = rays_r.encoding.clone().requires_grad_(True)
+    o_dec = copy.copy(dec)
+    o_dec.mlp_params = dec.mlp_params.clone().requires_grad_(True)
+    o_grid = O.lightplane_splatter_naive(o_rs, out_sizes, num_samples=S)
+    for g in o_grid:
+        g.retain_grad()
+    o_out = O.lightplane_renderer_naive(o_rr, o_grid, o_dec, num_samples=S, gain=1.0)
+    sum((o * u).sum() for o, u in zip(o_out, up)).backward()
+
+    _assert_close("chain: splatted grid", grid[0], o_grid[0].detach().numpy())
+    for nm, a, b in zip(("ray_length", "neg_log_t", "feature"), out, o_out):
+        _assert_close(f"chain: {nm}", a, b.detach().numpy())
+    _assert_close("chain: grad_mlp_params", params.grad, o_dec.mlp_params.grad.numpy())
+    _assert_close("chain: grad render encoding", rr.encoding.grad, o_rr.encoding.grad.numpy())
+    _assert_close("chain: grad of the splatted grid", grid[0].grad, o_grid[0].grad.numpy())
+    _assert_close("chain: grad splatted encoding (end to end)", rs.encoding.grad, o_rs.encoding.grad.numpy())
+
+
+_VARIANT_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+from tests.test_gpu_coherent import coherent_renderer_inputs
+from tests.test_gpu_parity import run_hip_renderer
+from lightplane_amd import _lib
+d = coherent_renderer_inputs({grid!r}, "48x80_az30_el45", seed=7, mask_oob={mask})
+out, gp, ge, gg, gc = run_hip_renderer(d, torch.device("cuda:0"), _lib.LP_KERNEL_AUTO)
+np.savez({path!r}, ray_length=out[0].detach().cpu().numpy(), neg_log_t=out[1].detach().cpu().numpy(),
+         feature=out[2].detach().cpu().numpy())
+"""
+
+
+@pytest.mark.parametrize("grid", ["triplane24_c16", "voxel18_c16_b2"])
+@pytest.mark.parametrize("variant", ["0", "3", "4"])
+def test_forward_variants_agree(grid, variant, tmp_path):
+    """Every forward instantiation the launcher can pick for C = 16 (LP_MFMA_FWD_VARIANT: 0 = software-pipelined,
+    3 / 4 = plain kernel at 3 / 4 waves per SIMD; variant 4 is what > 98 304 rays select, i.e. every 1080p batch) gives
+    the oracle's outputs.  The knob is read once per process: child processes."""
+    path = str(tmp_path / f"v{variant}.npz")
+    env = dict(os.environ, LP_MFMA_FWD_VARIANT=variant)
+    code = _VARIANT_CHILD.format(root=ROOT, grid=grid, mask=True, path=path)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    z = np.load(path)
+    d = coherent_renderer_inputs(grid, "48x80_az30_el45", seed=7, mask_oob=True)
+    o_out = O.lightplane_renderer_naive(d["rays"], d["grids"], d["decoder"], **d["cfg"])
+    for nm, o in zip(("ray_length", "neg_log_t", "feature"), o_out):
+        _assert_close(f"variant {variant}: {nm}", torch.from_numpy(z[nm]), o.detach().numpy())
+
+
+def test_1080p_c16_batch_uses_variant4_and_matches_oracle_subsample():
+    """A real 1080p x C = 16 batch (2 073 600 rays > 98 304: the launcher picks renderer_fwd_mfma_np<16, GM, 4>): a block
+    of 24 x 40 neighbouring pixels of the full-size launch equals the oracle of those rays (per-ray outputs do not
+    depend on the batch), S = 32 to keep the launch short."""
+    dev = _dev()
+    gen = torch.Generator().manual_seed(4)
+    sizes = grid_sizes_for((1, 64, 64, 64, 16), True)
+    grids = random_grids(gen, sizes)
+    dec = random_decoder(gen, 2, 2, 2, 16, 32, 3, std=0.15)
+    rays = pinhole_rays(1080, 1920, azimuth_deg=45.0, elevation_deg=30.0)
+    rays.encoding = torch.randn(rays.n_rays, 32, generator=gen)
+    ys, xs = torch.arange(500, 524), torch.arange(900, 940)
+    idx = (ys[:, None] * 1920 + xs[None, :]).reshape(-1)
+    hdec = lp.DecoderParams(dec.mlp_params.to(dev), dec.n_hidden_trunk, dec.n_hidden_opacity, dec.n_hidden_color, 3)
+    with torch.no_grad():
+        out = lp.lightplane_renderer(rays.to(dev), [g.to(dev) for g in grids], hdec, num_samples=32, gain=1.0)
+    o_out = O.lightplane_renderer_naive(rays[idx], grids, dec, num_samples=32, gain=1.0)
+    for nm, a, b in zip(("ray_length", "neg_log_t", "feature"), out, o_out):
+        _assert_close(f"1080p: {nm}", a[idx.to(dev)], b.detach().numpy())
