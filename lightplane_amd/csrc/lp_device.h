@@ -456,6 +456,21 @@ LP_DEV float sample_noise(int64_t ray, int step, int64_t n_rays, int s_tot, int3
 }
 
 // ---------------------------------------------------------------------------------------
+// run heads of the scatter walks
+// ---------------------------------------------------------------------------------------
+// Value of lane - 1 (lane 0: its own).  Cross-lane reads must NOT sit behind a short-circuit (`(r == 0) || x !=
+// __shfl_up(x, 1)`): the compiler turns the `||` into a branch, the shuffle then runs with lane 0 (and every other lane
+// that took the first alternative) disabled, and ds_bpermute returns 0 for a disabled SOURCE lane -- lane 1 compared its
+// row with 0 instead of lane 0's row, so a run starting at row 0 right behind a dead first ray (row -1) was merged into
+// the dead run and never flushed (found by tests/test_gpu_coherent.py, reproduced by scripts/scatter_plane_test.hip).
+// These helpers read first, with all lanes enabled, and combine afterwards.
+LP_DEV int lane_prev(int v) { return __shfl_up(v, 1); }
+LP_DEV bool run_head(int r, int row, int prev_row) { return (r == 0) | (row != prev_row); }
+LP_DEV bool run_head(int r, int row, int prev_row, int ok, int prev_ok) {
+  return (r == 0) | (row != prev_row) | (ok != prev_ok);
+}
+
+// ---------------------------------------------------------------------------------------
 // atomics: hardware fp32 add, result unused (global_atomic_add_f32, no CAS loop)
 // ---------------------------------------------------------------------------------------
 LP_DEV void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }

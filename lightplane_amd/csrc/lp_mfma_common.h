@@ -493,7 +493,8 @@ LP_DEV void scatter_plane_ax(float* gg, int base, int U, AxisTap u, AxisTap v, b
   // weights -> wT[slot][ray]; the two lanes of a ray write two slots each (slot k = u-bit + 2 v-bit)
   wT[(2 * h) * 32 + r] = dead ? 0.0f : wu[0] * wv[h];
   wT[(2 * h + 1) * 32 + r] = dead ? 0.0f : wu[1] * wv[h];
-  const bool head = (r == 0) || row0 != __shfl_up(row0, 1);
+  const int prow = lane_prev(row0);  // all lanes enabled: see run_head()
+  const bool head = run_head(r, row0, prow);
   const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head));
   const int koff = (grp & 1) + (grp >> 1) * U;
   const unsigned lane_off = (unsigned)koff * (unsigned)(C * 4) + (unsigned)(sub * 4);  // bytes inside a 2 x 2 cell
@@ -604,9 +605,9 @@ LP_DEV void scatter_grid(float* gg, const LpGrid& g, int b, float x, float y, fl
   for (int i = 0; i < 4; ++i) wT[(4 * h + i) * 32 + r] = h ? tp.w[4 + i] : tp.w[i];
   const int row0 = tp.row0;
   const int ok = (int)tp.ok;
-  const int prow = __shfl_up(row0, 1);
-  const int pok = __shfl_up(ok, 1);
-  const bool head = (r == 0) || row0 != prow || ok != pok;
+  const int prow = lane_prev(row0);
+  const int pok = lane_prev(ok);
+  const bool head = run_head(r, row0, prow, ok, pok);
   const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head));
   const bool voxel = g.D > 1 && g.H > 1 && g.W > 1;
   const int n_pass = voxel ? 2 : 1;

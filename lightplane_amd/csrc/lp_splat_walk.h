@@ -58,7 +58,8 @@ LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, floa
   }
   const int row0 = tp.row0, iu = tp.iu, cell = tp.cell;
   const int ok = (int)tp.ok;
-  const bool head = (r == 0) || row0 != __shfl_up(row0, 1) || ok != __shfl_up(ok, 1);
+  const int prow_ = lane_prev(row0), pok_ = lane_prev(ok);  // all lanes enabled: see run_head()
+  const bool head = run_head(r, row0, prow_, ok, pok_);
   const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head));
   {
     // merge axis A (wave-uniform): the axis of the first cell change of this walk

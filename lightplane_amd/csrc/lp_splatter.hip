@@ -93,7 +93,8 @@ LP_DEV void splat_walk(float* feat, float* wgt, const LpGrid& g, int b, float x,
   }
   const int row0 = tp.row0;
   const int ok = (int)tp.ok;
-  const bool head = (r == 0) || row0 != __shfl_up(row0, 1) || ok != __shfl_up(ok, 1);
+  const int prow_ = lane_prev(row0), pok_ = lane_prev(ok);  // all lanes enabled: see run_head()
+  const bool head = run_head(r, row0, prow_, ok, pok_);
   const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head));
   const bool voxel = g.D > 1 && g.H > 1 && g.W > 1;
   const int n_pass = voxel ? 2 : 1;
@@ -309,7 +310,8 @@ __global__ void __launch_bounds__(256, B == 4 ? 3 : 2) splat_bwd_walk_kernel(con
       }
       const int row0 = tp.row0;
       const int ok = (int)tp.ok;
-      const bool head = (r == 0) || row0 != __shfl_up(row0, 1) || ok != __shfl_up(ok, 1);
+      const int prow_ = lane_prev(row0), pok_ = lane_prev(ok);  // all lanes enabled: see run_head()
+      const bool head = run_head(r, row0, prow_, ok, pok_);
       const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head)) | (B == 8 ? 0x101u : 0x1111u);
       const int koff = (grp & 1) * tp.sv + (grp >> 1) * tp.st;
       const unsigned bit_lo = 1u << (2 * grp), bit_hi = 2u << (2 * grp);

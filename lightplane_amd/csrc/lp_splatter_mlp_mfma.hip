@@ -87,7 +87,8 @@ LP_DEV void splat_walk_lds(float* feat, float* wgt, const LpGrid& g, int b, floa
   for (int i = 0; i < 4; ++i) wT[(4 * h + i) * 32 + r] = h ? tp.w[4 + i] : tp.w[i];
   const int row0 = tp.row0;
   const int ok = (int)tp.ok;
-  const bool head = (r == 0) || row0 != __shfl_up(row0, 1) || ok != __shfl_up(ok, 1);
+  const int prow_ = lane_prev(row0), pok_ = lane_prev(ok);  // all lanes enabled: see run_head()
+  const bool head = run_head(r, row0, prow_, ok, pok_);
   const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head));
   const bool voxel = g.D > 1 && g.H > 1 && g.W > 1;
   const int n_pass = voxel ? 2 : 1;
