@@ -51,7 +51,8 @@
 extern "C" {
 #endif
 
-#define LP_VERSION 110 /* 0.1.10: stop_neg_log_t, float-pair -log T checkpoints + closing pair */
+#define LP_VERSION 200 /* 0.2.0: per-grid base pointers (zero-copy grid-lists), fused bg-colour / alpha epilogue,
+                           ray-embedding entry points; grad replicas removed */
 
 #define LP_MAX_GRIDS 8   /* grids per grid-list                         */
 #define LP_MAX_LAYERS 8  /* layers per MLP                              */
@@ -79,11 +80,16 @@ extern "C" {
 
 typedef struct LpGrid {
   int32_t B, D, H, W;  /* batch and spatial extent                         */
-  int64_t row_offset;  /* first row of this grid in the flat [rows,C] tensor */
+  int64_t row_offset;  /* first row of this grid in the tensor that holds it */
+  /* Zero-copy grid-lists (reference misc_utils.py:42-45 concatenates a list of grids on every call): a grid may
+   * live in its own allocation.  NULL = the grid lives in LpGridList.data (one flat tensor, increasing
+   * row_offsets); otherwise the [rows, C] tensor holding this grid, whose row `row_offset` (normally 0) is the
+   * grid's first cell.  Gradient buffers mirror this through the *_list fields of the argument structs. */
+  const float* data;
 } LpGrid;
 
 typedef struct LpGridList {
-  const float* data;   /* [rows, channels] fp32 (may be NULL when n_grids == 0) */
+  const float* data;   /* [rows, channels] fp32; may be NULL when n_grids == 0 or every grid carries its own pointer */
   int32_t n_grids;     /* 0 .. LP_MAX_GRIDS                                 */
   int32_t channels;    /* C                                                  */
   int64_t n_rows;      /* total rows (for bounds checks)                     */
@@ -156,12 +162,20 @@ typedef struct LpRendererArgs {
   float* grad_color_grid;  /* like color_grid.data  */
   float* grad_mlp_params;  /* [n_mlp_params]        */
   float* grad_encoding;    /* [N, encoding_dim] (written, not accumulated) */
-  /* optional de-contention workspace: n_grad_replicas extra zero-filled copies of grad_grid
-   * ([n_grad_replicas][rows*C]).  Workgroups spread their atomics over grad_grid and the
-   * replicas (same-row fp32 atomics serialise at ~25 ns each on MI355X; coherent image rays
-   * hammer the same plane rows), lp_renderer_backward then folds the replicas into grad_grid. */
-  float* grad_grid_replicas;
-  int32_t n_grad_replicas; /* 0 = none */
+  /* per-grid gradient buffers for grids that carry their own LpGrid.data pointer: entry g (shaped like the tensor
+   * grids[g].data points to, same row_offset) receives the gradient of grid g; NULL entries fall back to
+   * grad_grid / grad_color_grid. */
+  float* grad_grid_list[LP_MAX_GRIDS];
+  float* grad_color_grid_list[LP_MAX_GRIDS];
+  /* Fused epilogue of the module front-end (reference renderer_module.py:552-561; all optional):
+   *   bg_color != NULL : feature[r, c] += T_r * bg_color[c],  T_r = exp(-neg_log_t[r])
+   *   alpha    != NULL : alpha[r] = 1 - T_r (alpha_mode 1)  or  log T_r = -neg_log_t[r] (alpha_mode 2)
+   * neg_log_t is always written raw (the backward needs it).  The backward takes grad_feature w.r.t. the
+   * composited feature and grad_alpha [N] and folds both into the gradient of -log T. */
+  const float* bg_color;    /* [color_chn] */
+  float* alpha;             /* [N] */
+  const float* grad_alpha;  /* [N] (backward) */
+  int32_t alpha_mode;       /* 0 none, 1 alpha = 1 - T, 2 log transmittance */
   /* early ray termination (extension; the reference always marches every sample): > 0 = a wavefront stops
    * marching once -log T of all its rays has reached this value (their transmittance is below
    * exp(-stop_neg_log_t)); the backward skips the same samples.  ray_length / feature then miss
@@ -192,13 +206,33 @@ typedef struct LpSplatterArgs {
   float* grad_encoding;    /* [N, encoding_dim] (written)                          */
   float* grad_input_grid;  /* like input_grid.data (accumulated; MLP-splatter)     */
   float* grad_mlp_params;  /* [n_mlp_params]      (accumulated; MLP-splatter)      */
+  float* grad_input_grid_list[LP_MAX_GRIDS]; /* per-grid buffers (see LpGrid.data); NULL entries -> grad_input_grid */
 } LpSplatterArgs;
+
+/* Ray-direction embedding of the module front-end, fused into one kernel (reference renderer_module.py:578-601
+ * `_get_ray_embedding`: F.normalize -> harmonic embedding (ray_utils.py:181-212) -> Linear):
+ *   d = directions / max(|directions|, 1e-12)
+ *   emb = [sin(d_c 2^k)]_{c<3,k<n} ++ [sin(d_c 2^k + pi/2)]_{c<3,k<n} ++ d          (3 + 6 n values, index (p*3+c)*n+k)
+ *   out[r, e] = bias[e] + sum_i weight[e, i] emb[i]                                  (torch.nn.Linear layout)
+ * backward: grad_weight / grad_bias accumulate (atomics; caller zero-fills); directions get no gradient. */
+typedef struct LpRayEmbedArgs {
+  int64_t n_rays;
+  const float* directions;  /* [N,3] */
+  int32_t n_harmonics;      /* 0 .. 10 */
+  int32_t out_dim;          /* E <= LP_MAX_WIDTH */
+  const float* weight;      /* [E, 3 + 6 n] */
+  const float* bias;        /* [E] */
+  float* out;               /* [N, E] (forward) */
+  const float* grad_out;    /* [N, E] (backward) */
+  float* grad_weight;       /* [E, 3 + 6 n] */
+  float* grad_bias;         /* [E] */
+} LpRayEmbedArgs;
 
 int lp_version(void);
 const char* lp_last_error(void);
 /* sizeof() of the ABI structs as compiled into the library, for binding self-checks:
  * which = 0 LpGrid, 1 LpGridList, 2 LpRays, 3 LpMarch, 4 LpMlp, 5 LpRendererArgs,
- * 6 LpSplatterArgs; anything else returns -1. */
+ * 6 LpSplatterArgs, 7 LpRayEmbedArgs; anything else returns -1. */
 int lp_abi_sizeof(int which);
 
 /* Which kernel family LP_KERNEL_AUTO selects for these arguments (no launch; shapes only):
@@ -217,6 +251,10 @@ int lp_splatter_forward(const LpSplatterArgs* args, void* stream);
 int lp_splatter_normalize(float* feature, const float* weight, int64_t n_rows, int32_t channels,
                           void* stream);
 int lp_splatter_backward(const LpSplatterArgs* args, void* stream);
+
+/* <- LightplaneRenderer._get_ray_embedding (lightplane/renderer_module.py:578-601) and its autograd backward */
+int lp_ray_embedding_forward(const LpRayEmbedArgs* args, void* stream);
+int lp_ray_embedding_backward(const LpRayEmbedArgs* args, void* stream);
 
 /* out[i] = hash_randn(x1[i], x2[i], seed), i < n (test hook for the opacity-noise RNG). */
 int lp_hash_randn(const int32_t* x1, const int32_t* x2, float* out, int64_t n, int32_t seed,

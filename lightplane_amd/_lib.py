@@ -35,7 +35,7 @@ _i64p = C.POINTER(C.c_int64)
 
 class LpGrid(C.Structure):
     _fields_ = [("B", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("row_offset", C.c_int64)]
+                ("row_offset", C.c_int64), ("data", C.c_void_p)]
 
 
 class LpGridList(C.Structure):
@@ -73,7 +73,9 @@ class LpRendererArgs(C.Structure):
         ("grad_ray_length", C.c_void_p), ("grad_neg_log_t", C.c_void_p), ("grad_feature", C.c_void_p),
         ("grad_grid", C.c_void_p), ("grad_color_grid", C.c_void_p), ("grad_mlp_params", C.c_void_p),
         ("grad_encoding", C.c_void_p),
-        ("grad_grid_replicas", C.c_void_p), ("n_grad_replicas", C.c_int32), ("stop_neg_log_t", C.c_float),
+        ("grad_grid_list", C.c_void_p * LP_MAX_GRIDS), ("grad_color_grid_list", C.c_void_p * LP_MAX_GRIDS),
+        ("bg_color", C.c_void_p), ("alpha", C.c_void_p), ("grad_alpha", C.c_void_p), ("alpha_mode", C.c_int32),
+        ("stop_neg_log_t", C.c_float),
     ]
 
 
@@ -85,6 +87,15 @@ class LpSplatterArgs(C.Structure):
         ("mlp", LpMlp), ("kernel", C.c_int32), ("_pad", C.c_int32),
         ("grad_out", C.c_void_p), ("weight", C.c_void_p), ("grad_encoding", C.c_void_p),
         ("grad_input_grid", C.c_void_p), ("grad_mlp_params", C.c_void_p),
+        ("grad_input_grid_list", C.c_void_p * LP_MAX_GRIDS),
+    ]
+
+
+class LpRayEmbedArgs(C.Structure):
+    _fields_ = [
+        ("n_rays", C.c_int64), ("directions", C.c_void_p), ("n_harmonics", C.c_int32), ("out_dim", C.c_int32),
+        ("weight", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p), ("grad_out", C.c_void_p),
+        ("grad_weight", C.c_void_p), ("grad_bias", C.c_void_p),
     ]
 
 
@@ -96,6 +107,7 @@ EXPORTS = (
     "lp_version", "lp_last_error", "lp_abi_sizeof", "lp_renderer_forward", "lp_renderer_backward",
     "lp_splatter_forward", "lp_splatter_normalize", "lp_splatter_backward", "lp_hash_randn",
     "lp_renderer_corner_rows", "lp_renderer_kernel_family", "lp_splatter_kernel_family",
+    "lp_ray_embedding_forward", "lp_ray_embedding_backward",
 )
 
 
@@ -134,9 +146,14 @@ def lib() -> C.CDLL:
     L.lp_renderer_kernel_family.argtypes = [C.POINTER(LpRendererArgs)]
     L.lp_splatter_kernel_family.restype = C.c_int
     L.lp_splatter_kernel_family.argtypes = [C.POINTER(LpSplatterArgs)]
+    for name in ("lp_ray_embedding_forward", "lp_ray_embedding_backward"):
+        fn = getattr(L, name)
+        fn.restype = C.c_int
+        fn.argtypes = [C.POINTER(LpRayEmbedArgs), C.c_void_p]
     L.lp_abi_sizeof.restype = C.c_int
     L.lp_abi_sizeof.argtypes = [C.c_int]
-    for which, st in enumerate((LpGrid, LpGridList, LpRays, LpMarch, LpMlp, LpRendererArgs, LpSplatterArgs)):
+    for which, st in enumerate((LpGrid, LpGridList, LpRays, LpMarch, LpMlp, LpRendererArgs, LpSplatterArgs,
+                                LpRayEmbedArgs)):
         if L.lp_abi_sizeof(which) != C.sizeof(st):
             raise LightplaneHipError(
                 f"ABI mismatch: sizeof({st.__name__}) is {C.sizeof(st)} in the ctypes binding but "
@@ -214,16 +231,28 @@ def make_march(num_samples, num_samples_inf, mask_out_of_bounds_samples, contrac
     return m
 
 
-def make_grid_list(data: Optional[torch.Tensor], descs: Sequence[GridDesc], channels: int, n_rows: int) -> LpGridList:
+def make_grid_list(data, descs: Sequence[GridDesc], channels: int, n_rows: int) -> LpGridList:
+    """``data``: the flat ``[rows, C]`` tensor (grids at their ``row_offset``), or a LIST of per-grid tensors (zero-copy
+    grid-lists: every grid in its own allocation, addressed from row 0 of its own tensor), or ``None`` (shapes only)."""
     gl = LpGridList()
     assert len(descs) <= LP_MAX_GRIDS, f"at most {LP_MAX_GRIDS} grids per grid-list are supported"
-    gl.data = ptr(data)
+    per_grid = isinstance(data, (list, tuple))
+    gl.data = None if per_grid else ptr(data)
     gl.n_grids = len(descs)
     gl.channels = int(channels)
     gl.n_rows = int(n_rows)
     for i, d in enumerate(descs):
-        gl.grids[i] = LpGrid(d.B, d.D, d.H, d.W, d.row_offset)
+        if per_grid:
+            gl.grids[i] = LpGrid(d.B, d.D, d.H, d.W, 0, ptr(data[i]))
+        else:
+            gl.grids[i] = LpGrid(d.B, d.D, d.H, d.W, d.row_offset, None)
     return gl
+
+
+def fill_ptr_list(field, tensors) -> None:
+    """``field``: a ``c_void_p * LP_MAX_GRIDS`` array of an argument struct; entry g = pointer of ``tensors[g]``."""
+    for i in range(LP_MAX_GRIDS):
+        field[i] = ptr(tensors[i]) if (tensors is not None and i < len(tensors) and tensors[i] is not None) else None
 
 
 def make_mlp(dims: Sequence[int], offset: int) -> LpMlp:

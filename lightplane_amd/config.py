@@ -5,11 +5,9 @@
                        asserts, lightplane_renderer.py:464-467).  Default on.
 ``check_finite_grads`` run the reference's post-backward ``isfinite`` asserts
                        (lightplane_renderer.py:719-722; a device sync each).  Default off.
-``grad_replicas``      extra zero-filled copies of ``grad_grid`` the Renderer backward spreads its
-                       atomics over (folded into ``grad_grid`` after the kernel).  Same-row fp32
-                       atomics serialise on MI355X (~25 ns each) and image-coherent rays hit the
-                       same plane rows from every workgroup; with the run-merged scatter the effect
-                       measured on the 256x256 triplane benchmark is nil, so the default is 0.
+``fused_module_ops``   ``LightplaneRenderer.forward`` computes the harmonic ray embedding + its Linear layer in one HIP
+                       kernel and the background / alpha epilogue inside the render kernel (2 launches instead of
+                       ~17).  Off: the reference's PyTorch op chain around the functional renderer.  Default on.
 ``warn_generic_kernel`` warn (once per shape) when a call falls back to the shape-generic kernels, which
                        are one to two orders of magnitude slower than the MFMA / walk families.  Default on.
 ``stop_transmittance`` early ray termination of the Renderer (extension, see ``lightplane_renderer``): a wavefront stops
@@ -19,7 +17,6 @@ import os
 
 check_inputs: bool = os.environ.get("LIGHTPLANE_AMD_CHECK_INPUTS", "1") != "0"
 check_finite_grads: bool = os.environ.get("LIGHTPLANE_AMD_CHECK_FINITE", "0") == "1"
-_gr = os.environ.get("LIGHTPLANE_AMD_GRAD_REPLICAS")
-grad_replicas: int = int(_gr) if _gr is not None else 0
+fused_module_ops: bool = os.environ.get("LIGHTPLANE_AMD_FUSED_MODULE_OPS", "1") != "0"
 warn_generic_kernel: bool = os.environ.get("LIGHTPLANE_AMD_WARN_GENERIC", "1") != "0"
 stop_transmittance: float = float(os.environ.get("LIGHTPLANE_AMD_STOP_TRANSMITTANCE", "0"))

@@ -57,10 +57,35 @@ static int check_grid_list(const char* name, const LpGridList& gl, bool required
     if (ns < 2)
       return set_error(LP_EINVAL, "%s[%d]: Unexpected n non-singular dim of input grid (%d)", name, g, ns);
     const int64_t rows = (int64_t)d.B * d.D * d.H * d.W;
-    if (d.row_offset < 0 || d.row_offset + rows > gl.n_rows)
+    if (d.row_offset < 0) return set_error(LP_EINVAL, "%s[%d]: negative row_offset", name, g);
+    // a grid without its own pointer lives in the flat tensor: it has to fit
+    if (!d.data && d.row_offset + rows > gl.n_rows)
       return set_error(LP_EINVAL, "%s[%d]: rows [%lld, %lld) outside the flat tensor (%lld rows)", name, g,
                        (long long)d.row_offset, (long long)(d.row_offset + rows), (long long)gl.n_rows);
   }
+  return LP_OK;
+}
+
+// every grid gets an explicit base pointer: its own (zero-copy list) or the flat tensor's
+static bool normalize_grid_list(LpGridList& gl) {
+  bool all = true;
+  for (int g = 0; g < gl.n_grids; ++g) {
+    if (!gl.grids[g].data) gl.grids[g].data = gl.data;
+    all = all && gl.grids[g].data != nullptr;
+  }
+  for (int g = gl.n_grids > 0 ? gl.n_grids : 0; g < LP_MAX_GRIDS; ++g) gl.grids[g].data = nullptr;
+  return all;
+}
+// gradient buffers: entry g = its own buffer or the flat one; either every grid has one or none has
+static int normalize_grad_list(const char* name, float** list, float* flat, int n_grids) {
+  int have = 0;
+  for (int g = 0; g < LP_MAX_GRIDS; ++g) {
+    if (g >= n_grids) { list[g] = nullptr; continue; }
+    if (!list[g]) list[g] = flat;
+    have += list[g] != nullptr;
+  }
+  if (have != 0 && have != n_grids)
+    return set_error(LP_EINVAL, "%s: gradient buffers given for %d of %d grids (all or none)", name, have, n_grids);
   return LP_OK;
 }
 
@@ -87,10 +112,8 @@ static int check_renderer(const LpRendererArgs& a, bool backward) {
   if ((rc = check_march(a.march))) return rc;
   if ((rc = check_grid_list("grid", a.grid, true))) return rc;
   if ((rc = check_grid_list("color_grid", a.color_grid, false))) return rc;
-  if (a.rays.n_rays > 0 && !a.grid.data) return set_error(LP_ENULL, "grid.data is NULL");
   const bool two = a.color_grid.n_grids > 0;
   if (two) {
-    if (!a.color_grid.data) return set_error(LP_ENULL, "color_grid.data is NULL");
     if (a.color_grid.channels != a.grid.channels || a.color_grid.grids[0].B != a.grid.grids[0].B)
       return set_error(LP_EINVAL, "color_grid must share batch size and channel count with grid");
     if (a.trunk.n_layers != 0)
@@ -151,7 +174,6 @@ static int check_splatter(const LpSplatterArgs& a, bool backward) {
     // MLP-Splatter: MLP(sample(input_grid) + encoding) is splatted (reference lightplane_splatter.py:167-338)
     if ((rc = check_mlp("splatter", a.mlp, false))) return rc;
     if ((rc = check_grid_list("input_grid", a.input_grid, true))) return rc;
-    if (a.rays.n_rays > 0 && !a.input_grid.data) return set_error(LP_ENULL, "input_grid.data is NULL");
     if (a.input_grid.grids[0].B != a.out.grids[0].B)
       return set_error(LP_EINVAL, "input_grid batch %d != output grid batch %d", a.input_grid.grids[0].B,
                        a.out.grids[0].B);
@@ -198,6 +220,7 @@ int lp_abi_sizeof(int which) {
     case 4: return (int)sizeof(LpMlp);
     case 5: return (int)sizeof(LpRendererArgs);
     case 6: return (int)sizeof(LpSplatterArgs);
+    case 7: return (int)sizeof(LpRayEmbedArgs);
     default: return -1;
   }
 }
@@ -225,30 +248,51 @@ int lp_splatter_kernel_family(const LpSplatterArgs* args) {
   return ((C == 16 || C == 32) && args->out.n_rows < ((int64_t)1 << 31)) ? 1 : 0;
 }
 
+// copy of the caller's arguments with every per-grid pointer made explicit (what the kernels read)
+static int normalized_renderer_args(const LpRendererArgs* args, bool backward, LpRendererArgs& a) {
+  int rc = check_renderer(*args, backward);
+  if (rc) return rc;
+  a = *args;
+  const bool have_grid = normalize_grid_list(a.grid);
+  const bool have_cgrid = normalize_grid_list(a.color_grid);
+  if (a.rays.n_rays > 0 && !have_grid) return set_error(LP_ENULL, "grid.data is NULL (and a grid has no pointer of its own)");
+  if (a.rays.n_rays > 0 && !have_cgrid) return set_error(LP_ENULL, "color_grid.data is NULL (and a grid has no pointer of its own)");
+  if ((rc = normalize_grad_list("grad_grid", a.grad_grid_list, backward ? a.grad_grid : nullptr, a.grid.n_grids))) return rc;
+  if ((rc = normalize_grad_list("grad_color_grid", a.grad_color_grid_list, backward ? a.grad_color_grid : nullptr,
+                                a.color_grid.n_grids)))
+    return rc;
+  if (a.alpha_mode < 0 || a.alpha_mode > 2) return set_error(LP_EINVAL, "alpha_mode %d outside 0..2", a.alpha_mode);
+  if ((a.alpha || a.grad_alpha) && a.alpha_mode == 0)
+    return set_error(LP_EINVAL, "alpha / grad_alpha given but alpha_mode is 0");
+  return LP_OK;
+}
+
 int lp_renderer_forward(const LpRendererArgs* args, void* stream) {
   if (!args) return set_error(LP_ENULL, "args is NULL");
-  int rc = check_renderer(*args, false);
+  LpRendererArgs a;
+  int rc = normalized_renderer_args(args, false, a);
   if (rc) return rc;
   const char* why = "";
-  const int fam = select_renderer(*args, &why);
-  if (args->kernel == LP_KERNEL_MFMA && fam == 0)
+  const int fam = select_renderer(a, &why);
+  if (a.kernel == LP_KERNEL_MFMA && fam == 0)
     return set_error(LP_EUNSUPPORTED, "MFMA renderer kernel unavailable for this shape: %s", why);
-  if (fam == 1 && args->kernel != LP_KERNEL_GENERIC) return renderer_forward_mfma(*args, (hipStream_t)stream);
-  if (fam == 2 && args->kernel != LP_KERNEL_GENERIC) return renderer_forward_mfma_wide(*args, (hipStream_t)stream);
-  return renderer_forward_generic(*args, (hipStream_t)stream);
+  if (fam == 1 && a.kernel != LP_KERNEL_GENERIC) return renderer_forward_mfma(a, (hipStream_t)stream);
+  if (fam == 2 && a.kernel != LP_KERNEL_GENERIC) return renderer_forward_mfma_wide(a, (hipStream_t)stream);
+  return renderer_forward_generic(a, (hipStream_t)stream);
 }
 
 int lp_renderer_backward(const LpRendererArgs* args, void* stream) {
   if (!args) return set_error(LP_ENULL, "args is NULL");
-  int rc = check_renderer(*args, true);
+  LpRendererArgs a;
+  int rc = normalized_renderer_args(args, true, a);
   if (rc) return rc;
   const char* why = "";
-  const int fam = select_renderer(*args, &why);
-  if (args->kernel == LP_KERNEL_MFMA && fam == 0)
+  const int fam = select_renderer(a, &why);
+  if (a.kernel == LP_KERNEL_MFMA && fam == 0)
     return set_error(LP_EUNSUPPORTED, "MFMA renderer kernel unavailable for this shape: %s", why);
-  if (fam == 1 && args->kernel != LP_KERNEL_GENERIC) return renderer_backward_mfma(*args, (hipStream_t)stream);
-  if (fam == 2 && args->kernel != LP_KERNEL_GENERIC) return renderer_backward_mfma_wide(*args, (hipStream_t)stream);
-  return renderer_backward_generic(*args, (hipStream_t)stream);
+  if (fam == 1 && a.kernel != LP_KERNEL_GENERIC) return renderer_backward_mfma(a, (hipStream_t)stream);
+  if (fam == 2 && a.kernel != LP_KERNEL_GENERIC) return renderer_backward_mfma_wide(a, (hipStream_t)stream);
+  return renderer_backward_generic(a, (hipStream_t)stream);
 }
 
 int lp_renderer_corner_rows(const LpRendererArgs* args, int64_t* rows, void* stream) {
@@ -260,10 +304,26 @@ int lp_renderer_corner_rows(const LpRendererArgs* args, int64_t* rows, void* str
   return renderer_corner_rows_launch(*args, rows, (hipStream_t)stream);
 }
 
-int lp_splatter_forward(const LpSplatterArgs* args, void* stream) {
-  if (!args) return set_error(LP_ENULL, "args is NULL");
-  int rc = check_splatter(*args, false);
+static int normalized_splatter_args(const LpSplatterArgs* args, bool backward, LpSplatterArgs& a) {
+  int rc = check_splatter(*args, backward);
   if (rc) return rc;
+  a = *args;
+  if (a.mlp.n_layers > 0) {
+    if (!normalize_grid_list(a.input_grid) && a.rays.n_rays > 0)
+      return set_error(LP_ENULL, "input_grid.data is NULL (and a grid has no pointer of its own)");
+    if ((rc = normalize_grad_list("grad_input_grid", a.grad_input_grid_list, backward ? a.grad_input_grid : nullptr,
+                                  a.input_grid.n_grids)))
+      return rc;
+  }
+  return LP_OK;
+}
+
+int lp_splatter_forward(const LpSplatterArgs* args_, void* stream) {
+  if (!args_) return set_error(LP_ENULL, "args is NULL");
+  LpSplatterArgs a_;
+  int rc = normalized_splatter_args(args_, false, a_);
+  if (rc) return rc;
+  const LpSplatterArgs* args = &a_;
   if (args->mlp.n_layers > 0) {
     const bool fast = splatter_mlp_mfma_supported(*args);
     if (args->kernel == LP_KERNEL_MFMA && !fast)
@@ -280,10 +340,12 @@ int lp_splatter_normalize(float* feature, const float* weight, int64_t n_rows, i
   return splatter_normalize_launch(feature, weight, n_rows, channels, (hipStream_t)stream);
 }
 
-int lp_splatter_backward(const LpSplatterArgs* args, void* stream) {
-  if (!args) return set_error(LP_ENULL, "args is NULL");
-  int rc = check_splatter(*args, true);
+int lp_splatter_backward(const LpSplatterArgs* args_, void* stream) {
+  if (!args_) return set_error(LP_ENULL, "args is NULL");
+  LpSplatterArgs a_;
+  int rc = normalized_splatter_args(args_, true, a_);
   if (rc) return rc;
+  const LpSplatterArgs* args = &a_;
   if (args->mlp.n_layers > 0) {
     const bool fast = splatter_mlp_mfma_supported(*args);
     if (args->kernel == LP_KERNEL_MFMA && !fast)
@@ -297,6 +359,32 @@ int lp_splatter_backward(const LpSplatterArgs* args, void* stream) {
 /* developer hook (not part of include/lightplane_hip.h): per-phase cycle totals of the MFMA backward,
  * only in builds with -DLP_PHASE_TIMING (returns -1 otherwise) */
 int lp_debug_phase_cycles(unsigned long long* out16) { return debug_phase_cycles(out16); }
+
+static int check_ray_embed(const LpRayEmbedArgs& a, bool backward) {
+  if (a.n_rays < 0) return set_error(LP_EINVAL, "n_rays %lld < 0", (long long)a.n_rays);
+  if (a.n_harmonics < 0 || a.n_harmonics > 10) return set_error(LP_EUNSUPPORTED, "n_harmonics %d outside [0, 10]", a.n_harmonics);
+  if (a.out_dim < 1 || a.out_dim > LP_MAX_WIDTH) return set_error(LP_EUNSUPPORTED, "out_dim %d outside [1, %d]", a.out_dim, LP_MAX_WIDTH);
+  if (a.n_rays == 0) return LP_OK;
+  if (!a.directions) return set_error(LP_ENULL, "directions is NULL");
+  if (!backward && (!a.weight || !a.bias || !a.out)) return set_error(LP_ENULL, "weight / bias / out must be non-NULL");
+  if (backward && (!a.grad_out || (!a.grad_weight && !a.grad_bias)))
+    return set_error(LP_ENULL, "grad_out and at least one of grad_weight / grad_bias must be non-NULL");
+  return LP_OK;
+}
+
+int lp_ray_embedding_forward(const LpRayEmbedArgs* args, void* stream) {
+  if (!args) return set_error(LP_ENULL, "args is NULL");
+  const int rc = check_ray_embed(*args, false);
+  if (rc) return rc;
+  return ray_embedding_forward_launch(*args, (hipStream_t)stream);
+}
+
+int lp_ray_embedding_backward(const LpRayEmbedArgs* args, void* stream) {
+  if (!args) return set_error(LP_ENULL, "args is NULL");
+  const int rc = check_ray_embed(*args, true);
+  if (rc) return rc;
+  return ray_embedding_backward_launch(*args, (hipStream_t)stream);
+}
 
 int lp_hash_randn(const int32_t* x1, const int32_t* x2, float* out, int64_t n, int32_t seed, void* stream) {
   if (n < 0) return set_error(LP_EINVAL, "n < 0");

@@ -456,6 +456,41 @@ LP_DEV float sample_noise(int64_t ray, int step, int64_t n_rays, int s_tot, int3
 }
 
 // ---------------------------------------------------------------------------------------
+// fused module epilogue (LpRendererArgs.bg_color / alpha; reference renderer_module.py:552-561)
+// ---------------------------------------------------------------------------------------
+// forward: per-ray outputs.  feature + T * bg and 1 - T are formed like the reference's PyTorch ops (one rounding per
+// operation, accurate expf).
+LP_DEV void write_ray_outputs(const LpRendererArgs& a, int64_t ray_id, float len, float nlt, const float* facc) {
+  a.ray_length[ray_id] = len;
+  a.neg_log_t[ray_id] = nlt;
+  const bool epi = a.bg_color != nullptr || a.alpha != nullptr;
+  const float T = epi ? expf(-nlt) : 0.0f;
+  for (int c = 0; c < a.color_chn; ++c) {
+    float f = facc[c];
+    if (a.bg_color) f = f + T * a.bg_color[c];
+    a.feature[ray_id * a.color_chn + c] = f;
+  }
+  if (a.alpha) a.alpha[ray_id] = (a.alpha_mode == 2) ? -nlt : 1.0f - T;
+}
+// backward: gradient of the loss w.r.t. the final -log T, with the epilogue's terms folded in.  gfeat = upstream
+// gradient of the (composited) feature, which is also the gradient of the rendered feature.
+LP_DEV float epilogue_grad_nlt(const LpRendererArgs& a, int64_t rid, bool valid, float nlt_final, float g_nlt,
+                               const float* gfeat, int n_chn) {
+  if (a.bg_color == nullptr && a.grad_alpha == nullptr) return g_nlt;
+  const float T = expf(-nlt_final);
+  if (a.grad_alpha && valid) {
+    const float ga = a.grad_alpha[rid];
+    g_nlt += (a.alpha_mode == 2) ? -ga : ga * T;
+  }
+  if (a.bg_color) {
+    float s = 0.0f;
+    for (int c = 0; c < n_chn; ++c) s = fmaf(a.bg_color[c], gfeat[c], s);
+    g_nlt -= T * s;
+  }
+  return g_nlt;
+}
+
+// ---------------------------------------------------------------------------------------
 // run heads of the scatter walks
 // ---------------------------------------------------------------------------------------
 // Value of lane - 1 (lane 0: its own).  Cross-lane reads must NOT sit behind a short-circuit (`(r == 0) || x !=

@@ -61,7 +61,7 @@ LP_DEV void sample_list(const LpGridList& gl, int b, float x, float y, float z, 
     for (int k = 0; k < 8; ++k) {
       if (k < cs.n && cs.row[k] >= 0) {
         const float w = cs.w[k];
-        const float* src = gl.data + cs.row[k] * C;
+        const float* src = gl.grids[g].data + cs.row[k] * C;
         if ((C & 3) == 0) {
           for (int c = 0; c < C; c += 4) {
             const float4 v = *reinterpret_cast<const float4*>(src + c);
@@ -78,7 +78,8 @@ LP_DEV void sample_list(const LpGridList& gl, int b, float x, float y, float z, 
   }
 }
 
-LP_DEV void splat_list(const LpGridList& gl, float* grad, int b, float x, float y, float z,
+// grad[g]: gradient buffer of grid g (same row indexing as gl.grids[g].data)
+LP_DEV void splat_list(const LpGridList& gl, float* const* grad, int b, float x, float y, float z,
                        bool mask_oob, const float* d) {
   const int C = gl.channels;
   if (mask_oob && !point_in_bounds(x, y, z)) return;
@@ -88,7 +89,7 @@ LP_DEV void splat_list(const LpGridList& gl, float* grad, int b, float x, float 
     for (int k = 0; k < 8; ++k) {
       if (k < cs.n && cs.row[k] >= 0) {
         const float w = cs.w[k];
-        float* dst = grad + cs.row[k] * C;
+        float* dst = grad[g] + cs.row[k] * C;
         for (int c = 0; c < C; ++c) atomic_add_f32(dst + c, w * d[c]);
       }
     }

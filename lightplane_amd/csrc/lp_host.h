@@ -37,6 +37,9 @@ int splatter_mlp_forward_mfma(const LpSplatterArgs& a, hipStream_t stream);
 int splatter_mlp_backward_mfma(const LpSplatterArgs& a, hipStream_t stream);
 int splatter_normalize_launch(float* feature, const float* weight, int64_t n_rows, int channels,
                               hipStream_t stream);
+// ray-direction embedding of the module front-end: lp_ray_embedding.hip
+int ray_embedding_forward_launch(const LpRayEmbedArgs& a, hipStream_t stream);
+int ray_embedding_backward_launch(const LpRayEmbedArgs& a, hipStream_t stream);
 int hash_randn_launch(const int32_t* x1, const int32_t* x2, float* out, int64_t n, int32_t seed,
                       hipStream_t stream);
 

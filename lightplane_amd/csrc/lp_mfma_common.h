@@ -170,9 +170,9 @@ LP_DEV void gather_list(const LpGridList& gl, bool mask_oob, const Ray& ray, flo
 #pragma unroll
   for (int q = 0; q < C / 2; ++q) x0[q] = 0.0f;
   const float keep = (mask_oob && !point_in_bounds(x, y, z)) ? 0.0f : 1.0f;
-  const float* data = gl.data;
   for (int g = 0; g < gl.n_grids; ++g) {
     Taps t;
+    const float* data = gl.grids[g].data;  // per-grid base (the host normalises NULL to the flat tensor)
     grid_taps<false>(gl.grids[g], ray.b, x, y, z, t);
     if (FENCED) __builtin_amdgcn_sched_barrier(0);
     gather_taps4<C>(data, t.row, t.w, keep, h, x0);
@@ -198,7 +198,7 @@ LP_DEV void gather_features(const LpRendererArgs& a, const Ray& ray, float x, fl
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
         __builtin_amdgcn_sched_barrier(0);
-        gather_taps4<C>(a.grid.data, t[g].row, t[g].w, keep, h, x0);
+        gather_taps4<C>(a.grid.grids[g].data, t[g].row, t[g].w, keep, h, x0);
       }
       __builtin_amdgcn_sched_barrier(0);
     } else {
@@ -207,7 +207,7 @@ LP_DEV void gather_features(const LpRendererArgs& a, const Ray& ray, float x, fl
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, t[g].row[k], t[g].w[k] * keep, h, x0);
+        for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.grids[g].data, t[g].row[k], t[g].w[k] * keep, h, x0);
       }
     }
   } else if (GM == GM_VOXEL) {
@@ -215,32 +215,33 @@ LP_DEV void gather_features(const LpRendererArgs& a, const Ray& ray, float x, fl
     voxel_taps<false>(a.grid.grids[0], ray.b, x, y, z, t);
     if (FENCED) {
       __builtin_amdgcn_sched_barrier(0);
-      gather_taps4<C>(a.grid.data, t.row, t.w, keep, h, x0);
+      gather_taps4<C>(a.grid.grids[0].data, t.row, t.w, keep, h, x0);
       __builtin_amdgcn_sched_barrier(0);
-      gather_taps4<C>(a.grid.data, t.row + 4, t.w + 4, keep, h, x0);
+      gather_taps4<C>(a.grid.grids[0].data, t.row + 4, t.w + 4, keep, h, x0);
       __builtin_amdgcn_sched_barrier(0);
     } else {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
+      for (int k = 0; k < 8; ++k) gather_tap<C>(a.grid.grids[0].data, t.row[k], t.w[k] * keep, h, x0);
     }
   } else {
     for (int g = 0; g < a.grid.n_grids; ++g) {
       Taps t;
+      const float* data = a.grid.grids[g].data;
       grid_taps<false>(a.grid.grids[g], ray.b, x, y, z, t);
       if (FENCED) {
         __builtin_amdgcn_sched_barrier(0);
-        gather_taps4<C>(a.grid.data, t.row, t.w, keep, h, x0);
+        gather_taps4<C>(data, t.row, t.w, keep, h, x0);
         __builtin_amdgcn_sched_barrier(0);
         if (t.n == 8) {
-          gather_taps4<C>(a.grid.data, t.row + 4, t.w + 4, keep, h, x0);
+          gather_taps4<C>(data, t.row + 4, t.w + 4, keep, h, x0);
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
+        for (int k = 0; k < 4; ++k) gather_tap<C>(data, t.row[k], t.w[k] * keep, h, x0);
         if (t.n == 8) {
 #pragma unroll
-          for (int k = 4; k < 8; ++k) gather_tap<C>(a.grid.data, t.row[k], t.w[k] * keep, h, x0);
+          for (int k = 4; k < 8; ++k) gather_tap<C>(data, t.row[k], t.w[k] * keep, h, x0);
         }
       }
     }
@@ -407,7 +408,7 @@ LP_DEV Heads decode_prefetch(const LpRendererArgs& a, const float* lds, const Ra
   // ---- group 1: trunk layer 2  ||  plane 0 / voxel taps 0-3 ----
   if (GM == GM_TRIPLANE || GM == GM_VOXEL) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, tp[0].row[k], tp[0].w[k] * keep, h, nx.x0);
+    for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.grids[0].data, tp[0].row[k], tp[0].w[k] * keep, h, nx.x0);
   }
   acc = layer<16>(wl + M::WT2, t.h1, load_bias(lds, 1, h, zo));
 #pragma unroll
@@ -417,10 +418,10 @@ LP_DEV Heads decode_prefetch(const LpRendererArgs& a, const float* lds, const Ra
   // ---- group 2: opacity hidden layer  ||  plane 1 / voxel taps 4-7 ----
   if (GM == GM_TRIPLANE) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, tp[1].row[k], tp[1].w[k] * keep, h, nx.x0);
+    for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.grids[1].data, tp[1].row[k], tp[1].w[k] * keep, h, nx.x0);
   } else if (GM == GM_VOXEL) {
 #pragma unroll
-    for (int k = 4; k < 8; ++k) gather_tap<C>(a.grid.data, tp[0].row[k], tp[0].w[k] * keep, h, nx.x0);
+    for (int k = 4; k < 8; ++k) gather_tap<C>(a.grid.grids[0].data, tp[0].row[k], tp[0].w[k] * keep, h, nx.x0);
   }
   acc = layer<16>(wl + M::WO1, t.e, load_bias(lds, 2, h, zo));
 #pragma unroll
@@ -430,7 +431,7 @@ LP_DEV Heads decode_prefetch(const LpRendererArgs& a, const float* lds, const Ra
   // ---- group 3: colour hidden layer  ||  plane 2 ----
   if (GM == GM_TRIPLANE) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.data, tp[2].row[k], tp[2].w[k] * keep, h, nx.x0);
+    for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.grids[2].data, tp[2].row[k], tp[2].w[k] * keep, h, nx.x0);
   }
   float ein[16];
 #pragma unroll
@@ -682,7 +683,6 @@ inline bool is_canonical_triplane(const LpGridList& gl) {
 
 // second-generation backward (lp_renderer_mfma_bwd.hip); gm = GM_* grid-list shape
 int renderer_backward_mfma2(const LpRendererArgs& a, const MfmaParams& mp, int gm, hipStream_t stream);
-int fold_grad_replicas(const LpRendererArgs& a, hipStream_t stream);
 int debug_phase_cycles(unsigned long long* out);  // developer builds with -DLP_PHASE_TIMING, else -1
 
 }  // namespace lp

@@ -144,9 +144,7 @@ __global__ void __launch_bounds__(64) renderer_fwd_generic(const GenArgs ga) {
     }
   }
   if (valid) {
-    a.ray_length[ray_id] = len;
-    a.neg_log_t[ray_id] = nlt;
-    for (int c = 0; c < a.color_chn; ++c) a.feature[ray_id * a.color_chn + c] = facc[c];
+    write_ray_outputs(a, ray_id, len, nlt, facc);
     if (a.neg_log_t_ckpt)
       *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + n_ckpt - 1) * 2) = make_float2((float)s_last, nlt_lo);
   }
@@ -194,7 +192,8 @@ __global__ void __launch_bounds__(64) renderer_bwd_generic(const GenArgs ga) {
   for (int c = 0; c < Cc; ++c)
     gfeat[c] = (valid && a.grad_feature) ? a.grad_feature[rid * Cc + c] : 0.0f;
   const float g_len = (valid && a.grad_ray_length) ? a.grad_ray_length[rid] : 0.0f;
-  const float g_nlt = (valid && a.grad_neg_log_t) ? a.grad_neg_log_t[rid] : 0.0f;
+  const float g_nlt = epilogue_grad_nlt(a, rid, valid, a.neg_log_t[rid],
+                                        (valid && a.grad_neg_log_t) ? a.grad_neg_log_t[rid] : 0.0f, gfeat, Cc);
 
   const int s_tot = a.march.num_samples + a.march.num_samples_inf;
   const bool contract = a.march.contract_coords != 0;
@@ -279,9 +278,9 @@ __global__ void __launch_bounds__(64) renderer_bwd_generic(const GenArgs ga) {
         dx[c] = (act[p.x0 + c] > 0.0f) ? dx[c] : 0.0f;
         dhead[c] = (act[p.cx0 + c] > 0.0f) ? dhead[c] : 0.0f;
       }
-      if (a.grad_grid && live) splat_list(a.grid, a.grad_grid, ray.b, x, y, z, mask, dx);
-      if (a.grad_color_grid && live)
-        splat_list(a.color_grid, a.grad_color_grid, ray.b, x, y, z, mask, dhead);
+      if (a.grad_grid_list[0] && live) splat_list(a.grid, a.grad_grid_list, ray.b, x, y, z, mask, dx);
+      if (a.grad_color_grid_list[0] && live)
+        splat_list(a.color_grid, a.grad_color_grid_list, ray.b, x, y, z, mask, dhead);
     } else {
       // trunk output gradient = colour-input grad + opacity-input grad, through the ReLU
       for (int c = 0; c < hw; ++c) {
@@ -299,7 +298,7 @@ __global__ void __launch_bounds__(64) renderer_bwd_generic(const GenArgs ga) {
       } else {
         for (int c = 0; c < C; ++c) dx[c] = dy[c];
       }
-      if (a.grad_grid && live) splat_list(a.grid, a.grad_grid, ray.b, x, y, z, mask, dx);
+      if (a.grad_grid_list[0] && live) splat_list(a.grid, a.grad_grid_list, ray.b, x, y, z, mask, dx);
     }
   }
   if (valid && a.grad_encoding)

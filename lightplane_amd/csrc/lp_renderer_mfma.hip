@@ -88,9 +88,7 @@ __global__ void __launch_bounds__(256, 2) renderer_fwd_mfma(const LpRendererArgs
     }
   }
   if (valid && h == 0) {
-    a.ray_length[ray_id] = len;
-    a.neg_log_t[ray_id] = nlt;
-    for (int c = 0; c < a.color_chn; ++c) a.feature[ray_id * a.color_chn + c] = facc[c];
+    write_ray_outputs(a, ray_id, len, nlt, facc);
     if (a.neg_log_t_ckpt)
       *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + n_ckpt - 1) * 2) = make_float2((float)s_last, nlt_lo);
   }
@@ -206,9 +204,7 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_mfma_np(const LpRendere
     }
   }
   if (valid && h == 0) {
-    a.ray_length[ray_id] = len;
-    a.neg_log_t[ray_id] = nlt;
-    for (int c = 0; c < a.color_chn; ++c) a.feature[ray_id * a.color_chn + c] = facc[c];
+    write_ray_outputs(a, ray_id, len, nlt, facc);
     if (a.neg_log_t_ckpt)
       *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + n_ckpt - 1) * 2) = make_float2((float)s_last, nlt_lo);
   }
@@ -362,33 +358,10 @@ int renderer_forward_mfma(const LpRendererArgs& a, hipStream_t stream) {
   return check_launch("renderer_fwd_mfma");
 }
 
-// grad_grid[i] += sum_r replicas[r][i]  (float4 lanes; n is a multiple of 4 because C is)
-__global__ void fold_replicas_kernel(float* __restrict__ dst, const float* __restrict__ rep, int64_t n4, int n_rep) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
-  float4 s = reinterpret_cast<float4*>(dst)[i];
-  for (int r = 0; r < n_rep; ++r) {
-    const float4 v = reinterpret_cast<const float4*>(rep)[(int64_t)r * n4 + i];
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-  }
-  reinterpret_cast<float4*>(dst)[i] = s;
-}
-
-int fold_grad_replicas(const LpRendererArgs& a, hipStream_t stream) {
-  if (!a.grad_grid || !a.grad_grid_replicas || a.n_grad_replicas <= 0) return LP_OK;
-  const int64_t n = a.grid.n_rows * a.grid.channels;
-  if (n % 4 != 0) return set_error(LP_EINVAL, "grad replicas need rows*C divisible by 4");
-  const int64_t n4 = n / 4;
-  hipLaunchKernelGGL(fold_replicas_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, a.grad_grid,
-                     a.grad_grid_replicas, n4, a.n_grad_replicas);
-  return check_launch("fold_replicas_kernel");
-}
-
 int renderer_backward_mfma(const LpRendererArgs& a, hipStream_t stream) {
   const MfmaParams mp = make_params(a);
   if (n_blocks(a) == 0) return LP_OK;
-  const int rc = renderer_backward_mfma2(a, mp, grid_mode(a), stream);  // lp_renderer_mfma_bwd.hip
-  return rc ? rc : fold_grad_replicas(a, stream);
+  return renderer_backward_mfma2(a, mp, grid_mode(a), stream);  // lp_renderer_mfma_bwd.hip
 }
 
 }  // namespace lp

@@ -179,7 +179,8 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
   for (int c = 0; c < 4; ++c)
     gfeat[c] = (valid && a.grad_feature && c < a.color_chn) ? a.grad_feature[rid * a.color_chn + c] : 0.0f;
   const float g_len = (valid && a.grad_ray_length) ? a.grad_ray_length[rid] : 0.0f;
-  const float g_nlt = (valid && a.grad_neg_log_t) ? a.grad_neg_log_t[rid] : 0.0f;
+  const float g_nlt = epilogue_grad_nlt(a, rid, valid, a.neg_log_t[rid],
+                                        (valid && a.grad_neg_log_t) ? a.grad_neg_log_t[rid] : 0.0f, gfeat, 4);
 
   const bool want_params = a.grad_mlp_params != nullptr;
   const float delta0 = (a.march.num_samples > 1) ? (ray.far_t - ray.near_t) / (float)(a.march.num_samples - 1) : 1.0f;
@@ -198,10 +199,8 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
   float dwo2 = 0.0f, dwc2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   float dbo2 = 0.0f, dbc2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
-  const int rep = (int)(blockIdx.x % (unsigned)(a.n_grad_replicas + 1));
-  float* const gg = !a.grad_grid ? nullptr
-                    : (rep == 0 ? a.grad_grid : a.grad_grid_replicas + (int64_t)(rep - 1) * a.grid.n_rows * C);
-  float* const ggc = (tg) ? a.grad_color_grid : nullptr;
+  const bool gg = a.grad_grid_list[0] != nullptr;  // the host fills every entry or none
+  const bool ggc = tg && a.grad_color_grid_list[0] != nullptr;
 
 #ifdef LP_PHASE_TIMING
   unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -440,7 +439,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
         const bool live_c = valid && on && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
 #pragma unroll 1
         for (int g = 0; g < a.color_grid.n_grids; ++g)
-          scatter_grid<C>(ggc, a.color_grid.grids[g], ray.b, x, y, z, live_c, lane, xt, yt, mp.dbg);
+          scatter_grid<C>(a.grad_color_grid_list[g], a.color_grid.grids[g], ray.b, x, y, z, live_c, lane, xt, yt, mp.dbg);
       }
       acc = (f32x16){0};
     }
@@ -526,7 +525,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     if (gg && !(mp.dbg & 2)) {
       const int ng = (GM == GM_TRIPLANE) ? 3 : (GM == GM_VOXEL) ? 1 : a.grid.n_grids;
 #pragma unroll 1
-      for (int g = 0; g < ng; ++g) scatter_grid<C, GM>(gg, a.grid.grids[g], ray.b, x, y, z, live, lane, xt, yt, mp.dbg);
+      for (int g = 0; g < ng; ++g) scatter_grid<C, GM>(a.grad_grid_list[g], a.grid.grids[g], ray.b, x, y, z, live, lane, xt, yt, mp.dbg);
     }
   }
 

@@ -241,9 +241,7 @@ __global__ void __launch_bounds__(256, 2) renderer_fwd_mfma_w(const LpRendererAr
     }
   }
   if (valid && h == 0) {
-    a.ray_length[ray_id] = len;
-    a.neg_log_t[ray_id] = nlt;
-    for (int c = 0; c < a.color_chn; ++c) a.feature[ray_id * a.color_chn + c] = facc[c];
+    write_ray_outputs(a, ray_id, len, nlt, facc);
     if (a.neg_log_t_ckpt)
       *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + n_ckpt - 1) * 2) = make_float2((float)s_last, nlt_lo);
   }
@@ -360,7 +358,8 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
   for (int c = 0; c < 4; ++c)
     gfeat[c] = (valid && a.grad_feature && c < a.color_chn) ? a.grad_feature[rid * a.color_chn + c] : 0.0f;
   const float g_len = (valid && a.grad_ray_length) ? a.grad_ray_length[rid] : 0.0f;
-  const float g_nlt = (valid && a.grad_neg_log_t) ? a.grad_neg_log_t[rid] : 0.0f;
+  const float g_nlt = epilogue_grad_nlt(a, rid, valid, a.neg_log_t[rid],
+                                        (valid && a.grad_neg_log_t) ? a.grad_neg_log_t[rid] : 0.0f, gfeat, 4);
 
   const bool want_params = a.grad_mlp_params != nullptr;
   const float delta0 = (a.march.num_samples > 1) ? (ray.far_t - ray.near_t) / (float)(a.march.num_samples - 1) : 1.0f;
@@ -385,9 +384,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
   }
   float dbo2 = 0.0f, dbc2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
-  const int rep = (int)(blockIdx.x % (unsigned)(a.n_grad_replicas + 1));
-  float* const gg = !a.grad_grid ? nullptr
-                    : (rep == 0 ? a.grad_grid : a.grad_grid_replicas + (int64_t)(rep - 1) * a.grid.n_rows * C);
+  const bool gg = a.grad_grid_list[0] != nullptr;  // the host fills every entry or none
 
   float nlt = a.neg_log_t[rid];
   float suffix = 0.0f, p_next = 0.0f;
@@ -619,7 +616,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
     if (gg && !(mp.dbg & 2)) {
       const int ng = (GM == GM_TRIPLANE) ? 3 : (GM == GM_VOXEL) ? 1 : a.grid.n_grids;
 #pragma unroll 1
-      for (int g = 0; g < ng; ++g) scatter_grid<C, GM>(gg, a.grid.grids[g], ray.b, x, y, z, live, lane, xt, yt, mp.dbg);
+      for (int g = 0; g < ng; ++g) scatter_grid<C, GM>(a.grad_grid_list[g], a.grid.grids[g], ray.b, x, y, z, live, lane, xt, yt, mp.dbg);
     }
   }
 
@@ -789,8 +786,7 @@ int renderer_backward_mfma_wide(const LpRendererArgs& a, hipStream_t stream) {
   }
 #undef LP_BW
   if (rc) return rc;
-  if ((rc = check_launch("renderer_bwd_mfma_w"))) return rc;
-  return fold_grad_replicas(a, stream);
+  return check_launch("renderer_bwd_mfma_w");
 }
 
 }  // namespace lp

@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(64) splat_mlp_bwd_kernel(const SplatMlpArgs sa
       mlp_backward<false>(a.mlp_params, p.stage_ld, m, C, p.in, p.out, act, dy, dx, gparams, Xs, Ys, lane, live);
     if (live) {
       for (int c = 0; c < E; ++c) denc[c] += dx[c];
-      if (a.grad_input_grid) splat_list(a.input_grid, a.grad_input_grid, ray.b, x, y, z, false, dx);
+      if (a.grad_input_grid_list[0]) splat_list(a.input_grid, a.grad_input_grid_list, ray.b, x, y, z, false, dx);
     }
   }
   if (valid && a.grad_encoding)

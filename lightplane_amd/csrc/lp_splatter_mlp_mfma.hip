@@ -382,12 +382,12 @@ __global__ void __launch_bounds__(256, 2) splat_mlp_bwd_mfma(const LpSplatterArg
     LP_SCHED_FENCE();
     // ---- input-grid gradient: the Renderer's run-merged scatter of dxin ----
     __builtin_amdgcn_s_setprio(0);
-    if (a.grad_input_grid) {
+    if (a.grad_input_grid_list[0]) {
 #pragma unroll
       for (int q = 0; q < E / 2; ++q) xt[featq(q, h) * DX_LD + r] = acc[q];
 #pragma unroll 1
       for (int g = 0; g < a.input_grid.n_grids; ++g)
-        scatter_grid<E, GMI, false>(a.grad_input_grid, a.input_grid.grids[g], ray.b, x, y, z, live, lane, xt, yt, mp.dbg);
+        scatter_grid<E, GMI, false>(a.grad_input_grid_list[g], a.input_grid.grids[g], ray.b, x, y, z, live, lane, xt, yt, mp.dbg);
     }
   }
 

@@ -5,8 +5,10 @@ Constructor / forward arguments, ``state_dict`` keys (``mlp_params``,
 ``n_hidden_*``) and return values follow the reference's
 ``lightplane/renderer_module.py`` (`LightplaneRenderer` :38-601) and
 ``lightplane/splatter_module.py`` (`LightplaneSplatter` :25-161, `LightplaneMLPSplatter`
-:164-331), so checkpoints interchange.  The dense pre/post ops (harmonic embedding + Linear,
-background compositing, alpha) stay PyTorch-ROCm ops; the march is the HIP library.
+:164-331), so checkpoints interchange.  ``LightplaneRenderer.forward`` is two HIP launches: the harmonic ray
+embedding + its Linear layer (``lp_ray_embedding_forward``) and the march with the background / alpha epilogue
+fused in (``LpRendererArgs.bg_color`` / ``alpha``); ``config.fused_module_ops = False`` restores the reference's
+PyTorch op chain around the functional renderer (same numbers to fp32 round-off, ~17 launches).
 
 ``use_naive_impl=True`` is rejected: the pure-PyTorch implementation is this repository's
 test oracle (``oracle/``), not part of the product path.
@@ -24,7 +26,10 @@ from .grids import if_not_none_else
 from .params import (DecoderParams, SplatterParams, flattened_decoder_params_to_list, init_decoder_params,
                      init_splatter_params)
 from .rays import Rays, calc_harmonic_embedding, calc_harmonic_embedding_dim, jitter_near_far
-from .renderer import lightplane_renderer
+import ctypes
+
+from . import _lib, config
+from .renderer import _render, lightplane_renderer
 from .splatter import lightplane_mlp_splatter, lightplane_splatter
 
 logger = logging.getLogger(__name__)
@@ -33,6 +38,55 @@ _NAIVE_MSG = (
     "use_naive_impl=True is not available in lightplane_amd: the pure-PyTorch implementation is "
     "kept as the CPU test oracle under oracle/ and is never part of the product path."
 )
+
+
+class _RayEmbeddingFunction(torch.autograd.Function):
+    """``Linear(harmonic_embedding(normalize(directions)))`` as one HIP kernel per direction (reference
+    renderer_module.py:578-601 is normalize -> mul/add/sin/flatten/cat -> Linear: eight launches, and as many again in
+    autograd's backward).  Gradients flow to the Linear layer's weight and bias; ray directions are not
+    differentiable, as everywhere else in the Renderer (lightplane_renderer.py:724-756)."""
+
+    @staticmethod
+    def forward(ctx, directions, weight, bias, n_harmonics: int):
+        dev = directions.device
+        stream = _lib.current_stream(dev)
+        directions, weight, bias = directions.contiguous(), weight.contiguous(), bias.contiguous()
+        _lib.check_tensors(dev, {"rays.directions": directions, "harmonic_ray_embedding_linear.weight": weight,
+                                 "harmonic_ray_embedding_linear.bias": bias})
+        n, e = directions.shape[0], weight.shape[0]
+        assert weight.shape[1] == 3 + 6 * n_harmonics
+        out = torch.empty(n, e, device=dev, dtype=torch.float32)
+        a = _lib.LpRayEmbedArgs()
+        a.n_rays, a.directions, a.n_harmonics, a.out_dim = n, _lib.ptr(directions), int(n_harmonics), e
+        a.weight, a.bias, a.out = _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(out)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().lp_ray_embedding_forward(ctypes.byref(a), stream), "lp_ray_embedding_forward")
+        ctx.save_for_backward(directions, weight)
+        ctx.n_harmonics = int(n_harmonics)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        directions, weight = ctx.saved_tensors
+        need_w, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        if not (need_w or need_b):
+            return None, None, None, None
+        dev = directions.device
+        stream = _lib.current_stream(dev)
+        grad_out = grad_out.contiguous()
+        gw = torch.zeros_like(weight) if need_w else None
+        gb = torch.zeros(weight.shape[0], device=dev, dtype=torch.float32) if need_b else None
+        a = _lib.LpRayEmbedArgs()
+        a.n_rays, a.directions, a.n_harmonics, a.out_dim = directions.shape[0], _lib.ptr(directions), ctx.n_harmonics, weight.shape[0]
+        a.grad_out, a.grad_weight, a.grad_bias = _lib.ptr(grad_out), _lib.ptr(gw), _lib.ptr(gb)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().lp_ray_embedding_backward(ctypes.byref(a), stream), "lp_ray_embedding_backward")
+        return None, gw, gb, None
+
+
+def _fused_embedding_supported(n_harmonics: int, out_dim: int) -> bool:
+    # limits of lp_ray_embedding.hip (LDS staging of the backward)
+    return 0 <= n_harmonics <= 10 and 256 * (6 * n_harmonics + 3 + 1 + out_dim + 1) * 4 <= 150 * 1024
 
 
 class LightplaneRenderer(torch.nn.Module):
@@ -222,9 +276,14 @@ class LightplaneRenderer(torch.nn.Module):
         if not self.enable_direction_dependent_colors:
             return ray_directions.new_zeros(ray_directions.shape[0], self.rays_encoding_dim)
         assert self.ray_embedding_num_harmonics is not None
+        lin = self.harmonic_ray_embedding_linear
+        if (config.fused_module_ops and ray_directions.is_cuda and ray_directions.dtype == torch.float32
+                and not ray_directions.requires_grad
+                and _fused_embedding_supported(self.ray_embedding_num_harmonics, lin.weight.shape[0])):
+            return _RayEmbeddingFunction.apply(ray_directions, lin.weight, lin.bias, self.ray_embedding_num_harmonics)
         emb = calc_harmonic_embedding(torch.nn.functional.normalize(ray_directions, dim=-1),
                                       self.ray_embedding_num_harmonics)
-        return self.harmonic_ray_embedding_linear(emb)
+        return lin(emb)
 
     def _get_ray_encoding(self, ray_encoding, directions) -> torch.Tensor:
         if ray_encoding is not None:
@@ -272,8 +331,7 @@ class LightplaneRenderer(torch.nn.Module):
         if rays_jitter:
             r.near, r.far = jitter_near_far(r.near, r.far, num_samples)
 
-        ray_length, nlt, feature = lightplane_renderer(
-            r, feature_grid, self.get_decoder_params(),
+        kw = dict(
             num_samples=num_samples,
             gain=if_not_none_else(gain, self.gain),
             num_samples_inf=if_not_none_else(num_samples_inf, self.num_samples_inf),
@@ -285,6 +343,12 @@ class LightplaneRenderer(torch.nn.Module):
             scaffold=scaffold, color_grid=color_feature_grid, grid_sizes=grid_sizes,
             color_grid_sizes=color_grid_sizes,
         )
+        if config.fused_module_ops:
+            # background compositing and alpha inside the render kernel (and its backward): reference :552-561
+            ray_length, _, feature, alpha = _render(r, feature_grid, self.get_decoder_params(),
+                                                    bg_color=bg.to(torch.float32), alpha_mode=2 if return_log_t else 1, **kw)
+            return ray_length, alpha, feature
+        ray_length, nlt, feature = lightplane_renderer(r, feature_grid, self.get_decoder_params(), **kw)
         transmittance = torch.exp(-nlt)
         feature = feature + transmittance[..., None] * bg
         alpha = -nlt if return_log_t else 1 - transmittance

@@ -61,21 +61,28 @@ class _RendererCfg:
     scaffold_shape: Optional[Tuple[int, int, int, int]]
     kernel: int
     stop_neg_log_t: float = 0.0
+    n_grid_tensors: int = 1        # tensors the grid-list arrives in: 1 flat tensor, or one per grid (zero-copy list)
+    n_color_tensors: int = 0
+    grid_is_list: bool = False
+    alpha_mode: int = 0            # fused module epilogue: 0 none, 1 alpha = 1 - T, 2 log T
 
 
-def _fill_args(cfg: _RendererCfg, grid, color_grid, mlp_params, directions, origins, grid_idx, near, far,
+def _fill_args(cfg: _RendererCfg, grids, color_grids, mlp_params, directions, origins, grid_idx, near, far,
                encoding, scaffold) -> _lib.LpRendererArgs:
+    """``grids`` / ``color_grids``: tuples of tensors -- ONE flat ``[rows, C]`` tensor, or one ``[B, D, H, W, C]`` tensor
+    per grid (zero-copy grid-list: per-grid base pointers in the ABI)."""
     a = _lib.LpRendererArgs()
     a.rays = _lib.make_rays(directions, origins, grid_idx, near, far, encoding)
-    a.grid = _lib.make_grid_list(grid, cfg.descs, cfg.channels, cfg.n_rows)
+    a.grid = _lib.make_grid_list(list(grids) if cfg.grid_is_list else grids[0], cfg.descs, cfg.channels, cfg.n_rows)
     if cfg.color_descs is not None:
-        a.color_grid = _lib.make_grid_list(color_grid, cfg.color_descs, cfg.channels, cfg.color_n_rows)
+        a.color_grid = _lib.make_grid_list(list(color_grids) if cfg.grid_is_list else color_grids[0], cfg.color_descs,
+                                           cfg.channels, cfg.color_n_rows)
     else:
         a.color_grid = _lib.make_grid_list(None, [], 0, 0)
     if scaffold is not None:
         a.scaffold = _lib.ptr(scaffold)
         B, D, H, W = cfg.scaffold_shape
-        a.scaffold_shape = _lib.LpGrid(B, D, H, W, 0)
+        a.scaffold_shape = _lib.LpGrid(B, D, H, W, 0, None)
     a.march = _lib.make_march(cfg.num_samples, cfg.num_samples_inf, cfg.mask_out_of_bounds_samples,
                               cfg.contract_coords, cfg.disparity_at_inf)
     a.mlp_params = _lib.ptr(mlp_params)
@@ -90,6 +97,7 @@ def _fill_args(cfg: _RendererCfg, grid, color_grid, mlp_params, directions, orig
     a.noise_seed = ctypes.c_int32(int(cfg.noise_seed) & 0xFFFFFFFF).value
     a.kernel = cfg.kernel
     a.stop_neg_log_t = float(cfg.stop_neg_log_t)
+    a.alpha_mode = int(cfg.alpha_mode)
     return a
 
 
@@ -137,22 +145,32 @@ def kernel_family(rays: Rays, grid, decoder_params: DecoderParams, grid_sizes=No
 
 
 class LightplaneFunction(torch.autograd.Function):
-    """Autograd boundary of the Renderer (name kept from the reference, :296)."""
+    """Autograd boundary of the Renderer (name kept from the reference, :296).
+
+    The grid-list arrives as ``cfg.n_grid_tensors`` tensors (+ ``cfg.n_color_tensors`` for the colour grid-list): ONE
+    flat ``[rows, C]`` tensor, or one tensor PER GRID -- a list input is never concatenated (the reference's
+    ``flatten_grid``, misc_utils.py:42-45, copies the whole list every call and splits its gradient every backward):
+    the kernels take per-grid base pointers and write per-grid gradient buffers."""
 
     @staticmethod
-    def forward(ctx, grid, mlp_params, encoding, color_grid, cfg: _RendererCfg, directions, origins,
-                grid_idx, near, far, scaffold):
-        dev = grid.device
+    def forward(ctx, cfg: _RendererCfg, mlp_params, encoding, directions, origins, grid_idx, near, far, scaffold,
+                bg_color, *grid_tensors):
+        grids = tuple(g.contiguous() for g in grid_tensors[: cfg.n_grid_tensors])
+        color_grids = tuple(g.contiguous() for g in grid_tensors[cfg.n_grid_tensors:])
+        dev = grids[0].device
         stream = _lib.current_stream(dev)
-        grid, mlp_params, encoding = grid.contiguous(), mlp_params.contiguous(), encoding.contiguous()
-        color_grid = None if color_grid is None else color_grid.contiguous()
+        mlp_params, encoding = mlp_params.contiguous(), encoding.contiguous()
         n = directions.shape[0]
         ray_length = torch.empty(n, device=dev, dtype=torch.float32)
         nlt = torch.empty(n, device=dev, dtype=torch.float32)
         feature = torch.empty(n, cfg.color_chn, device=dev, dtype=torch.float32)
-        a = _fill_args(cfg, grid, color_grid, mlp_params, directions, origins, grid_idx, near, far, encoding,
+        alpha = torch.empty(n if cfg.alpha_mode else 0, device=dev, dtype=torch.float32)
+        a = _fill_args(cfg, grids, color_grids, mlp_params, directions, origins, grid_idx, near, far, encoding,
                        scaffold)
         a.ray_length, a.neg_log_t, a.feature = _lib.ptr(ray_length), _lib.ptr(nlt), _lib.ptr(feature)
+        if cfg.alpha_mode:
+            a.alpha = _lib.ptr(alpha)
+        a.bg_color = _lib.ptr(bg_color)
         # running -log T every LP_NLT_CKPT samples: O(N) state that keeps the backward's
         # transmittance reconstruction exact (the reference saves only the final value, :558-573)
         ckpt = torch.empty(n, _lib.n_nlt_ckpt(cfg.num_samples, cfg.num_samples_inf), device=dev, dtype=torch.float32)
@@ -161,46 +179,62 @@ class LightplaneFunction(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().lp_renderer_forward(ctypes.byref(a), stream), "lp_renderer_forward")
         # O(N) state only: the final -log T (the reference saves the same, :558-573)
-        ctx.save_for_backward(nlt, ckpt, grid, mlp_params, encoding, color_grid, directions, origins, grid_idx,
-                              near, far, scaffold)
+        ctx.save_for_backward(nlt, ckpt, mlp_params, encoding, directions, origins, grid_idx, near, far, scaffold,
+                              bg_color, *grids, *color_grids)
         ctx.cfg = cfg
-        return ray_length, nlt, feature
+        if not cfg.alpha_mode:
+            ctx.mark_non_differentiable(alpha)
+        return ray_length, nlt, feature, alpha
 
     @staticmethod
-    def backward(ctx, g_len, g_nlt, g_feat):
-        (nlt, ckpt, grid, mlp_params, encoding, color_grid, directions, origins, grid_idx, near, far,
-         scaffold) = ctx.saved_tensors
+    def backward(ctx, g_len, g_nlt, g_feat, g_alpha):
+        (nlt, ckpt, mlp_params, encoding, directions, origins, grid_idx, near, far, scaffold,
+         bg_color) = ctx.saved_tensors[:11]
         cfg: _RendererCfg = ctx.cfg
-        dev = grid.device
+        grids = ctx.saved_tensors[11: 11 + cfg.n_grid_tensors]
+        color_grids = ctx.saved_tensors[11 + cfg.n_grid_tensors:]
+        dev = grids[0].device
         stream = _lib.current_stream(dev)
-        need_grid, need_params, need_enc, need_cgrid = ctx.needs_input_grad[:4]
-        a = _fill_args(cfg, grid, color_grid, mlp_params, directions, origins, grid_idx, near, far, encoding,
+        need_params, need_enc = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        need_g = ctx.needs_input_grad[10: 10 + cfg.n_grid_tensors]
+        need_c = ctx.needs_input_grad[10 + cfg.n_grid_tensors:]
+        a = _fill_args(cfg, grids, color_grids, mlp_params, directions, origins, grid_idx, near, far, encoding,
                        scaffold)
         a.neg_log_t = _lib.ptr(nlt)
         a.neg_log_t_ckpt = _lib.ptr(ckpt)
+        a.bg_color = _lib.ptr(bg_color)
         g_len = None if g_len is None else g_len.contiguous()
         g_nlt = None if g_nlt is None else g_nlt.contiguous()
         g_feat = None if g_feat is None else g_feat.contiguous()
         a.grad_ray_length, a.grad_neg_log_t, a.grad_feature = _lib.ptr(g_len), _lib.ptr(g_nlt), _lib.ptr(g_feat)
-        grad_grid = torch.zeros_like(grid) if need_grid else None
+        if cfg.alpha_mode and g_alpha is not None:
+            g_alpha = g_alpha.contiguous()
+            a.grad_alpha = _lib.ptr(g_alpha)
+        # the kernels scatter into every grid of a list or into none: allocate all buffers if any grid needs one
+        grad_grids = [torch.zeros_like(g) for g in grids] if any(need_g) else None
+        grad_cgrids = [torch.zeros_like(g) for g in color_grids] if (color_grids and any(need_c)) else None
         grad_params = torch.zeros_like(mlp_params) if need_params else None
         grad_enc = torch.zeros_like(encoding) if need_enc else None
-        grad_cgrid = torch.zeros_like(color_grid) if (need_cgrid and color_grid is not None) else None
-        a.grad_grid, a.grad_mlp_params = _lib.ptr(grad_grid), _lib.ptr(grad_params)
-        a.grad_encoding, a.grad_color_grid = _lib.ptr(grad_enc), _lib.ptr(grad_cgrid)
-        replicas = None
-        if need_grid:
-            n_rep = int(config.grad_replicas)
-            if n_rep > 0:
-                replicas = torch.zeros(n_rep, grid.numel(), device=dev, dtype=torch.float32)
-                a.grad_grid_replicas, a.n_grad_replicas = _lib.ptr(replicas), n_rep
+        if grad_grids is not None:
+            if cfg.grid_is_list:
+                _lib.fill_ptr_list(a.grad_grid_list, grad_grids)
+            else:
+                a.grad_grid = _lib.ptr(grad_grids[0])
+        if grad_cgrids is not None:
+            if cfg.grid_is_list:
+                _lib.fill_ptr_list(a.grad_color_grid_list, grad_cgrids)
+            else:
+                a.grad_color_grid = _lib.ptr(grad_cgrids[0])
+        a.grad_mlp_params, a.grad_encoding = _lib.ptr(grad_params), _lib.ptr(grad_enc)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().lp_renderer_backward(ctypes.byref(a), stream), "lp_renderer_backward")
         if config.check_finite_grads:
-            for name, g in (("grid", grad_grid), ("mlp_params", grad_params), ("encoding", grad_enc),
-                            ("color_grid", grad_cgrid)):
+            for name, g in [("mlp_params", grad_params), ("encoding", grad_enc)] + \
+                    [("grid", g) for g in (grad_grids or [])] + [("color_grid", g) for g in (grad_cgrids or [])]:
                 assert g is None or torch.isfinite(g).all(), f"non-finite gradient w.r.t. {name}"
-        return (grad_grid, grad_params, grad_enc, grad_cgrid) + (None,) * 7
+        gg = [None] * cfg.n_grid_tensors if grad_grids is None else [g if nd else None for g, nd in zip(grad_grids, need_g)]
+        gc = [None] * cfg.n_color_tensors if grad_cgrids is None else [g if nd else None for g, nd in zip(grad_cgrids, need_c)]
+        return (None, grad_params, grad_enc) + (None,) * 7 + tuple(gg) + tuple(gc)
 
 
 def _decoder_dims(decoder_params: DecoderParams):
@@ -254,6 +288,19 @@ def lightplane_renderer(
     ``stop_transmittance`` (times depth / colour) and the returned negative log transmittance is the value
     reached at the stop (``>= -log(stop_transmittance)``), i.e. alpha is exact to ``stop_transmittance``.
     """
+    out = _render(rays, grid, decoder_params, num_samples, gain, num_samples_inf, mask_out_of_bounds_samples,
+                  contract_coords, disparity_at_inf, inject_noise_sigma, inject_noise_seed, scaffold, color_grid,
+                  grid_sizes, color_grid_sizes, kernel, stop_transmittance)
+    return out[0], out[1], out[2]
+
+
+def _render(rays: Rays, grid, decoder_params: DecoderParams, num_samples, gain, num_samples_inf=0,
+            mask_out_of_bounds_samples=False, contract_coords=False, disparity_at_inf=1e-5, inject_noise_sigma=0.0,
+            inject_noise_seed=None, scaffold=None, color_grid=None, grid_sizes=None, color_grid_sizes=None,
+            kernel=_lib.LP_KERNEL_AUTO, stop_transmittance=None, bg_color=None, alpha_mode=0):
+    """``lightplane_renderer`` plus the module front-end's fused epilogue: returns ``(ray_length, neg_log_t, feature,
+    alpha)``; with ``bg_color [color_chn]`` the feature is composited over it (``+ T * bg``), with ``alpha_mode`` 1 / 2
+    ``alpha`` is ``1 - T`` / ``log T`` (empty tensor otherwise) -- reference renderer_module.py:552-561, in-kernel."""
     if stop_transmittance is None:
         stop_transmittance = config.stop_transmittance
     stop_transmittance = float(stop_transmittance or 0.0)
@@ -261,16 +308,31 @@ def lightplane_renderer(
     stop_neg_log_t = -math.log(stop_transmittance) if stop_transmittance > 0.0 else 0.0
     grid, color_grid, grid_sizes, color_grid_sizes = check_grid_and_color_grid(
         grid, color_grid, grid_sizes, color_grid_sizes)
-    grid, color_grid, grid_sizes, color_grid_sizes = process_and_flatten_grid(
-        grid, color_grid, grid_sizes, color_grid_sizes)
+    grid_is_list = isinstance(grid, (list, tuple))
+    if grid_is_list:
+        # zero-copy grid-list: the tensors go to the kernels as they are (per-grid base pointers); the reference
+        # (and round 1) concatenated the list into one flat tensor on every call (misc_utils.py:42-45)
+        grid_tensors = tuple(grid)
+        grid_sizes = [list(g.shape) for g in grid_tensors]
+        color_tensors = tuple(color_grid) if color_grid is not None else ()
+        color_grid_sizes = [list(g.shape) for g in color_tensors] if color_grid is not None else None
+        for g in grid_tensors + color_tensors:
+            assert g.ndim == 5, "every grid of a grid-list has to be [B, D, H, W, C]"
+    else:
+        grid, color_grid, grid_sizes, color_grid_sizes = process_and_flatten_grid(
+            grid, color_grid, grid_sizes, color_grid_sizes)
+        grid_tensors = (grid,)
+        color_tensors = (color_grid,) if color_grid is not None else ()
     descs, channels, n_rows = make_grid_descs(grid_sizes)
-    assert grid.ndim == 2 and grid.shape[1] == channels and grid.shape[0] == n_rows, (
-        "flat grid tensor does not match grid_sizes")
+    if not grid_is_list:
+        assert grid.ndim == 2 and grid.shape[1] == channels and grid.shape[0] == n_rows, (
+            "flat grid tensor does not match grid_sizes")
     color_descs, color_n_rows = None, 0
     if color_grid is not None:
         color_descs, c_channels, color_n_rows = make_grid_descs(color_grid_sizes)
         assert c_channels == channels and color_descs[0].B == descs[0].B
-        assert color_grid.ndim == 2 and color_grid.shape == (color_n_rows, channels)
+        if not grid_is_list:
+            assert color_grid.ndim == 2 and color_grid.shape == (color_n_rows, channels)
 
     if mask_out_of_bounds_samples and contract_coords:
         warnings.warn(
@@ -289,12 +351,12 @@ def lightplane_renderer(
     assert rays.encoding is not None, "rays.encoding is required by the functional renderer"
     assert rays.encoding.shape[1] == dims_c[0], "ray_encoding should have the same dimension as dim_in_color"
     # every raw pointer handed to the kernels: same GPU as the grid, fp32 where the kernels read floats
-    _lib.check_tensors(
-        grid.device,
-        {"grid": grid, "color_grid": color_grid, "decoder_params.mlp_params": mlp_params,
-         "rays.directions": rays.directions, "rays.origins": rays.origins, "rays.near": rays.near,
-         "rays.far": rays.far, "rays.encoding": rays.encoding},
-        {"rays.grid_idx": rays.grid_idx, "scaffold": scaffold})
+    dev = grid_tensors[0].device
+    f32 = {"decoder_params.mlp_params": mlp_params, "rays.directions": rays.directions, "rays.origins": rays.origins,
+           "rays.near": rays.near, "rays.far": rays.far, "rays.encoding": rays.encoding, "bg_color": bg_color}
+    f32.update({f"grid[{i}]": g for i, g in enumerate(grid_tensors)})
+    f32.update({f"color_grid[{i}]": g for i, g in enumerate(color_tensors)})
+    _lib.check_tensors(dev, f32, {"rays.grid_idx": rays.grid_idx, "scaffold": scaffold})
 
     if inject_noise_sigma > 0.0:
         if inject_noise_seed is None:
@@ -315,6 +377,9 @@ def lightplane_renderer(
         assert scaffold.ndim == 4 and scaffold.shape[0] == B, "scaffold has to be [B, D, H, W]"
         scaffold_shape = tuple(int(v) for v in scaffold.shape)
         scaffold = scaffold.to(torch.float32).contiguous()
+    if bg_color is not None:
+        assert bg_color.ndim == 1 and bg_color.numel() == int(decoder_params.color_chn)
+        bg_color = bg_color.contiguous()
 
     cfg = _RendererCfg(
         descs=descs, channels=channels, n_rows=n_rows, color_descs=color_descs, color_n_rows=color_n_rows,
@@ -323,13 +388,12 @@ def lightplane_renderer(
         mask_out_of_bounds_samples=bool(mask_out_of_bounds_samples), contract_coords=bool(contract_coords),
         disparity_at_inf=float(disparity_at_inf), noise_sigma=float(inject_noise_sigma),
         noise_seed=int(inject_noise_seed), scaffold_shape=scaffold_shape, kernel=int(kernel),
-        stop_neg_log_t=stop_neg_log_t,
+        stop_neg_log_t=stop_neg_log_t, n_grid_tensors=len(grid_tensors), n_color_tensors=len(color_tensors),
+        grid_is_list=grid_is_list, alpha_mode=int(alpha_mode),
     )
     return LightplaneFunction.apply(
-        grid, mlp_params, rays.encoding, color_grid, cfg,
-        rays.directions.contiguous(), rays.origins.contiguous(), grid_idx, rays.near.contiguous(),
-        rays.far.contiguous(), scaffold,
-    )
+        cfg, mlp_params, rays.encoding, rays.directions.contiguous(), rays.origins.contiguous(), grid_idx,
+        rays.near.contiguous(), rays.far.contiguous(), scaffold, bg_color, *grid_tensors, *color_tensors)
 
 
 def renderer_corner_rows(rays: Rays, grid_sizes, num_samples: int, num_samples_inf: int = 0,

@@ -48,6 +48,8 @@ class _SplatterCfg:
     in_n_rows: int = 0
     mlp_dims: Optional[List[int]] = None
     kernel: int = 0
+    in_is_list: bool = False   # the input grid-list arrives as one tensor per grid (zero-copy) instead of a flat tensor
+    n_in_tensors: int = 1
 
 
 def _fill_args(cfg: _SplatterCfg, directions, origins, grid_idx, near, far, feature, mlp_params=None,
@@ -58,7 +60,8 @@ def _fill_args(cfg: _SplatterCfg, directions, origins, grid_idx, near, far, feat
                               cfg.contract_coords, cfg.disparity_at_inf)
     a.out = _lib.make_grid_list(None, cfg.descs, cfg.channels, cfg.n_rows)
     if cfg.mlp_dims is not None:
-        a.input_grid = _lib.make_grid_list(input_grid, cfg.in_descs, cfg.in_channels, cfg.in_n_rows)
+        a.input_grid = _lib.make_grid_list(list(input_grid) if cfg.in_is_list else input_grid[0], cfg.in_descs,
+                                           cfg.in_channels, cfg.in_n_rows)
         a.mlp_params = _lib.ptr(mlp_params)
         a.n_mlp_params = mlp_params.numel()
         a.mlp = _lib.make_mlp(cfg.mlp_dims, 0)
@@ -112,16 +115,18 @@ class LightplaneSplatterFunction(torch.autograd.Function):
 
 class LightplaneMLPSplatterFunction(torch.autograd.Function):
     """Autograd boundary of the MLP-Splatter (the reference routes both variants through
-    ``LightplaneSplatterFunction``, lightplane_splatter.py:341-700; the MLP path is :440-501, :608-700)."""
+    ``LightplaneSplatterFunction``, lightplane_splatter.py:341-700; the MLP path is :440-501, :608-700).  The input
+    grid-list arrives as one flat tensor or as one tensor per grid (never concatenated, see ``LpGrid.data``)."""
 
     @staticmethod
-    def forward(ctx, feature, mlp_params, input_grid, cfg: _SplatterCfg, directions, origins, grid_idx, near, far):
+    def forward(ctx, feature, mlp_params, cfg: _SplatterCfg, directions, origins, grid_idx, near, far, *input_grids):
         dev = feature.device
         stream = _lib.current_stream(dev)
-        feature, mlp_params, input_grid = feature.contiguous(), mlp_params.contiguous(), input_grid.contiguous()
+        feature, mlp_params = feature.contiguous(), mlp_params.contiguous()
+        input_grids = tuple(g.contiguous() for g in input_grids)
         out = torch.zeros(cfg.n_rows, cfg.channels, device=dev, dtype=torch.float32)
         weight = torch.zeros(cfg.n_rows, device=dev, dtype=torch.float32)
-        a = _fill_args(cfg, directions, origins, grid_idx, near, far, feature, mlp_params, input_grid)
+        a = _fill_args(cfg, directions, origins, grid_idx, near, far, feature, mlp_params, input_grids)
         a.out.data = _lib.ptr(out)
         a.out_feature, a.out_weight = _lib.ptr(out), _lib.ptr(weight)
         L = _lib.lib()
@@ -132,38 +137,45 @@ class LightplaneMLPSplatterFunction(torch.autograd.Function):
                 allreduce_sum_([out, weight], cfg.process_group)
             _lib.check(L.lp_splatter_normalize(out.data_ptr(), weight.data_ptr(), cfg.n_rows, cfg.channels, stream),
                        "lp_splatter_normalize")
-        ctx.save_for_backward(weight, feature, mlp_params, input_grid, directions, origins, grid_idx, near, far)
+        ctx.save_for_backward(weight, feature, mlp_params, directions, origins, grid_idx, near, far, *input_grids)
         ctx.cfg = cfg
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        weight, feature, mlp_params, input_grid, directions, origins, grid_idx, near, far = ctx.saved_tensors
+        weight, feature, mlp_params, directions, origins, grid_idx, near, far = ctx.saved_tensors[:8]
+        input_grids = ctx.saved_tensors[8:]
         cfg: _SplatterCfg = ctx.cfg
-        need_feat, need_params, need_grid = ctx.needs_input_grad[:3]
-        if not (need_feat or need_params or need_grid):
-            return (None,) * 9
+        need_feat, need_params = ctx.needs_input_grad[:2]
+        need_grids = ctx.needs_input_grad[8:]
+        if not (need_feat or need_params or any(need_grids)):
+            return (None,) * (8 + len(input_grids))
         dev = feature.device
         stream = _lib.current_stream(dev)
         grad_out = grad_out.contiguous()
         grad_feature = torch.zeros_like(feature) if need_feat else None
         grad_params = torch.zeros_like(mlp_params) if need_params else None
-        grad_in = torch.zeros_like(input_grid) if need_grid else None
-        a = _fill_args(cfg, directions, origins, grid_idx, near, far, feature, mlp_params, input_grid)
+        grad_in = [torch.zeros_like(g) for g in input_grids] if any(need_grids) else None
+        a = _fill_args(cfg, directions, origins, grid_idx, near, far, feature, mlp_params, input_grids)
         a.grad_out, a.weight = _lib.ptr(grad_out), _lib.ptr(weight)
-        a.grad_encoding, a.grad_mlp_params, a.grad_input_grid = (
-            _lib.ptr(grad_feature), _lib.ptr(grad_params), _lib.ptr(grad_in))
+        a.grad_encoding, a.grad_mlp_params = _lib.ptr(grad_feature), _lib.ptr(grad_params)
+        if grad_in is not None:
+            if cfg.in_is_list:
+                _lib.fill_ptr_list(a.grad_input_grid_list, grad_in)
+            else:
+                a.grad_input_grid = _lib.ptr(grad_in[0])
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().lp_splatter_backward(ctypes.byref(a), stream), "lp_splatter_backward")
         if cfg.process_group is not None:
             # ray-sharded MLP-Splatter: the MLP / input-grid gradients are partial sums over this rank's rays
             # (SURVEY.md 8(e)); grad_feature belongs to the local rays and stays local
             from .parallel import allreduce_sum_
-            allreduce_sum_([grad_params, grad_in], cfg.process_group)
+            allreduce_sum_([grad_params] + (grad_in or []), cfg.process_group)
         if config.check_finite_grads:
-            for g in (grad_feature, grad_params, grad_in):
+            for g in [grad_feature, grad_params] + (grad_in or []):
                 assert g is None or torch.isfinite(g).all()
-        return (grad_feature, grad_params, grad_in) + (None,) * 6
+        gi = [None] * len(input_grids) if grad_in is None else [g if nd else None for g, nd in zip(grad_in, need_grids)]
+        return (grad_feature, grad_params) + (None,) * 6 + tuple(gi)
 
 
 def _prep_rays(rays: Rays, B: int):
@@ -254,13 +266,20 @@ def lightplane_mlp_splatter(
         "mlp depth has to be bigger than 1 when using input_grid")
     assert input_grid is not None, "input_grid cannot be None when mlp_params is not None"
     check_grid(input_grid, input_grid_sizes)
-    input_grid, _, input_grid_sizes, _ = process_and_flatten_grid(input_grid, None, input_grid_sizes, None)
+    in_is_list = isinstance(input_grid, (list, tuple))
+    if in_is_list:  # zero-copy: one tensor per grid goes to the kernels as it is
+        in_tensors = tuple(input_grid)
+        input_grid_sizes = [list(g.shape) for g in in_tensors]
+    else:
+        input_grid, _, input_grid_sizes, _ = process_and_flatten_grid(input_grid, None, input_grid_sizes, None)
+        in_tensors = (input_grid,)
     in_descs, in_channels, in_n_rows = make_grid_descs(input_grid_sizes)
-    assert input_grid.ndim == 2 and input_grid.shape == (in_n_rows, in_channels), (
-        "flat input grid tensor does not match input_grid_sizes")
+    if not in_is_list:
+        assert input_grid.ndim == 2 and input_grid.shape == (in_n_rows, in_channels), (
+            "flat input grid tensor does not match input_grid_sizes")
     dims = int_list_of(mlp_params.n_hidden)
     assert rays.encoding is not None, "rays.encoding is required"
-    assert rays.encoding.dtype == torch.float32 and input_grid.dtype == torch.float32
+    assert rays.encoding.dtype == torch.float32
     assert dims[0] == in_channels == rays.encoding.shape[1], (
         f"MLP input width {dims[0]} must equal the input grid channels {in_channels} and the ray encoding "
         f"width {rays.encoding.shape[1]}")
@@ -271,12 +290,14 @@ def lightplane_mlp_splatter(
     from .params import mlp_numel
     assert flat_params.numel() == mlp_numel(dims), (
         f"The number of elements in mlp param should be {mlp_numel(dims)}. Got {flat_params.numel()} instead.")
-    _lib.check_tensors(rays.encoding.device, {"input_grid": input_grid, "mlp_params.mlp_params": flat_params})
+    f32 = {"mlp_params.mlp_params": flat_params}
+    f32.update({f"input_grid[{i}]": g for i, g in enumerate(in_tensors)})
+    _lib.check_tensors(rays.encoding.device, f32)
     cfg = _SplatterCfg(descs, channels, n_rows, int(num_samples), int(num_samples_inf),
                        bool(mask_out_of_bounds_samples), bool(contract_coords), float(disparity_at_inf),
-                       process_group, in_descs, in_channels, in_n_rows, dims, int(kernel))
-    out = LightplaneMLPSplatterFunction.apply(rays.encoding, flat_params, input_grid, cfg,
-                                              *_prep_rays(rays, descs[0].B))
+                       process_group, in_descs, in_channels, in_n_rows, dims, int(kernel), in_is_list, len(in_tensors))
+    out = LightplaneMLPSplatterFunction.apply(rays.encoding, flat_params, cfg, *_prep_rays(rays, descs[0].B),
+                                              *in_tensors)
     if return_list:
         return list(unflatten_grid(out, sizes))
     return out

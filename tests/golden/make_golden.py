@@ -105,6 +105,55 @@ def make_splatter(case):
     return rec
 
 
+# ---- Module level: the reference's LightplaneRenderer / LightplaneMLPSplatter modules on CPU with
+# use_naive_impl=True (renderer_module.py:419-563, splatter_module.py:164-331): harmonic ray embedding + Linear ->
+# render -> background / alpha, outputs and the gradients of every parameter.
+from tests.synth import MODULE_RENDERER_CASES, module_renderer_inputs  # noqa: E402
+
+
+def make_module_renderer(name):
+    spec = MODULE_RENDERER_CASES[name]
+    sizes, grids, rays, up, pgen = module_renderer_inputs(spec)
+    mod = ref.LightplaneRenderer(use_naive_impl=True, **spec["ctor"])
+    with torch.no_grad():
+        mod.mlp_params.copy_(torch.randn(mod.mlp_params.shape, generator=pgen) * 0.2)
+        mod.harmonic_ray_embedding_linear.weight.copy_(torch.randn(mod.harmonic_ray_embedding_linear.weight.shape, generator=pgen) * 0.3)
+        mod.harmonic_ray_embedding_linear.bias.copy_(torch.randn(mod.harmonic_ray_embedding_linear.bias.shape, generator=pgen) * 0.1)
+    gs = [g.clone().requires_grad_(True) for g in grids]
+    r = ref.Rays(directions=rays.directions, origins=rays.origins, grid_idx=rays.grid_idx, near=rays.near, far=rays.far)
+    out = mod(r, gs)
+    (sum((o * u).sum() for o, u in zip(out, up))).backward()
+    rec = {f"state__{k}": _np(v) for k, v in mod.state_dict().items()}
+    rec.update(ray_length=_np(out[0]), alpha=_np(out[1]), feature=_np(out[2]),
+               grad_mlp_params=_np(mod.mlp_params.grad),
+               grad_linear_weight=_np(mod.harmonic_ray_embedding_linear.weight.grad),
+               grad_linear_bias=_np(mod.harmonic_ray_embedding_linear.bias.grad))
+    for i, g in enumerate(gs):
+        rec[f"grad_grid{i}"] = _np(g.grad)
+    return rec
+
+
+def make_module_splatter():
+    """LightplaneSplatter module (splatter_module.py:25-161).  (The reference's LightplaneMLPSplatter cannot run with
+    use_naive_impl=True: its forward hands mlp_params to lightplane_splatter_naive, splatter_module.py:316-329, which
+    has no such argument -- the MLP variant is pinned through the functional goldens instead.)"""
+    from tests.synth import grid_sizes_for, random_rays
+    gen = torch.Generator().manual_seed(41)
+    mod = ref.LightplaneSplatter(num_samples=9, grid_chn=16, mask_out_of_bounds_samples=True, use_naive_impl=True)
+    rays = random_rays(gen, 40, 2, 16)
+    enc = torch.rand(40, 16, generator=gen).requires_grad_(True)
+    r = ref.Rays(directions=rays.directions, origins=rays.origins, grid_idx=rays.grid_idx, near=rays.near, far=rays.far,
+                 encoding=enc)
+    out_sizes = grid_sizes_for((2, 6, 5, 7, 16), True)
+    out = mod(r, out_sizes)
+    up = [torch.randn(*s, generator=gen) for s in out_sizes]
+    sum((o * u).sum() for o, u in zip(out, up)).backward()
+    rec = dict(grad_encoding=_np(enc.grad))
+    for i, o in enumerate(out):
+        rec[f"out{i}"] = _np(o)
+    return rec
+
+
 def make_randn():
     rec = {}
     for seed in (0, 5, 123456):
@@ -116,9 +165,20 @@ def make_randn():
     return rec
 
 
+def make_modules():
+    for name in MODULE_RENDERER_CASES:
+        np.savez_compressed(os.path.join(HERE, f"module_renderer__{name}.npz"), **make_module_renderer(name))
+        print("module renderer", name)
+    np.savez_compressed(os.path.join(HERE, "module_splatter.npz"), **make_module_splatter())
+    print("module splatter")
+
+
 def main():
     torch.manual_seed(0)
     only = set(sys.argv[1:])  # optional: case names to (re)generate; default = all
+    if only == {"modules"}:
+        make_modules()
+        return
     if only:
         for case in RENDERER_CASES:
             if case.name in only:
@@ -138,6 +198,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"splatter__{case.name}.npz"), **rec)
         print("splatter", case.name, rec["out0"].shape)
     np.savez_compressed(os.path.join(HERE, "randn.npz"), **make_randn())
+    make_modules()
     print("done")
 
 

@@ -278,3 +278,29 @@ SPLATTER_CASES = [
     SplatterCase("mlp2_voxel_in16_out32", seed=9, use_mlp=True, n_layers=2, feat_dim=16, in_base=(2, 4, 6, 5, 16),
                  contract=True, num_samples_inf=3, n_rays=33),
 ]
+
+
+# ---- Module level: configurations of the reference's LightplaneRenderer module whose outputs and
+# parameter gradients are pinned in tests/golden/module_renderer__*.npz (made by tests/golden/make_golden.py from the
+# reference module with use_naive_impl=True)
+MODULE_RENDERER_CASES = {
+    "triplane_c16_alpha": dict(ctor=dict(num_samples=17, color_chn=3, grid_chn=16, mlp_hidden_chn=32, bg_color=0.3, gain=2.0,
+                                         opacity_init_bias=-1.0, ray_embedding_num_harmonics=3),
+                               grid_base=(2, 6, 5, 7, 16), triplane=True, n_rays=70, seed=31),
+    "voxel_c32_logt_mask": dict(ctor=dict(num_samples=11, color_chn=3, grid_chn=32, mlp_hidden_chn=32, bg_color=(0.1, 0.5, 0.9),
+                                          gain=3.0, opacity_init_bias=-0.5, ray_embedding_num_harmonics=2,
+                                          return_log_transmittance=True, mask_out_of_bounds_samples=True, num_samples_inf=2),
+                                grid_base=(1, 5, 6, 4, 32), triplane=False, n_rays=45, seed=32),
+}
+
+
+def module_renderer_inputs(spec):
+    """(grid sizes, grids, rays without encoding, upstream gradients, generator for the module parameters)."""
+    gen = torch.Generator().manual_seed(spec["seed"])
+    sizes = grid_sizes_for(spec["grid_base"], spec["triplane"])
+    grids = [0.7 * g for g in random_grids(gen, sizes)]
+    rays = random_rays(gen, spec["n_rays"], spec["grid_base"][0], None)
+    n = spec["n_rays"]
+    up = (torch.randn(n, generator=gen), torch.randn(n, generator=gen), torch.randn(n, 3, generator=gen))
+    pgen = torch.Generator().manual_seed(spec["seed"] + 1000)
+    return sizes, grids, rays, up, pgen

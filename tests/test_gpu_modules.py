@@ -1,0 +1,235 @@
+"""GPU tests of the module front-ends and of ABI 0.2's additions: module-level parity against fixtures made by the
+REFERENCE's own modules, the fused ray-embedding kernels and bg / alpha epilogue (f3), zero-copy
+grid-lists (f4), and the ray-sharded path driven through the real autograd functions by two ranks on one GPU."""
+import copy
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import lightplane_amd as lp
+from lightplane_amd import _lib, grids as lp_grids
+from lightplane_amd.modules import _RayEmbeddingFunction
+from tests.synth import (MODULE_RENDERER_CASES, RENDERER_CASES, SPLATTER_CASES, grid_sizes_for, module_renderer_inputs,
+                         random_rays)
+from tests.test_gpu_parity import _assert_close, _dev, _rays_to, run_hip_mlp_splatter, run_hip_renderer
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build_module(spec, z, dev):
+    mod = lp.LightplaneRenderer(**spec["ctor"]).to(dev)
+    with torch.no_grad():
+        mod.mlp_params.copy_(torch.from_numpy(z["state__mlp_params"]).to(dev))
+        mod.harmonic_ray_embedding_linear.weight.copy_(torch.from_numpy(z["state__harmonic_ray_embedding_linear.weight"]).to(dev))
+        mod.harmonic_ray_embedding_linear.bias.copy_(torch.from_numpy(z["state__harmonic_ray_embedding_linear.bias"]).to(dev))
+    np.testing.assert_allclose(mod.bg_color.cpu().numpy(), z["state__bg_color"], rtol=0, atol=0)
+    return mod
+
+
+def _run_module(mod, spec, dev):
+    sizes, grids, rays, up, _ = module_renderer_inputs(spec)
+    gs = [g.to(dev).clone().requires_grad_(True) for g in grids]
+    out = mod(_rays_to(rays, dev), gs)
+    mod.zero_grad()
+    sum((o * u.to(dev)).sum() for o, u in zip(out, up)).backward()
+    return out, gs
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "torch_ops"])
+@pytest.mark.parametrize("name", list(MODULE_RENDERER_CASES))
+def test_module_renderer_matches_reference_module(name, fused, golden_dir):
+    """LightplaneRenderer.forward (harmonic embedding -> Linear -> render -> background / alpha) against numbers the
+    reference's LightplaneRenderer(use_naive_impl=True) produced (renderer_module.py:419-563): outputs and the gradients of
+    mlp_params, the embedding's Linear layer and the grids.  Both the fused path (2 launches) and the PyTorch op chain."""
+    dev = _dev()
+    spec = MODULE_RENDERER_CASES[name]
+    z = np.load(os.path.join(golden_dir, f"module_renderer__{name}.npz"))
+    old = lp.config.fused_module_ops
+    lp.config.fused_module_ops = fused
+    try:
+        mod = _build_module(spec, z, dev)
+        out, gs = _run_module(mod, spec, dev)
+    finally:
+        lp.config.fused_module_ops = old
+    for nm, o in zip(("ray_length", "alpha", "feature"), out):
+        _assert_close(f"{name}: {nm}", o, z[nm])
+    _assert_close(f"{name}: grad_mlp_params", mod.mlp_params.grad, z["grad_mlp_params"])
+    _assert_close(f"{name}: grad_linear_weight", mod.harmonic_ray_embedding_linear.weight.grad, z["grad_linear_weight"])
+    _assert_close(f"{name}: grad_linear_bias", mod.harmonic_ray_embedding_linear.bias.grad, z["grad_linear_bias"])
+    for i, g in enumerate(gs):
+        _assert_close(f"{name}: grad_grid{i}", g.grad, z[f"grad_grid{i}"])
+
+
+def test_module_splatter_matches_reference_module(golden_dir):
+    dev = _dev()
+    z = np.load(os.path.join(golden_dir, "module_splatter.npz"))
+    gen = torch.Generator().manual_seed(41)
+    mod = lp.LightplaneSplatter(num_samples=9, grid_chn=16, mask_out_of_bounds_samples=True)
+    rays = random_rays(gen, 40, 2, 16)
+    rays.encoding = torch.rand(40, 16, generator=gen)
+    out_sizes = grid_sizes_for((2, 6, 5, 7, 16), True)
+    up = [torch.randn(*s, generator=gen) for s in out_sizes]
+    r = _rays_to(rays, dev, True)
+    out = mod(r, out_sizes)
+    sum((o * u.to(dev)).sum() for o, u in zip(out, up)).backward()
+    for i, o in enumerate(out):
+        _assert_close(f"out{i}", o, z[f"out{i}"])
+    _assert_close("grad_encoding", r.encoding.grad, z["grad_encoding"])
+
+
+@pytest.mark.parametrize("n_h,e,n", [(3, 32, 1000), (0, 16, 257), (10, 64, 33), (2, 20, 5)])
+def test_ray_embedding_kernel_matches_torch_ops(n_h, e, n):
+    """lp_ray_embedding_{forward,backward} == Linear(calc_harmonic_embedding(normalize(d))) and its autograd gradients."""
+    dev = _dev()
+    gen = torch.Generator().manual_seed(n_h * 100 + e)
+    d = (torch.randn(n, 3, generator=gen) * torch.rand(n, 1, generator=gen) * 3).to(dev)
+    lin = torch.nn.Linear(3 + 6 * n_h, e).to(dev)
+    up = torch.randn(n, e, generator=gen).to(dev)
+    ref = lin(lp.calc_harmonic_embedding(torch.nn.functional.normalize(d, dim=-1), n_h))
+    (ref * up).sum().backward()
+    gw, gb = lin.weight.grad.clone(), lin.bias.grad.clone()
+    lin.zero_grad()
+    out = _RayEmbeddingFunction.apply(d, lin.weight, lin.bias, n_h)
+    (out * up).sum().backward()
+    _assert_close("embedding", out, ref.detach().cpu().numpy(), 2e-6)
+    _assert_close("grad weight", lin.weight.grad, gw.cpu().numpy(), 1e-5)
+    _assert_close("grad bias", lin.bias.grad, gb.cpu().numpy(), 1e-5)
+
+
+def test_grid_lists_are_zero_copy(monkeypatch):
+    """A list of grids reaches the kernels through per-grid base pointers (LpGrid.data): nothing is concatenated
+    (reference misc_utils.py:42-45 copies the list every call), the gradients are written into per-grid buffers, and the
+    results equal the flat-tensor input."""
+    dev = _dev()
+
+    def boom(*a, **k):
+        raise AssertionError("a grid-list was flattened (torch.cat) on the list path")
+
+    for case_name in ("triplane_plus_voxel", "colorgrid_c32_mixed", "triplane_h64_c32"):
+        d = next(c for c in RENDERER_CASES if c.name == case_name).build()
+        for kernel in (_lib.LP_KERNEL_GENERIC, _lib.LP_KERNEL_AUTO):
+            # flat input first (flatten_grid is the user's explicit call here)
+            rays = _rays_to(d["rays"], dev, True)
+            dec = d["decoder"]
+            params = dec.mlp_params.to(dev).clone().requires_grad_(True)
+            hdec = lp.DecoderParams(params, dec.n_hidden_trunk, dec.n_hidden_opacity, dec.n_hidden_color, dec.color_chn)
+            flat, sizes = lp.flatten_grid([g.to(dev) for g in d["grids"]])
+            flat = flat.clone().requires_grad_(True)
+            cflat, csizes = None, None
+            if d["color_grids"] is not None:
+                cflat, csizes = lp.flatten_grid([g.to(dev) for g in d["color_grids"]])
+                cflat = cflat.clone().requires_grad_(True)
+                csizes = csizes.tolist()
+            scaffold = None if d["scaffold"] is None else d["scaffold"].to(dev)
+            out_f = lp.lightplane_renderer(rays, flat, hdec, grid_sizes=sizes.tolist(), color_grid=cflat,
+                                           color_grid_sizes=csizes, scaffold=scaffold, kernel=kernel, **d["cfg"])
+            g_len, g_nlt, g_feat = (t.to(dev) for t in d["upstream"])
+            ((out_f[0] * g_len).sum() + (out_f[1] * g_nlt).sum() + (out_f[2] * g_feat).sum()).backward()
+            # list input with the flattening helpers booby-trapped
+            with monkeypatch.context() as m:
+                m.setattr(lp_grids, "_flatten_only", boom)
+                m.setattr(lp_grids, "flatten_grid", boom)
+                out_l, gp, ge, gg, gc = run_hip_renderer(d, dev, kernel)
+            for a, b in zip(out_l, out_f):
+                assert torch.equal(a, b), f"{case_name}: list and flat inputs give different outputs"
+            want = torch.cat([g.reshape(-1, g.shape[-1]) for g in gg], dim=0)
+            _assert_close(f"{case_name}: grid grads (list vs flat)", flat.grad, want.cpu().numpy(), 2e-5)
+            if gc is not None:
+                want = torch.cat([g.reshape(-1, g.shape[-1]) for g in gc], dim=0)
+                _assert_close(f"{case_name}: colour grid grads (list vs flat)", cflat.grad, want.cpu().numpy(), 2e-5)
+            _assert_close(f"{case_name}: params grads", params.grad, gp.cpu().numpy(), 2e-5)
+    # MLP-Splatter input grid-list
+    ds = next(c for c in SPLATTER_CASES if c.name == "mlp2_triplane_c16").build()
+    with monkeypatch.context() as m:
+        m.setattr(lp_grids, "_flatten_only", boom)
+        out, ge, gp, gin = run_hip_mlp_splatter(ds, dev)
+    rays = _rays_to(ds["rays"], dev, True)
+    flat, sizes = lp.flatten_grid([g.to(dev) for g in ds["in_grids"]])
+    flat = flat.clone().requires_grad_(True)
+    mlp = lp.SplatterParams(ds["mlp"].mlp_params.to(dev).clone().requires_grad_(True), ds["mlp"].n_hidden)
+    out_f = lp.lightplane_mlp_splatter(rays, ds["out_sizes"], mlp, flat, input_grid_sizes=sizes.tolist(), **ds["cfg"])
+    sum((o * u.to(dev)).sum() for o, u in zip(out_f, ds["upstream"])).backward()
+    for a, b in zip(out, out_f):
+        _assert_close("mlp-splatter out (list vs flat)", a, b.detach().cpu().numpy(), 2e-6)
+    want = torch.cat([g.reshape(-1, g.shape[-1]) for g in gin], dim=0)
+    _assert_close("mlp-splatter input grid grads (list vs flat)", flat.grad, want.cpu().numpy(), 2e-5)
+
+
+def test_fused_epilogue_matches_torch_ops_with_grads():
+    """Background compositing + alpha inside the render kernel and its backward == the PyTorch op chain, all gradient
+    families, for both alpha flavours and both kernel selections (cases of different kernel families)."""
+    dev = _dev()
+    from lightplane_amd.renderer import _render
+    for case_name in ("triplane_basic", "voxel_deep", "triplane_h64_c32", "voxel_inf_contract"):
+        d = next(c for c in RENDERER_CASES if c.name == case_name).build()
+        n, cc = d["rays"].n_rays, d["decoder"].color_chn
+        gen = torch.Generator().manual_seed(5)
+        bg = torch.rand(cc, generator=gen).to(dev)
+        g_alpha = torch.randn(n, generator=gen).to(dev)
+        g_len, _, g_feat = (t.to(dev) for t in d["upstream"])
+        for mode in (1, 2):
+            res = []
+            for fused in (True, False):
+                rays = _rays_to(d["rays"], dev, True)
+                dec = d["decoder"]
+                params = dec.mlp_params.to(dev).clone().requires_grad_(True)
+                hdec = lp.DecoderParams(params, dec.n_hidden_trunk, dec.n_hidden_opacity, dec.n_hidden_color, cc)
+                gs = [g.to(dev).clone().requires_grad_(True) for g in d["grids"]]
+                if fused:
+                    ray_length, _, feature, alpha = _render(rays, gs, hdec, bg_color=bg, alpha_mode=mode, **d["cfg"])
+                else:
+                    ray_length, nlt, feature = lp.lightplane_renderer(rays, gs, hdec, **d["cfg"])
+                    t = torch.exp(-nlt)
+                    feature = feature + t[:, None] * bg
+                    alpha = -nlt if mode == 2 else 1 - t
+                ((ray_length * g_len).sum() + (alpha * g_alpha).sum() + (feature * g_feat).sum()).backward()
+                res.append((ray_length, alpha, feature, params.grad, rays.encoding.grad, [g.grad for g in gs]))
+            (l0, a0, f0, p0, e0, g0), (l1, a1, f1, p1, e1, g1) = res
+            _assert_close(f"{case_name}/{mode}: alpha", a0, a1.detach().cpu().numpy(), 2e-6)
+            _assert_close(f"{case_name}/{mode}: feature", f0, f1.detach().cpu().numpy(), 2e-6)
+            _assert_close(f"{case_name}/{mode}: grad params", p0, p1.cpu().numpy(), 3e-5)
+            _assert_close(f"{case_name}/{mode}: grad encoding", e0, e1.cpu().numpy(), 3e-5)
+            for x, y in zip(g0, g1):
+                _assert_close(f"{case_name}/{mode}: grad grid", x, y.cpu().numpy(), 3e-5)
+
+
+def test_device_and_dtype_checks_raise_python_errors():
+    """A CPU-resident mlp_params (LightplaneRenderer builds its parameters on the CPU: a forgotten .to(device)), rays on
+    the CPU or float64 geometry raise AssertionError before any launch instead of faulting the GPU."""
+    dev = _dev()
+    d = RENDERER_CASES[0].build()
+    dec = d["decoder"]
+    rays = _rays_to(d["rays"], dev)
+    grids = [g.to(dev) for g in d["grids"]]
+    with pytest.raises(AssertionError, match="mlp_params"):
+        lp.lightplane_renderer(rays, grids, dec, **d["cfg"])  # dec.mlp_params is on the CPU
+    hdec = lp.DecoderParams(dec.mlp_params.to(dev), dec.n_hidden_trunk, dec.n_hidden_opacity, dec.n_hidden_color, dec.color_chn)
+    with pytest.raises(AssertionError, match="rays"):
+        lp.lightplane_renderer(d["rays"], grids, hdec, **d["cfg"])  # rays on the CPU
+    r64 = copy.copy(rays)
+    r64.origins = rays.origins.double()
+    with pytest.raises(AssertionError, match="float32"):
+        lp.lightplane_renderer(r64, grids, hdec, **d["cfg"])
+    ds = SPLATTER_CASES[0].build()
+    rs = _rays_to(ds["rays"], dev)
+    rs.near = ds["rays"].near  # CPU
+    with pytest.raises(AssertionError, match="near"):
+        lp.lightplane_splatter(rs, ds["out_sizes"], **ds["cfg"])
+
+
+def test_two_rank_ray_shards_equal_single_process():
+    """The multi-GPU path end to end with the REAL autograd functions: two ranks (gloo, both on this GPU) each render /
+    splat half of the rays; the all-reduced gradients / the all-reduced splat equal the single-process result."""
+    worker = os.path.join(ROOT, "tests", "dist_worker.py")
+    port = 29600 + (os.getpid() % 300)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), worker],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "DIST_OK" in out, out[-4000:]

@@ -13,7 +13,7 @@ from lightplane_amd import _lib, grids, params
 
 def test_library_loads_and_exports_every_declared_symbol():
     L = _lib.lib()
-    assert L.lp_version() == 110
+    assert L.lp_version() == 200
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "lightplane_hip.h")).read()
     declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(lp_[a-z_0-9]+)\s*\(", hdr, flags=re.M))
     assert declared == set(_lib.EXPORTS), f"header vs binding mismatch: {declared ^ set(_lib.EXPORTS)}"
@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_abi_struct_sizes_match():
     L = _lib.lib()
     for which, st in enumerate((_lib.LpGrid, _lib.LpGridList, _lib.LpRays, _lib.LpMarch, _lib.LpMlp,
-                                _lib.LpRendererArgs, _lib.LpSplatterArgs)):
+                                _lib.LpRendererArgs, _lib.LpSplatterArgs, _lib.LpRayEmbedArgs)):
         assert L.lp_abi_sizeof(which) == ctypes.sizeof(st)
     assert L.lp_abi_sizeof(99) == -1
 
@@ -158,6 +158,28 @@ def test_module_state_dict_keys_match_reference():
     assert len(s.state_dict()) == 0 and s.get_splatter_params() is None
 
 
+def test_abi_v2_validation_without_gpu():
+    """ABI 0.2 additions validate on the host: ray-embedding entry points, per-grid pointers, gradient-list consistency."""
+    L = _lib.lib()
+    e = _lib.LpRayEmbedArgs()
+    e.n_rays, e.n_harmonics, e.out_dim = 0, 3, 32
+    assert L.lp_ray_embedding_forward(ctypes.byref(e), None) == 0
+    assert L.lp_ray_embedding_backward(ctypes.byref(e), None) == 0
+    e.n_harmonics = 11
+    assert L.lp_ray_embedding_forward(ctypes.byref(e), None) == -2 and b"n_harmonics" in L.lp_last_error()
+    e.n_harmonics, e.n_rays = 3, 5
+    assert L.lp_ray_embedding_forward(ctypes.byref(e), None) == -3  # NULL buffers with rays to process
+    # a grid that carries its own pointer does not have to fit LpGridList.n_rows; one that does not, has to
+    a = _empty_renderer_args()
+    a.grid.n_rows = 1
+    assert L.lp_renderer_forward(ctypes.byref(a), None) == -1 and b"outside the flat tensor" in L.lp_last_error()
+    a.grid.grids[0].data = 0x1000
+    assert L.lp_renderer_forward(ctypes.byref(a), None) == 0
+    a = _empty_renderer_args()
+    a.alpha_mode = 3
+    assert L.lp_renderer_forward(ctypes.byref(a), None) == -1 and b"alpha_mode" in L.lp_last_error()
+
+
 def _gloo_worker(rank, world_size, port, ret):
     import torch.distributed as dist
     from lightplane_amd import parallel
@@ -176,6 +198,20 @@ def _gloo_worker(rank, world_size, port, ret):
         x = torch.arange(n, dtype=torch.float32)[lo:hi]
         (wv.sum() * x.sum()).backward()
         assert torch.allclose(w.grad, torch.full((5,), float(sum(range(n)))))
+        # several replicated tensors (grid + parameters: one coalesced launch on RCCL, one collective each on gloo);
+        # the tensors autograd hands to the all-reduce node are not modified in place (hooks see the local gradient)
+        g = torch.ones(7, 3, requires_grad=True)
+        p = torch.ones(4, requires_grad=True)
+        gv, pv = parallel.replicate_with_grad_allreduce([g, p])
+        seen = []
+        gv.register_hook(lambda t: seen.append(t.clone()))
+        ((gv.sum() + 2 * pv.sum()) * float(rank + 1)).backward()
+        assert torch.allclose(g.grad, torch.full((7, 3), 3.0)) and torch.allclose(p.grad, torch.full((4,), 6.0))
+        assert torch.allclose(seen[0], torch.full((7, 3), float(rank + 1)))
+        # odd-sized payload through the reduce-scatter path's bookkeeping is GPU-only; the flat path handles any size
+        odd = torch.full((11,), float(rank + 1))
+        parallel.allreduce_sum_([odd])
+        assert torch.allclose(odd, torch.full((11,), 3.0))
         ret[rank] = True
     finally:
         dist.destroy_process_group()
