@@ -1,0 +1,273 @@
+// lp_bf3.h -- the decoder's matrix products on the bf16 matrix cores at fp32 accuracy ("bf16x3").
+//
+// Why.  v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (64 FLOP/clk/SIMD) and, measured
+// (scripts/mfma_valu_overlap.hip, profiles/r02_mfma_valu_overlap.txt), does not overlap with VALU work at all: 16 of
+// them + 128 v_fma cost 1 793 cycles in one wave against 1 118 + 668 alone, and two waves per SIMD do not help
+// (M|V 1 659).  v_mfma_f32_32x32x16_bf16 does overlap (16 + 128 v_fma: 755 cycles against 520 + 634 alone) and moves
+// 8x the K per instruction in half the time.  So the fp32 MFMA caps the Renderer at (MFMA time + VALU time); the bf16
+// MFMA caps it at about the VALU time alone.
+//
+// How, without giving up fp32 accuracy.  Every fp32 operand is split EXACTLY into three bf16 limbs
+// (x = x1 + x2 + x3: 3 x 8 significand bits cover the 24 of an fp32; round-to-nearest splits, residuals formed in fp32
+// are exact) and a product is the six limb products of weight >= 2^-24:
+//     a w  ~=  a1 w1 + (a1 w2 + a2 w1) + (a1 w3 + a2 w2 + a3 w1)            (dropped terms: <= 3 * 2^-24 |a w|)
+// accumulated in the MFMA's fp32 accumulators.  Each bf16 x bf16 product is exact in fp32, so the result carries the
+// rounding of an fp32 dot product (measured against fp64 on random 32 x 32 layers: 4e-8 relative, the fp32 FMA chain of
+// torch.matmul: 1.5e-7 -- scripts/bf16x3_accuracy.py).  Weights are split once per workgroup while they are staged into
+// LDS; activations are split in registers (5.5 VALU instructions per value, the price of the scheme).
+//
+// Operand layout (v_mfma_f32_32x32x16_bf16: A = 32 x 16, B = 16 x 32, 8 bf16 = 4 VGPRs per lane and operand).
+// The lane <-> (ray, feature) mapping of the fp32 kernels is kept (lp_renderer_mfma.hip): lane (h, r) owns ray r and
+// the 16 features feat(q, h) of every 32-wide activation, which is also the accumulator layout of every 32 x 32 MFMA.
+//   B operand of chunk c (K slots 16c .. 16c+15): lane (h, r) supplies its values q = 8c .. 8c+7, i.e. features
+//     feat(8c + j, h), j = 0..7, packed in pairs (j even = low half).
+//   A operand of chunk c: lane (h, m) supplies W[feat(8c + j, h)][m], j = 0..7 (forward, Y^T = W^T X^T) or
+//     W[m][feat(8c + j, h)] (backward, dX^T = W dY^T).
+// A and B pair the same (half, slot j) by construction, so the K order inside the instruction is irrelevant.
+// LDS image: one 16-byte slot per (chunk, limb, half, lane m): offset (((chunk * 3 + limb) * 2 + half) * 32 + m) * 16;
+// a wave's ds_read_b128 walks 512 contiguous bytes per half: conflict-free.
+#pragma once
+#include "lp_mfma_common.h"
+
+namespace lp {
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+#define LP_MFMA_BF16(a, b, c) \
+  __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, (a)), __builtin_bit_cast(bf16x8_t, (b)), (c), 0, 0, 0)
+
+// (a, b) -> packed bf16 pair, round to nearest even (v_cvt_pk_bf16_f32): a in the low half
+LP_DEV unsigned pk_bf16(float a, float b) {
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+LP_DEV float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+LP_DEV float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// one fp32 -> three bf16 limbs (host / staging side, scalar)
+LP_DEV void split3_scalar(float x, unsigned short& l1, unsigned short& l2, unsigned short& l3) {
+  const unsigned p1 = pk_bf16(x, 0.0f);
+  const float r1 = x - bf16_lo(p1);
+  const unsigned p2 = pk_bf16(r1, 0.0f);
+  const float r2 = r1 - bf16_lo(p2);
+  const unsigned p3 = pk_bf16(r2, 0.0f);
+  l1 = (unsigned short)(p1 & 0xffffu);
+  l2 = (unsigned short)(p2 & 0xffffu);
+  l3 = (unsigned short)(p3 & 0xffffu);
+}
+
+// B operand: N values of this lane (N = 8 or 16 -> 1 or 2 chunks) -> three limbs, 4 packed dwords per chunk and limb
+template <int N>
+struct Limbs {
+  u32x4_t l1[N / 8], l2[N / 8], l3[N / 8];
+};
+template <int N>
+LP_DEV void split3(const float (&v)[N], Limbs<N>& o) {
+#pragma unroll
+  for (int c = 0; c < N / 8; ++c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float a = v[8 * c + 2 * i], b = v[8 * c + 2 * i + 1];
+      const unsigned p1 = pk_bf16(a, b);
+      const float ra = a - bf16_lo(p1), rb = b - bf16_hi(p1);
+      const unsigned p2 = pk_bf16(ra, rb);
+      const float sa = ra - bf16_lo(p2), sb = rb - bf16_hi(p2);
+      o.l1[c][i] = p1;
+      o.l2[c][i] = p2;
+      o.l3[c][i] = pk_bf16(sa, sb);
+    }
+  }
+}
+
+constexpr int BF3_SLOT = 16;                        // bytes per (lane) slot
+constexpr int BF3_CHUNK = 3 * 2 * 32 * BF3_SLOT;    // bytes per chunk: 3 limbs x 2 halves x 32 lanes = 3 KB
+
+// A operand of limb `limb` of chunk `chunk` for this lane; `img` is the LDS image (+ the opaque zero that keeps the
+// reads inside the sample loop)
+LP_DEV u32x4_t bf3_a(const char* img, int chunk, int limb, int lane) {
+  return *reinterpret_cast<const u32x4_t*>(img + chunk * BF3_CHUNK + (limb * 2 + (lane >> 5)) * (32 * BF3_SLOT) + (lane & 31) * BF3_SLOT);
+}
+
+// acc += W-image chunks [chunk0, chunk0 + NCH) x B limbs; the six products of weight >= 2^-24, small ones first
+template <int NCH>
+LP_DEV f32x16 layer_bf3(const char* img, int chunk0, int lane, const Limbs<8 * NCH>& b, f32x16 acc) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const u32x4_t w1 = bf3_a(img, chunk0 + c, 0, lane), w2 = bf3_a(img, chunk0 + c, 1, lane), w3 = bf3_a(img, chunk0 + c, 2, lane);
+    acc = LP_MFMA_BF16(w3, b.l1[c], acc);
+    acc = LP_MFMA_BF16(w2, b.l2[c], acc);
+    acc = LP_MFMA_BF16(w1, b.l3[c], acc);
+    acc = LP_MFMA_BF16(w2, b.l1[c], acc);
+    acc = LP_MFMA_BF16(w1, b.l2[c], acc);
+    acc = LP_MFMA_BF16(w1, b.l1[c], acc);
+  }
+  return acc;
+}
+
+// The same product chunk by chunk straight from the fp32 values: the limbs of only ONE chunk (12 registers) and one A
+// operand (4 registers) are live at a time -- what the register-starved backward kernel uses.
+template <int NCH>
+LP_DEV f32x16 layer_bf3v(const char* img, int chunk0, int lane, const float (&v)[8 * NCH], f32x16 acc) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    u32x4_t l1, l2, l3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float a = v[8 * c + 2 * i], b = v[8 * c + 2 * i + 1];
+      const unsigned p1 = pk_bf16(a, b);
+      const float ra = a - bf16_lo(p1), rb = b - bf16_hi(p1);
+      const unsigned p2 = pk_bf16(ra, rb);
+      l1[i] = p1;
+      l2[i] = p2;
+      l3[i] = pk_bf16(ra - bf16_lo(p2), rb - bf16_hi(p2));
+    }
+    {
+      const u32x4_t w3 = bf3_a(img, chunk0 + c, 2, lane);
+      acc = LP_MFMA_BF16(w3, l1, acc);
+    }
+    {
+      const u32x4_t w2 = bf3_a(img, chunk0 + c, 1, lane);
+      acc = LP_MFMA_BF16(w2, l2, acc);
+      acc = LP_MFMA_BF16(w2, l1, acc);
+    }
+    {
+      const u32x4_t w1 = bf3_a(img, chunk0 + c, 0, lane);
+      acc = LP_MFMA_BF16(w1, l3, acc);
+      acc = LP_MFMA_BF16(w1, l2, acc);
+      acc = LP_MFMA_BF16(w1, l1, acc);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return acc;
+}
+
+// Stage one weight matrix W [rows_in x 32] (row-major, leading dimension ld, inside mlp_params at `off`) as limb
+// image chunks.  FWD: slot (chunk c, half h, lane m, j) = W[feat(8c + j, h)][m]; otherwise (backward / dX form)
+// W[m][feat(8c + j, h)] with rows m >= rows_in zero.  n_chunks = rows_in / 16 (forward) or 2 (backward).
+template <bool FWD>
+LP_DEV void stage_matrix_bf3(char* img, int chunk0, int n_chunks, const float* P, int64_t off, int rows_in, int ld, int tid,
+                             int n_threads) {
+  for (int i = tid; i < n_chunks * 2 * 32 * 8; i += n_threads) {
+    const int j = i & 7, m = (i >> 3) & 31, h = (i >> 8) & 1, c = i >> 9;
+    const int f = featq(8 * c + j, h);
+    float w;
+    if (FWD) w = (f < rows_in) ? P[off + (int64_t)f * ld + m] : 0.0f;
+    else w = (m < rows_in) ? P[off + (int64_t)m * ld + f] : 0.0f;
+    unsigned short l1, l2, l3;
+    split3_scalar(w, l1, l2, l3);
+    char* base = img + (chunk0 + c) * BF3_CHUNK + (h * 32 + m) * BF3_SLOT + j * 2;
+    *reinterpret_cast<unsigned short*>(base) = l1;
+    *reinterpret_cast<unsigned short*>(base + 2 * 32 * BF3_SLOT) = l2;
+    *reinterpret_cast<unsigned short*>(base + 4 * 32 * BF3_SLOT) = l3;
+  }
+}
+
+// LDS map of the bf16x3 kernels of the default shape (trunk [C,32,32], heads [32,32,.]):
+//   [0, F32_END)           the fp32 small stuff of Lds (biases, output layers of the heads, beyond-far table); the four
+//                          32 x 33 fp32 matrices of the fp32 kernels are NOT staged
+//   forward image          chunks: t1 (C/16), t2 (2), o1 (2), c1 (2)
+//   backward image         chunks: c1, o1, t2, t1 (2 each; only the backward kernel stages it)
+template <int C>
+struct LdsBf3 {
+  static constexpr int SMALL = Lds::BIAS;                     // float offset of the reused small block inside Lds
+  static constexpr int SMALL_FLOATS = Lds::FWD_END - Lds::BIAS;
+  static constexpr int FWD_IMG = SMALL_FLOATS * 4;            // byte offset of the forward image
+  static constexpr int CH_T1 = 0, CH_T2 = C / 16, CH_O1 = CH_T2 + 2, CH_C1 = CH_O1 + 2, N_FWD = CH_C1 + 2;
+  static constexpr int BWD_IMG = FWD_IMG + N_FWD * BF3_CHUNK;
+  static constexpr int CB_C1 = 0, CB_O1 = 2, CB_T2 = 4, CB_T1 = 6, N_BWD = 8;
+  static constexpr int FWD_END = BWD_IMG;                     // bytes, forward kernels
+  static constexpr int BWD_END = BWD_IMG + N_BWD * BF3_CHUNK; // bytes, backward kernel (before the per-wave tiles)
+};
+
+// stage the small fp32 block (at float offset 0 of `lds`: indices are Lds::X - Lds::BIAS) and the forward image
+template <int C>
+LP_DEV void stage_weights_bf3(const LpRendererArgs& a, const MfmaParams& mp, float* lds, bool with_backward, int n_threads) {
+  using M = Lds;
+  const float* P = a.mlp_params;
+  const int tid = threadIdx.x;
+  float* sm = lds - M::BIAS;  // so that sm[M::X] addresses the small block
+  for (int i = tid; i < 32; i += n_threads) {
+    sm[M::BIAS + i] = P[mp.b_t1 + i];
+    sm[M::BIAS + 32 + i] = P[mp.b_t2 + i];
+    sm[M::BIAS + 64 + i] = P[mp.b_o1 + i];
+    sm[M::BIAS + 96 + i] = P[mp.b_c1 + i];
+    sm[M::WO2 + i] = P[mp.w_o2 + i];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sm[M::WC2 + i * 4 + c] = (c < a.color_chn) ? P[mp.w_c2 + (int64_t)i * mp.ldc2 + c] : 0.0f;
+  }
+  for (int i = tid; i < MAX_INF; i += n_threads) sm[M::INF + i] = (i < a.march.num_samples_inf) ? inf_scale(i, a.march) : 0.0f;
+  if (tid == 0) {
+    sm[M::HB + 0] = P[mp.b_o2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sm[M::HB + 1 + c] = (c < a.color_chn) ? P[mp.b_c2 + c] : 0.0f;
+  }
+  using L = LdsBf3<C>;
+  char* img = reinterpret_cast<char*>(lds) + L::FWD_IMG;
+  stage_matrix_bf3<true>(img, L::CH_T1, C / 16, P, mp.w_t1, C, 32, tid, n_threads);
+  stage_matrix_bf3<true>(img, L::CH_T2, 2, P, mp.w_t2, 32, 32, tid, n_threads);
+  stage_matrix_bf3<true>(img, L::CH_O1, 2, P, mp.w_o1, 32, 32, tid, n_threads);
+  stage_matrix_bf3<true>(img, L::CH_C1, 2, P, mp.w_c1, 32, 32, tid, n_threads);
+  if (with_backward) {
+    char* bimg = reinterpret_cast<char*>(lds) + L::BWD_IMG;
+    stage_matrix_bf3<false>(bimg, L::CB_C1, 2, P, mp.w_c1, 32, 32, tid, n_threads);
+    stage_matrix_bf3<false>(bimg, L::CB_O1, 2, P, mp.w_o1, 32, 32, tid, n_threads);
+    stage_matrix_bf3<false>(bimg, L::CB_T2, 2, P, mp.w_t2, 32, 32, tid, n_threads);
+    stage_matrix_bf3<false>(bimg, L::CB_T1, 2, P, mp.w_t1, C, 32, tid, n_threads);
+  }
+}
+
+// bias of layer `which` (0 t1, 1 t2, 2 o1, 3 c1) in accumulator order; `sm` = small block base (sm[Lds::X] valid)
+LP_DEV f32x16 load_bias_bf3(const float* sm, int which, int h, int zo) { return load_bias(sm, which, h, zo); }
+
+// Per-ray pre-activation of the colour hidden layer: cb = b_c1 + W_c1^T enc.  relu(W^T (e + enc) + b) = relu(W^T e + cb),
+// so the colour layer reuses the limbs of e (already split for the opacity layer) instead of splitting e + enc again.
+template <int C>
+LP_DEV void color_prebias_bf3(const float* sm, const char* fimg, int lane, const float (&enc)[16], float (&cb)[16]) {
+  Limbs<16> b;
+  split3<16>(enc, b);
+  const f32x16 acc = layer_bf3<2>(fimg, LdsBf3<C>::CH_C1, lane, b, load_bias_bf3(sm, 3, lane >> 5, 0));
+#pragma unroll
+  for (int q = 0; q < 16; ++q) cb[q] = acc[q];
+}
+
+// Decoder of one sample, default shape.  t.x0 in; fills t.h1 / t.e / t.ho / t.hc (post-ReLU) like decode_prefetch.
+template <int C, int NC>
+LP_DEV Heads decode_bf3(const float* sm, const char* fimg_, int lane, const float (&cb)[16], Act<C>& t, int zo) {
+  using L = LdsBf3<C>;
+  const int h = lane >> 5;
+  const char* fimg = fimg_ + zo;
+  f32x16 acc;
+  {
+    Limbs<C / 2> b;
+    split3<C / 2>(t.x0, b);
+    acc = layer_bf3<C / 16>(fimg, L::CH_T1, lane, b, load_bias_bf3(sm, 0, h, zo));
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t.h1[q] = fmaxf(acc[q], 0.0f);
+  }
+  {
+    Limbs<16> b;
+    split3<16>(t.h1, b);
+    acc = layer_bf3<2>(fimg, L::CH_T2, lane, b, load_bias_bf3(sm, 1, h, zo));
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t.e[q] = fmaxf(acc[q], 0.0f);
+  }
+  {
+    Limbs<16> b;
+    split3<16>(t.e, b);
+    acc = layer_bf3<2>(fimg, L::CH_O1, lane, b, load_bias_bf3(sm, 2, h, zo));
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t.ho[q] = fmaxf(acc[q], 0.0f);
+    f32x16 c0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) c0[q] = cb[q];
+    acc = layer_bf3<2>(fimg, L::CH_C1, lane, b, c0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t.hc[q] = fmaxf(acc[q], 0.0f);
+  }
+  return heads_forward<NC>(sm, h, t.ho, t.hc, zo);
+}
+
+}  // namespace lp

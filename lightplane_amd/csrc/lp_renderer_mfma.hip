@@ -29,6 +29,7 @@
 // body is one branch-free basic block so that the scheduler can actually interleave the two.
 //
 #include "lp_mfma_common.h"
+#include "lp_bf3.h"
 
 namespace lp {
 
@@ -210,6 +211,72 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_mfma_np(const LpRendere
   }
 }
 
+// Forward of the default shape (trunk [C,32,32], heads [32,32,.]) with the matrix products on the bf16 matrix cores at
+// fp32 accuracy (lp_bf3.h: exact 3-limb splits, six limb products): the MFMA time all but disappears behind the VALU
+// work (interpolation, splits, activations, compositing) instead of adding to it as the fp32 MFMA's does.
+template <int C, int GM, int OCC, int NC>
+__global__ void __launch_bounds__(256, OCC) renderer_fwd_bf3(const LpRendererArgs a, const MfmaParams mp) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_weights_bf3<C>(a, mp, lds, false, 256);
+  __syncthreads();
+  const float* sm = lds - Lds::BIAS;  // small fp32 block: sm[Lds::X]
+  const char* fimg = reinterpret_cast<const char*>(lds) + LdsBf3<C>::FWD_IMG;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, r = lane & 31;
+  const int64_t ray_id = ((int64_t)blockIdx.x * WAVES + wave) * RAYS_PER_WAVE + r;
+  const bool valid = ray_id < a.rays.n_rays;
+  const int64_t rid = valid ? ray_id : 0;
+  const Ray ray = load_ray(a.rays, rid);
+  float cb[16];  // per-ray pre-activation of the colour hidden layer (replaces the ray encoding in the loop)
+  {
+    float enc[16];
+    load_encoding(a, rid, h, enc);
+    color_prebias_bf3<C>(sm, fimg, lane, enc, cb);
+  }
+  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
+  const int n_ckpt = ckpt_count(a.march);
+  const float delta0 = (a.march.num_samples > 1) ? (ray.far_t - ray.near_t) / (float)(a.march.num_samples - 1) : 1.0f;
+  float nlt = 0.0f, nlt_lo = 0.0f, t_prev = 1.0f, len = 0.0f, depth_prev = 0.0f;
+  int s_last = s_tot - 1;  // last sample marched
+  float facc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  Sample<C> nx;
+  Act<C> t;
+  for (int s = 0; s < s_tot; ++s) {
+    fetch_sample<C, GM, true>(a, sm, ray, s, h, nx);
+    const float depth = nx.depth, occ = nx.occ;
+#pragma unroll
+    for (int q = 0; q < C / 2; ++q) t.x0[q] = nx.x0[q];
+    const int zo = opaque_zero();
+    const Heads hd = decode_bf3<C, NC>(sm, fimg, lane, cb, t, zo);
+    const float delta = (s == 0) ? delta0 : depth - depth_prev;
+    depth_prev = depth;
+    float raw = hd.raw_o;
+    if (a.noise_sigma > 0.0f) raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
+    const float opacity = a.gain * softplus_f(raw) * occ;
+    nlt_add(nlt, nlt_lo, opacity * delta);
+    if (a.neg_log_t_ckpt && valid && h == 0) {
+      const int ck = ckpt_index(s, a.march);
+      if (ck >= 0) *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + ck) * 2) = make_float2(nlt, nlt_lo);
+    }
+    const float tr = __expf(-nlt);
+    const float w = t_prev - tr;
+    t_prev = tr;
+    len = fmaf(w, depth, len);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) facc[c] = fmaf(w, sigmoid_f(hd.raw_c[c]) * occ, facc[c]);
+    // early termination (off unless stop_neg_log_t > 0): every ray of this wave is opaque
+    if (a.stop_neg_log_t > 0.0f && __ballot(valid && nlt < a.stop_neg_log_t) == 0) {
+      s_last = s;
+      break;
+    }
+  }
+  if (valid && h == 0) {
+    write_ray_outputs(a, ray_id, len, nlt, facc);
+    if (a.neg_log_t_ckpt)
+      *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + n_ckpt - 1) * 2) = make_float2((float)s_last, nlt_lo);
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
@@ -311,6 +378,24 @@ static int launch_fwd(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t
   // C=16: 256x256 rays 0.82 vs 0.86 ms, 512x512 rays 3.02 vs 2.85 ms at 4 waves/SIMD
   static const int forced = getenv("LP_MFMA_FWD_VARIANT") ? atoi(getenv("LP_MFMA_FWD_VARIANT")) : -1;
   const int variant = forced >= 0 ? forced : (C == 32 ? 3 : (a.rays.n_rays > 3 * 32768 ? 4 : 0));
+  // default shape: matrix products as bf16x3 on the bf16 matrix cores (lp_bf3.h); LP_MFMA_F32 keeps the fp32 MFMA kernels
+  static const bool f32_mfma = getenv("LP_MFMA_F32") != nullptr;
+  static const int bf3_occ = getenv("LP_BF3_OCC") ? atoi(getenv("LP_BF3_OCC")) : 0;
+  if (!mp.tg && !is_flex(mp) && !f32_mfma) {
+    const size_t lds3 = (size_t)LdsBf3<C>::FWD_END;
+    const int occ = bf3_occ ? bf3_occ : (a.rays.n_rays > 2 * 32768 ? 3 : 2);
+#define LP_BF3_LAUNCH(OCCV, NCV)                                                                                  \
+    do {                                                                                                          \
+      if ((rc = set_lds(renderer_fwd_bf3<C, GM, OCCV, NCV>, lds3))) return rc;                                   \
+      hipLaunchKernelGGL((renderer_fwd_bf3<C, GM, OCCV, NCV>), dim3(n_blocks(a)), dim3(256), lds3, stream, a, mp); \
+    } while (0)
+    const bool nc3 = a.color_chn <= 3 && !no_nc3;
+    if (occ >= 4 && C == 16) { if (nc3) LP_BF3_LAUNCH(4, 3); else LP_BF3_LAUNCH(4, 4); }
+    else if (occ == 3 || occ >= 4) { if (nc3) LP_BF3_LAUNCH(3, 3); else LP_BF3_LAUNCH(3, 4); }
+    else { if (nc3) LP_BF3_LAUNCH(2, 3); else LP_BF3_LAUNCH(2, 4); }
+#undef LP_BF3_LAUNCH
+    return LP_OK;
+  }
   if (mp.tg) {
     // two gathers per sample: two waves/SIMD and the run-time-loop grid-list variant (the triplane / voxel
     // specialisations at three waves/SIMD spill 160-230 registers with C = 32)

