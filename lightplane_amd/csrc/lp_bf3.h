@@ -107,41 +107,86 @@ LP_DEV f32x16 layer_bf3(const char* img, int chunk0, int lane, const Limbs<8 * N
   return acc;
 }
 
-// The same product chunk by chunk straight from the fp32 values: the limbs of only ONE chunk (12 registers) and one A
-// operand (4 registers) are live at a time -- what the register-starved backward kernel uses.
-template <int NCH>
-LP_DEV f32x16 layer_bf3v(const char* img, int chunk0, int lane, const float (&v)[8 * NCH], f32x16 acc) {
+// One chunk (8 values) -> its three limbs, 4 packed dwords each (22 VALU instructions per pair of values x 4)
+LP_DEV void split3_chunk(const float* v, u32x4_t& l1, u32x4_t& l2, u32x4_t& l3) {
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    u32x4_t l1, l2, l3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float a = v[8 * c + 2 * i], b = v[8 * c + 2 * i + 1];
-      const unsigned p1 = pk_bf16(a, b);
-      const float ra = a - bf16_lo(p1), rb = b - bf16_hi(p1);
-      const unsigned p2 = pk_bf16(ra, rb);
-      l1[i] = p1;
-      l2[i] = p2;
-      l3[i] = pk_bf16(ra - bf16_lo(p2), rb - bf16_hi(p2));
-    }
-    {
-      const u32x4_t w3 = bf3_a(img, chunk0 + c, 2, lane);
-      acc = LP_MFMA_BF16(w3, l1, acc);
-    }
-    {
-      const u32x4_t w2 = bf3_a(img, chunk0 + c, 1, lane);
-      acc = LP_MFMA_BF16(w2, l2, acc);
-      acc = LP_MFMA_BF16(w2, l1, acc);
-    }
-    {
-      const u32x4_t w1 = bf3_a(img, chunk0 + c, 0, lane);
-      acc = LP_MFMA_BF16(w1, l3, acc);
-      acc = LP_MFMA_BF16(w1, l2, acc);
-      acc = LP_MFMA_BF16(w1, l1, acc);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+  for (int i = 0; i < 4; ++i) {
+    const float a = v[2 * i], b = v[2 * i + 1];
+    const unsigned p1 = pk_bf16(a, b);
+    const float ra = a - bf16_lo(p1), rb = b - bf16_hi(p1);
+    const unsigned p2 = pk_bf16(ra, rb);
+    l1[i] = p1;
+    l2[i] = p2;
+    l3[i] = pk_bf16(ra - bf16_lo(p2), rb - bf16_hi(p2));
+  }
+}
+// the six limb products of one chunk, one A operand live at a time
+LP_DEV f32x16 chunk_bf3(const char* img, int chunk, int lane, const u32x4_t& l1, const u32x4_t& l2, const u32x4_t& l3, f32x16 acc) {
+  {
+    const u32x4_t w3 = bf3_a(img, chunk, 2, lane);
+    acc = LP_MFMA_BF16(w3, l1, acc);
+  }
+  {
+    const u32x4_t w2 = bf3_a(img, chunk, 1, lane);
+    acc = LP_MFMA_BF16(w2, l2, acc);
+    acc = LP_MFMA_BF16(w2, l1, acc);
+  }
+  {
+    const u32x4_t w1 = bf3_a(img, chunk, 0, lane);
+    acc = LP_MFMA_BF16(w1, l3, acc);
+    acc = LP_MFMA_BF16(w1, l2, acc);
+    acc = LP_MFMA_BF16(w1, l1, acc);
   }
   return acc;
+}
+// issue order "1 MFMA, ~7 VALU" x 6: the split of the next chunk (44 VALU) rides in the shadow of this chunk's six
+// dependent MFMAs (6 x 32 cycles)
+LP_DEV void bf3_interleave_hint() {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read (A operand)
+    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // VALU
+  }
+}
+
+// The same product chunk by chunk straight from the fp32 values, software-pipelined: the limbs of chunk c + 1 are split
+// while the MFMAs of chunk c run; only one chunk's limbs (+ the next one's being formed) are live.
+template <int NCH>
+LP_DEV f32x16 layer_bf3v(const char* img, int chunk0, int lane, const float (&v)[8 * NCH], f32x16 acc) {
+  u32x4_t l1, l2, l3;
+  split3_chunk(v, l1, l2, l3);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    u32x4_t n1 = l1, n2 = l2, n3 = l3;
+    acc = chunk_bf3(img, chunk0 + c, lane, l1, l2, l3, acc);
+    if (c + 1 < NCH) {
+      split3_chunk(v + 8 * (c + 1), n1, n2, n3);
+      bf3_interleave_hint();
+    }
+    l1 = n1; l2 = n2; l3 = n3;
+  }
+  return acc;
+}
+
+// Two layers that read the SAME input (the opacity and the colour hidden layer both read e): every chunk is split once
+// and feeds two independent accumulator chains (which also keeps the matrix pipe busy back to back).
+template <int NCH>
+LP_DEV void layer2_bf3v(const char* img, int chunk_a, int chunk_b, int lane, const float (&v)[8 * NCH], f32x16& acc_a,
+                        f32x16& acc_b) {
+  u32x4_t l1, l2, l3;
+  split3_chunk(v, l1, l2, l3);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    u32x4_t n1 = l1, n2 = l2, n3 = l3;
+    acc_a = chunk_bf3(img, chunk_a + c, lane, l1, l2, l3, acc_a);
+    acc_b = chunk_bf3(img, chunk_b + c, lane, l1, l2, l3, acc_b);
+    if (c + 1 < NCH) {
+      split3_chunk(v + 8 * (c + 1), n1, n2, n3);
+      bf3_interleave_hint();
+    }
+    l1 = n1; l2 = n2; l3 = n3;
+  }
 }
 
 // Stage one weight matrix W [rows_in x 32] (row-major, leading dimension ld, inside mlp_params at `off`) as limb
@@ -239,33 +284,20 @@ LP_DEV Heads decode_bf3(const float* sm, const char* fimg_, int lane, const floa
   using L = LdsBf3<C>;
   const int h = lane >> 5;
   const char* fimg = fimg_ + zo;
-  f32x16 acc;
-  {
-    Limbs<C / 2> b;
-    split3<C / 2>(t.x0, b);
-    acc = layer_bf3<C / 16>(fimg, L::CH_T1, lane, b, load_bias_bf3(sm, 0, h, zo));
+  f32x16 acc = layer_bf3v<C / 16>(fimg, L::CH_T1, lane, t.x0, load_bias_bf3(sm, 0, h, zo));
 #pragma unroll
-    for (int q = 0; q < 16; ++q) t.h1[q] = fmaxf(acc[q], 0.0f);
-  }
-  {
-    Limbs<16> b;
-    split3<16>(t.h1, b);
-    acc = layer_bf3<2>(fimg, L::CH_T2, lane, b, load_bias_bf3(sm, 1, h, zo));
+  for (int q = 0; q < 16; ++q) t.h1[q] = fmaxf(acc[q], 0.0f);
+  acc = layer_bf3v<2>(fimg, L::CH_T2, lane, t.h1, load_bias_bf3(sm, 1, h, zo));
 #pragma unroll
-    for (int q = 0; q < 16; ++q) t.e[q] = fmaxf(acc[q], 0.0f);
-  }
-  {
-    Limbs<16> b;
-    split3<16>(t.e, b);
-    acc = layer_bf3<2>(fimg, L::CH_O1, lane, b, load_bias_bf3(sm, 2, h, zo));
+  for (int q = 0; q < 16; ++q) t.e[q] = fmaxf(acc[q], 0.0f);
+  f32x16 acc_o = load_bias_bf3(sm, 2, h, zo), acc_c;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) t.ho[q] = fmaxf(acc[q], 0.0f);
-    f32x16 c0;
+  for (int q = 0; q < 16; ++q) acc_c[q] = cb[q];
+  layer2_bf3v<2>(fimg, L::CH_O1, L::CH_C1, lane, t.e, acc_o, acc_c);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) c0[q] = cb[q];
-    acc = layer_bf3<2>(fimg, L::CH_C1, lane, b, c0);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) t.hc[q] = fmaxf(acc[q], 0.0f);
+  for (int q = 0; q < 16; ++q) {
+    t.ho[q] = fmaxf(acc_o[q], 0.0f);
+    t.hc[q] = fmaxf(acc_c[q], 0.0f);
   }
   return heads_forward<NC>(sm, h, t.ho, t.hc, zo);
 }

@@ -713,6 +713,11 @@ __global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs 
   float dbo2 = 0.0f, dbc2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   const bool gg = a.grad_grid_list[0] != nullptr;
 
+#ifdef LP_PHASE_TIMING
+  unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = __builtin_readcyclecounter();
+  int ph_cur = 9;
+#endif
   float nlt = a.neg_log_t[rid];
   float suffix = 0.0f, p_next = 0.0f;
   Sample<C> nx;
@@ -729,6 +734,7 @@ __global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs 
     const char* const bi = bimg + zo;
 
     // ---------------- forward recompute (bf16x3) ----------------
+    LP_MARK("fwd");
     float h1[16], e[16];
     unsigned ho_mask = 0, hc_mask = 0;
     Heads hd;
@@ -746,20 +752,18 @@ __global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs 
       }
       float ho[16], hc[16];
       {
-        Limbs<16> b;
-        split3<16>(e, b);
-        acc = layer_bf3<2>(fi, L::CH_O1, lane, b, load_bias(sm, 2, h, zo));
-#pragma unroll
-        for (int q = 0; q < 16; ++q) ho[q] = fmaxf(acc[q], 0.0f);
-        f32x16 c0;
+        f32x16 acc_o = load_bias(sm, 2, h, zo), acc_c;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float4 v = *reinterpret_cast<const float4*>(cbt + zo + ((i + cb_rot) & 3) * 4);
-          c0[4 * i] = v.x; c0[4 * i + 1] = v.y; c0[4 * i + 2] = v.z; c0[4 * i + 3] = v.w;
+          acc_c[4 * i] = v.x; acc_c[4 * i + 1] = v.y; acc_c[4 * i + 2] = v.z; acc_c[4 * i + 3] = v.w;
         }
-        acc = layer_bf3<2>(fi, L::CH_C1, lane, b, c0);
+        layer2_bf3v<2>(fi, L::CH_O1, L::CH_C1, lane, e, acc_o, acc_c);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) hc[q] = fmaxf(acc[q], 0.0f);
+        for (int q = 0; q < 16; ++q) {
+          ho[q] = fmaxf(acc_o[q], 0.0f);
+          hc[q] = fmaxf(acc_c[q], 0.0f);
+        }
       }
       hd = heads_forward<NC>(sm, h, ho, hc, zo);
 #pragma unroll
@@ -777,6 +781,7 @@ __global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs 
     }
 
     // ---------------- compositing, backward ----------------
+    LP_MARK("compositing");
     const float depth_prev =
         PLAIN ? ray.near_t + lin01((s > 0) ? s - 1 : 0, a.march.num_samples) * (ray.far_t - ray.near_t)
               : sample_depth_tab((s > 0) ? s - 1 : 0, a.march, ray.near_t, ray.far_t, sm + M::INF);
@@ -816,6 +821,7 @@ __global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs 
     for (int c = 0; c < 4; ++c) drc[c] = (c < NC && contrib) ? w * gfeat[c] * occ * sg[c] * (1.0f - sg[c]) : 0.0f;
 
     // ---------------- output layers of the heads (VALU) ----------------
+    LP_MARK("heads_bwd");
     float dhc[16];
     {
       const float* wc2 = sm + M::WC2 + 16 * h + opaque_zero();
@@ -867,6 +873,7 @@ __global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs 
     LP_SCHED_FENCE();
 
     // ---------------- colour hidden layer (X tile = e: shared with the opacity layer below) ----------------
+    LP_MARK("c1");
     __builtin_amdgcn_s_setprio(1);
     f32x16 acc = (f32x16){0};
     {
@@ -885,6 +892,7 @@ __global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs 
     }
     LP_SCHED_FENCE();
     // ---------------- opacity hidden layer ----------------
+    LP_MARK("o1");
     {
       float dho[16];
 #pragma unroll
@@ -908,6 +916,7 @@ __global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs 
     for (int q = 0; q < 16; ++q) de[q] = (e[q] > 0.0f) ? acc[q] : 0.0f;
     LP_SCHED_FENCE();
     // ---------------- trunk layer 2 ----------------
+    LP_MARK("t2");
     float dh1[16];
     {
       if (want_params) {
@@ -925,6 +934,7 @@ __global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs 
     }
     LP_SCHED_FENCE();
     // ---------------- trunk layer 1 ----------------
+    LP_MARK("t1");
     {
       if (want_params) {
 #pragma unroll
@@ -946,10 +956,12 @@ __global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs 
     }
     LP_SCHED_FENCE();
     // ---------------- next (nearer) sample + grid gradient ----------------
+    LP_MARK("fetch");
     __builtin_amdgcn_s_setprio(0);
     const bool live = valid && on && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
     if (s > 0) fetch_sample<C, GM, true, PLAIN>(a, sm, ray, s - 1, h, nx);
     LP_SCHED_FENCE();
+    LP_MARK("scatter");
     if (gg && !(mp.dbg & 2)) {
       const int ng = (GM == GM_TRIPLANE) ? 3 : (GM == GM_VOXEL) ? 1 : a.grid.n_grids;
 #pragma unroll 1
@@ -959,6 +971,12 @@ __global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs 
   }
 
   // ---------------- epilogue ----------------
+  LP_MARK("epilogue");
+#ifdef LP_PHASE_TIMING
+  if (lane == 0) {
+    for (int i = 0; i < 10; ++i) atomicAdd(&g_phase[i], ph[i]);
+  }
+#endif
   // d enc = W_c1 D ; dW_c1 += enc (x) D   (one product each, after the sweep)
   {
     Limbs<16> b;
@@ -1063,11 +1081,11 @@ static int launch_bwd2(const LpRendererArgs& a, const MfmaParams& mp, hipStream_
   const bool plain = !(a.noise_sigma > 0.0f) && !a.march.contract_coords && !a.scaffold && a.march.num_samples_inf == 0 &&
                      !(a.stop_neg_log_t > 0.0f);
   const bool flex = !(mp.hid == HID && mp.t1 && mp.t2 && mp.oh && mp.ch && !mp.tg);
-  // EXPERIMENTAL, opt-in (LP_BF3_BWD=1): recompute + dX chains as bf16x3 on the bf16 matrix cores.  Numerically it
-  // passes every parity test, but with both limb images (45 KB) the workgroup has to be eight waves and the kernel
-  // needs ~330 registers at two waves per SIMD (73-92 spilled): measured on MI355X it is no faster than the fp32 MFMA
-  // kernel at cfg 2 (2.58 ms both) and 13 % slower at cfg 4.  See DESIGN.md 4.2c for what a round-3 version needs.
-  static const bool bf3_bwd = getenv("LP_BF3_BWD") != nullptr && getenv("LP_MFMA_F32") == nullptr;
+  // C = 16, default shape: recompute + dX chains as bf16x3 on the bf16 matrix cores (renderer_bwd_bf3).  Measured on
+  // MI355X: cfg 2 backward 2.58 -> 2.42 ms, 1080p x S=128 73.7 -> 68.0 ms.  C = 32 keeps the fp32-MFMA kernel: both limb
+  // images + the tiles + the cb records do not fit the 160 KB LDS, and with 51 spilled registers the C = 32 instantiation
+  // measured no gain (cfg 4: 164 ms either way).  LP_MFMA_F32 / LP_MFMA_F32_BWD select the fp32-MFMA kernel.
+  static const bool bf3_bwd = getenv("LP_MFMA_F32") == nullptr && getenv("LP_MFMA_F32_BWD") == nullptr;
   if (C == 16 && !flex && !mp.tg && bf3_bwd) {  // C = 32: the images + tiles + cb records do not fit the 160 KB
     if (a.color_chn <= 3)
       return plain ? launch_bwd3<16, GM, true, 3>(a, mp, stream) : launch_bwd3<16, GM, false, 3>(a, mp, stream);

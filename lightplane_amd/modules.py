@@ -235,8 +235,19 @@ class LightplaneRenderer(torch.nn.Module):
                                scaffold=None, gain=None, mask_out_of_bounds_samples=None, contract_coords=None,
                                directions=None):
         """(opacity ``[n_rays, n_pts]``, colour ``[n_rays, n_pts, color_chn]``) at ``pts`` (reference
-        :183-241).  The colour comes from a second single-sample render with gain 1e30 (weight 1 - exp(-x) = 1;
-        a point whose softplus underflows to exactly 0 would report colour 0)."""
+        :183-241).
+
+        Implementation: two single-sample renders through the HIP Renderer (a ray with ``near = far = 0`` and one
+        sample sits at its origin; the interval length of a single-sample march is 1, so ``-log T`` is the opacity;
+        with gain 1e30 the compositing weight ``1 - exp(-x)`` is 1, so the rendered feature is the colour).
+        Documented deviations from the reference's naive decoder:
+        * colour is 0 (not ``sigmoid(raw)``) at a point whose ``softplus(raw opacity)`` underflows to exactly 0 in
+          fp32 (raw < -103: the point is empty to 1e-45), and at points the scaffold / out-of-bounds mask removes;
+        * the colour has ``color_chn`` channels, not the padded width (>= 16) of the reference's colour head;
+        * autograd through the returned opacity does not see the colour branch (two separate renders), and grids
+          have to be passed as a list (flat tensors + sizes are not accepted here);
+        * cost: two marches (2 x 12 gathers + 2 decoder evaluations per point) -- meant for scaffolds and
+          diagnostics, not for inner loops."""
         n_rays, n_pts, _ = pts.shape
         if rays_encoding is not None:
             assert tuple(rays_encoding.shape) == (n_rays, self.rays_encoding_dim)

@@ -403,11 +403,11 @@ sys.exit(pytest.main([{root!r} + "/tests/test_gpu_parity.py", "-m", "gpu", "-q",
 """
 
 
-@pytest.mark.parametrize("env", [{"LP_MFMA_F32": "1"}, {"LP_BF3_BWD": "1"}], ids=["fp32_mfma_kernels", "bf3_backward"])
+@pytest.mark.parametrize("env", [{"LP_MFMA_F32": "1"}, {"LP_MFMA_F32_BWD": "1"}], ids=["fp32_mfma_kernels", "fp32_mfma_backward_only"])
 def test_golden_suite_on_the_other_kernel_families(env):
-    """The default decoder shape runs the bf16x3 forward + the fp32-MFMA backward; this runs the golden / cfg-2-sized /
-    early-termination Renderer tests once more on (i) the fp32-MFMA forward kernels (LP_MFMA_F32) and (ii) the experimental
-    bf16x3 backward (LP_BF3_BWD), so that every kernel that can be launched is held to the oracle."""
+    """The default decoder shape runs the bf16x3 forward and (C = 16) the bf16x3 backward; this runs the golden /
+    cfg-2-sized / early-termination Renderer tests once more on the fp32-MFMA kernels they replace (still what C = 32
+    backward passes and LP_MFMA_F32 select), so that every kernel that can be launched is held to the oracle."""
     r = subprocess.run([sys.executable, "-c", _GOLDEN_CHILD.format(root=ROOT)], cwd=ROOT, env=dict(os.environ, **env),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
