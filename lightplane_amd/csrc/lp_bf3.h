@@ -120,19 +120,74 @@ LP_DEV void split3_chunk(const float* v, u32x4_t& l1, u32x4_t& l2, u32x4_t& l3) 
     l3[i] = pk_bf16(ra - bf16_lo(p2), rb - bf16_hi(p2));
   }
 }
+// ---- A-operand loaders -------------------------------------------------------------------------------------------
+// (a) slot image (stage_matrix_bf3): one ds_read_b128 per limb and chunk; one image per orientation
+struct ASlots {
+  const char* img;
+  int chunk0;
+  LP_DEV u32x4_t operator()(int c, int limb, int lane) const { return bf3_a(img, chunk0 + c, limb, lane); }
+};
+// (b) ONE row-major image per layer serving both orientations: limb p of W[row k_in][col m_out] at
+//     layer + p * limb_stride + (k_in * RM_LD + m_out) * 2.  RM_LD = 36 elements (72 B rows): the backward's two
+//     ds_read_b64 per lane and the forward's transposed reads are bank-conflict free.
+constexpr int RM_LD = 36;
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+//     backward (dX) form: lane (k = l & 31, h) needs W[k][feat(8c + j, h)], j = 0..7 = columns 16c + 4h .. +3 and 16c + 8 + 4h .. +3
+struct ARowsBwd {
+  const char* layer;
+  int limb_stride, row_mask;  // row_mask = rows - 1: lanes beyond a 16-row matrix re-read valid rows (their output rows are unused)
+  LP_DEV u32x4_t operator()(int c, int limb, int lane) const {
+    const char* p = layer + limb * limb_stride + (((lane & 31) & row_mask) * RM_LD + 16 * c + 4 * (lane >> 5)) * 2;
+    const u32x2_t a = *reinterpret_cast<const u32x2_t*>(p), b = *reinterpret_cast<const u32x2_t*>(p + 16);
+    return (u32x4_t){a.x, a.y, b.x, b.y};
+  }
+};
+//     forward form: lane (m = l & 31, h) needs W[feat(8c + j, h)][m] = column m of rows 16c + 4h .. +3 and 16c + 8 + 4h .. +3:
+//     two ds_read_b64_tr_b16.  Semantics (scripts/tr_b16_probe.hip, profiles/r02_tr_b16_probe.txt): inside a group of 16
+//     lanes, lane i receives element (i & 3) of the four b16 supplied by lanes 4j + (i >> 2), j = 0..3.  So supplier lane
+//     s = 4j + q addresses row (base + j), columns m0 + 4q .. +3 (m0 = first column of the group), and lane i ends up with
+//     rows base .. base + 3 of column m0 + i.
+struct AColsFwd {
+  const char* layer;
+  int limb_stride;
+  LP_DEV u32x4_t operator()(int c, int limb, int lane) const {
+    const int s = lane & 15, m0 = lane & 16, h = lane >> 5;
+    const char* p = layer + limb * limb_stride + ((16 * c + 4 * h + (s >> 2)) * RM_LD + m0 + 4 * (s & 3)) * 2;
+    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr;
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 8 * RM_LD * 2));
+    const u32x2_t ua = __builtin_bit_cast(u32x2_t, a), ub = __builtin_bit_cast(u32x2_t, b);
+    return (u32x4_t){ua.x, ua.y, ub.x, ub.y};
+  }
+};
+// stage W [rows x 32] (row-major in mlp_params at off, leading dimension ld) as the three row-major limb images
+LP_DEV void stage_matrix_rm(char* layer, int limb_stride, const float* P, int64_t off, int rows, int ld, int tid, int n_threads) {
+  for (int i = tid; i < rows * 32; i += n_threads) {
+    const int k = i >> 5, m = i & 31;
+    unsigned short l1, l2, l3;
+    split3_scalar(P[off + (int64_t)k * ld + m], l1, l2, l3);
+    char* base = layer + (k * RM_LD + m) * 2;
+    *reinterpret_cast<unsigned short*>(base) = l1;
+    *reinterpret_cast<unsigned short*>(base + limb_stride) = l2;
+    *reinterpret_cast<unsigned short*>(base + 2 * limb_stride) = l3;
+  }
+}
+
 // the six limb products of one chunk, one A operand live at a time
-LP_DEV f32x16 chunk_bf3(const char* img, int chunk, int lane, const u32x4_t& l1, const u32x4_t& l2, const u32x4_t& l3, f32x16 acc) {
+template <class A>
+LP_DEV f32x16 chunk_bf3(const A& a, int c, int lane, const u32x4_t& l1, const u32x4_t& l2, const u32x4_t& l3, f32x16 acc) {
   {
-    const u32x4_t w3 = bf3_a(img, chunk, 2, lane);
+    const u32x4_t w3 = a(c, 2, lane);
     acc = LP_MFMA_BF16(w3, l1, acc);
   }
   {
-    const u32x4_t w2 = bf3_a(img, chunk, 1, lane);
+    const u32x4_t w2 = a(c, 1, lane);
     acc = LP_MFMA_BF16(w2, l2, acc);
     acc = LP_MFMA_BF16(w2, l1, acc);
   }
   {
-    const u32x4_t w1 = bf3_a(img, chunk, 0, lane);
+    const u32x4_t w1 = a(c, 0, lane);
     acc = LP_MFMA_BF16(w1, l3, acc);
     acc = LP_MFMA_BF16(w1, l2, acc);
     acc = LP_MFMA_BF16(w1, l1, acc);
@@ -152,14 +207,14 @@ LP_DEV void bf3_interleave_hint() {
 
 // The same product chunk by chunk straight from the fp32 values, software-pipelined: the limbs of chunk c + 1 are split
 // while the MFMAs of chunk c run; only one chunk's limbs (+ the next one's being formed) are live.
-template <int NCH>
-LP_DEV f32x16 layer_bf3v(const char* img, int chunk0, int lane, const float (&v)[8 * NCH], f32x16 acc) {
+template <int NCH, class A>
+LP_DEV f32x16 layer_bf3v(const A& a, int lane, const float (&v)[8 * NCH], f32x16 acc) {
   u32x4_t l1, l2, l3;
   split3_chunk(v, l1, l2, l3);
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     u32x4_t n1 = l1, n2 = l2, n3 = l3;
-    acc = chunk_bf3(img, chunk0 + c, lane, l1, l2, l3, acc);
+    acc = chunk_bf3(a, c, lane, l1, l2, l3, acc);
     if (c + 1 < NCH) {
       split3_chunk(v + 8 * (c + 1), n1, n2, n3);
       bf3_interleave_hint();
@@ -168,25 +223,33 @@ LP_DEV f32x16 layer_bf3v(const char* img, int chunk0, int lane, const float (&v)
   }
   return acc;
 }
+template <int NCH>
+LP_DEV f32x16 layer_bf3v(const char* img, int chunk0, int lane, const float (&v)[8 * NCH], f32x16 acc) {
+  return layer_bf3v<NCH>(ASlots{img, chunk0}, lane, v, acc);
+}
 
 // Two layers that read the SAME input (the opacity and the colour hidden layer both read e): every chunk is split once
 // and feeds two independent accumulator chains (which also keeps the matrix pipe busy back to back).
-template <int NCH>
-LP_DEV void layer2_bf3v(const char* img, int chunk_a, int chunk_b, int lane, const float (&v)[8 * NCH], f32x16& acc_a,
-                        f32x16& acc_b) {
+template <int NCH, class A1, class A2>
+LP_DEV void layer2_bf3v(const A1& a1, const A2& a2, int lane, const float (&v)[8 * NCH], f32x16& acc_a, f32x16& acc_b) {
   u32x4_t l1, l2, l3;
   split3_chunk(v, l1, l2, l3);
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     u32x4_t n1 = l1, n2 = l2, n3 = l3;
-    acc_a = chunk_bf3(img, chunk_a + c, lane, l1, l2, l3, acc_a);
-    acc_b = chunk_bf3(img, chunk_b + c, lane, l1, l2, l3, acc_b);
+    acc_a = chunk_bf3(a1, c, lane, l1, l2, l3, acc_a);
+    acc_b = chunk_bf3(a2, c, lane, l1, l2, l3, acc_b);
     if (c + 1 < NCH) {
       split3_chunk(v + 8 * (c + 1), n1, n2, n3);
       bf3_interleave_hint();
     }
     l1 = n1; l2 = n2; l3 = n3;
   }
+}
+template <int NCH>
+LP_DEV void layer2_bf3v(const char* img, int chunk_a, int chunk_b, int lane, const float (&v)[8 * NCH], f32x16& acc_a,
+                        f32x16& acc_b) {
+  layer2_bf3v<NCH>(ASlots{img, chunk_a}, ASlots{img, chunk_b}, lane, v, acc_a, acc_b);
 }
 
 // Stage one weight matrix W [rows_in x 32] (row-major, leading dimension ld, inside mlp_params at `off`) as limb
@@ -227,9 +290,8 @@ struct LdsBf3 {
   static constexpr int BWD_END = BWD_IMG + N_BWD * BF3_CHUNK; // bytes, backward kernel (before the per-wave tiles)
 };
 
-// stage the small fp32 block (at float offset 0 of `lds`: indices are Lds::X - Lds::BIAS) and the forward image
-template <int C>
-LP_DEV void stage_weights_bf3(const LpRendererArgs& a, const MfmaParams& mp, float* lds, bool with_backward, int n_threads) {
+// stage the small fp32 block (at float offset 0 of `lds`: indices are Lds::X - Lds::BIAS; n_inf entries of the beyond-far table)
+LP_DEV void stage_small_bf3(const LpRendererArgs& a, const MfmaParams& mp, float* lds, int n_inf, int n_threads) {
   using M = Lds;
   const float* P = a.mlp_params;
   const int tid = threadIdx.x;
@@ -243,12 +305,20 @@ LP_DEV void stage_weights_bf3(const LpRendererArgs& a, const MfmaParams& mp, flo
 #pragma unroll
     for (int c = 0; c < 4; ++c) sm[M::WC2 + i * 4 + c] = (c < a.color_chn) ? P[mp.w_c2 + (int64_t)i * mp.ldc2 + c] : 0.0f;
   }
-  for (int i = tid; i < MAX_INF; i += n_threads) sm[M::INF + i] = (i < a.march.num_samples_inf) ? inf_scale(i, a.march) : 0.0f;
+  for (int i = tid; i < n_inf; i += n_threads) sm[M::INF + i] = (i < a.march.num_samples_inf) ? inf_scale(i, a.march) : 0.0f;
   if (tid == 0) {
     sm[M::HB + 0] = P[mp.b_o2];
 #pragma unroll
     for (int c = 0; c < 4; ++c) sm[M::HB + 1 + c] = (c < a.color_chn) ? P[mp.b_c2 + c] : 0.0f;
   }
+}
+
+// small block + the forward slot image (+ the backward one)
+template <int C>
+LP_DEV void stage_weights_bf3(const LpRendererArgs& a, const MfmaParams& mp, float* lds, bool with_backward, int n_threads) {
+  const float* P = a.mlp_params;
+  const int tid = threadIdx.x;
+  stage_small_bf3(a, mp, lds, MAX_INF, n_threads);
   using L = LdsBf3<C>;
   char* img = reinterpret_cast<char*>(lds) + L::FWD_IMG;
   stage_matrix_bf3<true>(img, L::CH_T1, C / 16, P, mp.w_t1, C, 32, tid, n_threads);
@@ -264,18 +334,44 @@ LP_DEV void stage_weights_bf3(const LpRendererArgs& a, const MfmaParams& mp, flo
   }
 }
 
+// LDS map of the 4-wave bf16x3 backward: small block with a 64-entry beyond-far table, then ONE row-major limb image per
+// layer (both orientations are read from it, see ARowsBwd / AColsFwd): 24 KB with C = 16 instead of 45 KB of slot images
+template <int C>
+struct LdsBf3Rm {
+  static constexpr int N_INF = 64;
+  static constexpr int SMALL_BYTES = (Lds::INF - Lds::BIAS + N_INF) * 4;
+  static constexpr int ST_T1 = C * RM_LD * 2, ST_32 = 32 * RM_LD * 2;      // limb strides (bytes)
+  static constexpr int IMG = SMALL_BYTES;
+  static constexpr int L_T1 = IMG, L_T2 = L_T1 + 3 * ST_T1, L_O1 = L_T2 + 3 * ST_32, L_C1 = L_O1 + 3 * ST_32;
+  static constexpr int END = L_C1 + 3 * ST_32;
+  static_assert(SMALL_BYTES % 16 == 0 && END % 16 == 0, "16-byte alignment of the LDS regions");
+};
+template <int C>
+LP_DEV void stage_weights_rm(const LpRendererArgs& a, const MfmaParams& mp, float* lds, int n_threads) {
+  using R = LdsBf3Rm<C>;
+  stage_small_bf3(a, mp, lds, R::N_INF, n_threads);
+  char* b = reinterpret_cast<char*>(lds);
+  const float* P = a.mlp_params;
+  stage_matrix_rm(b + R::L_T1, R::ST_T1, P, mp.w_t1, C, 32, threadIdx.x, n_threads);
+  stage_matrix_rm(b + R::L_T2, R::ST_32, P, mp.w_t2, 32, 32, threadIdx.x, n_threads);
+  stage_matrix_rm(b + R::L_O1, R::ST_32, P, mp.w_o1, 32, 32, threadIdx.x, n_threads);
+  stage_matrix_rm(b + R::L_C1, R::ST_32, P, mp.w_c1, 32, 32, threadIdx.x, n_threads);
+}
+
 // bias of layer `which` (0 t1, 1 t2, 2 o1, 3 c1) in accumulator order; `sm` = small block base (sm[Lds::X] valid)
 LP_DEV f32x16 load_bias_bf3(const float* sm, int which, int h, int zo) { return load_bias(sm, which, h, zo); }
 
 // Per-ray pre-activation of the colour hidden layer: cb = b_c1 + W_c1^T enc.  relu(W^T (e + enc) + b) = relu(W^T e + cb),
 // so the colour layer reuses the limbs of e (already split for the opacity layer) instead of splitting e + enc again.
-template <int C>
-LP_DEV void color_prebias_bf3(const float* sm, const char* fimg, int lane, const float (&enc)[16], float (&cb)[16]) {
-  Limbs<16> b;
-  split3<16>(enc, b);
-  const f32x16 acc = layer_bf3<2>(fimg, LdsBf3<C>::CH_C1, lane, b, load_bias_bf3(sm, 3, lane >> 5, 0));
+template <class A>
+LP_DEV void color_prebias_bf3(const float* sm, const A& a_c1, int lane, const float (&enc)[16], float (&cb)[16]) {
+  const f32x16 acc = layer_bf3v<2>(a_c1, lane, enc, load_bias_bf3(sm, 3, lane >> 5, 0));
 #pragma unroll
   for (int q = 0; q < 16; ++q) cb[q] = acc[q];
+}
+template <int C>
+LP_DEV void color_prebias_bf3(const float* sm, const char* fimg, int lane, const float (&enc)[16], float (&cb)[16]) {
+  color_prebias_bf3(sm, ASlots{fimg, LdsBf3<C>::CH_C1}, lane, enc, cb);
 }
 
 // Decoder of one sample, default shape.  t.x0 in; fills t.h1 / t.e / t.ho / t.hc (post-ReLU) like decode_prefetch.

@@ -18,6 +18,8 @@
 // consecutive lanes per row (conflict-free), the quadrant reads are conflict-free once the 16
 // features of a quadrant are dealt to the MFMA lanes as even | odd | even (pi() below).
 #include "lp_mfma_common.h"
+#include <type_traits>
+
 #include "lp_bf3.h"
 
 namespace lp {
@@ -624,22 +626,39 @@ struct LdsB3 {  // per-wave area behind the images (floats)
   static constexpr int TS = 2 * 32 * T_LD;
   static constexpr int PER_WAVE = TS + 5 * 32;
 };
-constexpr int WAVES3 = 8;
+// NW = 8: eight-wave workgroups, slot images in both orientations (one workgroup per CU).
+// NW = 4: four-wave workgroups, ONE row-major limb image per layer read plainly by the dX chains and through
+//         ds_read_b64_tr_b16 by the recompute (lp_bf3.h): 81 KB per workgroup, so TWO independent workgroups share a CU
+//         and a SIMD hosts waves in unrelated phases again -- the eight waves of NW = 8 are barrier-locked into the same
+//         phase, so its two waves per SIMD fight for the same pipe instead of overlapping.
+template <int C, int NW>
+struct Bf3Lds {
+  static constexpr int IMG_END = (NW == 8) ? LdsBf3<C>::BWD_END : LdsBf3Rm<C>::END;  // bytes before the per-wave tiles
+  static constexpr int CB = IMG_END + NW * LdsB3::PER_WAVE * 4;                       // lane-private cb records
+  // the cb records live in LDS where they fit (C = 16); with C = 32 the image is 3.4 KB larger and two workgroups per CU
+  // only fit if cb stays in registers
+  static constexpr bool CB_LDS = (NW == 8) ? (C == 16) : (CB + NW * 64 * 16 * 4) * 2 <= 160 * 1024;
+  static constexpr int TOTAL = CB + (CB_LDS ? NW * 64 * 16 * 4 : 0);
+};
 
-template <int C, int GM, bool PLAIN, int NC>
-__global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs a, const MfmaParams mp) {
+template <int C, int GM, bool PLAIN, int NC, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(const LpRendererArgs a, const MfmaParams mp) {
   using M = Lds;
   using L = LdsBf3<C>;
+  using R = LdsBf3Rm<C>;
   using B = LdsB3;
+  constexpr int WAVES3 = NW;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_weights_bf3<C>(a, mp, lds, true, 512);
+  if (NW == 8) stage_weights_bf3<C>(a, mp, lds, true, 64 * NW);
+  else stage_weights_rm<C>(a, mp, lds, 64 * NW);
   const float* const sm = lds - M::BIAS;  // small fp32 block: sm[Lds::X]
-  const char* const fimg = reinterpret_cast<const char*>(lds) + L::FWD_IMG;
-  const char* const bimg = reinterpret_cast<const char*>(lds) + L::BWD_IMG;
+  const char* const fimg = reinterpret_cast<const char*>(lds) + L::FWD_IMG;   // NW = 8 only
+  const char* const bimg = reinterpret_cast<const char*>(lds) + L::BWD_IMG;   // NW = 8 only
+  const char* const rimg = reinterpret_cast<const char*>(lds);                // NW = 4: layer offsets R::L_* are absolute
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // scalar: every per-wave base below is an SGPR
   const int h = lane >> 5, r = lane & 31;
-  float* const wave0 = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + L::BWD_END);
+  float* const wave0 = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + Bf3Lds<C, NW>::IMG_END);
   float* const wv = wave0 + wave * B::PER_WAVE;
   float* const xt = wv + B::XT;
   float* const yt = wv + B::YT;
@@ -675,15 +694,20 @@ __global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs 
   }
   // per-ray pre-activation of the colour hidden layer, cb = b_c1 + W_c1^T enc: read once per sample, so it lives in LDS
   // (lane-private 64-byte records behind the tiles, the four 16-byte quarters rotated by lane >> 2: conflict-free)
+  constexpr bool CBL = Bf3Lds<C, NW>::CB_LDS;
   float* const cbt = wave0 + WAVES3 * B::PER_WAVE + (wave * 64 + lane) * 16;
   const int cb_rot = (lane >> 2) & 3;
+  float cb[16];  // (dead after this block when the records live in LDS)
   {
-    float enc[16], cb[16];
+    float enc[16];
     load_encoding(a, rid, h, enc);
-    color_prebias_bf3<C>(sm, fimg, lane, enc, cb);
+    if constexpr (NW == 8) color_prebias_bf3(sm, ASlots{fimg, L::CH_C1}, lane, enc, cb);
+    else color_prebias_bf3(sm, AColsFwd{rimg + R::L_C1, R::ST_32}, lane, enc, cb);
+    if (CBL) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<float4*>(cbt + ((i + cb_rot) & 3) * 4) = make_float4(cb[4 * i], cb[4 * i + 1], cb[4 * i + 2], cb[4 * i + 3]);
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<float4*>(cbt + ((i + cb_rot) & 3) * 4) = make_float4(cb[4 * i], cb[4 * i + 1], cb[4 * i + 2], cb[4 * i + 3]);
+    }
   }
   float dsum[16];  // D = sum over samples of d hc
 #pragma unroll
@@ -699,6 +723,7 @@ __global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs 
   const float delta0 = (a.march.num_samples > 1) ? (ray.far_t - ray.near_t) / (float)(a.march.num_samples - 1) : 1.0f;
 
   // dW quadrant of this wave: quadrant (mi, ni) = wave & 3 over the rays of the source waves [v0, v0 + 4)
+  // (NW = 8: two groups of four waves, each over four source waves; NW = 4: every wave over all four)
   const int mi = (wave & 3) >> 1, ni = wave & 1;
   const int v0 = 4 * (wave >> 2);
   const int m16 = lane & 15, ka = lane >> 4;
@@ -706,6 +731,7 @@ __global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs 
   const int b_off = B::YT + (16 * ni + pi16(m16)) * T_LD + 8 * ka;
   // trunk layer 1 has only C input rows: with C == 16 its two quadrants (ni) are split over four ray groups instead
   const int a_off_t1 = (C == 16) ? B::XT + pi16(m16) * T_LD + 8 * ka : a_off;
+  // (NW = 8: four ray groups of two source waves; NW = 4: two groups -- wave >> 1 -- of two source waves)
   const int t1_v0 = (C == 16) ? 2 * (wave >> 1) : v0, t1_v1 = (C == 16) ? 2 * (wave >> 1) + 2 : v0 + 4;
   f32x4 dq_t1 = {0, 0, 0, 0}, dq_t2 = {0, 0, 0, 0}, dq_o1 = {0, 0, 0, 0}, dq_c1 = {0, 0, 0, 0};
   float db_t1 = 0.0f, db_t2 = 0.0f, db_o1 = 0.0f, db_c1 = 0.0f;
@@ -730,8 +756,20 @@ __global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs 
     for (int q = 0; q < C / 2; ++q) x0[q] = nx.x0[q];
     const int zo = opaque_zero();
     const float* ldz = sm + zo;
-    const char* const fi = fimg + zo;
-    const char* const bi = bimg + zo;
+    // A-operand loaders of the four layers (0 t1, 1 t2, 2 o1, 3 c1), forward (recompute) and backward (dX) form
+    auto Af = [&](auto layer) {
+      constexpr int l = decltype(layer)::value;
+      if constexpr (NW == 8) return ASlots{fimg + zo, l == 0 ? L::CH_T1 : l == 1 ? L::CH_T2 : l == 2 ? L::CH_O1 : L::CH_C1};
+      else return AColsFwd{rimg + zo + (l == 0 ? R::L_T1 : l == 1 ? R::L_T2 : l == 2 ? R::L_O1 : R::L_C1), l == 0 ? R::ST_T1 : R::ST_32};
+    };
+    auto Ab = [&](auto layer) {
+      constexpr int l = decltype(layer)::value;
+      if constexpr (NW == 8) return ASlots{bimg + zo, l == 0 ? L::CB_T1 : l == 1 ? L::CB_T2 : l == 2 ? L::CB_O1 : L::CB_C1};
+      else return ARowsBwd{rimg + zo + (l == 0 ? R::L_T1 : l == 1 ? R::L_T2 : l == 2 ? R::L_O1 : R::L_C1), l == 0 ? R::ST_T1 : R::ST_32,
+                           l == 0 ? C - 1 : 31};
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
 
     // ---------------- forward recompute (bf16x3) ----------------
     LP_MARK("fwd");
@@ -741,24 +779,29 @@ __global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs 
     {
       f32x16 acc;
       {
-        acc = layer_bf3v<C / 16>(fi, L::CH_T1, lane, x0, load_bias(sm, 0, h, zo));
+        acc = layer_bf3v<C / 16>(Af(I0{}), lane, x0, load_bias(sm, 0, h, zo));
 #pragma unroll
         for (int q = 0; q < 16; ++q) h1[q] = fmaxf(acc[q], 0.0f);
       }
       {
-        acc = layer_bf3v<2>(fi, L::CH_T2, lane, h1, load_bias(sm, 1, h, zo));
+        acc = layer_bf3v<2>(Af(I1{}), lane, h1, load_bias(sm, 1, h, zo));
 #pragma unroll
         for (int q = 0; q < 16; ++q) e[q] = fmaxf(acc[q], 0.0f);
       }
       float ho[16], hc[16];
       {
         f32x16 acc_o = load_bias(sm, 2, h, zo), acc_c;
+        if (CBL) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float4 v = *reinterpret_cast<const float4*>(cbt + zo + ((i + cb_rot) & 3) * 4);
-          acc_c[4 * i] = v.x; acc_c[4 * i + 1] = v.y; acc_c[4 * i + 2] = v.z; acc_c[4 * i + 3] = v.w;
+          for (int i = 0; i < 4; ++i) {
+            const float4 v = *reinterpret_cast<const float4*>(cbt + zo + ((i + cb_rot) & 3) * 4);
+            acc_c[4 * i] = v.x; acc_c[4 * i + 1] = v.y; acc_c[4 * i + 2] = v.z; acc_c[4 * i + 3] = v.w;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc_c[q] = cb[q];
         }
-        layer2_bf3v<2>(fi, L::CH_O1, L::CH_C1, lane, e, acc_o, acc_c);
+        layer2_bf3v<2>(Af(I2{}), Af(I3{}), lane, e, acc_o, acc_c);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           ho[q] = fmaxf(acc_o[q], 0.0f);
@@ -881,7 +924,7 @@ __global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs 
         tile_store_fm(xt, r, h, e);
         tile_store_fm(yt, r, h, dhc);
       }
-      acc = layer_bf3v<2>(bi, L::CB_C1, lane, dhc, acc);
+      acc = layer_bf3v<2>(Ab(I3{}), lane, dhc, acc);
 #pragma unroll
       for (int q = 0; q < 16; ++q) dsum[q] += dhc[q];
       if (want_params) {
@@ -904,7 +947,7 @@ __global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs 
         dho[4 * j + 3] = (ho_mask & (1u << (4 * j + 3))) ? dro * wo.w : 0.0f;
       }
       if (want_params) tile_store_fm(yt, r, h, dho);  // the X tile still holds e
-      acc = layer_bf3v<2>(bi, L::CB_O1, lane, dho, acc);
+      acc = layer_bf3v<2>(Ab(I2{}), lane, dho, acc);
       if (want_params) {
         lds_barrier();
         dq_o1 = dw_quadrant<B::PER_WAVE>(wave0, a_off, b_off, v0, v0 + 4, dq_o1, db_o1);
@@ -923,7 +966,7 @@ __global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs 
         tile_store_fm(xt, r, h, h1);
         tile_store_fm(yt, r, h, de);
       }
-      acc = layer_bf3v<2>(bi, L::CB_T2, lane, de, (f32x16){0});
+      acc = layer_bf3v<2>(Ab(I1{}), lane, de, (f32x16){0});
       if (want_params) {
         lds_barrier();
         dq_t2 = dw_quadrant<B::PER_WAVE>(wave0, a_off, b_off, v0, v0 + 4, dq_t2, db_t2);
@@ -942,7 +985,7 @@ __global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs 
         tile_store_fm(yt, r, h, dh1);
       }
       if (gg) {
-        acc = layer_bf3v<2>(bi, L::CB_T1, lane, dh1, (f32x16){0});  // rows >= C: zero weights
+        acc = layer_bf3v<2>(Ab(I0{}), lane, dh1, (f32x16){0});  // rows >= C of the result are unused
       }
       if (want_params) {
         lds_barrier();
@@ -979,9 +1022,9 @@ __global__ void __launch_bounds__(512, 1) renderer_bwd_bf3(const LpRendererArgs 
 #endif
   // d enc = W_c1 D ; dW_c1 += enc (x) D   (one product each, after the sweep)
   {
-    Limbs<16> b;
-    split3<16>(dsum, b);
-    const f32x16 acc = layer_bf3<2>(bimg, L::CB_C1, lane, b, (f32x16){0});
+    f32x16 acc;
+    if constexpr (NW == 8) acc = layer_bf3v<2>(ASlots{bimg, L::CB_C1}, lane, dsum, (f32x16){0});
+    else acc = layer_bf3v<2>(ARowsBwd{rimg + R::L_C1, R::ST_32, 31}, lane, dsum, (f32x16){0});
     if (valid && a.grad_encoding) {
       float4* dst = reinterpret_cast<float4*>(a.grad_encoding + ray_id * HID + 4 * h);
 #pragma unroll
@@ -1062,16 +1105,24 @@ static int launch_bwd2p(const LpRendererArgs& a, const MfmaParams& mp, hipStream
   return LP_OK;
 }
 
-template <int C, int GM, bool PLAIN, int NC>
-static int launch_bwd3(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
-  constexpr size_t lds = (size_t)LdsBf3<C>::BWD_END + (size_t)WAVES3 * (LdsB3::PER_WAVE + 64 * 16) * sizeof(float);
-  static_assert(lds <= 160 * 1024, "one 8-wave workgroup must fit the 160 KB LDS");
-  const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_bf3<C, GM, PLAIN, NC>,
+template <int C, int GM, bool PLAIN, int NC, int NW>
+static int launch_bwd3w(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
+  constexpr size_t lds = (size_t)Bf3Lds<C, NW>::TOTAL;
+  static_assert(lds * (NW == 8 ? 1 : 2) <= 160 * 1024, "the workgroups of one CU must fit the 160 KB LDS");
+  static_assert(NW == 8 || 2 * lds <= 160 * 1024, "two 4-wave workgroups per CU");
+  const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_bf3<C, GM, PLAIN, NC, NW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-  const unsigned nb = (unsigned)((a.rays.n_rays + WAVES3 * RAYS_PER_WAVE - 1) / (WAVES3 * RAYS_PER_WAVE));
-  hipLaunchKernelGGL((renderer_bwd_bf3<C, GM, PLAIN, NC>), dim3(nb), dim3(512), lds, stream, a, mp);
+  const unsigned nb = (unsigned)((a.rays.n_rays + NW * RAYS_PER_WAVE - 1) / (NW * RAYS_PER_WAVE));
+  hipLaunchKernelGGL((renderer_bwd_bf3<C, GM, PLAIN, NC, NW>), dim3(nb), dim3(64 * NW), lds, stream, a, mp);
   return LP_OK;
+}
+template <int C, int GM, bool PLAIN, int NC>
+static int launch_bwd3(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
+  // four-wave workgroups (two per CU) unless the beyond-far table does not fit their small block; LP_BF3_NW=8 for A/B
+  static const int forced = getenv("LP_BF3_NW") ? atoi(getenv("LP_BF3_NW")) : 0;
+  const bool nw4 = forced ? forced == 4 : a.march.num_samples_inf <= LdsBf3Rm<C>::N_INF;
+  return nw4 ? launch_bwd3w<C, GM, PLAIN, NC, 4>(a, mp, stream) : launch_bwd3w<C, GM, PLAIN, NC, 8>(a, mp, stream);
 }
 
 // PLAIN = the common configuration (no opacity noise, no contraction, no scaffold, no beyond-far
@@ -1081,15 +1132,16 @@ static int launch_bwd2(const LpRendererArgs& a, const MfmaParams& mp, hipStream_
   const bool plain = !(a.noise_sigma > 0.0f) && !a.march.contract_coords && !a.scaffold && a.march.num_samples_inf == 0 &&
                      !(a.stop_neg_log_t > 0.0f);
   const bool flex = !(mp.hid == HID && mp.t1 && mp.t2 && mp.oh && mp.ch && !mp.tg);
-  // C = 16, default shape: recompute + dX chains as bf16x3 on the bf16 matrix cores (renderer_bwd_bf3).  Measured on
-  // MI355X: cfg 2 backward 2.58 -> 2.42 ms, 1080p x S=128 73.7 -> 68.0 ms.  C = 32 keeps the fp32-MFMA kernel: both limb
-  // images + the tiles + the cb records do not fit the 160 KB LDS, and with 51 spilled registers the C = 32 instantiation
-  // measured no gain (cfg 4: 164 ms either way).  LP_MFMA_F32 / LP_MFMA_F32_BWD select the fp32-MFMA kernel.
+  // default shape: recompute + dX chains as bf16x3 on the bf16 matrix cores (renderer_bwd_bf3).  Measured on MI355X
+  // (C = 16): cfg 2 backward 2.57 -> 2.31 ms, 1080p x S=128 73.6 -> 65.2 ms.  LP_MFMA_F32 / LP_MFMA_F32_BWD select the
+  // fp32-MFMA kernel.  C = 32 stays on the fp32-MFMA kernel unless LP_BF3_C32=1: its 3.4 KB larger image leaves no room
+  // for the cb records, with cb in registers the kernel spills 77 and measures 165 ms against 164 ms at cfg 4.
   static const bool bf3_bwd = getenv("LP_MFMA_F32") == nullptr && getenv("LP_MFMA_F32_BWD") == nullptr;
-  if (C == 16 && !flex && !mp.tg && bf3_bwd) {  // C = 32: the images + tiles + cb records do not fit the 160 KB
+  static const bool bf3_c32 = getenv("LP_BF3_C32") != nullptr && atoi(getenv("LP_BF3_C32")) != 0;
+  if ((C == 16 || bf3_c32) && !flex && !mp.tg && bf3_bwd) {
     if (a.color_chn <= 3)
-      return plain ? launch_bwd3<16, GM, true, 3>(a, mp, stream) : launch_bwd3<16, GM, false, 3>(a, mp, stream);
-    return plain ? launch_bwd3<16, GM, true, 4>(a, mp, stream) : launch_bwd3<16, GM, false, 4>(a, mp, stream);
+      return plain ? launch_bwd3<C, GM, true, 3>(a, mp, stream) : launch_bwd3<C, GM, false, 3>(a, mp, stream);
+    return plain ? launch_bwd3<C, GM, true, 4>(a, mp, stream) : launch_bwd3<C, GM, false, 4>(a, mp, stream);
   }
   if (mp.tg)  // two-grid decoder
     return plain ? launch_bwd2p<C, GM_GENERIC, true, true, true>(a, mp, stream)
