@@ -394,7 +394,9 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     // the four layer phases are coupled to the sibling waves by two barriers each: run them at raised priority
     // so that the co-resident wave of the other workgroup (gathering / scattering) does not stretch them for
     // all four waves (-2.4% kernel time)
+#ifndef LP_NO_PRIO
     __builtin_amdgcn_s_setprio(1);
+#endif
     if (ch) {
       if (want_params) {
         float ein[16];
@@ -917,7 +919,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
 
     // ---------------- colour hidden layer (X tile = e: shared with the opacity layer below) ----------------
     LP_MARK("c1");
+#ifndef LP_NO_PRIO
     __builtin_amdgcn_s_setprio(1);
+#endif
     f32x16 acc = (f32x16){0};
     {
       if (want_params) {

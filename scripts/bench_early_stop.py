@@ -4,19 +4,14 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import lightplane_amd as lp
-from bench import make_workload, S, COLOR
+from bench import RendererWorkload
+from lightplane_amd import _lib
 
 dev = torch.device("cuda:0")
 lp.config.check_inputs = False
 gain = float(os.environ.get("GAIN", "60"))
-rays_c, grids_c, dec_c, sizes, up_c = make_workload(0, dev)
-rays = rays_c.to(dev)
-flat, _ = lp.flatten_grid([g.to(dev) for g in grids_c])
-flat.requires_grad_(True)
-params = dec_c.mlp_params.to(dev).requires_grad_(True)
-rays.encoding.requires_grad_(True)
-dec = lp.DecoderParams(params, dec_c.n_hidden_trunk, dec_c.n_hidden_opacity, dec_c.n_hidden_color, COLOR)
-up = [u.to(dev) for u in up_c]
+wl = RendererWorkload("cfg2", 0, dev, None, _lib.LP_KERNEL_AUTO)
+rays, flat, params, dec, up, sizes, S = wl.rays, wl.flat, wl.params, wl.dec, wl.up, wl.sizes, wl.S
 
 def step(stop):
     flat.grad = params.grad = rays.encoding.grad = None

@@ -1,16 +1,25 @@
 #!/bin/bash
-# rocprofv3 kernel trace of bench.py (+ PMC passes). Outputs under gpurun_out/prof*.
+# rocprofv3 of bench.py: per workload (cfg2 = the headline command without the `extras` runs, cfg3, cfg4) one kernel trace
+# and PMC passes (own runs: --pmc is never combined with other trace domains).  Outputs under gpurun_out/prof_<w>, pmcN_<w>;
+# scripts/summarize_profiles.py condenses them into profiles/.
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_bench.txt 2>&1
-tail -1 $R/gpurun_out/prof_bench.txt
-find $R/gpurun_out/prof -type f | head
-f=$(find $R/gpurun_out/prof -name "*kernel_stats.csv" | head -1); echo "== $f"; head -8 "$f"
-# PMC pass 1: SQ counters for the two renderer kernels
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_ANY --output-format csv -d $R/gpurun_out/pmc1 -o pmc -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc1.txt 2>&1
-rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_INSTS_SALU --output-format csv -d $R/gpurun_out/pmc2 -o pmc -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc2.txt 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc3 -o pmc -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc3.txt 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/pmc4 -o pmc -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc4.txt 2>&1
-find $R/gpurun_out/pmc1 -type f | head -5
+rm -rf $R/gpurun_out/prof_* $R/gpurun_out/pmc[1-4]_*
+run() {  # workload, steps (trace), steps (pmc)
+  w=$1
+  B="python $R/bench.py --workload $w --no-cpu-baseline --no-extras"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$w -o bench -- $B --steps $2 --warmup 3 > $R/gpurun_out/prof_$w.txt 2>&1
+  tail -1 $R/gpurun_out/prof_$w.txt | cut -c1-300
+  P="$B --steps $3 --warmup 1"
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_ANY --output-format csv -d $R/gpurun_out/pmc1_$w -o pmc -- $P > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_INSTS_SALU --output-format csv -d $R/gpurun_out/pmc2_$w -o pmc -- $P > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc3_$w -o pmc -- $P > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/pmc4_$w -o pmc -- $P > /dev/null 2>&1
+}
+run cfg2 200 3
+run cfg3 50 3
+run cfg4 5 1
+find $R/gpurun_out/prof_* $R/gpurun_out/pmc[1-4]_* -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" -size +512k -delete
+ls $R/gpurun_out/prof_cfg2 $R/gpurun_out/pmc1_cfg2

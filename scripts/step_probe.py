@@ -27,9 +27,37 @@ def f_list():
 def f_module():
     o = module(rays_m, planes)
     (o[0].sum() + o[2].sum()).backward()
+def count_kernels(f):
+    """GPU kernels (names) of one call, from torch.profiler."""
+    from torch.profiler import ProfilerActivity, profile
+    f(); torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        f(); torch.cuda.synchronize()
+    names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA and "Memcpy" not in e.name and "Memset" not in e.name]
+    return names
+
+
+lp.config.check_inputs = False
+for fused in (True, False):
+    lp.config.fused_module_ops = fused
+    names = count_kernels(f_module)
+    ours = [n for n in names if "lp::" in n]
+    print(f"module fwd+bwd, fused_module_ops={fused}: {len(names)} kernels ({len(ours)} lp::, cat copies: {sum('Cat' in n for n in names)})")
+    if fused:
+        print("   ", [n.split("(")[0][:60] for n in names])
+lp.config.fused_module_ops = True
+names = count_kernels(f_list)
+print(f"functional, list of planes: {len(names)} kernels, cat copies: {sum('Cat' in n for n in names)}")
 for chk in (True, False):
     lp.config.check_inputs = chk
-    for name, f in (("functional, flat grid", f_flat), ("functional, list of planes", f_list), ("module", f_module)):
+    def f_module_ops():
+        lp.config.fused_module_ops = False
+        try:
+            f_module()
+        finally:
+            lp.config.fused_module_ops = True
+    for name, f in (("functional, flat grid", f_flat), ("functional, list of planes", f_list), ("module (fused)", f_module),
+                    ("module (PyTorch op chain)", f_module_ops)):
         for _ in range(20): f()
         torch.cuda.synchronize(); t = time.perf_counter()
         for _ in range(200): f()
