@@ -203,9 +203,9 @@ def event_times(wl, reps):
     return fwd_ms, bwd_ms
 
 
-def pmc_traffic(kernel_substr):
+def pmc_traffic(workload, kernel_substr):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r*_pmc_summary.json:
-    (FETCH_SIZE + WRITE_SIZE) * 1024 from separate --pmc runs of this command).  Not measured in this run."""
+    (FETCH_SIZE + WRITE_SIZE) * 1024 from separate --pmc runs of `bench.py --workload <w>`).  Not measured in this run."""
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_summary.json")))
     for f in reversed(files):
         try:
@@ -213,7 +213,7 @@ def pmc_traffic(kernel_substr):
         except Exception:
             continue
         for k, v in d.items():
-            if kernel_substr in k and "hbm_bytes_per_launch" in v:
+            if k.startswith(workload + ":") and kernel_substr in k and "hbm_bytes_per_launch" in v:
                 return int(v["hbm_bytes_per_launch"]), os.path.relpath(f, REPO)
     return None, None
 
@@ -300,7 +300,7 @@ def cpu_baseline(wl):
 def measure_extra(name, dev, kernel, reps):
     """Short single-GPU measurement of another configuration (events only) for the `extras` block."""
     wl = make_workload(name, 0, dev, None, kernel)
-    for _ in range(2):
+    for _ in range(2 if name in ("cfg4", "1080p_s128") else 10):
         wl.step()
     torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats(dev)
@@ -382,8 +382,8 @@ def main():
 
     if rank == 0:
         roof = wl.roofline(fwd_ms, bwd_ms)
-        traffic, src = pmc_traffic("renderer_bwd_mfma" if isinstance(wl, RendererWorkload) else "splat_fwd_walk")
-        roof["traffic"] = traffic if args.workload == "cfg2" else None
+        traffic, src = pmc_traffic(args.workload, "renderer_bwd" if isinstance(wl, RendererWorkload) else "splat_fwd_walk")
+        roof["traffic"] = traffic
         roof["traffic_source"] = (f"{src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, NOT measured in "
                                   f"this run; L2 -> fabric requests, i.e. one 64 B write request per atomic segment") if src else None
         if isinstance(wl, RendererWorkload) and args.workload in ("cfg2", "1080p_s128"):
