@@ -317,6 +317,49 @@ def measure_extra(name, dev, kernel, reps):
     return out
 
 
+def kernel_times(wl, reps):
+    """Mean device time of the lp::renderer_fwd* / lp::renderer_bwd* kernels per step, from torch.profiler's device
+    timestamps: for batches whose kernels are as short as the host side of a call, events around Python calls would
+    measure the host."""
+    from torch.profiler import ProfilerActivity, profile
+    for _ in range(3):
+        wl.step()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(reps):
+            wl.step()
+        torch.cuda.synchronize()
+    fwd = bwd = 0.0
+    for e in prof.events():
+        if e.device_type != torch.autograd.DeviceType.CUDA:
+            continue
+        if "lp::renderer_fwd" in e.name:
+            fwd += e.device_time_total
+        elif "lp::renderer_bwd" in e.name:
+            bwd += e.device_time_total
+    return fwd / reps / 1e3, bwd / reps / 1e3
+
+
+def measure_small_batch(dev, kernel, reps):
+    """A NeRF-style training batch (4 096 rays x 128 samples, cfg 2's grid and decoder): kernel times with the
+    segment-parallel backward (default) and with one sweep per ray."""
+    name = "small_64x64_s128"
+    RENDER_CFGS[name] = (64, 64, 128, 16, 64, "small batch: Renderer fwd+bwd, 64x64 rays, triplane 64^2x16ch, 128 samples")
+    wl = RendererWorkload(name, 0, dev, None, kernel)
+    n_seg = lp.backward_segments(wl.rays, None, wl.dec, num_samples=wl.S, grid_sizes=wl.sizes)
+    saved = lp.config.segment_backward
+    try:
+        lp.config.segment_backward = True
+        f1, b1 = kernel_times(wl, reps)
+        lp.config.segment_backward = False
+        f0, b0 = kernel_times(wl, reps)
+    finally:
+        lp.config.segment_backward = saved
+    return {"workload": wl.desc, "rays": wl.n_rays, "backward_segments": n_seg, "fwd_ms": round(f1, 4), "bwd_ms": round(b1, 4),
+            "bwd_ms_one_sweep_per_ray": round(b0, 4), "fwd_ms_one_sweep_per_ray": round(f0, 4), "reps": reps,
+            "timing": "torch.profiler device time of the lp:: kernels"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -408,6 +451,7 @@ def main():
                 "splatter_cfg3": measure_extra("cfg3", dev, args.kernel, 10),
                 "renderer_1080p_s128": measure_extra("1080p_s128", dev, args.kernel, 4),
                 "renderer_cfg4_shard": measure_extra("cfg4", dev, args.kernel, 3),
+                "renderer_small_batch": measure_small_batch(dev, args.kernel, 20),
             }
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only
             res["cpu_baseline"] = cpu_baseline(wl)

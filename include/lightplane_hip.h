@@ -51,8 +51,9 @@
 extern "C" {
 #endif
 
-#define LP_VERSION 200 /* 0.2.0: per-grid base pointers (zero-copy grid-lists), fused bg-colour / alpha epilogue,
-                           ray-embedding entry points; grad replicas removed */
+#define LP_VERSION 201 /* 0.2.0: per-grid base pointers (zero-copy grid-lists), fused bg-colour / alpha epilogue,
+                           ray-embedding entry points; grad replicas removed
+                           0.2.1: segment-parallel backward for small batches (LpRendererArgs.seg_prefix) */
 
 #define LP_MAX_GRIDS 8   /* grids per grid-list                         */
 #define LP_MAX_LAYERS 8  /* layers per MLP                              */
@@ -182,6 +183,14 @@ typedef struct LpRendererArgs {
    * contributions of at most exp(-stop_neg_log_t) per unit of depth / colour, and neg_log_t is the value
    * reached at the stop (>= stop_neg_log_t) instead of the value after the last sample.  0 = exact. */
   float stop_neg_log_t;
+  /* Segment-parallel backward for small batches (extension).  A backward sweep is serial along the ray, so a batch
+   * with fewer rays than the GPU has wave slots (65 536 fill an MI355X once) leaves most of the chip idle.  With seg_prefix != NULL the
+   * forward also saves, per ray and per block of LP_NLT_CKPT regular samples, the running sums (ray_length,
+   * feature[0..3]) after the block's last sample -- [N, lp_renderer_backward_segments(args), 8] floats -- and the
+   * backward sweeps every block of a ray in its own workgroup (the part of d loss / d opacity_s that depends on the
+   * samples behind the block comes from the saved sums).  grad_encoding is then ACCUMULATED (caller zero-fills).
+   * Pass the same pointer to forward and backward, and only when lp_renderer_backward_segments() > 1. */
+  float* seg_prefix;
 } LpRendererArgs;
 
 typedef struct LpSplatterArgs {
@@ -234,6 +243,11 @@ const char* lp_last_error(void);
  * which = 0 LpGrid, 1 LpGridList, 2 LpRays, 3 LpMarch, 4 LpMlp, 5 LpRendererArgs,
  * 6 LpSplatterArgs, 7 LpRayEmbedArgs; anything else returns -1. */
 int lp_abi_sizeof(int which);
+
+/* Number of ray segments the backward of these arguments can be split into (see LpRendererArgs.seg_prefix): 1 when the
+ * selected kernel has no segmented form, when the march has beyond-far samples or early termination, or when the
+ * batch fills the GPU without it; otherwise ceil(num_samples / LP_NLT_CKPT).  Depends on shapes only (no launch). */
+int lp_renderer_backward_segments(const LpRendererArgs* args);
 
 /* Which kernel family LP_KERNEL_AUTO selects for these arguments (no launch; shapes only):
  *   lp_renderer_kernel_family: 0 shape-generic VALU kernels, 1 MFMA hidden-32 family, 2 MFMA hidden-64 family

@@ -22,7 +22,7 @@ from .params import (
 )
 from .rays import Rays, calc_harmonic_embedding, calc_harmonic_embedding_dim, jitter_near_far
 from . import config  # noqa: E402
-from .renderer import LightplaneFunction, lightplane_renderer  # noqa: E402
+from .renderer import LightplaneFunction, backward_segments, kernel_family, lightplane_renderer  # noqa: E402
 from .splatter import (LightplaneMLPSplatterFunction, LightplaneSplatterFunction, lightplane_mlp_splatter,  # noqa: E402
                        lightplane_splatter)
 from .modules import LightplaneMLPSplatter, LightplaneRenderer, LightplaneSplatter  # noqa: E402
@@ -30,7 +30,7 @@ from .modules import LightplaneMLPSplatter, LightplaneRenderer, LightplaneSplatt
 __all__ = [
     "lightplane_renderer", "lightplane_splatter", "lightplane_mlp_splatter", "LightplaneRenderer",
     "LightplaneSplatter", "LightplaneMLPSplatter", "LightplaneFunction", "LightplaneSplatterFunction",
-    "LightplaneMLPSplatterFunction", "config",
+    "LightplaneMLPSplatterFunction", "config", "kernel_family", "backward_segments",
     "Rays", "DecoderParams", "SplatterParams", "init_decoder_params", "init_splatter_params",
     "flatten_decoder_params", "flatten_splatter_params", "flattened_decoder_params_to_list",
     "flattened_triton_decoder_to_list", "get_triton_function_input_dims", "flatten_grid",

@@ -75,7 +75,7 @@ class LpRendererArgs(C.Structure):
         ("grad_encoding", C.c_void_p),
         ("grad_grid_list", C.c_void_p * LP_MAX_GRIDS), ("grad_color_grid_list", C.c_void_p * LP_MAX_GRIDS),
         ("bg_color", C.c_void_p), ("alpha", C.c_void_p), ("grad_alpha", C.c_void_p), ("alpha_mode", C.c_int32),
-        ("stop_neg_log_t", C.c_float),
+        ("stop_neg_log_t", C.c_float), ("seg_prefix", C.c_void_p),
     ]
 
 
@@ -107,6 +107,7 @@ EXPORTS = (
     "lp_version", "lp_last_error", "lp_abi_sizeof", "lp_renderer_forward", "lp_renderer_backward",
     "lp_splatter_forward", "lp_splatter_normalize", "lp_splatter_backward", "lp_hash_randn",
     "lp_renderer_corner_rows", "lp_renderer_kernel_family", "lp_splatter_kernel_family",
+    "lp_renderer_backward_segments",
     "lp_ray_embedding_forward", "lp_ray_embedding_backward",
 )
 
@@ -144,6 +145,8 @@ def lib() -> C.CDLL:
     L.lp_renderer_corner_rows.argtypes = [C.POINTER(LpRendererArgs), C.c_void_p, C.c_void_p]
     L.lp_renderer_kernel_family.restype = C.c_int
     L.lp_renderer_kernel_family.argtypes = [C.POINTER(LpRendererArgs)]
+    L.lp_renderer_backward_segments.restype = C.c_int
+    L.lp_renderer_backward_segments.argtypes = [C.POINTER(LpRendererArgs)]
     L.lp_splatter_kernel_family.restype = C.c_int
     L.lp_splatter_kernel_family.argtypes = [C.POINTER(LpSplatterArgs)]
     for name in ("lp_ray_embedding_forward", "lp_ray_embedding_backward"):

@@ -8,6 +8,9 @@
 ``fused_module_ops``   ``LightplaneRenderer.forward`` computes the harmonic ray embedding + its Linear layer in one HIP
                        kernel and the background / alpha epilogue inside the render kernel (2 launches instead of
                        ~17).  Off: the reference's PyTorch op chain around the functional renderer.  Default on.
+``segment_backward``   small Renderer batches (<= 32 768 rays, default decoder shape, 16 channels): the backward sweeps every
+                       block of 32 samples of a ray in its own workgroup, from running sums the forward saves per block
+                       (32 B per ray and block).  Default on.
 ``warn_generic_kernel`` warn (once per shape) when a call falls back to the shape-generic kernels, which
                        are one to two orders of magnitude slower than the MFMA / walk families.  Default on.
 ``stop_transmittance`` early ray termination of the Renderer (extension, see ``lightplane_renderer``): a wavefront stops
@@ -18,5 +21,6 @@ import os
 check_inputs: bool = os.environ.get("LIGHTPLANE_AMD_CHECK_INPUTS", "1") != "0"
 check_finite_grads: bool = os.environ.get("LIGHTPLANE_AMD_CHECK_FINITE", "0") == "1"
 fused_module_ops: bool = os.environ.get("LIGHTPLANE_AMD_FUSED_MODULE_OPS", "1") != "0"
+segment_backward: bool = os.environ.get("LIGHTPLANE_AMD_SEGMENT_BACKWARD", "1") != "0"
 warn_generic_kernel: bool = os.environ.get("LIGHTPLANE_AMD_WARN_GENERIC", "1") != "0"
 stop_transmittance: float = float(os.environ.get("LIGHTPLANE_AMD_STOP_TRANSMITTANCE", "0"))

@@ -241,6 +241,13 @@ int lp_renderer_kernel_family(const LpRendererArgs* args) {
   return select_renderer(*args, &why);
 }
 
+int lp_renderer_backward_segments(const LpRendererArgs* args) {
+  if (!args) return set_error(LP_ENULL, "args is NULL");
+  const char* why = "";
+  if (args->kernel == LP_KERNEL_GENERIC || select_renderer(*args, &why) != 1) return 1;
+  return renderer_mfma_segments(*args);
+}
+
 int lp_splatter_kernel_family(const LpSplatterArgs* args) {
   if (!args) return set_error(LP_ENULL, "args is NULL");
   if (args->mlp.n_layers > 0) return splatter_mlp_mfma_supported(*args) ? 2 : 0;
@@ -264,6 +271,8 @@ static int normalized_renderer_args(const LpRendererArgs* args, bool backward, L
   if (a.alpha_mode < 0 || a.alpha_mode > 2) return set_error(LP_EINVAL, "alpha_mode %d outside 0..2", a.alpha_mode);
   if ((a.alpha || a.grad_alpha) && a.alpha_mode == 0)
     return set_error(LP_EINVAL, "alpha / grad_alpha given but alpha_mode is 0");
+  // the segment sums are written / used only where lp_renderer_backward_segments() says so (same rule both ways)
+  if (a.seg_prefix && lp_renderer_backward_segments(&a) <= 1) a.seg_prefix = nullptr;
   return LP_OK;
 }
 

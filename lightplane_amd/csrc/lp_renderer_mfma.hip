@@ -264,6 +264,15 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_bf3(const LpRendererArg
     len = fmaf(w, depth, len);
 #pragma unroll
     for (int c = 0; c < NC; ++c) facc[c] = fmaf(w, sigmoid_f(hd.raw_c[c]) * occ, facc[c]);
+    // segment-parallel backward (LpRendererArgs.seg_prefix): the running sums after every block of LP_NLT_CKPT samples
+    if (a.seg_prefix && valid && h == 0 && s < a.march.num_samples) {
+      const int ck = ckpt_index(s, a.march);
+      if (ck >= 0) {
+        float4* dst = reinterpret_cast<float4*>(a.seg_prefix + (ray_id * segment_count(a.march) + ck) * 8);
+        dst[0] = make_float4(len, facc[0], facc[1], facc[2]);
+        if (NC == 4) dst[1] = make_float4(facc[3], 0.0f, 0.0f, 0.0f);
+      }
+    }
     // early termination (off unless stop_neg_log_t > 0): every ray of this wave is opaque
     if (a.stop_neg_log_t > 0.0f && __ballot(valid && nlt < a.stop_neg_log_t) == 0) {
       s_last = s;
@@ -346,6 +355,23 @@ static MfmaParams make_params(const LpRendererArgs& a) {
 }
 
 static bool is_flex(const MfmaParams& p) { return !(p.hid == HID && p.t1 && p.t2 && p.oh && p.ch && !p.tg); }
+
+// Segment-parallel backward (LpRendererArgs.seg_prefix): available where renderer_fwd_bf3 / renderer_bwd_bf3 run (default
+// decoder shape, C = 16), without beyond-far samples and early termination; worth it while the batch leaves wave slots
+// idle (a 4-wave workgroup per 128 rays, two workgroups per CU: 65 536 rays fill the chip once).  Measured on MI355X
+// (scripts/bench_small_batch.py, S = 128, backward kernel): 4 096 rays 1.80 -> 0.51 ms, 16 384 rays 1.80 -> 0.88 ms,
+// 32 768 rays 1.75 -> 1.53 ms, 49 152 rays 2.12 -> 2.22 ms: on up to 32 768 rays.
+// LP_SEGMENTS=0 / 1 switches it off / on regardless of the batch size (A/B, tests).
+int renderer_mfma_segments(const LpRendererArgs& a) {
+  static const bool bf3 = getenv("LP_MFMA_F32") == nullptr && getenv("LP_MFMA_F32_BWD") == nullptr;
+  static const int forced = getenv("LP_SEGMENTS") ? atoi(getenv("LP_SEGMENTS")) : -1;
+  if (!bf3 || forced == 0 || a.grid.channels != 16 || is_flex(make_params(a))) return 1;
+  if (a.march.num_samples_inf != 0 || a.stop_neg_log_t > 0.0f) return 1;
+  const int n_seg = (a.march.num_samples + LP_NLT_CKPT - 1) / LP_NLT_CKPT;
+  if (n_seg < 2) return 1;
+  if (forced < 0 && a.rays.n_rays > 32768) return 1;
+  return n_seg;
+}
 
 static int grid_mode(const LpRendererArgs& a) {
   auto is_voxel = [](const LpGrid& g) { return g.D > 1 && g.H > 1 && g.W > 1; };

@@ -643,7 +643,7 @@ struct Bf3Lds {
   static constexpr int TOTAL = CB + (CB_LDS ? NW * 64 * 16 * 4 : 0);
 };
 
-template <int C, int GM, bool PLAIN, int NC, int NW>
+template <int C, int GM, bool PLAIN, int NC, int NW, bool SEG = false>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(const LpRendererArgs a, const MfmaParams mp) {
   using M = Lds;
   using L = LdsBf3<C>;
@@ -666,7 +666,13 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
   float* const yt = wv + B::YT;
   float* const ts = wv + B::TS;
 
-  const int64_t ray_id = ((int64_t)blockIdx.x * WAVES3 + wave) * RAYS_PER_WAVE + r;
+  // segment-parallel sweep (LpRendererArgs.seg_prefix): workgroup = (128 rays, one block of LP_NLT_CKPT samples)
+  // (SEG is its own instantiation: the full-batch kernel keeps its register allocation)
+  constexpr bool seg_on = SEG;
+  const int n_seg = seg_on ? segment_count(a.march) : 1;
+  const int blk = seg_on ? (int)blockIdx.x / n_seg : (int)blockIdx.x;
+  const int seg = seg_on ? (int)blockIdx.x - blk * n_seg : 0;
+  const int64_t ray_id = ((int64_t)blk * WAVES3 + wave) * RAYS_PER_WAVE + r;
   const bool valid = ray_id < a.rays.n_rays;
   const int64_t rid = valid ? ray_id : 0;
   const Ray ray = load_ray(a.rays, rid);
@@ -694,6 +700,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
     }
     __syncthreads();  // ts[] is reused by the sample loop
   }
+  const int s_lo = seg_on ? seg * LP_NLT_CKPT : 0;
+  if (seg_on) s_begin = (s_lo + LP_NLT_CKPT - 1 < s_tot - 1) ? s_lo + LP_NLT_CKPT - 1 : s_tot - 1;
   // per-ray pre-activation of the colour hidden layer, cb = b_c1 + W_c1^T enc: read once per sample, so it lives in LDS
   // (lane-private 64-byte records behind the tiles, the four 16-byte quarters rotated by lane >> 2: conflict-free)
   constexpr bool CBL = Bf3Lds<C, NW>::CB_LDS;
@@ -747,10 +755,23 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
   int ph_cur = 9;
 #endif
   float nlt = a.neg_log_t[rid];
+  // d loss / d (opacity delta)_s = T_s p_s - sum_{i > s} w_i p_i, p_i = g_len depth_i + sum_c g_c colour_ic: the running
+  // `suffix` carries the second term; a segment starts it from the sums the forward saved behind its last sample
   float suffix = 0.0f, p_next = 0.0f;
+  if (seg_on && seg < n_seg - 1) {
+    const float4* pj = reinterpret_cast<const float4*>(a.seg_prefix + (rid * n_seg + seg) * 8);
+    const float4* pt = reinterpret_cast<const float4*>(a.seg_prefix + (rid * n_seg + n_seg - 1) * 8);
+    const float4 j0 = pj[0], t0 = pt[0];
+    float rest = g_len * (t0.x - j0.x);
+    rest = fmaf(gfeat[0], t0.y - j0.y, rest);
+    rest = fmaf(gfeat[1], t0.z - j0.z, rest);
+    rest = fmaf(gfeat[2], t0.w - j0.w, rest);
+    if (NC == 4) rest = fmaf(gfeat[3], pt[1].x - pj[1].x, rest);
+    suffix = -rest;
+  }
   Sample<C> nx;
   fetch_sample<C, GM, false, PLAIN>(a, sm, ray, s_begin, h, nx);
-  for (int s = s_begin; s >= 0; --s) {
+  for (int s = s_begin; s >= s_lo; --s) {
     const bool on = PLAIN || s <= s_last_w;
     const float depth = nx.depth, occ = nx.occ, x = nx.x, y = nx.y, z = nx.z;
     float x0[C / 2];
@@ -1006,7 +1027,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
     LP_MARK("fetch");
     __builtin_amdgcn_s_setprio(0);
     const bool live = valid && on && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
-    if (s > 0) fetch_sample<C, GM, true, PLAIN>(a, sm, ray, s - 1, h, nx);
+    if (s > s_lo) fetch_sample<C, GM, true, PLAIN>(a, sm, ray, s - 1, h, nx);
     LP_SCHED_FENCE();
     LP_MARK("scatter");
     if (gg && !(mp.dbg & 2)) {
@@ -1029,10 +1050,16 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
     f32x16 acc;
     if constexpr (NW == 8) acc = layer_bf3v<2>(ASlots{bimg, L::CB_C1}, lane, dsum, (f32x16){0});
     else acc = layer_bf3v<2>(ARowsBwd{rimg + R::L_C1, R::ST_32, 31}, lane, dsum, (f32x16){0});
-    if (valid && a.grad_encoding) {
+    if (valid && a.grad_encoding && !seg_on) {
       float4* dst = reinterpret_cast<float4*>(a.grad_encoding + ray_id * HID + 4 * h);
 #pragma unroll
       for (int j = 0; j < 4; ++j) dst[2 * j] = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+    } else if (valid && a.grad_encoding) {  // the segments of a ray add up
+      float* dst = a.grad_encoding + ray_id * HID + 4 * h;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomic_add_f32(dst + 8 * j + i, acc[4 * j + i]);
     }
   }
   if (want_params) {
@@ -1109,20 +1136,25 @@ static int launch_bwd2p(const LpRendererArgs& a, const MfmaParams& mp, hipStream
   return LP_OK;
 }
 
-template <int C, int GM, bool PLAIN, int NC, int NW>
+template <int C, int GM, bool PLAIN, int NC, int NW, bool SEG = false>
 static int launch_bwd3w(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
   constexpr size_t lds = (size_t)Bf3Lds<C, NW>::TOTAL;
   static_assert(lds * (NW == 8 ? 1 : 2) <= 160 * 1024, "the workgroups of one CU must fit the 160 KB LDS");
   static_assert(NW == 8 || 2 * lds <= 160 * 1024, "two 4-wave workgroups per CU");
-  const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_bf3<C, GM, PLAIN, NC, NW>,
+  const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_bf3<C, GM, PLAIN, NC, NW, SEG>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-  const unsigned nb = (unsigned)((a.rays.n_rays + NW * RAYS_PER_WAVE - 1) / (NW * RAYS_PER_WAVE));
-  hipLaunchKernelGGL((renderer_bwd_bf3<C, GM, PLAIN, NC, NW>), dim3(nb), dim3(64 * NW), lds, stream, a, mp);
+  const unsigned nb = (unsigned)((a.rays.n_rays + NW * RAYS_PER_WAVE - 1) / (NW * RAYS_PER_WAVE)) *
+                      (SEG ? (unsigned)((a.march.num_samples + LP_NLT_CKPT - 1) / LP_NLT_CKPT) : 1u);
+  hipLaunchKernelGGL((renderer_bwd_bf3<C, GM, PLAIN, NC, NW, SEG>), dim3(nb), dim3(64 * NW), lds, stream, a, mp);
   return LP_OK;
 }
 template <int C, int GM, bool PLAIN, int NC>
 static int launch_bwd3(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
+  // segment-parallel sweep of a small batch (seg_prefix survives lp_api.hip only where renderer_mfma_segments() > 1)
+  if constexpr (C == 16) {
+    if (a.seg_prefix) return launch_bwd3w<C, GM, PLAIN, NC, 4, true>(a, mp, stream);
+  }
   // four-wave workgroups (two per CU) unless the beyond-far table does not fit their small block; LP_BF3_NW=8 for A/B
   static const int forced = getenv("LP_BF3_NW") ? atoi(getenv("LP_BF3_NW")) : 0;
   const bool nw4 = forced ? forced == 4 : a.march.num_samples_inf <= LdsBf3Rm<C>::N_INF;

@@ -122,10 +122,8 @@ def _warn_if_generic(a, cfg: _RendererCfg) -> None:
             f"color={cfg.dims_color}, color_chn={cfg.color_chn}, separate colour grid={cfg.color_descs is not None}.")
 
 
-def kernel_family(rays: Rays, grid, decoder_params: DecoderParams, grid_sizes=None, color_grid=None,
-                  color_grid_sizes=None) -> int:
-    """Kernel family ``LP_KERNEL_AUTO`` selects for these shapes: 0 generic, 1 MFMA hidden-32, 2 MFMA hidden-64
-    (``lp_renderer_kernel_family``; needs no GPU)."""
+def _shape_args(grid, decoder_params: DecoderParams, grid_sizes=None, color_grid=None, color_grid_sizes=None):
+    """``LpRendererArgs`` carrying shapes only (no pointers) -- what the library's selection queries look at."""
     if isinstance(grid, (list, tuple)):
         grid_sizes = [list(g.shape) for g in grid]
     descs, channels, n_rows = make_grid_descs(grid_sizes)
@@ -141,7 +139,27 @@ def kernel_family(rays: Rays, grid, decoder_params: DecoderParams, grid_sizes=No
     n_t, n_o = mlp_numel(dims_t), mlp_numel(dims_o)
     a.trunk, a.opacity, a.color = _lib.make_mlp(dims_t, 0), _lib.make_mlp(dims_o, n_t), _lib.make_mlp(dims_c, n_t + n_o)
     a.color_chn = int(decoder_params.color_chn)
+    return a
+
+
+def kernel_family(rays: Rays, grid, decoder_params: DecoderParams, grid_sizes=None, color_grid=None,
+                  color_grid_sizes=None) -> int:
+    """Kernel family ``LP_KERNEL_AUTO`` selects for these shapes: 0 generic, 1 MFMA hidden-32, 2 MFMA hidden-64
+    (``lp_renderer_kernel_family``; needs no GPU)."""
+    a = _shape_args(grid, decoder_params, grid_sizes, color_grid, color_grid_sizes)
     return int(_lib.lib().lp_renderer_kernel_family(ctypes.byref(a)))
+
+
+def backward_segments(rays: Rays, grid, decoder_params: DecoderParams, num_samples: int, num_samples_inf: int = 0,
+                      grid_sizes=None, color_grid=None, color_grid_sizes=None, stop_transmittance: float = 0.0,
+                      **_unused) -> int:
+    """Number of ray segments the backward of this call is split into (``lp_renderer_backward_segments``; needs no
+    GPU): 1 = one sweep per ray, > 1 = small batch, every block of 32 samples of a ray in its own workgroup."""
+    a = _shape_args(grid, decoder_params, grid_sizes, color_grid, color_grid_sizes)
+    a.rays.n_rays = int(rays.directions.shape[0])
+    a.march.num_samples, a.march.num_samples_inf = int(num_samples), int(num_samples_inf)
+    a.stop_neg_log_t = -math.log(stop_transmittance) if stop_transmittance and stop_transmittance > 0 else 0.0
+    return int(_lib.lib().lp_renderer_backward_segments(ctypes.byref(a)))
 
 
 class LightplaneFunction(torch.autograd.Function):
@@ -175,11 +193,19 @@ class LightplaneFunction(torch.autograd.Function):
         # transmittance reconstruction exact (the reference saves only the final value, :558-573)
         ckpt = torch.empty(n, _lib.n_nlt_ckpt(cfg.num_samples, cfg.num_samples_inf), device=dev, dtype=torch.float32)
         a.neg_log_t_ckpt = _lib.ptr(ckpt)
+        # small batches: the backward sweeps every block of LP_NLT_CKPT samples of a ray in its own workgroup, from
+        # running sums the forward saves per block (lightplane_hip.h, LpRendererArgs.seg_prefix)
+        seg = None
+        if config.segment_backward and any(ctx.needs_input_grad):
+            n_seg = _lib.lib().lp_renderer_backward_segments(ctypes.byref(a))
+            if n_seg > 1:
+                seg = torch.empty(n, n_seg, 8, device=dev, dtype=torch.float32)
+                a.seg_prefix = _lib.ptr(seg)
         _warn_if_generic(a, cfg)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().lp_renderer_forward(ctypes.byref(a), stream), "lp_renderer_forward")
         # O(N) state only: the final -log T (the reference saves the same, :558-573)
-        ctx.save_for_backward(nlt, ckpt, mlp_params, encoding, directions, origins, grid_idx, near, far, scaffold,
+        ctx.save_for_backward(nlt, ckpt, seg, mlp_params, encoding, directions, origins, grid_idx, near, far, scaffold,
                               bg_color, *grids, *color_grids)
         ctx.cfg = cfg
         if not cfg.alpha_mode:
@@ -188,11 +214,11 @@ class LightplaneFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_len, g_nlt, g_feat, g_alpha):
-        (nlt, ckpt, mlp_params, encoding, directions, origins, grid_idx, near, far, scaffold,
-         bg_color) = ctx.saved_tensors[:11]
+        (nlt, ckpt, seg, mlp_params, encoding, directions, origins, grid_idx, near, far, scaffold,
+         bg_color) = ctx.saved_tensors[:12]
         cfg: _RendererCfg = ctx.cfg
-        grids = ctx.saved_tensors[11: 11 + cfg.n_grid_tensors]
-        color_grids = ctx.saved_tensors[11 + cfg.n_grid_tensors:]
+        grids = ctx.saved_tensors[12: 12 + cfg.n_grid_tensors]
+        color_grids = ctx.saved_tensors[12 + cfg.n_grid_tensors:]
         dev = grids[0].device
         stream = _lib.current_stream(dev)
         need_params, need_enc = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
@@ -202,6 +228,7 @@ class LightplaneFunction(torch.autograd.Function):
                        scaffold)
         a.neg_log_t = _lib.ptr(nlt)
         a.neg_log_t_ckpt = _lib.ptr(ckpt)
+        a.seg_prefix = _lib.ptr(seg)
         a.bg_color = _lib.ptr(bg_color)
         g_len = None if g_len is None else g_len.contiguous()
         g_nlt = None if g_nlt is None else g_nlt.contiguous()

@@ -154,6 +154,60 @@ def test_renderer_coherent_early_termination_exact_when_off():
 
 
 # --------------------------------------------------------------------------------------------------------------
+# segment-parallel backward of small batches (LpRendererArgs.seg_prefix)
+# --------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("grid,num_samples,kw", [
+    ("triplane24_c16", 80, dict()),                                # 3 segments, ragged last one (16 samples)
+    ("triplane24_c16", 64, dict(mask_oob=False)),                  # 2 full segments
+    ("triplane24_c16", 33, dict()),                                # second segment = a single sample
+    ("triplane_plus_voxel_c16", 72, dict()),                       # run-time grid-list loop
+    ("voxel18_c16_b2", 96, dict(color_chn=4)),                     # NC = 4: the fourth colour sum lives in the second float4
+    ("triplane24_c16", 70, dict(scaffold=True, noise=True)),       # non-PLAIN instantiation
+], ids=["triplane_s80", "triplane_s64_nomask", "triplane_s33", "mixed_s72", "voxel_b2_rgba_s96", "triplane_scaffold_noise_s70"])
+def test_segmented_backward(grid, num_samples, kw):
+    """4 096-ray image, S > 32: the backward runs one workgroup per (128 rays, block of 32 samples) and has to agree with
+    the oracle AND with the one-workgroup-per-128-rays sweep of the same kernel (same recompute, so no ReLU-flip slack:
+    1e-5 of the largest entry)."""
+    dev = _dev()
+    kw = dict(kw)
+    noise = kw.pop("noise", False)
+    # (seed 11 puts one ReLU pre-activation of the S = 33 case within round-off of zero: a single flipped sample, 62 entries
+    # per plane up to 2.9e-2 / relative L2 3e-3 between the kernel and the fp32 oracle -- scripts/diag_s33.py)
+    d = coherent_renderer_inputs(grid, "64x64_axis", num_samples=num_samples, seed=3 if num_samples == 33 else 11, **kw)
+    if noise:
+        d["cfg"] = dict(d["cfg"], inject_noise_sigma=0.3, inject_noise_seed=5)
+    n_seg = (num_samples + 31) // 32
+    assert lp.backward_segments(d["rays"], d["grids"], d["decoder"], **d["cfg"]) == n_seg
+    assert lp.config.segment_backward
+    try:
+        lp.config.segment_backward = False
+        ref = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO)
+    finally:
+        lp.config.segment_backward = True
+    got = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO)
+    for a, b in zip(got[0], ref[0]):
+        assert torch.equal(a, b)  # the forward is the same kernel, it only saves more
+    flat = lambda r: [r[1], r[2]] + list(r[3]) + list(r[4] or [])
+    for i, (a, b) in enumerate(zip(flat(got), flat(ref))):
+        err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+        assert err <= 1e-5, f"gradient tensor {i}: segmented vs single sweep {err:.3e}"
+    check_renderer(d, dev, _lib.LP_KERNEL_AUTO, f"segmented {grid}/S={num_samples}")
+
+
+def test_segmented_backward_is_not_used_where_it_cannot_be():
+    d = coherent_renderer_inputs("triplane24_c16", "64x64_axis", num_samples=64)
+    q = lambda **over: lp.backward_segments(d["rays"], d["grids"], d["decoder"], **dict(d["cfg"], **over))
+    assert q() == 2
+    assert q(num_samples=32) == 1
+    assert q(num_samples_inf=2) == 1                                                    # beyond-far samples
+    d32 = coherent_renderer_inputs("voxel20_c32", "64x64_axis", num_samples=64)        # C = 32: fp32-MFMA backward
+    assert lp.backward_segments(d32["rays"], d32["grids"], d32["decoder"], **d32["cfg"]) == 1
+    big = pinhole_rays(256, 256, enc_dim=32, gen=torch.Generator().manual_seed(0))      # 65 536 rays fill the chip
+    assert lp.backward_segments(big, d["grids"], d["decoder"], **d["cfg"]) == 1
+
+
+# --------------------------------------------------------------------------------------------------------------
 # Splatter / MLP-Splatter, coherent rays
 # --------------------------------------------------------------------------------------------------------------
 

@@ -13,7 +13,7 @@ from lightplane_amd import _lib, grids, params
 
 def test_library_loads_and_exports_every_declared_symbol():
     L = _lib.lib()
-    assert L.lp_version() == 200
+    assert L.lp_version() == 201
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "lightplane_hip.h")).read()
     declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(lp_[a-z_0-9]+)\s*\(", hdr, flags=re.M))
     assert declared == set(_lib.EXPORTS), f"header vs binding mismatch: {declared ^ set(_lib.EXPORTS)}"
@@ -178,6 +178,35 @@ def test_abi_v2_validation_without_gpu():
     a = _empty_renderer_args()
     a.alpha_mode = 3
     assert L.lp_renderer_forward(ctypes.byref(a), None) == -1 and b"alpha_mode" in L.lp_last_error()
+
+
+def test_backward_segments_query_without_gpu():
+    """lp_renderer_backward_segments (ABI 0.2.1) looks at shapes only: blocks of 32 samples for a small batch of the
+    default decoder shape with 16 channels, 1 everywhere else."""
+    L = _lib.lib()
+    a = _empty_renderer_args()
+    a.rays.n_rays = 4096
+    for s, want in ((8, 1), (32, 1), (33, 2), (64, 2), (65, 3), (256, 8)):
+        a.march.num_samples = s
+        assert L.lp_renderer_backward_segments(ctypes.byref(a)) == want
+    a.march.num_samples = 128
+    a.rays.n_rays = 1 << 16
+    assert L.lp_renderer_backward_segments(ctypes.byref(a)) == 1          # fills the GPU without it
+    a.rays.n_rays = 4096
+    a.march.num_samples_inf = 1
+    assert L.lp_renderer_backward_segments(ctypes.byref(a)) == 1          # beyond-far samples
+    a.march.num_samples_inf = 0
+    a.stop_neg_log_t = 4.0
+    assert L.lp_renderer_backward_segments(ctypes.byref(a)) == 1          # early termination
+    a.stop_neg_log_t = 0.0
+    a.kernel = _lib.LP_KERNEL_GENERIC
+    assert L.lp_renderer_backward_segments(ctypes.byref(a)) == 1
+    a.kernel = _lib.LP_KERNEL_AUTO
+    assert L.lp_renderer_backward_segments(ctypes.byref(a)) == 4
+    # zero rays with a prefix buffer: validated, nothing launched
+    a.rays.n_rays = 0
+    a.seg_prefix = 0x1000
+    assert L.lp_renderer_forward(ctypes.byref(a), None) == 0
 
 
 def _gloo_worker(rank, world_size, port, ret):
