@@ -67,6 +67,8 @@ extern "C" {
  * the final -log T) -- the backward starts there (see stop_neg_log_t).
  * O(N) memory: 2 * (ceil(S/LP_NLT_CKPT) + S_inf + 1) floats per ray. */
 #define LP_NLT_CKPT 32
+/* samples per ray segment of the segment-parallel backward (LpRendererArgs.seg_prefix) */
+#define LP_SEG_LEN 16
 
 /* error codes (negative; positive values are hipError_t) */
 #define LP_OK 0
@@ -185,8 +187,8 @@ typedef struct LpRendererArgs {
   float stop_neg_log_t;
   /* Segment-parallel backward for small batches (extension).  A backward sweep is serial along the ray, so a batch
    * with fewer rays than the GPU has wave slots (65 536 fill an MI355X once) leaves most of the chip idle.  With seg_prefix != NULL the
-   * forward also saves, per ray and per block of LP_NLT_CKPT regular samples, the running sums (ray_length,
-   * feature[0..3]) after the block's last sample -- [N, lp_renderer_backward_segments(args), 8] floats -- and the
+   * forward also saves, per ray and per block of LP_SEG_LEN regular samples, the state after the block's last sample
+   * -- [N, lp_renderer_backward_segments(args), 8] floats: ray_length, feature[0..3], -log T (hi, lo), 0 -- and the
    * backward sweeps every block of a ray in its own workgroup (the part of d loss / d opacity_s that depends on the
    * samples behind the block comes from the saved sums).  grad_encoding is then ACCUMULATED (caller zero-fills).
    * Pass the same pointer to forward and backward, and only when lp_renderer_backward_segments() > 1. */
@@ -246,7 +248,7 @@ int lp_abi_sizeof(int which);
 
 /* Number of ray segments the backward of these arguments can be split into (see LpRendererArgs.seg_prefix): 1 when the
  * selected kernel has no segmented form, when the march has beyond-far samples or early termination, or when the
- * batch fills the GPU without it; otherwise ceil(num_samples / LP_NLT_CKPT).  Depends on shapes only (no launch). */
+ * batch fills the GPU without it; otherwise ceil(num_samples / LP_SEG_LEN).  Depends on shapes only (no launch). */
 int lp_renderer_backward_segments(const LpRendererArgs* args);
 
 /* Which kernel family LP_KERNEL_AUTO selects for these arguments (no launch; shapes only):

@@ -109,8 +109,8 @@ LP_DEV int ckpt_end_index(const LpMarch& m) {
   return (m.num_samples + LP_NLT_CKPT - 1) / LP_NLT_CKPT + m.num_samples_inf;
 }
 LP_DEV int ckpt_count(const LpMarch& m) { return ckpt_end_index(m) + 1; }
-// blocks of LP_NLT_CKPT regular samples = ray segments of the segment-parallel backward (LpRendererArgs.seg_prefix)
-LP_DEV int segment_count(const LpMarch& m) { return (m.num_samples + LP_NLT_CKPT - 1) / LP_NLT_CKPT; }
+// blocks of LP_SEG_LEN regular samples = ray segments of the segment-parallel backward (LpRendererArgs.seg_prefix)
+LP_DEV int segment_count(const LpMarch& m) { return (m.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN; }
 
 LP_DEV float contract_one(float p, float n) {
   const float a = fabsf(p);

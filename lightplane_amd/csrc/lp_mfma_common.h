@@ -49,6 +49,8 @@ struct MfmaParams {
   // two-grid decoder (separate colour grid, no trunk): t1 = trunk layer 1 present, tg = colour grid-list present,
   // hin = input width of the heads (grid channels with tg, hid otherwise) = width of the ray encoding
   int t1, tg, hin;
+  // segment-parallel backward: LP_SEG_LEN-sample blocks per workgroup (chosen at launch, see launch_bwd3)
+  int seg_blocks;
 };
 
 // LDS map (floats).  Weight matrices are kept ONCE, row-major [in][W_LD] with a padded row

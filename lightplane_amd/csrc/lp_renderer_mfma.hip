@@ -264,14 +264,11 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_bf3(const LpRendererArg
     len = fmaf(w, depth, len);
 #pragma unroll
     for (int c = 0; c < NC; ++c) facc[c] = fmaf(w, sigmoid_f(hd.raw_c[c]) * occ, facc[c]);
-    // segment-parallel backward (LpRendererArgs.seg_prefix): the running sums after every block of LP_NLT_CKPT samples
-    if (a.seg_prefix && valid && h == 0 && s < a.march.num_samples) {
-      const int ck = ckpt_index(s, a.march);
-      if (ck >= 0) {
-        float4* dst = reinterpret_cast<float4*>(a.seg_prefix + (ray_id * segment_count(a.march) + ck) * 8);
-        dst[0] = make_float4(len, facc[0], facc[1], facc[2]);
-        if (NC == 4) dst[1] = make_float4(facc[3], 0.0f, 0.0f, 0.0f);
-      }
+    // segment-parallel backward (LpRendererArgs.seg_prefix): the state after every block of LP_SEG_LEN samples
+    if (a.seg_prefix && valid && h == 0 && (((s + 1) % LP_SEG_LEN) == 0 || s == a.march.num_samples - 1)) {
+      float4* dst = reinterpret_cast<float4*>(a.seg_prefix + (ray_id * segment_count(a.march) + s / LP_SEG_LEN) * 8);
+      dst[0] = make_float4(len, facc[0], facc[1], facc[2]);
+      dst[1] = make_float4(NC == 4 ? facc[3] : 0.0f, nlt, nlt_lo, 0.0f);
     }
     // early termination (off unless stop_neg_log_t > 0): every ray of this wave is opaque
     if (a.stop_neg_log_t > 0.0f && __ballot(valid && nlt < a.stop_neg_log_t) == 0) {
@@ -351,6 +348,7 @@ static MfmaParams make_params(const LpRendererArgs& a) {
   p.b_c2 = p.b_c1 + (p.ch ? H : 0);
   static const int dbg = getenv("LP_MFMA_DEBUG") ? atoi(getenv("LP_MFMA_DEBUG")) : 0;
   p.dbg = dbg;
+  p.seg_blocks = 1;
   return p;
 }
 
@@ -367,7 +365,7 @@ int renderer_mfma_segments(const LpRendererArgs& a) {
   static const int forced = getenv("LP_SEGMENTS") ? atoi(getenv("LP_SEGMENTS")) : -1;
   if (!bf3 || forced == 0 || a.grid.channels != 16 || is_flex(make_params(a))) return 1;
   if (a.march.num_samples_inf != 0 || a.stop_neg_log_t > 0.0f) return 1;
-  const int n_seg = (a.march.num_samples + LP_NLT_CKPT - 1) / LP_NLT_CKPT;
+  const int n_seg = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
   if (n_seg < 2) return 1;
   if (forced < 0 && a.rays.n_rays > 32768) return 1;
   return n_seg;

@@ -666,10 +666,12 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
   float* const yt = wv + B::YT;
   float* const ts = wv + B::TS;
 
-  // segment-parallel sweep (LpRendererArgs.seg_prefix): workgroup = (128 rays, one block of LP_NLT_CKPT samples)
+  // segment-parallel sweep (LpRendererArgs.seg_prefix): workgroup = (128 rays, one block of LP_SEG_LEN samples)
   // (SEG is its own instantiation: the full-batch kernel keeps its register allocation)
   constexpr bool seg_on = SEG;
-  const int n_seg = seg_on ? segment_count(a.march) : 1;
+  const int n_rec = seg_on ? segment_count(a.march) : 1;                        // saved states per ray
+  const int seg_len = LP_SEG_LEN * mp.seg_blocks;                               // samples per workgroup
+  const int n_seg = seg_on ? (a.march.num_samples + seg_len - 1) / seg_len : 1;  // workgroups per 128 rays
   const int blk = seg_on ? (int)blockIdx.x / n_seg : (int)blockIdx.x;
   const int seg = seg_on ? (int)blockIdx.x - blk * n_seg : 0;
   const int64_t ray_id = ((int64_t)blk * WAVES3 + wave) * RAYS_PER_WAVE + r;
@@ -700,8 +702,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
     }
     __syncthreads();  // ts[] is reused by the sample loop
   }
-  const int s_lo = seg_on ? seg * LP_NLT_CKPT : 0;
-  if (seg_on) s_begin = (s_lo + LP_NLT_CKPT - 1 < s_tot - 1) ? s_lo + LP_NLT_CKPT - 1 : s_tot - 1;
+  const int s_lo = seg_on ? seg * seg_len : 0;
+  if (seg_on) s_begin = (s_lo + seg_len - 1 < s_tot - 1) ? s_lo + seg_len - 1 : s_tot - 1;
   // per-ray pre-activation of the colour hidden layer, cb = b_c1 + W_c1^T enc: read once per sample, so it lives in LDS
   // (lane-private 64-byte records behind the tiles, the four 16-byte quarters rotated by lane >> 2: conflict-free)
   constexpr bool CBL = Bf3Lds<C, NW>::CB_LDS;
@@ -758,16 +760,20 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
   // d loss / d (opacity delta)_s = T_s p_s - sum_{i > s} w_i p_i, p_i = g_len depth_i + sum_c g_c colour_ic: the running
   // `suffix` carries the second term; a segment starts it from the sums the forward saved behind its last sample
   float suffix = 0.0f, p_next = 0.0f;
-  if (seg_on && seg < n_seg - 1) {
-    const float4* pj = reinterpret_cast<const float4*>(a.seg_prefix + (rid * n_seg + seg) * 8);
-    const float4* pt = reinterpret_cast<const float4*>(a.seg_prefix + (rid * n_seg + n_seg - 1) * 8);
-    const float4 j0 = pj[0], t0 = pt[0];
-    float rest = g_len * (t0.x - j0.x);
-    rest = fmaf(gfeat[0], t0.y - j0.y, rest);
-    rest = fmaf(gfeat[1], t0.z - j0.z, rest);
-    rest = fmaf(gfeat[2], t0.w - j0.w, rest);
-    if (NC == 4) rest = fmaf(gfeat[3], pt[1].x - pj[1].x, rest);
-    suffix = -rest;
+  if (seg_on) {
+    const float4* pj = reinterpret_cast<const float4*>(a.seg_prefix + (rid * n_rec + s_begin / LP_SEG_LEN) * 8);
+    const float4* pt = reinterpret_cast<const float4*>(a.seg_prefix + (rid * n_rec + n_rec - 1) * 8);
+    const float4 j0 = pj[0], j1 = pj[1], t0 = pt[0];
+    nlt = j1.y;     // -log T behind the segment's last sample (a segment may end between two checkpoints)
+    nlt_lo = j1.z;
+    if (seg < n_seg - 1) {
+      float rest = g_len * (t0.x - j0.x);
+      rest = fmaf(gfeat[0], t0.y - j0.y, rest);
+      rest = fmaf(gfeat[1], t0.z - j0.z, rest);
+      rest = fmaf(gfeat[2], t0.w - j0.w, rest);
+      if (NC == 4) rest = fmaf(gfeat[3], pt[1].x - j1.x, rest);
+      suffix = -rest;
+    }
   }
   Sample<C> nx;
   fetch_sample<C, GM, false, PLAIN>(a, sm, ray, s_begin, h, nx);
@@ -1137,15 +1143,30 @@ static int launch_bwd2p(const LpRendererArgs& a, const MfmaParams& mp, hipStream
 }
 
 template <int C, int GM, bool PLAIN, int NC, int NW, bool SEG = false>
-static int launch_bwd3w(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
+static int launch_bwd3w(const LpRendererArgs& a, const MfmaParams& mp_, hipStream_t stream) {
+  MfmaParams mp = mp_;
+  const unsigned ray_blocks = (unsigned)((a.rays.n_rays + NW * RAYS_PER_WAVE - 1) / (NW * RAYS_PER_WAVE));
+  unsigned segs = 1;
+  if (SEG) {
+    // as many segments as keep the launch within one round of resident workgroups (2 per CU): every workgroup pays
+    // the weight staging and the dW flush once, so a second round costs more than longer segments do.  Measured
+    // (scripts/bench_small_batch.py, S = 128): 16-sample segments 4 096 rays 0.39 ms / 16 384 rays 1.13 ms, 32-sample
+    // segments 0.51 / 0.88 ms.
+    static const int forced = getenv("LP_SEG_BLOCKS") ? atoi(getenv("LP_SEG_BLOCKS")) : 0;
+    const int n_rec = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
+    int m = 1;
+    while (m < n_rec && (uint64_t)ray_blocks * ((n_rec + m - 1) / m) > 512u) ++m;
+    if (forced > 0) m = forced < n_rec ? forced : n_rec;
+    mp.seg_blocks = m;
+    segs = (unsigned)((n_rec + m - 1) / m);
+  }
   constexpr size_t lds = (size_t)Bf3Lds<C, NW>::TOTAL;
   static_assert(lds * (NW == 8 ? 1 : 2) <= 160 * 1024, "the workgroups of one CU must fit the 160 KB LDS");
   static_assert(NW == 8 || 2 * lds <= 160 * 1024, "two 4-wave workgroups per CU");
   const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_bf3<C, GM, PLAIN, NC, NW, SEG>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-  const unsigned nb = (unsigned)((a.rays.n_rays + NW * RAYS_PER_WAVE - 1) / (NW * RAYS_PER_WAVE)) *
-                      (SEG ? (unsigned)((a.march.num_samples + LP_NLT_CKPT - 1) / LP_NLT_CKPT) : 1u);
+  const unsigned nb = ray_blocks * segs;
   hipLaunchKernelGGL((renderer_bwd_bf3<C, GM, PLAIN, NC, NW, SEG>), dim3(nb), dim3(64 * NW), lds, stream, a, mp);
   return LP_OK;
 }

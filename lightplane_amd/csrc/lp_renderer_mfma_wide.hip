@@ -723,6 +723,7 @@ static MfmaParams make_params_w(const LpRendererArgs& a, int H) {
   p.b_c2 = p.b_c1 + H;
   static const int dbg = getenv("LP_MFMA_DEBUG") ? atoi(getenv("LP_MFMA_DEBUG")) : 0;
   p.dbg = dbg;
+  p.seg_blocks = 1;
   return p;
 }
 

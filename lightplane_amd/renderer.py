@@ -154,7 +154,7 @@ def backward_segments(rays: Rays, grid, decoder_params: DecoderParams, num_sampl
                       grid_sizes=None, color_grid=None, color_grid_sizes=None, stop_transmittance: float = 0.0,
                       **_unused) -> int:
     """Number of ray segments the backward of this call is split into (``lp_renderer_backward_segments``; needs no
-    GPU): 1 = one sweep per ray, > 1 = small batch, every block of 32 samples of a ray in its own workgroup."""
+    GPU): 1 = one sweep per ray, > 1 = small batch, every block of 16 samples of a ray in its own workgroup."""
     a = _shape_args(grid, decoder_params, grid_sizes, color_grid, color_grid_sizes)
     a.rays.n_rays = int(rays.directions.shape[0])
     a.march.num_samples, a.march.num_samples_inf = int(num_samples), int(num_samples_inf)
@@ -193,7 +193,7 @@ class LightplaneFunction(torch.autograd.Function):
         # transmittance reconstruction exact (the reference saves only the final value, :558-573)
         ckpt = torch.empty(n, _lib.n_nlt_ckpt(cfg.num_samples, cfg.num_samples_inf), device=dev, dtype=torch.float32)
         a.neg_log_t_ckpt = _lib.ptr(ckpt)
-        # small batches: the backward sweeps every block of LP_NLT_CKPT samples of a ray in its own workgroup, from
+        # small batches: the backward sweeps every block of LP_SEG_LEN samples of a ray in its own workgroup, from
         # running sums the forward saves per block (lightplane_hip.h, LpRendererArgs.seg_prefix)
         seg = None
         if config.segment_backward and any(ctx.needs_input_grad):

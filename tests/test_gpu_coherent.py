@@ -70,6 +70,7 @@ IMAGES = {
     "64x64_axis": (64, 64, 0.0, 0.0),
     "48x80_az30_el45": (48, 80, 30.0, 45.0),  # 80 is not a multiple of 32: runs straddle image rows inside a wave
 }
+BIG_IMAGE = {"128x128_az20_el30": (128, 128, 20.0, 30.0)}  # segmented-backward test only (16 384 rays)
 GRIDS = {
     # name: (base, triplane, extra_voxel, separate colour grid, n_layers, batch)
     "triplane24_c16": ((1, 24, 24, 24, 16), True, False, False, (2, 2, 2), 1),
@@ -83,7 +84,7 @@ GRIDS = {
 def coherent_renderer_inputs(grid_name, image_name, mask_oob=True, num_samples=24, seed=0, hidden=32, color_chn=3,
                              scaffold=False):
     base, tri, extra, sep, n_layers, batch = GRIDS[grid_name]
-    height, width, az, el = IMAGES[image_name]
+    height, width, az, el = {**IMAGES, **BIG_IMAGE}[image_name]
     gen = torch.Generator().manual_seed(seed)
     B, C = base[0], base[-1]
     sizes = grid_sizes_for(base, tri)
@@ -158,26 +159,29 @@ def test_renderer_coherent_early_termination_exact_when_off():
 # --------------------------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("grid,num_samples,kw", [
-    ("triplane24_c16", 80, dict()),                                # 3 segments, ragged last one (16 samples)
-    ("triplane24_c16", 64, dict(mask_oob=False)),                  # 2 full segments
-    ("triplane24_c16", 33, dict()),                                # second segment = a single sample
+    ("triplane24_c16", 88, dict()),                                # 6 segments, ragged last one (8 samples)
+    ("triplane24_c16", 64, dict(mask_oob=False)),                  # 4 full segments
+    ("triplane24_c16", 33, dict()),                                # third segment = a single sample
     ("triplane_plus_voxel_c16", 72, dict()),                       # run-time grid-list loop
     ("voxel18_c16_b2", 96, dict(color_chn=4)),                     # NC = 4: the fourth colour sum lives in the second float4
     ("triplane24_c16", 70, dict(scaffold=True, noise=True)),       # non-PLAIN instantiation
-], ids=["triplane_s80", "triplane_s64_nomask", "triplane_s33", "mixed_s72", "voxel_b2_rgba_s96", "triplane_scaffold_noise_s70"])
+    ("triplane24_c16", 80, dict(image="128x128_az20_el30")),       # 128 ray blocks x 5 states > 512: segments of 32, 32, 16
+], ids=["triplane_s88", "triplane_s64_nomask", "triplane_s33", "mixed_s72", "voxel_b2_rgba_s96", "triplane_scaffold_noise_s70",
+        "triplane_16k_rays_s80"])
 def test_segmented_backward(grid, num_samples, kw):
-    """4 096-ray image, S > 32: the backward runs one workgroup per (128 rays, block of 32 samples) and has to agree with
+    """4 096-ray image, S > 16: the backward runs one workgroup per (128 rays, block of 16 samples) and has to agree with
     the oracle AND with the one-workgroup-per-128-rays sweep of the same kernel (same recompute, so no ReLU-flip slack:
     1e-5 of the largest entry)."""
     dev = _dev()
     kw = dict(kw)
     noise = kw.pop("noise", False)
+    image = kw.pop("image", "64x64_axis")
     # (seed 11 puts one ReLU pre-activation of the S = 33 case within round-off of zero: a single flipped sample, 62 entries
     # per plane up to 2.9e-2 / relative L2 3e-3 between the kernel and the fp32 oracle -- scripts/diag_s33.py)
-    d = coherent_renderer_inputs(grid, "64x64_axis", num_samples=num_samples, seed=3 if num_samples == 33 else 11, **kw)
+    d = coherent_renderer_inputs(grid, image, num_samples=num_samples, seed=3 if num_samples == 33 else 11, **kw)
     if noise:
         d["cfg"] = dict(d["cfg"], inject_noise_sigma=0.3, inject_noise_seed=5)
-    n_seg = (num_samples + 31) // 32
+    n_seg = (num_samples + 15) // 16
     assert lp.backward_segments(d["rays"], d["grids"], d["decoder"], **d["cfg"]) == n_seg
     assert lp.config.segment_backward
     try:
@@ -198,8 +202,8 @@ def test_segmented_backward(grid, num_samples, kw):
 def test_segmented_backward_is_not_used_where_it_cannot_be():
     d = coherent_renderer_inputs("triplane24_c16", "64x64_axis", num_samples=64)
     q = lambda **over: lp.backward_segments(d["rays"], d["grids"], d["decoder"], **dict(d["cfg"], **over))
-    assert q() == 2
-    assert q(num_samples=32) == 1
+    assert q() == 4
+    assert q(num_samples=16) == 1
     assert q(num_samples_inf=2) == 1                                                    # beyond-far samples
     d32 = coherent_renderer_inputs("voxel20_c32", "64x64_axis", num_samples=64)        # C = 32: fp32-MFMA backward
     assert lp.backward_segments(d32["rays"], d32["grids"], d32["decoder"], **d32["cfg"]) == 1
@@ -222,7 +226,7 @@ SPLATS = {
 
 def coherent_splatter_inputs(name, image_name, mask_oob=True, num_samples=24, seed=0, mlp=None):
     base, tri, batch = SPLATS[name]
-    height, width, az, el = IMAGES[image_name]
+    height, width, az, el = {**IMAGES, **BIG_IMAGE}[image_name]
     gen = torch.Generator().manual_seed(seed)
     out_sizes = grid_sizes_for(base, tri)
     C = base[-1]

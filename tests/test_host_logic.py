@@ -181,12 +181,12 @@ def test_abi_v2_validation_without_gpu():
 
 
 def test_backward_segments_query_without_gpu():
-    """lp_renderer_backward_segments (ABI 0.2.1) looks at shapes only: blocks of 32 samples for a small batch of the
+    """lp_renderer_backward_segments (ABI 0.2.1) looks at shapes only: blocks of 16 samples for a small batch of the
     default decoder shape with 16 channels, 1 everywhere else."""
     L = _lib.lib()
     a = _empty_renderer_args()
     a.rays.n_rays = 4096
-    for s, want in ((8, 1), (32, 1), (33, 2), (64, 2), (65, 3), (256, 8)):
+    for s, want in ((8, 1), (16, 1), (17, 2), (64, 4), (65, 5), (256, 16)):
         a.march.num_samples = s
         assert L.lp_renderer_backward_segments(ctypes.byref(a)) == want
     a.march.num_samples = 128
@@ -202,7 +202,7 @@ def test_backward_segments_query_without_gpu():
     a.kernel = _lib.LP_KERNEL_GENERIC
     assert L.lp_renderer_backward_segments(ctypes.byref(a)) == 1
     a.kernel = _lib.LP_KERNEL_AUTO
-    assert L.lp_renderer_backward_segments(ctypes.byref(a)) == 4
+    assert L.lp_renderer_backward_segments(ctypes.byref(a)) == 8
     # zero rays with a prefix buffer: validated, nothing launched
     a.rays.n_rays = 0
     a.seg_prefix = 0x1000
