@@ -1193,6 +1193,10 @@ static int launch_bwd2(const LpRendererArgs& a, const MfmaParams& mp, hipStream_
   // (C = 16): cfg 2 backward 2.57 -> 2.31 ms, 1080p x S=128 73.6 -> 65.2 ms.  LP_MFMA_F32 / LP_MFMA_F32_BWD select the
   // fp32-MFMA kernel.  C = 32 stays on the fp32-MFMA kernel unless LP_BF3_C32=1: its 3.4 KB larger image leaves no room
   // for the cb records, with cb in registers the kernel spills 77 and measures 165 ms against 164 ms at cfg 4.
+#ifdef LP_DEV_ONE  // development aid: compile ONE instantiation (seconds instead of minutes) for register / ISA studies,
+                   // e.g. scripts/kernel_resources.py lp_renderer_mfma_bwd.hip -DLP_DEV_ONE
+  return launch_bwd3w<C, GM, true, 3, 4>(a, mp, stream);
+#else
   static const bool bf3_bwd = getenv("LP_MFMA_F32") == nullptr && getenv("LP_MFMA_F32_BWD") == nullptr;
   static const bool bf3_c32 = getenv("LP_BF3_C32") != nullptr && atoi(getenv("LP_BF3_C32")) != 0;
   if ((C == 16 || bf3_c32) && !flex && !mp.tg && bf3_bwd) {
@@ -1211,6 +1215,7 @@ static int launch_bwd2(const LpRendererArgs& a, const MfmaParams& mp, hipStream_
     return plain ? launch_bwd2p<C, GM, true, false, false, 3>(a, mp, stream)
                  : launch_bwd2p<C, GM, false, false, false, 3>(a, mp, stream);
   return plain ? launch_bwd2p<C, GM, true, false>(a, mp, stream) : launch_bwd2p<C, GM, false, false>(a, mp, stream);
+#endif
 }
 
 int renderer_backward_mfma2(const LpRendererArgs& a, const MfmaParams& mp, int gm, hipStream_t stream) {
@@ -1221,7 +1226,12 @@ int renderer_backward_mfma2(const LpRendererArgs& a, const MfmaParams& mp, int g
     case GM_VOXEL: rc = launch_bwd2<CV, GM_VOXEL>(a, mp, stream); break;       \
     default: rc = launch_bwd2<CV, GM_GENERIC>(a, mp, stream); break;           \
   }
+#ifdef LP_DEV_ONE
+  rc = launch_bwd2<16, GM_TRIPLANE>(a, mp, stream);
+  (void)gm;
+#else
   if (a.grid.channels == 16) { LP_B2(16) } else { LP_B2(32) }
+#endif
 #undef LP_B2
   if (rc) return rc;
   return check_launch("renderer_bwd_mfma2");
