@@ -26,10 +26,12 @@ FLAGS += os.environ.get("LP_BUILD_FLAGS", "").split()
 
 # Per-file flags.  The Renderer backward sits at the register limit (256 VGPRs at two waves per SIMD); MachineLICM hoists
 # ~25 loop-invariant address / constant computations out of the sample loop, which the allocator then spills and
-# reloads inside it -- and a reload costs ~300 cycles there.  Without it: 28 instead of 52 spilled
-# registers, 22 instead of 34 scratch instructions per sample, for ~60 rematerialised VALU instructions.
+# reloads inside it -- and a reload costs ~300 cycles there.  Without MachineLICM: 28 instead of 52
+# spilled registers, 22 instead of 34 scratch instructions per sample; with the register allocator additionally allowed
+# to sink (= recompute at the use) instead of spilling: 4 spilled registers and NO scratch instruction in the sample loop,
+# for ~280 rematerialised VALU instructions (of ~3 400 per sample).
 FILE_FLAGS = {
-    "lp_renderer_mfma_bwd.hip": os.environ.get("LP_BWD_FLAGS", "-mllvm -disable-machine-licm").split(),
+    "lp_renderer_mfma_bwd.hip": os.environ.get("LP_BWD_FLAGS", "-mllvm -disable-machine-licm -mllvm -sink-insts-to-avoid-spills=1").split(),
 }
 
 
