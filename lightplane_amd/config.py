@@ -8,7 +8,7 @@
 ``fused_module_ops``   ``LightplaneRenderer.forward`` computes the harmonic ray embedding + its Linear layer in one HIP
                        kernel and the background / alpha epilogue inside the render kernel (2 launches instead of
                        ~17).  Off: the reference's PyTorch op chain around the functional renderer.  Default on.
-``segment_backward``   small Renderer batches (<= 32 768 rays, default decoder shape, 16 channels): the backward sweeps every
+``segment_backward``   small Renderer batches (<= 32 768 rays, default decoder shape): the backward sweeps every
                        block of 16 samples of a ray in its own workgroup, from running sums the forward saves per block
                        (32 B per ray and block).  Default on.
 ``warn_generic_kernel`` warn (once per shape) when a call falls back to the shape-generic kernels, which

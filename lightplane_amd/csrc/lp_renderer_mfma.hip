@@ -355,7 +355,7 @@ static MfmaParams make_params(const LpRendererArgs& a) {
 static bool is_flex(const MfmaParams& p) { return !(p.hid == HID && p.t1 && p.t2 && p.oh && p.ch && !p.tg); }
 
 // Segment-parallel backward (LpRendererArgs.seg_prefix): available where renderer_fwd_bf3 / renderer_bwd_bf3 run (default
-// decoder shape, C = 16), without beyond-far samples and early termination; worth it while the batch leaves wave slots
+// decoder shape), without beyond-far samples and early termination; worth it while the batch leaves wave slots
 // idle (a 4-wave workgroup per 128 rays, two workgroups per CU: 65 536 rays fill the chip once).  Measured on MI355X
 // (scripts/bench_small_batch.py, S = 128, backward kernel): 4 096 rays 1.80 -> 0.51 ms, 16 384 rays 1.80 -> 0.88 ms,
 // 32 768 rays 1.75 -> 1.53 ms, 49 152 rays 2.12 -> 2.22 ms: on up to 32 768 rays.
@@ -363,7 +363,8 @@ static bool is_flex(const MfmaParams& p) { return !(p.hid == HID && p.t1 && p.t2
 int renderer_mfma_segments(const LpRendererArgs& a) {
   static const bool bf3 = getenv("LP_MFMA_F32") == nullptr && getenv("LP_MFMA_F32_BWD") == nullptr;
   static const int forced = getenv("LP_SEGMENTS") ? atoi(getenv("LP_SEGMENTS")) : -1;
-  if (!bf3 || forced == 0 || a.grid.channels != 16 || is_flex(make_params(a))) return 1;
+  static const bool bf3_c32 = getenv("LP_BF3_C32") == nullptr || atoi(getenv("LP_BF3_C32")) != 0;
+  if (!bf3 || forced == 0 || (a.grid.channels != 16 && !bf3_c32) || is_flex(make_params(a))) return 1;
   if (a.march.num_samples_inf != 0 || a.stop_neg_log_t > 0.0f) return 1;
   const int n_seg = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
   if (n_seg < 2) return 1;

@@ -1173,9 +1173,7 @@ static int launch_bwd3w(const LpRendererArgs& a, const MfmaParams& mp_, hipStrea
 template <int C, int GM, bool PLAIN, int NC>
 static int launch_bwd3(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
   // segment-parallel sweep of a small batch (seg_prefix survives lp_api.hip only where renderer_mfma_segments() > 1)
-  if constexpr (C == 16) {
-    if (a.seg_prefix) return launch_bwd3w<C, GM, PLAIN, NC, 4, true>(a, mp, stream);
-  }
+  if (a.seg_prefix) return launch_bwd3w<C, GM, PLAIN, NC, 4, true>(a, mp, stream);
   // four-wave workgroups (two per CU) unless the beyond-far table does not fit their small block; LP_BF3_NW=8 for A/B
   static const int forced = getenv("LP_BF3_NW") ? atoi(getenv("LP_BF3_NW")) : 0;
   const bool nw4 = forced ? forced == 4 : a.march.num_samples_inf <= LdsBf3Rm<C>::N_INF;
@@ -1191,14 +1189,15 @@ static int launch_bwd2(const LpRendererArgs& a, const MfmaParams& mp, hipStream_
   const bool flex = !(mp.hid == HID && mp.t1 && mp.t2 && mp.oh && mp.ch && !mp.tg);
   // default shape: recompute + dX chains as bf16x3 on the bf16 matrix cores (renderer_bwd_bf3).  Measured on MI355X
   // (C = 16): cfg 2 backward 2.57 -> 2.31 ms, 1080p x S=128 73.6 -> 65.2 ms.  LP_MFMA_F32 / LP_MFMA_F32_BWD select the
-  // fp32-MFMA kernel.  C = 32 stays on the fp32-MFMA kernel unless LP_BF3_C32=1: its 3.4 KB larger image leaves no room
-  // for the cb records, with cb in registers the kernel spills 77 and measures 165 ms against 164 ms at cfg 4.
+  // fp32-MFMA kernel.  C = 32: the 3.4 KB larger image leaves no room for the cb records, so cb stays in registers; with
+  // the build's default flags that kernel spilled 77 registers and measured 165 ms against the fp32-MFMA kernel's 164 ms at
+  // cfg 4; compiled spill-free (build.py, FILE_FLAGS) it measures 133 ms against 160 ms.  LP_BF3_C32=0: fp32-MFMA kernel.
 #ifdef LP_DEV_ONE  // development aid: compile ONE instantiation (seconds instead of minutes) for register / ISA studies,
                    // e.g. scripts/kernel_resources.py lp_renderer_mfma_bwd.hip -DLP_DEV_ONE
   return launch_bwd3w<C, GM, true, 3, 4>(a, mp, stream);
 #else
   static const bool bf3_bwd = getenv("LP_MFMA_F32") == nullptr && getenv("LP_MFMA_F32_BWD") == nullptr;
-  static const bool bf3_c32 = getenv("LP_BF3_C32") != nullptr && atoi(getenv("LP_BF3_C32")) != 0;
+  static const bool bf3_c32 = getenv("LP_BF3_C32") == nullptr || atoi(getenv("LP_BF3_C32")) != 0;
   if ((C == 16 || bf3_c32) && !flex && !mp.tg && bf3_bwd) {
     if (a.color_chn <= 3)
       return plain ? launch_bwd3<C, GM, true, 3>(a, mp, stream) : launch_bwd3<C, GM, false, 3>(a, mp, stream);

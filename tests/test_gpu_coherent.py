@@ -166,8 +166,9 @@ def test_renderer_coherent_early_termination_exact_when_off():
     ("voxel18_c16_b2", 96, dict(color_chn=4)),                     # NC = 4: the fourth colour sum lives in the second float4
     ("triplane24_c16", 70, dict(scaffold=True, noise=True)),       # non-PLAIN instantiation
     ("triplane24_c16", 80, dict(image="128x128_az20_el30")),       # 128 ray blocks x 5 states > 512: segments of 32, 32, 16
+    ("voxel20_c32", 72, dict()),                                   # C = 32 instantiations
 ], ids=["triplane_s88", "triplane_s64_nomask", "triplane_s33", "mixed_s72", "voxel_b2_rgba_s96", "triplane_scaffold_noise_s70",
-        "triplane_16k_rays_s80"])
+        "triplane_16k_rays_s80", "voxel_c32_s72"])
 def test_segmented_backward(grid, num_samples, kw):
     """4 096-ray image, S > 16: the backward runs one workgroup per (128 rays, block of 16 samples) and has to agree with
     the oracle AND with the one-workgroup-per-128-rays sweep of the same kernel (same recompute, so no ReLU-flip slack:
@@ -205,8 +206,10 @@ def test_segmented_backward_is_not_used_where_it_cannot_be():
     assert q() == 4
     assert q(num_samples=16) == 1
     assert q(num_samples_inf=2) == 1                                                    # beyond-far samples
-    d32 = coherent_renderer_inputs("voxel20_c32", "64x64_axis", num_samples=64)        # C = 32: fp32-MFMA backward
-    assert lp.backward_segments(d32["rays"], d32["grids"], d32["decoder"], **d32["cfg"]) == 1
+    d32 = coherent_renderer_inputs("voxel20_c32", "64x64_axis", num_samples=64)        # C = 32: the same kernels
+    assert lp.backward_segments(d32["rays"], d32["grids"], d32["decoder"], **d32["cfg"]) == 4
+    dflex = coherent_renderer_inputs("triplane24_c16", "64x64_axis", num_samples=64, hidden=16)  # flex family: fp32-MFMA backward
+    assert lp.backward_segments(dflex["rays"], dflex["grids"], dflex["decoder"], **dflex["cfg"]) == 1
     big = pinhole_rays(256, 256, enc_dim=32, gen=torch.Generator().manual_seed(0))      # 65 536 rays fill the chip
     assert lp.backward_segments(big, d["grids"], d["decoder"], **d["cfg"]) == 1
 
