@@ -6,7 +6,8 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp
-rm -rf $R/gpurun_out/prof_* $R/gpurun_out/pmc[1-4]_*
+WL=${@:-cfg2 cfg3 cfg4}   # workloads to (re-)profile
+for w in $WL; do rm -rf $R/gpurun_out/prof_$w $R/gpurun_out/prof_$w.txt $R/gpurun_out/pmc[1-4]_$w; done
 run() {  # workload, steps (trace), steps (pmc)
   w=$1
   B="python $R/bench.py --workload $w --no-cpu-baseline --no-extras"
@@ -18,8 +19,12 @@ run() {  # workload, steps (trace), steps (pmc)
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc3_$w -o pmc -- $P > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/pmc4_$w -o pmc -- $P > /dev/null 2>&1
 }
-run cfg2 200 3
-run cfg3 50 3
-run cfg4 5 1
+for w in $WL; do
+  case $w in
+    cfg2) run cfg2 200 3 ;;
+    cfg3) run cfg3 50 3 ;;
+    cfg4) run cfg4 5 1 ;;
+  esac
+done
 find $R/gpurun_out/prof_* $R/gpurun_out/pmc[1-4]_* -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" -size +512k -delete
 ls $R/gpurun_out/prof_cfg2 $R/gpurun_out/pmc1_cfg2
