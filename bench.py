@@ -342,19 +342,19 @@ def kernel_times(wl, reps):
 
 def measure_small_batch(dev, kernel, reps):
     """A NeRF-style training batch (4 096 rays x 128 samples, cfg 2's grid and decoder): kernel times with the
-    segment-parallel backward (default) and with one sweep per ray."""
+    segment-parallel forward / backward (default; forward = segment march + combine pass) and with one sweep per ray."""
     name = "small_64x64_s128"
     RENDER_CFGS[name] = (64, 64, 128, 16, 64, "small batch: Renderer fwd+bwd, 64x64 rays, triplane 64^2x16ch, 128 samples")
     wl = RendererWorkload(name, 0, dev, None, kernel)
     n_seg = lp.backward_segments(wl.rays, None, wl.dec, num_samples=wl.S, grid_sizes=wl.sizes)
-    saved = lp.config.segment_backward
+    saved = lp.config.segment_backward, lp.config.segment_forward
     try:
-        lp.config.segment_backward = True
+        lp.config.segment_backward = lp.config.segment_forward = True
         f1, b1 = kernel_times(wl, reps)
-        lp.config.segment_backward = False
+        lp.config.segment_backward = lp.config.segment_forward = False
         f0, b0 = kernel_times(wl, reps)
     finally:
-        lp.config.segment_backward = saved
+        lp.config.segment_backward, lp.config.segment_forward = saved
     return {"workload": wl.desc, "rays": wl.n_rays, "backward_segments": n_seg, "fwd_ms": round(f1, 4), "bwd_ms": round(b1, 4),
             "bwd_ms_one_sweep_per_ray": round(b0, 4), "fwd_ms_one_sweep_per_ray": round(f0, 4), "reps": reps,
             "timing": "torch.profiler device time of the lp:: kernels"}

@@ -149,7 +149,7 @@ typedef struct LpRendererArgs {
   float noise_sigma;      /* > 0: add sigma * hash_randn to the raw opacity      */
   int32_t noise_seed;
   int32_t kernel;         /* LP_KERNEL_*                                         */
-  int32_t _pad;
+  int32_t seg_forward_off; /* 1: with seg_prefix, the forward still marches every ray in one sweep (see seg_prefix) */
   /* forward outputs (written, not accumulated) */
   float* ray_length;      /* [N]                                                 */
   float* neg_log_t;       /* [N]  negative log transmittance after the last sample */
@@ -191,6 +191,9 @@ typedef struct LpRendererArgs {
    * -- [N, lp_renderer_backward_segments(args), 8] floats: ray_length, feature[0..3], -log T (hi, lo), 0 -- and the
    * backward sweeps every block of a ray in its own workgroup (the part of d loss / d opacity_s that depends on the
    * samples behind the block comes from the saved sums).  grad_encoding is then ACCUMULATED (caller zero-fills).
+   * The forward itself is segment-parallel too unless seg_forward_off is set: one workgroup per (128 rays, segment)
+   * writes segment-local sums into the records and a combine pass chains them (compositing is associative) -- outputs
+   * then differ from the single sweep by rounding (~1e-7 relative).
    * Pass the same pointer to forward and backward, and only when lp_renderer_backward_segments() > 1. */
   float* seg_prefix;
 } LpRendererArgs;

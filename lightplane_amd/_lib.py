@@ -67,7 +67,7 @@ class LpRendererArgs(C.Structure):
         ("mlp_params", C.c_void_p), ("n_mlp_params", C.c_int64),
         ("trunk", LpMlp), ("opacity", LpMlp), ("color", LpMlp),
         ("color_chn", C.c_int32), ("gain", C.c_float), ("noise_sigma", C.c_float),
-        ("noise_seed", C.c_int32), ("kernel", C.c_int32), ("_pad", C.c_int32),
+        ("noise_seed", C.c_int32), ("kernel", C.c_int32), ("seg_forward_off", C.c_int32),
         ("ray_length", C.c_void_p), ("neg_log_t", C.c_void_p), ("feature", C.c_void_p),
         ("neg_log_t_ckpt", C.c_void_p),
         ("grad_ray_length", C.c_void_p), ("grad_neg_log_t", C.c_void_p), ("grad_feature", C.c_void_p),

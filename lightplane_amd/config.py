@@ -11,6 +11,8 @@
 ``segment_backward``   small Renderer batches (<= 32 768 rays, default decoder shape): the backward sweeps every
                        block of 16 samples of a ray in its own workgroup, from running sums the forward saves per block
                        (32 B per ray and block).  Default on.
+``segment_forward``    the forward of such a batch marches the segments in parallel too (one workgroup per 128 rays and
+                       segment + a combine pass; outputs differ from the single sweep by rounding, ~1e-7).  Default on.
 ``warn_generic_kernel`` warn (once per shape) when a call falls back to the shape-generic kernels, which
                        are one to two orders of magnitude slower than the MFMA / walk families.  Default on.
 ``stop_transmittance`` early ray termination of the Renderer (extension, see ``lightplane_renderer``): a wavefront stops
@@ -22,5 +24,6 @@ check_inputs: bool = os.environ.get("LIGHTPLANE_AMD_CHECK_INPUTS", "1") != "0"
 check_finite_grads: bool = os.environ.get("LIGHTPLANE_AMD_CHECK_FINITE", "0") == "1"
 fused_module_ops: bool = os.environ.get("LIGHTPLANE_AMD_FUSED_MODULE_OPS", "1") != "0"
 segment_backward: bool = os.environ.get("LIGHTPLANE_AMD_SEGMENT_BACKWARD", "1") != "0"
+segment_forward: bool = os.environ.get("LIGHTPLANE_AMD_SEGMENT_FORWARD", "1") != "0"
 warn_generic_kernel: bool = os.environ.get("LIGHTPLANE_AMD_WARN_GENERIC", "1") != "0"
 stop_transmittance: float = float(os.environ.get("LIGHTPLANE_AMD_STOP_TRANSMITTANCE", "0"))

@@ -214,7 +214,11 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_mfma_np(const LpRendere
 // Forward of the default shape (trunk [C,32,32], heads [32,32,.]) with the matrix products on the bf16 matrix cores at
 // fp32 accuracy (lp_bf3.h: exact 3-limb splits, six limb products): the MFMA time all but disappears behind the VALU
 // work (interpolation, splits, activations, compositing) instead of adding to it as the fp32 MFMA's does.
-template <int C, int GM, int OCC, int NC>
+// SEGF (small batches, LpRendererArgs.seg_prefix): a workgroup marches ONE segment (mp.seg_blocks blocks of LP_SEG_LEN
+// samples) of its 128 rays, starting from transmittance 1, and only writes the segment-local running sums into the ray's
+// state records; renderer_fwd_combine chains the segments.  Compositing is associative: a segment with local sums
+// (L, F, N = -log T over the segment) behind a prefix of transmittance T_0 contributes (T_0 L, T_0 F) and N.
+template <int C, int GM, int OCC, int NC, bool SEGF = false>
 __global__ void __launch_bounds__(256, OCC) renderer_fwd_bf3(const LpRendererArgs a, const MfmaParams mp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_weights_bf3<C>(a, mp, lds, false, 256);
@@ -223,7 +227,11 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_bf3(const LpRendererArg
   const char* fimg = reinterpret_cast<const char*>(lds) + LdsBf3<C>::FWD_IMG;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, r = lane & 31;
-  const int64_t ray_id = ((int64_t)blockIdx.x * WAVES + wave) * RAYS_PER_WAVE + r;
+  const int seg_len = LP_SEG_LEN * mp.seg_blocks;
+  const int n_seg = SEGF ? (a.march.num_samples + seg_len - 1) / seg_len : 1;
+  const int blk = SEGF ? (int)blockIdx.x / n_seg : (int)blockIdx.x;
+  const int seg = SEGF ? (int)blockIdx.x - blk * n_seg : 0;
+  const int64_t ray_id = ((int64_t)blk * WAVES + wave) * RAYS_PER_WAVE + r;
   const bool valid = ray_id < a.rays.n_rays;
   const int64_t rid = valid ? ray_id : 0;
   const Ray ray = load_ray(a.rays, rid);
@@ -241,7 +249,13 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_bf3(const LpRendererArg
   float facc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   Sample<C> nx;
   Act<C> t;
-  for (int s = 0; s < s_tot; ++s) {
+  const int s_lo = SEGF ? seg * seg_len : 0;
+  const int s_hi = SEGF ? ((s_lo + seg_len < s_tot) ? s_lo + seg_len : s_tot) : s_tot;
+  if (SEGF && s_lo > 0) {  // interval length of the segment's first sample
+    sample_geometry<C>(a, sm, ray, s_lo - 1, nx);
+    depth_prev = nx.depth;
+  }
+  for (int s = s_lo; s < s_hi; ++s) {
     fetch_sample<C, GM, true>(a, sm, ray, s, h, nx);
     const float depth = nx.depth, occ = nx.occ;
 #pragma unroll
@@ -254,7 +268,7 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_bf3(const LpRendererArg
     if (a.noise_sigma > 0.0f) raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
     const float opacity = a.gain * softplus_f(raw) * occ;
     nlt_add(nlt, nlt_lo, opacity * delta);
-    if (a.neg_log_t_ckpt && valid && h == 0) {
+    if (!SEGF && a.neg_log_t_ckpt && valid && h == 0) {
       const int ck = ckpt_index(s, a.march);
       if (ck >= 0) *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + ck) * 2) = make_float2(nlt, nlt_lo);
     }
@@ -265,6 +279,7 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_bf3(const LpRendererArg
 #pragma unroll
     for (int c = 0; c < NC; ++c) facc[c] = fmaf(w, sigmoid_f(hd.raw_c[c]) * occ, facc[c]);
     // segment-parallel backward (LpRendererArgs.seg_prefix): the state after every block of LP_SEG_LEN samples
+    // (SEGF: relative to the segment's start; renderer_fwd_combine makes it absolute)
     if (a.seg_prefix && valid && h == 0 && (((s + 1) % LP_SEG_LEN) == 0 || s == a.march.num_samples - 1)) {
       float4* dst = reinterpret_cast<float4*>(a.seg_prefix + (ray_id * segment_count(a.march) + s / LP_SEG_LEN) * 8);
       dst[0] = make_float4(len, facc[0], facc[1], facc[2]);
@@ -276,11 +291,49 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_bf3(const LpRendererArg
       break;
     }
   }
-  if (valid && h == 0) {
+  if (!SEGF && valid && h == 0) {
     write_ray_outputs(a, ray_id, len, nlt, facc);
     if (a.neg_log_t_ckpt)
       *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + n_ckpt - 1) * 2) = make_float2((float)s_last, nlt_lo);
   }
+}
+
+// Chains the segments of a segmented forward (one thread per ray): turns the segment-local state records into the
+// absolute ones the backward reads, writes the -log T checkpoints and the ray's outputs.
+__global__ void __launch_bounds__(256) renderer_fwd_combine(const LpRendererArgs a, int seg_blocks) {
+  const int64_t ray_id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (ray_id >= a.rays.n_rays) return;
+  const int S = a.march.num_samples;
+  const int n_rec = segment_count(a.march), n_ckpt = ckpt_count(a.march);
+  float4* rec = reinterpret_cast<float4*>(a.seg_prefix + ray_id * n_rec * 8);
+  // state at the start of the current segment
+  float n0 = 0.0f, n0_lo = 0.0f, l0 = 0.0f, f0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, t0 = 1.0f;
+  float nlt = 0.0f, nlt_lo = 0.0f, len = 0.0f, f[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int b = 0; b < n_rec; ++b) {
+    if (b > 0 && b % seg_blocks == 0) {  // a new segment starts behind everything accumulated so far
+      n0 = nlt; n0_lo = nlt_lo; l0 = len; t0 = __expf(-nlt);
+      for (int c = 0; c < 4; ++c) f0[c] = f[c];
+    }
+    const float4 r0 = rec[2 * b], r1 = rec[2 * b + 1];
+    nlt = n0; nlt_lo = n0_lo;
+    nlt_add(nlt, nlt_lo, r1.y);
+    nlt_add(nlt, nlt_lo, r1.z);
+    len = fmaf(t0, r0.x, l0);
+    f[0] = fmaf(t0, r0.y, f0[0]);
+    f[1] = fmaf(t0, r0.z, f0[1]);
+    f[2] = fmaf(t0, r0.w, f0[2]);
+    f[3] = fmaf(t0, r1.x, f0[3]);
+    rec[2 * b] = make_float4(len, f[0], f[1], f[2]);
+    rec[2 * b + 1] = make_float4(f[3], nlt, nlt_lo, 0.0f);
+    const int s_end = ((b + 1) * LP_SEG_LEN < S ? (b + 1) * LP_SEG_LEN : S) - 1;  // last sample of the block
+    if (a.neg_log_t_ckpt) {
+      const int ck = ckpt_index(s_end, a.march);
+      if (ck >= 0) *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + ck) * 2) = make_float2(nlt, nlt_lo);
+    }
+  }
+  write_ray_outputs(a, ray_id, len, nlt, f);
+  if (a.neg_log_t_ckpt)
+    *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + n_ckpt - 1) * 2) = make_float2((float)(S - 1), nlt_lo);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -409,6 +462,29 @@ static int launch_fwd(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t
   if (!mp.tg && !is_flex(mp) && !f32_mfma) {
     const size_t lds3 = (size_t)LdsBf3<C>::FWD_END;
     const int occ = bf3_occ ? bf3_occ : (a.rays.n_rays > 2 * 32768 ? 3 : 2);
+    // small batch with state records (seg_prefix survives lp_api.hip only where renderer_mfma_segments() > 1): one
+    // workgroup per (128 rays, segment) + the combine pass.  LP_SEG_FWD=0: one march per ray (the records are written all
+    // the same).  Segment length: as for the backward, as many segments as fit one round of resident workgroups.
+    static const bool seg_fwd = getenv("LP_SEG_FWD") == nullptr || atoi(getenv("LP_SEG_FWD")) != 0;
+    if (a.seg_prefix && seg_fwd && !a.seg_forward_off) {
+      MfmaParams ms = mp;
+      const int n_rec = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
+      static const int forced = getenv("LP_SEG_BLOCKS") ? atoi(getenv("LP_SEG_BLOCKS")) : 0;
+      int m = 1;
+      while (m < n_rec && (uint64_t)n_blocks(a) * ((n_rec + m - 1) / m) > 512u) ++m;
+      if (forced > 0) m = forced < n_rec ? forced : n_rec;
+      ms.seg_blocks = m;
+      const unsigned nb = n_blocks(a) * (unsigned)((n_rec + m - 1) / m);
+      if (a.color_chn <= 3 && !no_nc3) {
+        if ((rc = set_lds(renderer_fwd_bf3<C, GM, 2, 3, true>, lds3))) return rc;
+        hipLaunchKernelGGL((renderer_fwd_bf3<C, GM, 2, 3, true>), dim3(nb), dim3(256), lds3, stream, a, ms);
+      } else {
+        if ((rc = set_lds(renderer_fwd_bf3<C, GM, 2, 4, true>, lds3))) return rc;
+        hipLaunchKernelGGL((renderer_fwd_bf3<C, GM, 2, 4, true>), dim3(nb), dim3(256), lds3, stream, a, ms);
+      }
+      hipLaunchKernelGGL(renderer_fwd_combine, dim3((unsigned)((a.rays.n_rays + 255) / 256)), dim3(256), 0, stream, a, m);
+      return LP_OK;
+    }
 #define LP_BF3_LAUNCH(OCCV, NCV)                                                                                  \
     do {                                                                                                          \
       if ((rc = set_lds(renderer_fwd_bf3<C, GM, OCCV, NCV>, lds3))) return rc;                                   \

@@ -195,17 +195,24 @@ class LightplaneFunction(torch.autograd.Function):
         a.neg_log_t_ckpt = _lib.ptr(ckpt)
         # small batches: the backward sweeps every block of LP_SEG_LEN samples of a ray in its own workgroup, from
         # running sums the forward saves per block (lightplane_hip.h, LpRendererArgs.seg_prefix)
+        # ... and the forward marches the segments in parallel as well (config.segment_forward)
         seg = None
-        if config.segment_backward and any(ctx.needs_input_grad):
+        want_bwd_seg = config.segment_backward and any(ctx.needs_input_grad)
+        if want_bwd_seg or config.segment_forward:
             n_seg = _lib.lib().lp_renderer_backward_segments(ctypes.byref(a))
             if n_seg > 1:
                 seg = torch.empty(n, n_seg, 8, device=dev, dtype=torch.float32)
                 a.seg_prefix = _lib.ptr(seg)
+                a.seg_forward_off = 0 if config.segment_forward else 1
+        if not want_bwd_seg:
+            seg_for_backward = None
+        else:
+            seg_for_backward = seg
         _warn_if_generic(a, cfg)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().lp_renderer_forward(ctypes.byref(a), stream), "lp_renderer_forward")
         # O(N) state only: the final -log T (the reference saves the same, :558-573)
-        ctx.save_for_backward(nlt, ckpt, seg, mlp_params, encoding, directions, origins, grid_idx, near, far, scaffold,
+        ctx.save_for_backward(nlt, ckpt, seg_for_backward, mlp_params, encoding, directions, origins, grid_idx, near, far, scaffold,
                               bg_color, *grids, *color_grids)
         ctx.cfg = cfg
         if not cfg.alpha_mode:

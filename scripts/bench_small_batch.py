@@ -34,12 +34,12 @@ def main():
         bench.RENDER_CFGS[name] = (H, W, S, 16, 64, name)
         wl = bench.RendererWorkload(name, 0, dev, None, lp._lib.LP_KERNEL_AUTO)
         n_seg = lp.backward_segments(wl.rays, None, wl.dec, num_samples=S, grid_sizes=wl.sizes)
-        lp.config.segment_backward = True
+        lp.config.segment_backward = lp.config.segment_forward = True
         f1, b1 = kernel_ms(wl, args.reps)
-        lp.config.segment_backward = False
+        lp.config.segment_backward = lp.config.segment_forward = False
         f0, b0 = kernel_ms(wl, args.reps)
-        lp.config.segment_backward = True
-        print(f"{H * W:8d} {S:4d} {n_seg:8d} | {f1:8.3f} {b1:8.3f} | {f0:8.3f} {b0:8.3f} | {b0 / b1:5.2f}x", flush=True)
+        lp.config.segment_backward = lp.config.segment_forward = True
+        print(f"{H * W:8d} {S:4d} {n_seg:8d} | {f1:8.3f} {b1:8.3f} | {f0:8.3f} {b0:8.3f} | {b0 / b1:5.2f}x  fwd {f0 / f1:5.2f}x", flush=True)
 
 
 if __name__ == "__main__":

@@ -192,7 +192,24 @@ def test_segmented_backward(grid, num_samples, kw):
         lp.config.segment_backward = True
     got = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO)
     for a, b in zip(got[0], ref[0]):
-        assert torch.equal(a, b)  # the forward is the same kernel, it only saves more
+        assert torch.equal(a, b)  # the same (segmented) forward in both runs
+    # the segmented forward (one workgroup per segment + combine pass) against the single march: rounding only
+    try:
+        lp.config.segment_forward = False
+        single = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO)
+    finally:
+        lp.config.segment_forward = True
+    for nm, a, b in zip(("ray_length", "neg_log_t", "feature"), got[0], single[0]):
+        err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+        assert err <= 2e-6, f"{nm}: segmented forward vs single march {err:.3e}"
+    with torch.no_grad():  # inference: no gradient state, still segmented
+        rays = d["rays"].to(dev)
+        dec = d["decoder"]
+        hdec = lp.DecoderParams(dec.mlp_params.to(dev), dec.n_hidden_trunk, dec.n_hidden_opacity, dec.n_hidden_color, dec.color_chn)
+        out = lp.lightplane_renderer(rays, [g.to(dev) for g in d["grids"]], hdec,
+                                     scaffold=None if d["scaffold"] is None else d["scaffold"].to(dev), **d["cfg"])
+    for a, b in zip(out, got[0]):
+        assert torch.equal(a, b.detach())
     flat = lambda r: [r[1], r[2]] + list(r[3]) + list(r[4] or [])
     for i, (a, b) in enumerate(zip(flat(got), flat(ref))):
         err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
