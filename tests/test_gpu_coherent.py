@@ -217,6 +217,44 @@ def test_segmented_backward(grid, num_samples, kw):
     check_renderer(d, dev, _lib.LP_KERNEL_AUTO, f"segmented {grid}/S={num_samples}")
 
 
+@pytest.mark.parametrize("alpha_mode", [1, 2])
+def test_segmented_march_with_fused_epilogue(alpha_mode):
+    """Background compositing + alpha written by the combine pass of the segmented forward, their gradients folded into the
+    segmented backward: against the single march / single sweep of the same kernels."""
+    from lightplane_amd.renderer import _render
+    dev = _dev()
+    d = coherent_renderer_inputs("triplane24_c16", "64x64_axis", num_samples=56, seed=7)
+    gen = torch.Generator().manual_seed(1)
+    n = d["rays"].n_rays
+    up = [torch.randn(n, generator=gen).to(dev), torch.randn(n, generator=gen).to(dev),
+          torch.randn(n, 3, generator=gen).to(dev), torch.randn(n, generator=gen).to(dev)]
+    bg = torch.tensor([0.2, 0.7, 0.4], device=dev)
+
+    def run():
+        rays = d["rays"].to(dev)
+        rays.encoding = rays.encoding.clone().requires_grad_(True)
+        dec = d["decoder"]
+        params = dec.mlp_params.to(dev).clone().requires_grad_(True)
+        hdec = lp.DecoderParams(params, dec.n_hidden_trunk, dec.n_hidden_opacity, dec.n_hidden_color, dec.color_chn)
+        grids = [g.to(dev).clone().requires_grad_(True) for g in d["grids"]]
+        out = _render(rays, grids, hdec, bg_color=bg, alpha_mode=alpha_mode, **d["cfg"])
+        sum((o * u).sum() for o, u in zip(out, up)).backward()
+        return [o.detach() for o in out], [params.grad, rays.encoding.grad] + [g.grad for g in grids]
+
+    out1, g1 = run()
+    try:
+        lp.config.segment_forward = lp.config.segment_backward = False
+        out0, g0 = run()
+    finally:
+        lp.config.segment_forward = lp.config.segment_backward = True
+    for i, (a, b) in enumerate(zip(out1, out0)):
+        err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+        assert err <= 2e-6, f"output {i}: {err:.3e}"
+    for i, (a, b) in enumerate(zip(g1, g0)):
+        err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+        assert err <= 2e-5, f"gradient tensor {i}: {err:.3e}"
+
+
 def test_segmented_backward_is_not_used_where_it_cannot_be():
     d = coherent_renderer_inputs("triplane24_c16", "64x64_axis", num_samples=64)
     q = lambda **over: lp.backward_segments(d["rays"], d["grids"], d["decoder"], **dict(d["cfg"], **over))
