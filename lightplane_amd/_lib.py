@@ -212,6 +212,9 @@ def current_stream(device: torch.device) -> Optional[int]:
             f"lightplane_amd kernels run on the GPU only (got tensors on '{device}'); "
             "there is no CPU path -- the CPU oracle lives under oracle/ for tests."
         )
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # what Triton's launcher uses: no Stream object built
+    if raw is not None:
+        return raw(device.index if device.index is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(device).cuda_stream
 
 

@@ -215,6 +215,11 @@ class LightplaneFunction(torch.autograd.Function):
         ctx.save_for_backward(nlt, ckpt, seg_for_backward, mlp_params, encoding, directions, origins, grid_idx, near, far, scaffold,
                               bg_color, *grids, *color_grids)
         ctx.cfg = cfg
+        # the backward re-uses the filled argument block (its pointers stay valid: every tensor behind them is saved above)
+        a.ray_length = a.feature = a.alpha = None
+        if seg_for_backward is None:
+            a.seg_prefix = None
+        ctx.args = a
         if not cfg.alpha_mode:
             ctx.mark_non_differentiable(alpha)
         return ray_length, nlt, feature, alpha
@@ -231,24 +236,22 @@ class LightplaneFunction(torch.autograd.Function):
         need_params, need_enc = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         need_g = ctx.needs_input_grad[10: 10 + cfg.n_grid_tensors]
         need_c = ctx.needs_input_grad[10 + cfg.n_grid_tensors:]
-        a = _fill_args(cfg, grids, color_grids, mlp_params, directions, origins, grid_idx, near, far, encoding,
-                       scaffold)
-        a.neg_log_t = _lib.ptr(nlt)
-        a.neg_log_t_ckpt = _lib.ptr(ckpt)
-        a.seg_prefix = _lib.ptr(seg)
-        a.bg_color = _lib.ptr(bg_color)
+        a = ctx.args  # filled by the forward: rays, grids, decoder, march, neg_log_t, checkpoints, segment states, bg_color
         g_len = None if g_len is None else g_len.contiguous()
         g_nlt = None if g_nlt is None else g_nlt.contiguous()
         g_feat = None if g_feat is None else g_feat.contiguous()
         a.grad_ray_length, a.grad_neg_log_t, a.grad_feature = _lib.ptr(g_len), _lib.ptr(g_nlt), _lib.ptr(g_feat)
-        if cfg.alpha_mode and g_alpha is not None:
-            g_alpha = g_alpha.contiguous()
-            a.grad_alpha = _lib.ptr(g_alpha)
+        # (the block may be re-used by a second backward through the same graph: every gradient field is assigned)
+        g_alpha = g_alpha.contiguous() if (cfg.alpha_mode and g_alpha is not None) else None
+        a.grad_alpha = _lib.ptr(g_alpha)
         # the kernels scatter into every grid of a list or into none: allocate all buffers if any grid needs one
         grad_grids = [torch.zeros_like(g) for g in grids] if any(need_g) else None
         grad_cgrids = [torch.zeros_like(g) for g in color_grids] if (color_grids and any(need_c)) else None
         grad_params = torch.zeros_like(mlp_params) if need_params else None
         grad_enc = torch.zeros_like(encoding) if need_enc else None
+        a.grad_grid = a.grad_color_grid = None
+        for i in range(_lib.LP_MAX_GRIDS):
+            a.grad_grid_list[i] = a.grad_color_grid_list[i] = None
         if grad_grids is not None:
             if cfg.grid_is_list:
                 _lib.fill_ptr_list(a.grad_grid_list, grad_grids)
