@@ -20,7 +20,9 @@ Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the wor
 kernel; Splatter: the forward walk): SURVEY.md 8(d)'s algorithmic bytes per launch divided by that kernel's mean
 launch time, measured with HIP events on the launch stream (torch's current stream is the stream the C ABI launches on).
 At N = 1 with the default workload the line also carries `extras`: the other configurations measured the same way
-(short runs), so that every number quoted in DESIGN.md / README.md can be recomputed from the driver's BENCH file, and
+(short runs), so that every number quoted in DESIGN.md / README.md can be recomputed from the driver's BENCH file (at
+N > 1 `extras` holds north_star's reporting batches instead: 1920x1080 rays per GPU at S = 128 and the cfg 4 shard,
+through the same sharded step with its RCCL all-reduce, bounded by a watchdog), and
 `cpu_baseline`: the CPU oracle (oracle/lightplane_oracle.py, the PyTorch restatement of the reference's naive path)
 timed on the host cores of rank 0, on BASELINE configs[0] (cfg 1) and on a ray subsample of the benchmarked workload.
 """
@@ -360,6 +362,29 @@ def measure_small_batch(dev, kernel, reps):
             "timing": "torch.profiler device time of the lp:: kernels"}
 
 
+def measure_sharded(name, rank, world, dev, pg, kernel, steps):
+    """N > 1: one of the 1080p-per-rank configurations through the same ray-sharded step (grid / decoder gradients
+    all-reduced over RCCL inside the step), timed like the headline: barrier + synchronize on both sides, max over ranks.
+    Every rank runs this."""
+    wl = make_workload(name, rank, dev, pg, kernel)
+    wl.step()
+    torch.distributed.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    torch.distributed.barrier()
+    torch.cuda.synchronize(dev)
+    t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    ms = float(t.item()) / steps * 1e3
+    out = {"workload": wl.desc, "rays_per_gpu": wl.n_rays, "n_gpus": world, "steps": steps, "ms_per_step": round(ms, 3),
+           "Mrays_per_s_fwd_bwd": round(wl.n_rays * world / ms / 1e3, 4)}
+    del wl
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -423,7 +448,32 @@ def main():
 
     fwd_ms, bwd_ms = event_times(wl, max(5, min(steps, 20)))
 
-    if rank == 0:
+    # N > 1, default workload: north_star's reporting batches (1920x1080 rays per GPU) through the same sharded step, so
+    # that the driver's scaling runs carry them.  A watchdog bounds the leg: if it has not finished in time, rank 0
+    # prints the headline line without it and every rank exits (a stuck collective cannot take the run with it).
+    sharded = None
+    watchdog_fired = []
+    if world > 1 and args.workload == "cfg2" and not args.no_extras:
+        import threading
+        done = threading.Event()
+        line_ready = {}
+
+        def bail():
+            if done.is_set():
+                return
+            watchdog_fired.append(True)
+            if rank == 0 and "res" in line_ready:
+                r = dict(line_ready["res"])
+                r["extras_error"] = "1080p legs did not finish within the watchdog limit"
+                print(json.dumps(r), flush=True)
+            os._exit(0)
+
+        timer = threading.Timer(float(os.environ.get("LP_BENCH_EXTRAS_TIMEOUT", "240")), bail)
+        timer.daemon = True
+    else:
+        timer = None
+
+    def headline():
         roof = wl.roofline(fwd_ms, bwd_ms)
         traffic, src = pmc_traffic(args.workload, "renderer_bwd" if isinstance(wl, RendererWorkload) else "splat_fwd_walk")
         roof["traffic"] = traffic
@@ -446,6 +496,26 @@ def main():
         }
         if isinstance(wl, RendererWorkload):
             res["mlp_fp32_frac_of_peak"] = round(wl.mlp_flops_fwdbwd() / ((fwd_ms + bwd_ms) * 1e-3) / FP32_PEAK, 5)
+        return res
+
+    if timer is not None:
+        if rank == 0:
+            line_ready["res"] = headline()
+        timer.start()
+        sharded = {}
+        for key, name, st in (("renderer_1080p_s128", "1080p_s128", 3), ("renderer_cfg4_shard", "cfg4", 2)):
+            try:
+                sharded[key] = measure_sharded(name, rank, world, dev, pg, args.kernel, st)
+            except Exception as e:  # (a failing rank leaves the others in a collective: the watchdog ends the run)
+                sharded[key] = {"error": repr(e)}
+                break
+        done.set()
+        timer.cancel()
+
+    if rank == 0:
+        res = headline()
+        if sharded is not None:
+            res["extras"] = sharded
         if world == 1 and args.workload == "cfg2" and not args.no_extras:
             res["extras"] = {
                 "splatter_cfg3": measure_extra("cfg3", dev, args.kernel, 10),
