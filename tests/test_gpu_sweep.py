@@ -108,6 +108,40 @@ def test_renderer_sweep(i):
             _check(f"{case}: grad_color_grid{k}", a, b, c)
 
 
+def _segmented_case(i):
+    """Default decoder shape, 17 .. 130 samples, no beyond-far samples: the segment-parallel forward + backward (ragged
+    last segments, partial waves, several grid batch entries, the non-PLAIN instantiations)."""
+    rnd = random.Random(3000 + i)
+    C = rnd.choice([16, 32])
+    tri = rnd.random() < 0.5
+    B = rnd.choice([1, 2, 3])
+    contract = rnd.random() < 0.3
+    kw = dict(seed=9000 + i, n_rays=rnd.choice([1, 33, 130, 300, 1000]), grid_base=(B, rnd.randint(3, 9), rnd.randint(3, 9), rnd.randint(3, 9), C),
+              is_triplane=tri, extra_voxel=tri and rnd.random() < 0.3, n_layers=(2, 2, 2), hidden=32,
+              color_chn=rnd.choice([1, 3, 3, 4]), num_samples=rnd.choice([17, 31, 32, 33, 48, 65, 100, 130]), num_samples_inf=0,
+              gain=rnd.choice([1.0, 3.0]), mask_oob=(not contract) and rnd.random() < 0.4, contract=contract,
+              scaffold_size=(rnd.randint(2, 6), rnd.randint(2, 6), rnd.randint(2, 6)) if rnd.random() < 0.3 else None,
+              noise_sigma=rnd.choice([0.0, 0.0, 0.7]), noise_seed=rnd.randint(0, 2 ** 20), param_std=0.25)
+    return RendererCase(f"segsweep{i}", **kw)
+
+
+@pytest.mark.parametrize("i", range(16))
+def test_renderer_segmented_sweep(i):
+    case = _segmented_case(i)
+    d = case.build()
+    dev = _dev()
+    assert lp.backward_segments(d["rays"], d["grids"], d["decoder"], **d["cfg"]) == (case.num_samples + 15) // 16
+    out, gp, ge, gg, _ = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO)
+    o_out, o_gp, o_ge, o_gg, _ = run_oracle_renderer64(d)
+    r_out, r_gp, r_ge, r_gg, _ = run_oracle_renderer(d)
+    for nm, a, b, c in (("ray_length", out[0], o_out[0], r_out[0]), ("neg_log_t", out[1], o_out[1], r_out[1]),
+                        ("feature", out[2], o_out[2], r_out[2]), ("grad_mlp_params", gp, o_gp, r_gp),
+                        ("grad_encoding", ge, o_ge, r_ge)):
+        _check(f"{case}: {nm}", a, b, c)
+    for k, (a, b, c) in enumerate(zip(gg, o_gg, r_gg)):
+        _check(f"{case}: grad_grid{k}", a, b, c)
+
+
 def _splatter_case(i):
     rnd = random.Random(2000 + i)
     C = rnd.choice([16, 32, 32, 8])
