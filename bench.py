@@ -58,6 +58,8 @@ RENDER_CFGS = {
                                        "2-layer/32-hidden MLPs, 3 colour ch, grid replicated + grad all-reduce"),
     "1080p_s128": (1080, 1920, 128, 16, 64, "1080p_s128: Renderer fwd+bwd, 1920x1080 rays/GPU, triplane 64^2x16ch, "
                                             "128 samples, 2-layer/32-hidden MLPs, 3 colour ch"),
+    "small": (64, 64, 128, 16, 64, "small batch: Renderer fwd+bwd, 64x64 rays, triplane 64^2x16ch, 128 samples "
+                                   "(segment-parallel march, DESIGN.md 4.9)"),
 }
 HIDDEN, COLOR = 32, 3
 
@@ -345,9 +347,7 @@ def kernel_times(wl, reps):
 def measure_small_batch(dev, kernel, reps):
     """A NeRF-style training batch (4 096 rays x 128 samples, cfg 2's grid and decoder): kernel times with the
     segment-parallel forward / backward (default; forward = segment march + combine pass) and with one sweep per ray."""
-    name = "small_64x64_s128"
-    RENDER_CFGS[name] = (64, 64, 128, 16, 64, "small batch: Renderer fwd+bwd, 64x64 rays, triplane 64^2x16ch, 128 samples")
-    wl = RendererWorkload(name, 0, dev, None, kernel)
+    wl = RendererWorkload("small", 0, dev, None, kernel)
     n_seg = lp.backward_segments(wl.rays, None, wl.dec, num_samples=wl.S, grid_sizes=wl.sizes)
     saved = lp.config.segment_backward, lp.config.segment_forward
     try:
@@ -391,7 +391,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: >= 0.5 s of work: 200 for cfg2 / cfg3, "
                                                             "10 for the 1080p workloads)")
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "1080p_s128", "cfg3"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "1080p_s128", "cfg3", "small"])
     ap.add_argument("--kernel", type=int, default=_lib.LP_KERNEL_AUTO)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the short runs of the other configurations (N = 1 only)")

@@ -24,6 +24,7 @@ for w in $WL; do
     cfg2) run cfg2 200 3 ;;
     cfg3) run cfg3 50 3 ;;
     cfg4) run cfg4 5 1 ;;
+    small) run small 200 3 ;;
   esac
 done
 find $R/gpurun_out/prof_* $R/gpurun_out/pmc[1-4]_* -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" -size +512k -delete

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Condense gpurun_out/{prof_<w>,pmc1..4_<w>} (rocprofv3 CSV output of scripts/gpu_profile.sh, w in cfg2 / cfg3 / cfg4) into
+"""Condense gpurun_out/{prof_<w>,pmc1..4_<w>} (rocprofv3 CSV output of scripts/gpu_profile.sh, w in cfg2 / cfg3 / cfg4 / small) into
 the tracked files under profiles/:  r<NN>_kernel_stats_<w>.csv (top kernels of the kernel trace), r<NN>_bench_line_<w>.json
 (the bench line of the traced run) and r<NN>_pmc_summary.json (per-dispatch averages of the PMC passes + derived traffic)."""
 import collections
@@ -16,9 +16,10 @@ P = os.path.join(REPO, "profiles")
 os.makedirs(P, exist_ok=True)
 CMD = {"cfg2": "python bench.py --workload cfg2 --no-cpu-baseline --no-extras --steps 200 --warmup 3",
        "cfg3": "python bench.py --workload cfg3 --no-cpu-baseline --no-extras --steps 50 --warmup 3",
-       "cfg4": "python bench.py --workload cfg4 --no-cpu-baseline --no-extras --steps 5 --warmup 3"}
+       "cfg4": "python bench.py --workload cfg4 --no-cpu-baseline --no-extras --steps 5 --warmup 3",
+       "small": "python bench.py --workload small --no-cpu-baseline --no-extras --steps 200 --warmup 3"}
 out = {}
-for w in ("cfg2", "cfg3", "cfg4"):
+for w in ("cfg2", "cfg3", "cfg4", "small"):
     stats = glob.glob(os.path.join(G, f"prof_{w}", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
