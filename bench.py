@@ -322,7 +322,7 @@ def measure_extra(name, dev, kernel, reps):
 
 
 def kernel_times(wl, reps):
-    """Mean device time of the lp::renderer_fwd* / lp::renderer_bwd* kernels per step, from torch.profiler's device
+    """Median device time of the lp::renderer_fwd* / lp::renderer_bwd* kernels per step, from torch.profiler's device
     timestamps: for batches whose kernels are as short as the host side of a call, events around Python calls would
     measure the host."""
     from torch.profiler import ProfilerActivity, profile
@@ -333,15 +333,19 @@ def kernel_times(wl, reps):
         for _ in range(reps):
             wl.step()
         torch.cuda.synchronize()
-    fwd = bwd = 0.0
+    per_kernel = {}  # kernel name -> device times of its launches (us)
     for e in prof.events():
-        if e.device_type != torch.autograd.DeviceType.CUDA:
+        if e.device_type != torch.autograd.DeviceType.CUDA or not ("lp::renderer_fwd" in e.name or "lp::renderer_bwd" in e.name):
             continue
-        if "lp::renderer_fwd" in e.name:
-            fwd += e.device_time_total
-        elif "lp::renderer_bwd" in e.name:
-            bwd += e.device_time_total
-    return fwd / reps / 1e3, bwd / reps / 1e3
+        per_kernel.setdefault(e.name.split("(")[0].replace("void ", ""), []).append(e.device_time_total)
+    # median per kernel (a launch that shared the GPU with an allocator sync or a clock ramp does not move it), times the
+    # launches per step
+    med = {k: sorted(v)[len(v) // 2] * (len(v) / reps) for k, v in per_kernel.items()}
+    kernel_times.last = {k: {"launches": len(v), "median_ms": round(sorted(v)[len(v) // 2] / 1e3, 4),
+                             "max_ms": round(max(v) / 1e3, 4)} for k, v in per_kernel.items()}
+    fwd = sum(t for k, t in med.items() if "renderer_fwd" in k)
+    bwd = sum(t for k, t in med.items() if "renderer_bwd" in k)
+    return fwd / 1e3, bwd / 1e3
 
 
 def measure_small_batch(dev, kernel, reps):
@@ -353,12 +357,13 @@ def measure_small_batch(dev, kernel, reps):
     try:
         lp.config.segment_backward = lp.config.segment_forward = True
         f1, b1 = kernel_times(wl, reps)
+        kernels = kernel_times.last
         lp.config.segment_backward = lp.config.segment_forward = False
         f0, b0 = kernel_times(wl, reps)
     finally:
         lp.config.segment_backward, lp.config.segment_forward = saved
     return {"workload": wl.desc, "rays": wl.n_rays, "backward_segments": n_seg, "fwd_ms": round(f1, 4), "bwd_ms": round(b1, 4),
-            "bwd_ms_one_sweep_per_ray": round(b0, 4), "fwd_ms_one_sweep_per_ray": round(f0, 4), "reps": reps,
+            "bwd_ms_one_sweep_per_ray": round(b0, 4), "fwd_ms_one_sweep_per_ray": round(f0, 4), "reps": reps, "kernels": kernels,
             "timing": "torch.profiler device time of the lp:: kernels"}
 
 
