@@ -140,13 +140,13 @@ class SplatterWorkload:
     desc = "cfg3: Splatter fwd+bwd, 256x256 rays/GPU x 32ch encoding -> 128^3x32ch voxel grid, 256 samples"
     roofline_kernel = "splatter forward walk"
 
-    def __init__(self, rank, dev, pg):
+    def __init__(self, rank, dev, pg, image=(256, 256)):
         from tests.synth import pinhole_rays
 
         self.pg, self.S, self.C, self.G = pg, 256, 32, 128
         gen = torch.Generator().manual_seed(100 + rank)
         az, el = camera_pose("cfg2", rank)
-        self.rays_c = pinhole_rays(256, 256, gen=gen, azimuth_deg=az, elevation_deg=el)
+        self.rays_c = pinhole_rays(image[0], image[1], gen=gen, azimuth_deg=az, elevation_deg=el)
         self.rays_c.encoding = torch.rand(self.rays_c.n_rays, self.C, generator=gen)
         self.rays = self.rays_c.to(dev)
         self.rays.encoding.requires_grad_(True)

@@ -166,7 +166,7 @@ LP_DEV void splat_walk(float* feat, float* wgt, const LpGrid& g, int b, float x,
 }
 
 template <int C, int RPW>
-__global__ void __launch_bounds__(256) splat_fwd_walk_kernel(const LpSplatterArgs a, int dbg) {
+__global__ void __launch_bounds__(256) splat_fwd_walk_kernel(const LpSplatterArgs a, int dbg, int n_seg) {
   constexpr int LD = RPW + 4;  // row stride of the transposed encoding tile [channel][ray]
   constexpr int NQ = 64 / RPW;
   constexpr int CPL = C / 16;
@@ -174,7 +174,10 @@ __global__ void __launch_bounds__(256) splat_fwd_walk_kernel(const LpSplatterArg
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane / RPW, r = lane % RPW;
   float* tile = lds[wave];
-  const int64_t ray_id = ((int64_t)blockIdx.x * 4 + wave) * RPW + r;
+  // small batches: blockIdx = (ray block, segment of the march) -- samples are independent, so a segment is just a
+  // sub-range of the sample loop (splat_segments() on the host)
+  const int blk = (int)blockIdx.x / n_seg, seg = (int)blockIdx.x - blk * n_seg;
+  const int64_t ray_id = ((int64_t)blk * 4 + wave) * RPW + r;
   const bool valid = ray_id < a.rays.n_rays;
   const int64_t rid = valid ? ray_id : 0;
   const Ray ray = load_ray(a.rays, rid);
@@ -203,7 +206,9 @@ __global__ void __launch_bounds__(256) splat_fwd_walk_kernel(const LpSplatterArg
   const int s_tot = a.march.num_samples + a.march.num_samples_inf;
   const bool contract = a.march.contract_coords != 0;
   const bool mask = a.march.mask_out_of_bounds != 0;
-  for (int s = 0; s < s_tot; ++s) {
+  const int per_seg = (s_tot + n_seg - 1) / n_seg;
+  const int s_lo = seg * per_seg, s_hi = (s_lo + per_seg < s_tot) ? s_lo + per_seg : s_tot;
+  for (int s = s_lo; s < s_hi; ++s) {
     const float depth = sample_depth(s, a.march, ray.near_t, ray.far_t);
     float x, y, z;
     sample_point(ray, depth, contract, x, y, z);
@@ -269,13 +274,14 @@ __global__ void __launch_bounds__(256) splat_bwd_kernel(const LpSplatterArgs a) 
 // lane groups at the end.  (The per-ray kernel below re-derives the geometry in every lane and reads eight rows
 // per ray and sample.)
 template <int C, int B>
-__global__ void __launch_bounds__(256, B == 4 ? 3 : 2) splat_bwd_walk_kernel(const LpSplatterArgs a) {
+__global__ void __launch_bounds__(256, B == 4 ? 3 : 2) splat_bwd_walk_kernel(const LpSplatterArgs a, int n_seg) {
   constexpr int RPW = 16, CPL = C / 16, NQ = 4, SPQ = 2;
   __shared__ __attribute__((aligned(16))) float lds[4][8 * RPW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane / RPW, r = lane % RPW, sub = lane & 15, grp = lane >> 4;
   float* wT = lds[wave];
-  const int64_t ray0 = ((int64_t)blockIdx.x * 4 + wave) * RPW;
+  const int blk = (int)blockIdx.x / n_seg, seg = (int)blockIdx.x - blk * n_seg;  // (ray block, segment of the march)
+  const int64_t ray0 = ((int64_t)blk * 4 + wave) * RPW;
   const int64_t ray_id = ray0 + r;
   const bool valid = ray_id < a.rays.n_rays;
   const int64_t rid = valid ? ray_id : 0;
@@ -288,7 +294,9 @@ __global__ void __launch_bounds__(256, B == 4 ? 3 : 2) splat_bwd_walk_kernel(con
   const int s_tot = a.march.num_samples + a.march.num_samples_inf;
   const bool contract = a.march.contract_coords != 0;
   const bool mask_oob = a.march.mask_out_of_bounds != 0;
-  for (int s = 0; s < s_tot; ++s) {
+  const int per_seg = (s_tot + n_seg - 1) / n_seg;
+  const int s_lo = seg * per_seg, s_hi = (s_lo + per_seg < s_tot) ? s_lo + per_seg : s_tot;
+  for (int s = s_lo; s < s_hi; ++s) {
     const float depth = sample_depth(s, a.march, ray.near_t, ray.far_t);
     float x, y, z;
     sample_point(ray, depth, contract, x, y, z);
@@ -376,7 +384,11 @@ __global__ void __launch_bounds__(256, B == 4 ? 3 : 2) splat_bwd_walk_kernel(con
       float v = acc[j][i];
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
-      if (grp == 0 && ray0 + i < a.rays.n_rays) a.grad_encoding[(ray0 + i) * C + sub + 16 * j] = v;
+      if (grp == 0 && ray0 + i < a.rays.n_rays) {
+        float* dst = a.grad_encoding + (ray0 + i) * C + sub + 16 * j;
+        if (n_seg > 1) atomic_add_f32(dst, v);  // the segments of a ray add up (the launcher zero-fills)
+        else *dst = v;
+      }
     }
   }
 }
@@ -433,18 +445,34 @@ __global__ void __launch_bounds__(256) hash_randn_kernel(const int32_t* x1, cons
     }                                                                                          \
   } while (0)
 
+// Small batches: a wave marches 16 rays one sample after the other, so fewer than ~16 k rays leave most of the chip idle.
+// The samples of a ray are independent in the Splatter, so the march is cut into segments of at least 16 samples, as many
+// as bring the launch to ~3 workgroups per CU (LP_SPLAT_SEGMENTS=1 switches it off).  Walk kernels on MI355X, 256 samples
+// into a 128^3 x 32 grid (scripts/bench_small_batch.py --splatter, profiles/r02_small_batch.txt): 4 096 rays forward
+// 1.31 -> 0.28 ms, backward 1.19 -> 0.23 ms; 16 384 rays 1.29 -> 0.89 / 1.16 -> 0.81 ms; at 32 768 rays (512 ray blocks)
+// two segments no longer pay for the backward (1.17 -> 1.29 ms), hence the 768.
+static int splat_segments(const LpSplatterArgs& a, unsigned ray_blocks) {
+  static const int forced = getenv("LP_SPLAT_SEGMENTS") ? atoi(getenv("LP_SPLAT_SEGMENTS")) : 0;
+  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
+  int n = forced > 0 ? forced : (int)(768u / (ray_blocks ? ray_blocks : 1u));
+  if (n > s_tot / 16) n = s_tot / 16;
+  return n < 1 ? 1 : n;
+}
+
 int splatter_forward_launch(const LpSplatterArgs& a, hipStream_t stream) {
   const int Cw = a.out.channels;
   static const bool no_walk = getenv("LP_SPLAT_NO_WALK") != nullptr;  // A/B timing knob
   if ((Cw == 16 || Cw == 32) && a.out.n_rows < ((int64_t)1 << 31) && !no_walk) {
     static const int rpw = getenv("LP_SPLAT_RPW") ? atoi(getenv("LP_SPLAT_RPW")) : 16;
     static const int dbg = getenv("LP_SPLAT_DEBUG") ? atoi(getenv("LP_SPLAT_DEBUG")) : 0;  // timing experiments
-    const unsigned blocks = (unsigned)((a.rays.n_rays + 4 * rpw - 1) / (4 * rpw));
-    if (blocks == 0) return LP_OK;
-    if (Cw == 16 && rpw == 32) hipLaunchKernelGGL((splat_fwd_walk_kernel<16, 32>), dim3(blocks), dim3(256), 0, stream, a, dbg);
-    else if (Cw == 16) hipLaunchKernelGGL((splat_fwd_walk_kernel<16, 16>), dim3(blocks), dim3(256), 0, stream, a, dbg);
-    else if (rpw == 32) hipLaunchKernelGGL((splat_fwd_walk_kernel<32, 32>), dim3(blocks), dim3(256), 0, stream, a, dbg);
-    else hipLaunchKernelGGL((splat_fwd_walk_kernel<32, 16>), dim3(blocks), dim3(256), 0, stream, a, dbg);
+    const unsigned ray_blocks = (unsigned)((a.rays.n_rays + 4 * rpw - 1) / (4 * rpw));
+    if (ray_blocks == 0) return LP_OK;
+    const int n_seg = splat_segments(a, ray_blocks);
+    const unsigned blocks = ray_blocks * (unsigned)n_seg;
+    if (Cw == 16 && rpw == 32) hipLaunchKernelGGL((splat_fwd_walk_kernel<16, 32>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg);
+    else if (Cw == 16) hipLaunchKernelGGL((splat_fwd_walk_kernel<16, 16>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg);
+    else if (rpw == 32) hipLaunchKernelGGL((splat_fwd_walk_kernel<32, 32>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg);
+    else hipLaunchKernelGGL((splat_fwd_walk_kernel<32, 16>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg);
     return check_launch("splat_fwd_walk_kernel");
   }
   LP_SPLAT_DISPATCH(splat_fwd_kernel);
@@ -458,11 +486,17 @@ int splatter_backward_launch(const LpSplatterArgs& a, hipStream_t stream) {
   for (int g = 0; g < a.out.n_grids; ++g)
     voxels = voxels && a.out.grids[g].D > 1 && a.out.grids[g].H > 1 && a.out.grids[g].W > 1;
   if ((Cw == 16 || Cw == 32) && voxels && a.out.n_rows < ((int64_t)1 << 31) && !no_walk) {
-    const unsigned blocks = (unsigned)((a.rays.n_rays + 63) / 64);
-    if (blocks == 0) return LP_OK;
+    const unsigned ray_blocks = (unsigned)((a.rays.n_rays + 63) / 64);
+    if (ray_blocks == 0) return LP_OK;
+    const int n_seg = splat_segments(a, ray_blocks);
+    if (n_seg > 1) {  // the segments accumulate into grad_encoding
+      const hipError_t e = hipMemsetAsync(a.grad_encoding, 0, (size_t)a.rays.n_rays * Cw * sizeof(float), stream);
+      if (e != hipSuccess) return set_error((int)e, "hipMemsetAsync(grad_encoding): %s", hipGetErrorString(e));
+    }
+    const unsigned blocks = ray_blocks * (unsigned)n_seg;
     // batches of 8 rays; batches of 4 at three waves/SIMD measured the same (cfg 3)
-    if (Cw == 16) hipLaunchKernelGGL((splat_bwd_walk_kernel<16, 8>), dim3(blocks), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((splat_bwd_walk_kernel<32, 8>), dim3(blocks), dim3(256), 0, stream, a);
+    if (Cw == 16) hipLaunchKernelGGL((splat_bwd_walk_kernel<16, 8>), dim3(blocks), dim3(256), 0, stream, a, n_seg);
+    else hipLaunchKernelGGL((splat_bwd_walk_kernel<32, 8>), dim3(blocks), dim3(256), 0, stream, a, n_seg);
     return check_launch("splat_bwd_walk_kernel");
   }
   LP_SPLAT_DISPATCH(splat_bwd_kernel);

@@ -343,6 +343,15 @@ def test_splatter_coherent_image(name, image, mask):
     check_splatter(d, _dev(), f"{name}/{image}/mask={mask}")
 
 
+@pytest.mark.parametrize("name", list(SPLATS))
+@pytest.mark.parametrize("num_samples", [37, 70])
+def test_splatter_segmented_march(name, num_samples):
+    """Small batch, more than 32 samples: the march of the voxel walk kernels is cut into segments (one workgroup per
+    64 rays and segment; the backward's segments accumulate grad_encoding with atomics)."""
+    d = coherent_splatter_inputs(name, "48x80_az30_el45", num_samples=num_samples, seed=2)
+    check_splatter(d, _dev(), f"segmented {name}/S={num_samples}")
+
+
 @pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
 @pytest.mark.parametrize("name,mlp", [
     ("voxel24_c32", dict(feat_dim=32)),
