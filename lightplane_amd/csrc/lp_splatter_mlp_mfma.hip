@@ -26,6 +26,7 @@ constexpr int TM_LD = 36;  // row stride of the feature-major tiles
 struct MlpSplatParams {
   int64_t w1, w2, b1, b2;  // float offsets inside mlp_params
   int dbg;
+  int n_seg;  // small batches: segments the march is cut into (blockIdx = (128 rays, segment); samples are independent)
 };
 
 struct LdsS {
@@ -183,7 +184,8 @@ __global__ void __launch_bounds__(256, 2) splat_mlp_fwd_mfma(const LpSplatterArg
   float* const wv = lds + M::END + wave * M::PER_WAVE;
   float* const vt = wv + M::XT;
   float* const wT = wv + M::YT;
-  const int64_t ray_id = ((int64_t)blockIdx.x * WAVES + wave) * RAYS_PER_WAVE + r;
+  const int blk = (int)blockIdx.x / mp.n_seg, seg = (int)blockIdx.x - blk * mp.n_seg;
+  const int64_t ray_id = ((int64_t)blk * WAVES + wave) * RAYS_PER_WAVE + r;
   const bool valid = ray_id < a.rays.n_rays;
   const int64_t rid = valid ? ray_id : 0;
   const Ray ray = load_ray(a.rays, rid);
@@ -195,7 +197,9 @@ __global__ void __launch_bounds__(256, 2) splat_mlp_fwd_mfma(const LpSplatterArg
   }
   const int s_tot = a.march.num_samples + a.march.num_samples_inf;
   const bool mask = a.march.mask_out_of_bounds != 0;
-  for (int s = 0; s < s_tot; ++s) {
+  const int per_seg = (s_tot + mp.n_seg - 1) / mp.n_seg;
+  const int s_lo = seg * per_seg, s_hi = (s_lo + per_seg < s_tot) ? s_lo + per_seg : s_tot;
+  for (int s = s_lo; s < s_hi; ++s) {
     Sample<E> sm;
     fetch_sample<E, GMI, true>(rv, lds_inf, ray, s, h, sm);
     const bool live = valid && !(mask && !point_in_bounds(sm.x, sm.y, sm.z));
@@ -272,7 +276,8 @@ __global__ void __launch_bounds__(256, 2) splat_mlp_bwd_mfma(const LpSplatterArg
   float* const wv = wave0 + wave * M::PER_WAVE;
   float* const xt = wv + M::XT;
   float* const yt = wv + M::YT;
-  const int64_t ray_id = ((int64_t)blockIdx.x * WAVES + wave) * RAYS_PER_WAVE + r;
+  const int blk = (int)blockIdx.x / mp.n_seg, seg = (int)blockIdx.x - blk * mp.n_seg;
+  const int64_t ray_id = ((int64_t)blk * WAVES + wave) * RAYS_PER_WAVE + r;
   const bool valid = ray_id < a.rays.n_rays;
   const int64_t rid = valid ? ray_id : 0;
   const Ray ray = load_ray(a.rays, rid);
@@ -303,7 +308,9 @@ __global__ void __launch_bounds__(256, 2) splat_mlp_bwd_mfma(const LpSplatterArg
   f32x4m dq1 = {0, 0, 0, 0}, dq2 = {0, 0, 0, 0};
   float db1 = 0.0f, db2 = 0.0f;
 
-  for (int s = 0; s < s_tot; ++s) {
+  const int per_seg = (s_tot + mp.n_seg - 1) / mp.n_seg;
+  const int s_lo = seg * per_seg, s_hi = (s_lo + per_seg < s_tot) ? s_lo + per_seg : s_tot;
+  for (int s = s_lo; s < s_hi; ++s) {
     Sample<E> sm;
     fetch_sample<E, GMI, true>(rv, lds_inf, ray, s, h, sm);
     const float x = sm.x, y = sm.y, z = sm.z;
@@ -391,11 +398,16 @@ __global__ void __launch_bounds__(256, 2) splat_mlp_bwd_mfma(const LpSplatterArg
     }
   }
 
-  if (valid && a.grad_encoding) {
+  if (valid && a.grad_encoding && mp.n_seg == 1) {
 #pragma unroll
     for (int j = 0; j < E / 8; ++j)
       *reinterpret_cast<float4*>(a.grad_encoding + ray_id * E + 8 * j + 4 * h) =
           make_float4(denc[4 * j], denc[4 * j + 1], denc[4 * j + 2], denc[4 * j + 3]);
+  } else if (valid && a.grad_encoding) {  // the segments of a ray add up (the launcher zero-fills)
+#pragma unroll
+    for (int j = 0; j < E / 8; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) atomic_add_f32(a.grad_encoding + ray_id * E + 8 * j + 4 * h + i, denc[4 * j + i]);
   }
   if (want_params) {
     float* G = a.grad_mlp_params;
@@ -437,7 +449,7 @@ static int grid_mode_of(const LpGridList& gl) {
 }
 
 template <typename K>
-static int launch_m(K kernel, const LpSplatterArgs& a, hipStream_t stream) {
+static int launch_m(K kernel, const LpSplatterArgs& a, hipStream_t stream, bool backward) {
   const size_t lds = LdsS::TOTAL * sizeof(float);
   const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -454,36 +466,47 @@ static int launch_m(K kernel, const LpSplatterArgs& a, hipStream_t stream) {
   static const int dbg = getenv("LP_MFMA_DEBUG") ? atoi(getenv("LP_MFMA_DEBUG")) : 0;
   mp.dbg = dbg;
   const unsigned nb = (unsigned)((a.rays.n_rays + WAVES * RAYS_PER_WAVE - 1) / (WAVES * RAYS_PER_WAVE));
-  hipLaunchKernelGGL(kernel, dim3(nb), dim3(256), lds, stream, a, rv, mp);
+  // small batches (see splat_segments in lp_splatter.hip): segments of >= 16 samples, within one round of workgroups
+  static const int forced = getenv("LP_SPLAT_SEGMENTS") ? atoi(getenv("LP_SPLAT_SEGMENTS")) : 0;
+  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
+  int n_seg = forced > 0 ? forced : (int)(512u / (nb ? nb : 1u));
+  if (n_seg > s_tot / 16) n_seg = s_tot / 16;
+  if (n_seg < 1) n_seg = 1;
+  mp.n_seg = n_seg;
+  if (backward && n_seg > 1 && a.grad_encoding) {
+    const hipError_t e2 = hipMemsetAsync(a.grad_encoding, 0, (size_t)a.rays.n_rays * E * sizeof(float), stream);
+    if (e2 != hipSuccess) return set_error((int)e2, "hipMemsetAsync(grad_encoding): %s", hipGetErrorString(e2));
+  }
+  hipLaunchKernelGGL(kernel, dim3(nb * (unsigned)n_seg), dim3(256), lds, stream, a, rv, mp);
   return LP_OK;
 }
 
-#define LP_DISPATCH_M(KERNEL)                                                                  \
+#define LP_DISPATCH_M(KERNEL, BWD)                                                                \
   do {                                                                                         \
     const int E = a.mlp.dims[0], CO = a.mlp.dims[2], gm = grid_mode_of(a.input_grid);          \
     if (E == 16 && CO == 16) {                                                                 \
-      rc = gm == GM_TRIPLANE ? launch_m(KERNEL<16, 16, GM_TRIPLANE>, a, stream)                \
-           : gm == GM_VOXEL  ? launch_m(KERNEL<16, 16, GM_VOXEL>, a, stream)                   \
-                             : launch_m(KERNEL<16, 16, GM_GENERIC>, a, stream);                \
+      rc = gm == GM_TRIPLANE ? launch_m(KERNEL<16, 16, GM_TRIPLANE>, a, stream, BWD)                \
+           : gm == GM_VOXEL  ? launch_m(KERNEL<16, 16, GM_VOXEL>, a, stream, BWD)                   \
+                             : launch_m(KERNEL<16, 16, GM_GENERIC>, a, stream, BWD);                \
     } else if (E == 16) {                                                                      \
-      rc = gm == GM_TRIPLANE ? launch_m(KERNEL<16, 32, GM_TRIPLANE>, a, stream)                \
-           : gm == GM_VOXEL  ? launch_m(KERNEL<16, 32, GM_VOXEL>, a, stream)                   \
-                             : launch_m(KERNEL<16, 32, GM_GENERIC>, a, stream);                \
+      rc = gm == GM_TRIPLANE ? launch_m(KERNEL<16, 32, GM_TRIPLANE>, a, stream, BWD)                \
+           : gm == GM_VOXEL  ? launch_m(KERNEL<16, 32, GM_VOXEL>, a, stream, BWD)                   \
+                             : launch_m(KERNEL<16, 32, GM_GENERIC>, a, stream, BWD);                \
     } else if (CO == 16) {                                                                     \
-      rc = gm == GM_TRIPLANE ? launch_m(KERNEL<32, 16, GM_TRIPLANE>, a, stream)                \
-           : gm == GM_VOXEL  ? launch_m(KERNEL<32, 16, GM_VOXEL>, a, stream)                   \
-                             : launch_m(KERNEL<32, 16, GM_GENERIC>, a, stream);                \
+      rc = gm == GM_TRIPLANE ? launch_m(KERNEL<32, 16, GM_TRIPLANE>, a, stream, BWD)                \
+           : gm == GM_VOXEL  ? launch_m(KERNEL<32, 16, GM_VOXEL>, a, stream, BWD)                   \
+                             : launch_m(KERNEL<32, 16, GM_GENERIC>, a, stream, BWD);                \
     } else {                                                                                   \
-      rc = gm == GM_TRIPLANE ? launch_m(KERNEL<32, 32, GM_TRIPLANE>, a, stream)                \
-           : gm == GM_VOXEL  ? launch_m(KERNEL<32, 32, GM_VOXEL>, a, stream)                   \
-                             : launch_m(KERNEL<32, 32, GM_GENERIC>, a, stream);                \
+      rc = gm == GM_TRIPLANE ? launch_m(KERNEL<32, 32, GM_TRIPLANE>, a, stream, BWD)                \
+           : gm == GM_VOXEL  ? launch_m(KERNEL<32, 32, GM_VOXEL>, a, stream, BWD)                   \
+                             : launch_m(KERNEL<32, 32, GM_GENERIC>, a, stream, BWD);                \
     }                                                                                          \
   } while (0)
 
 int splatter_mlp_forward_mfma(const LpSplatterArgs& a, hipStream_t stream) {
   if (a.rays.n_rays == 0) return LP_OK;
   int rc;
-  LP_DISPATCH_M(splat_mlp_fwd_mfma);
+  LP_DISPATCH_M(splat_mlp_fwd_mfma, false);
   if (rc) return rc;
   return check_launch("splat_mlp_fwd_mfma");
 }
@@ -491,7 +514,7 @@ int splatter_mlp_forward_mfma(const LpSplatterArgs& a, hipStream_t stream) {
 int splatter_mlp_backward_mfma(const LpSplatterArgs& a, hipStream_t stream) {
   if (a.rays.n_rays == 0) return LP_OK;
   int rc;
-  LP_DISPATCH_M(splat_mlp_bwd_mfma);
+  LP_DISPATCH_M(splat_mlp_bwd_mfma, true);
   if (rc) return rc;
   return check_launch("splat_mlp_bwd_mfma");
 }

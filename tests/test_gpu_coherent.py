@@ -363,6 +363,17 @@ def test_mlp_splatter_coherent_image(name, mlp, kernel):
     check_mlp_splatter(d, _dev(), kernel, f"{name}/mlp")
 
 
+@pytest.mark.parametrize("name,mlp", [
+    ("voxel24_c32", dict(feat_dim=32)),
+    ("triplane32_c16", dict(feat_dim=16, in_triplane=True)),
+], ids=["voxel_32_32", "triplane_16_16"])
+def test_mlp_splatter_segmented_march(name, mlp):
+    """Small batch, 70 samples: the MLP-Splatter's march is cut into segments (parameter / input-grid gradients are
+    atomics anyway, grad_encoding accumulates over the segments)."""
+    d = coherent_splatter_inputs(name, "48x80_az30_el45", num_samples=70, seed=4, mlp=mlp)
+    check_mlp_splatter(d, _dev(), _lib.LP_KERNEL_AUTO, f"segmented {name}/mlp")
+
+
 def test_splatter_coherent_32_rays_per_wave():
     """The same coherent Splatter cases with 32 rays per wave (LP_SPLAT_RPW is read once per process)."""
     env = dict(os.environ, LP_SPLAT_RPW="32")
