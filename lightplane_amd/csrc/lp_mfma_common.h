@@ -51,6 +51,7 @@ struct MfmaParams {
   int t1, tg, hin;
   // segment-parallel backward: LP_SEG_LEN-sample blocks per workgroup (chosen at launch, see launch_bwd3)
   int seg_blocks;
+  int seg_fwd;  // forward of the flex / two-grid shapes: 1 = this launch marches segments (segment-local state records)
 };
 
 // LDS map (floats).  Weight matrices are kept ONCE, row-major [in][W_LD] with a padded row

@@ -156,7 +156,14 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_mfma_np(const LpRendere
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, r = lane & 31;
-  const int64_t ray_id = ((int64_t)blockIdx.x * WAVES + wave) * RAYS_PER_WAVE + r;
+  // flex / two-grid shapes, small batch (mp.seg_fwd, see renderer_fwd_bf3 SEGF): a workgroup marches one segment from
+  // transmittance 1 and leaves segment-local state records for renderer_fwd_combine
+  const bool segf = FLEX && mp.seg_fwd != 0;
+  const int seg_len = LP_SEG_LEN * mp.seg_blocks;
+  const int n_seg = segf ? (a.march.num_samples + seg_len - 1) / seg_len : 1;
+  const int blk = segf ? (int)blockIdx.x / n_seg : (int)blockIdx.x;
+  const int seg = segf ? (int)blockIdx.x - blk * n_seg : 0;
+  const int64_t ray_id = ((int64_t)blk * WAVES + wave) * RAYS_PER_WAVE + r;
   const bool valid = ray_id < a.rays.n_rays;
   const int64_t rid = valid ? ray_id : 0;
   const Ray ray = load_ray(a.rays, rid);
@@ -170,7 +177,13 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_mfma_np(const LpRendere
   float facc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   Sample<C> nx;
   Act<C> t;
-  for (int s = 0; s < s_tot; ++s) {
+  const int s_lo = segf ? seg * seg_len : 0;
+  const int s_hi = segf ? ((s_lo + seg_len < s_tot) ? s_lo + seg_len : s_tot) : s_tot;
+  if (segf && s_lo > 0) {  // interval length of the segment's first sample
+    sample_geometry<C>(a, lds, ray, s_lo - 1, nx);
+    depth_prev = nx.depth;
+  }
+  for (int s = s_lo; s < s_hi; ++s) {
     fetch_sample<C, GM, true>(a, lds, ray, s, h, nx);
     const float depth = nx.depth, occ = nx.occ;
 #pragma unroll
@@ -188,7 +201,7 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_mfma_np(const LpRendere
     if (a.noise_sigma > 0.0f) raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
     const float opacity = a.gain * softplus_f(raw) * occ;
     nlt_add(nlt, nlt_lo, opacity * delta);
-    if (a.neg_log_t_ckpt && valid && h == 0) {
+    if (!segf && a.neg_log_t_ckpt && valid && h == 0) {
       const int ck = ckpt_index(s, a.march);
       if (ck >= 0) *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + ck) * 2) = make_float2(nlt, nlt_lo);
     }
@@ -198,13 +211,19 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_mfma_np(const LpRendere
     len = fmaf(w, depth, len);
 #pragma unroll
     for (int c = 0; c < NC; ++c) facc[c] = fmaf(w, sigmoid_f(hd.raw_c[c]) * occ, facc[c]);
+    // state records of the segment-parallel backward (absolute; segf: relative to the segment's start)
+    if (FLEX && a.seg_prefix && valid && h == 0 && (((s + 1) % LP_SEG_LEN) == 0 || s == a.march.num_samples - 1)) {
+      float4* dst = reinterpret_cast<float4*>(a.seg_prefix + (ray_id * segment_count(a.march) + s / LP_SEG_LEN) * 8);
+      dst[0] = make_float4(len, facc[0], facc[1], facc[2]);
+      dst[1] = make_float4(NC == 4 ? facc[3] : 0.0f, nlt, nlt_lo, 0.0f);
+    }
     // early termination (off unless stop_neg_log_t > 0): every ray of this wave is opaque
     if (a.stop_neg_log_t > 0.0f && __ballot(valid && nlt < a.stop_neg_log_t) == 0) {
       s_last = s;
       break;
     }
   }
-  if (valid && h == 0) {
+  if (!segf && valid && h == 0) {
     write_ray_outputs(a, ray_id, len, nlt, facc);
     if (a.neg_log_t_ckpt)
       *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + n_ckpt - 1) * 2) = make_float2((float)s_last, nlt_lo);
@@ -402,6 +421,7 @@ static MfmaParams make_params(const LpRendererArgs& a) {
   static const int dbg = getenv("LP_MFMA_DEBUG") ? atoi(getenv("LP_MFMA_DEBUG")) : 0;
   p.dbg = dbg;
   p.seg_blocks = 1;
+  p.seg_fwd = 0;
   return p;
 }
 
@@ -417,7 +437,9 @@ int renderer_mfma_segments(const LpRendererArgs& a) {
   static const bool bf3 = getenv("LP_MFMA_F32") == nullptr && getenv("LP_MFMA_F32_BWD") == nullptr;
   static const int forced = getenv("LP_SEGMENTS") ? atoi(getenv("LP_SEGMENTS")) : -1;
   static const bool bf3_c32 = getenv("LP_BF3_C32") == nullptr || atoi(getenv("LP_BF3_C32")) != 0;
-  if (!bf3 || forced == 0 || (a.grid.channels != 16 && !bf3_c32) || is_flex(make_params(a))) return 1;
+  // (default shape: the bf16x3 kernels; flex / two-grid shapes: the FLEX instantiations of the fp32-MFMA kernels)
+  const bool flex = is_flex(make_params(a));
+  if (forced == 0 || (!flex && (!bf3 || (a.grid.channels != 16 && !bf3_c32)))) return 1;
   if (a.march.num_samples_inf != 0 || a.stop_neg_log_t > 0.0f) return 1;
   const int n_seg = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
   if (n_seg < 2) return 1;
@@ -497,14 +519,33 @@ static int launch_fwd(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t
 #undef LP_BF3_LAUNCH
     return LP_OK;
   }
-  if (mp.tg) {
-    // two gathers per sample: two waves/SIMD and the run-time-loop grid-list variant (the triplane / voxel
-    // specialisations at three waves/SIMD spill 160-230 registers with C = 32)
-    if ((rc = set_lds(renderer_fwd_mfma_np<C, GM_GENERIC, 2, true, true>, lds))) return rc;
-    hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM_GENERIC, 2, true, true>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
-  } else if (is_flex(mp)) {
-    if ((rc = set_lds(renderer_fwd_mfma_np<C, GM, 3, true>, lds))) return rc;
-    hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM, 3, true>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
+  if (mp.tg || is_flex(mp)) {
+    // small batch with state records: segment march + combine pass, as for the default shape above
+    static const bool seg_fwd = getenv("LP_SEG_FWD") == nullptr || atoi(getenv("LP_SEG_FWD")) != 0;
+    MfmaParams ms = mp;
+    unsigned nb = n_blocks(a);
+    const bool segf = a.seg_prefix && seg_fwd && !a.seg_forward_off;
+    if (segf) {
+      const int n_rec = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
+      static const int forced = getenv("LP_SEG_BLOCKS") ? atoi(getenv("LP_SEG_BLOCKS")) : 0;
+      int m = 1;
+      while (m < n_rec && (uint64_t)nb * ((n_rec + m - 1) / m) > 512u) ++m;
+      if (forced > 0) m = forced < n_rec ? forced : n_rec;
+      ms.seg_blocks = m;
+      ms.seg_fwd = 1;
+      nb *= (unsigned)((n_rec + m - 1) / m);
+    }
+    if (mp.tg) {
+      // two gathers per sample: two waves/SIMD and the run-time-loop grid-list variant (the triplane / voxel
+      // specialisations at three waves/SIMD spill 160-230 registers with C = 32)
+      if ((rc = set_lds(renderer_fwd_mfma_np<C, GM_GENERIC, 2, true, true>, lds))) return rc;
+      hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM_GENERIC, 2, true, true>), dim3(nb), dim3(256), lds, stream, a, ms);
+    } else {
+      if ((rc = set_lds(renderer_fwd_mfma_np<C, GM, 3, true>, lds))) return rc;
+      hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM, 3, true>), dim3(nb), dim3(256), lds, stream, a, ms);
+    }
+    if (segf)
+      hipLaunchKernelGGL(renderer_fwd_combine, dim3((unsigned)((a.rays.n_rays + 255) / 256)), dim3(256), 0, stream, a, ms.seg_blocks);
   } else if (variant == 3 && a.color_chn <= 3 && !no_nc3) {
     if ((rc = set_lds(renderer_fwd_mfma_np<C, GM, 3, false, false, 3>, lds))) return rc;
     hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM, 3, false, false, 3>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);

@@ -131,7 +131,16 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
   float* const enct = wv + B::ENC;
   float* const ts = wv + B::TS;
 
-  const int64_t ray_id = ((int64_t)blockIdx.x * WAVES + wave) * RAYS_PER_WAVE + r;
+  // segment-parallel sweep of a small batch (LpRendererArgs.seg_prefix; flex / two-grid shapes: a run-time switch of the
+  // FLEX instantiations -- the default shape has its own kernel below): workgroup = (128 rays, mp.seg_blocks blocks of
+  // LP_SEG_LEN samples)
+  const bool seg_on = FLEX && a.seg_prefix != nullptr;
+  const int n_rec = seg_on ? segment_count(a.march) : 1;
+  const int seg_len = LP_SEG_LEN * mp.seg_blocks;
+  const int n_seg = seg_on ? (a.march.num_samples + seg_len - 1) / seg_len : 1;
+  const int blk = seg_on ? (int)blockIdx.x / n_seg : (int)blockIdx.x;
+  const int seg = seg_on ? (int)blockIdx.x - blk * n_seg : 0;
+  const int64_t ray_id = ((int64_t)blk * WAVES + wave) * RAYS_PER_WAVE + r;
   const bool valid = ray_id < a.rays.n_rays;
   const int64_t rid = valid ? ray_id : 0;
   const Ray ray = load_ray(a.rays, rid);
@@ -174,6 +183,8 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     }
     __syncthreads();  // ts[] is reused by the sample loop
   }
+  const int s_lo = seg_on ? seg * seg_len : 0;
+  if (seg_on) s_begin = (s_lo + seg_len - 1 < s_tot - 1) ? s_lo + seg_len - 1 : s_tot - 1;
 
   float denc[16];
 #pragma unroll
@@ -213,9 +224,24 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
 #endif
   float nlt = a.neg_log_t[rid];
   float suffix = 0.0f, p_next = 0.0f;
+  if (seg_on) {  // start of a segment: -log T and the sums behind its last sample, from the forward's state records
+    const float4* pj = reinterpret_cast<const float4*>(a.seg_prefix + (rid * n_rec + s_begin / LP_SEG_LEN) * 8);
+    const float4* pt = reinterpret_cast<const float4*>(a.seg_prefix + (rid * n_rec + n_rec - 1) * 8);
+    const float4 j0 = pj[0], j1 = pj[1], t0 = pt[0];
+    nlt = j1.y;
+    nlt_lo = j1.z;
+    if (seg < n_seg - 1) {
+      float rest = g_len * (t0.x - j0.x);
+      rest = fmaf(gfeat[0], t0.y - j0.y, rest);
+      rest = fmaf(gfeat[1], t0.z - j0.z, rest);
+      rest = fmaf(gfeat[2], t0.w - j0.w, rest);
+      rest = fmaf(gfeat[3], pt[1].x - j1.x, rest);
+      suffix = -rest;
+    }
+  }
   Sample<C> nx;
   fetch_sample<C, GM, false, PLAIN>(a, lds, ray, s_begin, h, nx);
-  for (int s = s_begin; s >= 0; --s) {
+  for (int s = s_begin; s >= s_lo; --s) {
     const bool on = PLAIN || s <= s_last_w;  // wave-uniform; false only for samples a sibling wave still marches
     const float depth = nx.depth, occ = nx.occ, x = nx.x, y = nx.y, z = nx.z;
     float x0[C / 2];
@@ -525,7 +551,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     const bool live = valid && on && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
     // gather with one plane's loads in flight at a time (registers), consumed before the atomics
     // below are issued: no wait ever has to drain the atomics
-    if (s > 0) fetch_sample<C, GM, true, PLAIN>(a, lds, ray, s - 1, h, nx);
+    if (s > s_lo) fetch_sample<C, GM, true, PLAIN>(a, lds, ray, s - 1, h, nx);
     LP_SCHED_FENCE();
     LP_MARK("scatter");
     if (gg && !(mp.dbg & 2)) {
@@ -542,12 +568,21 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     for (int i = 0; i < 10; ++i) atomicAdd(&g_phase[i], ph[i]);
   }
 #endif
-  if (valid && a.grad_encoding) {
+  if (valid && a.grad_encoding && !seg_on) {
     float4* dst = reinterpret_cast<float4*>(a.grad_encoding + ray_id * hin + 4 * h);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (!FLEX || 8 * j + 4 * h < hin)
         dst[2 * j] = make_float4(denc[4 * j], denc[4 * j + 1], denc[4 * j + 2], denc[4 * j + 3]);
+    }
+  } else if (valid && a.grad_encoding) {  // the segments of a ray add up
+    float* dst = a.grad_encoding + ray_id * hin + 4 * h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (8 * j + 4 * h < hin) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomic_add_f32(dst + 8 * j + i, denc[4 * j + i]);
+      }
     }
   }
   if (want_params) {
@@ -1131,13 +1166,33 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
 // host side
 // ---------------------------------------------------------------------------------------
 
+// LP_SEG_LEN-sample blocks per segment of a segment-parallel launch: as many segments as keep it within one round of
+// resident workgroups (every workgroup stages the weights and flushes its dW once)
+static int seg_blocks_for(const LpRendererArgs& a, unsigned ray_blocks) {
+  static const int forced = getenv("LP_SEG_BLOCKS") ? atoi(getenv("LP_SEG_BLOCKS")) : 0;
+  const int n_rec = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
+  int m = 1;
+  while (m < n_rec && (uint64_t)ray_blocks * ((n_rec + m - 1) / m) > 512u) ++m;
+  if (forced > 0) m = forced < n_rec ? forced : n_rec;
+  return m;
+}
+
 template <int C, int GM, bool PLAIN, bool FLEX, bool TG = false, int NC = 4>
-static int launch_bwd2p(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
+static int launch_bwd2p(const LpRendererArgs& a_, const MfmaParams& mp_, hipStream_t stream) {
+  LpRendererArgs a = a_;
+  MfmaParams mp = mp_;
   const size_t lds = (mp.dbg & 16) ? 100 * 1024 : LdsB::END * sizeof(float);  // dbg 16: one workgroup per CU
   const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_mfma2<C, GM, PLAIN, FLEX, TG, NC>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-  const unsigned nb = (unsigned)((a.rays.n_rays + WAVES * RAYS_PER_WAVE - 1) / (WAVES * RAYS_PER_WAVE));
+  unsigned nb = (unsigned)((a.rays.n_rays + WAVES * RAYS_PER_WAVE - 1) / (WAVES * RAYS_PER_WAVE));
+  if (FLEX && a.seg_prefix) {  // small batch of a flex / two-grid shape: one workgroup per (128 rays, segment)
+    const int n_rec = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
+    mp.seg_blocks = seg_blocks_for(a, nb);
+    nb *= (unsigned)((n_rec + mp.seg_blocks - 1) / mp.seg_blocks);
+  } else {
+    a.seg_prefix = nullptr;  // (the default shape reaches this kernel only through LP_MFMA_F32*, without segments)
+  }
   hipLaunchKernelGGL((renderer_bwd_mfma2<C, GM, PLAIN, FLEX, TG, NC>), dim3(nb), dim3(256), lds, stream, a, mp);
   return LP_OK;
 }

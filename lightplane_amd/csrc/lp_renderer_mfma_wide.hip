@@ -724,6 +724,7 @@ static MfmaParams make_params_w(const LpRendererArgs& a, int H) {
   static const int dbg = getenv("LP_MFMA_DEBUG") ? atoi(getenv("LP_MFMA_DEBUG")) : 0;
   p.dbg = dbg;
   p.seg_blocks = 1;
+  p.seg_fwd = 0;
   return p;
 }
 

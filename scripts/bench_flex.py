@@ -7,7 +7,7 @@ import lightplane_amd as lp
 from lightplane_amd import _lib
 from tests.synth import grid_sizes_for, pinhole_rays, random_decoder, random_grids
 dev = torch.device("cuda:0"); lp.config.check_inputs = False; lp.config.warn_generic_kernel = False
-C = 16; S = 128; n = 256
+C = 16; S = 128; n = int(os.environ.get("NPIX", "256"))
 def t(f, k=3):
     f(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

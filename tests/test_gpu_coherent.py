@@ -167,8 +167,10 @@ def test_renderer_coherent_early_termination_exact_when_off():
     ("triplane24_c16", 70, dict(scaffold=True, noise=True)),       # non-PLAIN instantiation
     ("triplane24_c16", 80, dict(image="128x128_az20_el30")),       # 128 ray blocks x 5 states > 512: segments of 32, 32, 16
     ("voxel20_c32", 72, dict()),                                   # C = 32 instantiations
+    ("voxel20_c32", 50, dict(hidden=16)),                          # flex family (fp32-MFMA kernels, run-time segment switch)
+    ("two_grid_triplane_c16", 66, dict()),                         # two-grid decoder: second scatter per sample
 ], ids=["triplane_s88", "triplane_s64_nomask", "triplane_s33", "mixed_s72", "voxel_b2_rgba_s96", "triplane_scaffold_noise_s70",
-        "triplane_16k_rays_s80", "voxel_c32_s72"])
+        "triplane_16k_rays_s80", "voxel_c32_s72", "voxel_flex_h16_s50", "two_grid_s66"])
 def test_segmented_backward(grid, num_samples, kw):
     """4 096-ray image, S > 16: the backward runs one workgroup per (128 rays, block of 16 samples) and has to agree with
     the oracle AND with the one-workgroup-per-128-rays sweep of the same kernel (same recompute, so no ReLU-flip slack:
@@ -183,7 +185,7 @@ def test_segmented_backward(grid, num_samples, kw):
     if noise:
         d["cfg"] = dict(d["cfg"], inject_noise_sigma=0.3, inject_noise_seed=5)
     n_seg = (num_samples + 15) // 16
-    assert lp.backward_segments(d["rays"], d["grids"], d["decoder"], **d["cfg"]) == n_seg
+    assert lp.backward_segments(d["rays"], d["grids"], d["decoder"], color_grid=d["color_grids"], **d["cfg"]) == n_seg
     assert lp.config.segment_backward
     try:
         lp.config.segment_backward = False
@@ -207,6 +209,7 @@ def test_segmented_backward(grid, num_samples, kw):
         dec = d["decoder"]
         hdec = lp.DecoderParams(dec.mlp_params.to(dev), dec.n_hidden_trunk, dec.n_hidden_opacity, dec.n_hidden_color, dec.color_chn)
         out = lp.lightplane_renderer(rays, [g.to(dev) for g in d["grids"]], hdec,
+                                     color_grid=None if d["color_grids"] is None else [g.to(dev) for g in d["color_grids"]],
                                      scaffold=None if d["scaffold"] is None else d["scaffold"].to(dev), **d["cfg"])
     for a, b in zip(out, got[0]):
         assert torch.equal(a, b.detach())
@@ -263,8 +266,10 @@ def test_segmented_backward_is_not_used_where_it_cannot_be():
     assert q(num_samples_inf=2) == 1                                                    # beyond-far samples
     d32 = coherent_renderer_inputs("voxel20_c32", "64x64_axis", num_samples=64)        # C = 32: the same kernels
     assert lp.backward_segments(d32["rays"], d32["grids"], d32["decoder"], **d32["cfg"]) == 4
-    dflex = coherent_renderer_inputs("triplane24_c16", "64x64_axis", num_samples=64, hidden=16)  # flex family: fp32-MFMA backward
-    assert lp.backward_segments(dflex["rays"], dflex["grids"], dflex["decoder"], **dflex["cfg"]) == 1
+    dflex = coherent_renderer_inputs("triplane24_c16", "64x64_axis", num_samples=64, hidden=16)  # flex family: the same
+    assert lp.backward_segments(dflex["rays"], dflex["grids"], dflex["decoder"], **dflex["cfg"]) == 4
+    dwide = coherent_renderer_inputs("triplane24_c16", "64x64_axis", num_samples=64, hidden=64)  # width-64 family: not yet
+    assert lp.backward_segments(dwide["rays"], dwide["grids"], dwide["decoder"], **dwide["cfg"]) == 1
     big = pinhole_rays(256, 256, enc_dim=32, gen=torch.Generator().manual_seed(0))      # 65 536 rays fill the chip
     assert lp.backward_segments(big, d["grids"], d["decoder"], **d["cfg"]) == 1
 
