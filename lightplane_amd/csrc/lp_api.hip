@@ -244,8 +244,9 @@ int lp_renderer_kernel_family(const LpRendererArgs* args) {
 int lp_renderer_backward_segments(const LpRendererArgs* args) {
   if (!args) return set_error(LP_ENULL, "args is NULL");
   const char* why = "";
-  if (args->kernel == LP_KERNEL_GENERIC || select_renderer(*args, &why) != 1) return 1;
-  return renderer_mfma_segments(*args);
+  if (args->kernel == LP_KERNEL_GENERIC) return 1;
+  const int fam = select_renderer(*args, &why);
+  return fam == 1 ? renderer_mfma_segments(*args) : fam == 2 ? renderer_mfma_wide_segments(*args) : 1;
 }
 
 int lp_splatter_kernel_family(const LpSplatterArgs* args) {

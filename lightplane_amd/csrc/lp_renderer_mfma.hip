@@ -355,6 +355,11 @@ __global__ void __launch_bounds__(256) renderer_fwd_combine(const LpRendererArgs
     *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + n_ckpt - 1) * 2) = make_float2((float)(S - 1), nlt_lo);
 }
 
+int renderer_forward_combine_launch(const LpRendererArgs& a, int seg_blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(renderer_fwd_combine, dim3((unsigned)((a.rays.n_rays + 255) / 256)), dim3(256), 0, stream, a, seg_blocks);
+  return LP_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------

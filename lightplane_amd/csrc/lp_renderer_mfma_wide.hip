@@ -187,7 +187,14 @@ __global__ void __launch_bounds__(256, 2) renderer_fwd_mfma_w(const LpRendererAr
   const float* lds_inf = lds + (M::INF - Lds::INF);  // sample_geometry() reads its table at Lds::INF
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, r = lane & 31;
-  const int64_t ray_id = ((int64_t)blockIdx.x * WAVES + wave) * RAYS_PER_WAVE + r;
+  // small batch (mp.seg_fwd, see renderer_fwd_bf3 SEGF in lp_renderer_mfma.hip): a workgroup marches one segment from
+  // transmittance 1 and leaves segment-local state records for renderer_fwd_combine
+  const bool segf = mp.seg_fwd != 0;
+  const int seg_len = LP_SEG_LEN * mp.seg_blocks;
+  const int n_seg = segf ? (a.march.num_samples + seg_len - 1) / seg_len : 1;
+  const int blk = segf ? (int)blockIdx.x / n_seg : (int)blockIdx.x;
+  const int seg = segf ? (int)blockIdx.x - blk * n_seg : 0;
+  const int64_t ray_id = ((int64_t)blk * WAVES + wave) * RAYS_PER_WAVE + r;
   const bool valid = ray_id < a.rays.n_rays;
   const int64_t rid = valid ? ray_id : 0;
   const Ray ray = load_ray(a.rays, rid);
@@ -199,7 +206,14 @@ __global__ void __launch_bounds__(256, 2) renderer_fwd_mfma_w(const LpRendererAr
   float nlt = 0.0f, nlt_lo = 0.0f, t_prev = 1.0f, len = 0.0f, depth_prev = 0.0f;
   int s_last = s_tot - 1;  // last sample marched
   float facc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  for (int s = 0; s < s_tot; ++s) {
+  const int s_lo = segf ? seg * seg_len : 0;
+  const int s_hi = segf ? ((s_lo + seg_len < s_tot) ? s_lo + seg_len : s_tot) : s_tot;
+  if (segf && s_lo > 0) {  // interval length of the segment's first sample
+    Sample<C> pv;
+    sample_geometry<C>(a, lds_inf, ray, s_lo - 1, pv);
+    depth_prev = pv.depth;
+  }
+  for (int s = s_lo; s < s_hi; ++s) {
     Sample<C> nx;
     fetch_sample<C, GM, true>(a, lds_inf, ray, s, h, nx);
     const float depth = nx.depth, occ = nx.occ;
@@ -225,7 +239,7 @@ __global__ void __launch_bounds__(256, 2) renderer_fwd_mfma_w(const LpRendererAr
     if (a.noise_sigma > 0.0f) raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
     const float opacity = a.gain * softplus_f(raw) * occ;
     nlt_add(nlt, nlt_lo, opacity * delta);
-    if (a.neg_log_t_ckpt && valid && h == 0) {
+    if (!segf && a.neg_log_t_ckpt && valid && h == 0) {
       const int ck = ckpt_index(s, a.march);
       if (ck >= 0) *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + ck) * 2) = make_float2(nlt, nlt_lo);
     }
@@ -235,12 +249,18 @@ __global__ void __launch_bounds__(256, 2) renderer_fwd_mfma_w(const LpRendererAr
     len = fmaf(w, depth, len);
 #pragma unroll
     for (int c = 0; c < 4; ++c) facc[c] = fmaf(w, sigmoid_f(hd.raw_c[c]) * occ, facc[c]);
+    // state records of the segment-parallel backward (absolute; segf: relative to the segment's start)
+    if (a.seg_prefix && valid && h == 0 && (((s + 1) % LP_SEG_LEN) == 0 || s == a.march.num_samples - 1)) {
+      float4* dst = reinterpret_cast<float4*>(a.seg_prefix + (ray_id * segment_count(a.march) + s / LP_SEG_LEN) * 8);
+      dst[0] = make_float4(len, facc[0], facc[1], facc[2]);
+      dst[1] = make_float4(facc[3], nlt, nlt_lo, 0.0f);
+    }
     if (a.stop_neg_log_t > 0.0f && __ballot(valid && nlt < a.stop_neg_log_t) == 0) {  // early termination
       s_last = s;
       break;
     }
   }
-  if (valid && h == 0) {
+  if (!segf && valid && h == 0) {
     write_ray_outputs(a, ray_id, len, nlt, facc);
     if (a.neg_log_t_ckpt)
       *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + n_ckpt - 1) * 2) = make_float2((float)s_last, nlt_lo);
@@ -320,7 +340,14 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
   float* const yt = wv + M::YT;
   float* const ts = wv + M::TS;
 
-  const int64_t ray_id = ((int64_t)blockIdx.x * WAVES + wave) * RAYS_PER_WAVE + r;
+  // segment-parallel sweep of a small batch (LpRendererArgs.seg_prefix, see renderer_bwd_bf3): run-time switch
+  const bool seg_on = a.seg_prefix != nullptr;
+  const int n_rec = seg_on ? segment_count(a.march) : 1;
+  const int seg_len = LP_SEG_LEN * mp.seg_blocks;
+  const int n_seg = seg_on ? (a.march.num_samples + seg_len - 1) / seg_len : 1;
+  const int blk = seg_on ? (int)blockIdx.x / n_seg : (int)blockIdx.x;
+  const int seg = seg_on ? (int)blockIdx.x - blk * n_seg : 0;
+  const int64_t ray_id = ((int64_t)blk * WAVES + wave) * RAYS_PER_WAVE + r;
   const bool valid = ray_id < a.rays.n_rays;
   const int64_t rid = valid ? ray_id : 0;
   const Ray ray = load_ray(a.rays, rid);
@@ -353,6 +380,8 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
     }
     __syncthreads();  // ts[] is reused by the sample loop
   }
+  const int s_lo = seg_on ? seg * seg_len : 0;
+  if (seg_on) s_begin = (s_lo + seg_len - 1 < s_tot - 1) ? s_lo + seg_len - 1 : s_tot - 1;
   float gfeat[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -388,9 +417,24 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
 
   float nlt = a.neg_log_t[rid];
   float suffix = 0.0f, p_next = 0.0f;
+  if (seg_on) {  // start of a segment: -log T and the sums behind its last sample, from the forward's state records
+    const float4* pj = reinterpret_cast<const float4*>(a.seg_prefix + (rid * n_rec + s_begin / LP_SEG_LEN) * 8);
+    const float4* pt = reinterpret_cast<const float4*>(a.seg_prefix + (rid * n_rec + n_rec - 1) * 8);
+    const float4 j0 = pj[0], j1 = pj[1], t0 = pt[0];
+    nlt = j1.y;
+    nlt_lo = j1.z;
+    if (seg < n_seg - 1) {
+      float rest = g_len * (t0.x - j0.x);
+      rest = fmaf(gfeat[0], t0.y - j0.y, rest);
+      rest = fmaf(gfeat[1], t0.z - j0.z, rest);
+      rest = fmaf(gfeat[2], t0.w - j0.w, rest);
+      rest = fmaf(gfeat[3], pt[1].x - j1.x, rest);
+      suffix = -rest;
+    }
+  }
   Sample<C> nx;
   fetch_sample<C, GM, true, PLAIN>(a, lds_inf, ray, s_begin, h, nx);
-  for (int s = s_begin; s >= 0; --s) {
+  for (int s = s_begin; s >= s_lo; --s) {
     const bool on = PLAIN || s <= s_last_w;  // wave-uniform; false only for samples a sibling wave still marches
     const float depth = nx.depth, occ = nx.occ, x = nx.x, y = nx.y, z = nx.z;
     float x0[C / 2];
@@ -611,7 +655,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
     LP_SCHED_FENCE();
     // ---------------- next (nearer) sample + grid gradient ----------------
     const bool live = valid && on && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
-    if (s > 0) fetch_sample<C, GM, true, PLAIN>(a, lds_inf, ray, s - 1, h, nx);
+    if (s > s_lo) fetch_sample<C, GM, true, PLAIN>(a, lds_inf, ray, s - 1, h, nx);
     LP_SCHED_FENCE();
     if (gg && !(mp.dbg & 2)) {
       const int ng = (GM == GM_TRIPLANE) ? 3 : (GM == GM_VOXEL) ? 1 : a.grid.n_grids;
@@ -621,7 +665,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
   }
 
   // ---------------- epilogue ----------------
-  if (valid && a.grad_encoding) {
+  if (valid && a.grad_encoding && !seg_on) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       float4* dst = reinterpret_cast<float4*>(a.grad_encoding + ray_id * H + 32 * b + 4 * h);
@@ -630,6 +674,14 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
         dst[2 * j] = make_float4(denc[16 * b + 4 * j], denc[16 * b + 4 * j + 1], denc[16 * b + 4 * j + 2],
                                  denc[16 * b + 4 * j + 3]);
     }
+  } else if (valid && a.grad_encoding) {  // the segments of a ray add up
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          atomic_add_f32(a.grad_encoding + ray_id * H + 32 * b + 4 * h + 8 * j + i, denc[16 * b + 4 * j + i]);
   }
   if (want_params) {
     float* G = a.grad_mlp_params;
@@ -735,41 +787,77 @@ static int grid_mode_w(const LpRendererArgs& a) {
   return GM_GENERIC;
 }
 
+// Segment-parallel march of a small batch (LpRendererArgs.seg_prefix; same rules as renderer_mfma_segments)
+int renderer_mfma_wide_segments(const LpRendererArgs& a) {
+  static const int forced = getenv("LP_SEGMENTS") ? atoi(getenv("LP_SEGMENTS")) : -1;
+  if (forced == 0 || a.march.num_samples_inf != 0 || a.stop_neg_log_t > 0.0f) return 1;
+  const int n_seg = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
+  if (n_seg < 2) return 1;
+  if (forced < 0 && a.rays.n_rays > 32768) return 1;
+  return n_seg;
+}
+
+// LP_SEG_LEN-sample blocks per segment: as many segments as keep the launch within `slots` resident workgroups (one round)
+static int wide_seg_blocks(const LpRendererArgs& a, unsigned slots) {
+  static const int forced = getenv("LP_SEG_BLOCKS") ? atoi(getenv("LP_SEG_BLOCKS")) : 0;
+  const unsigned nb = (unsigned)((a.rays.n_rays + WAVES * RAYS_PER_WAVE - 1) / (WAVES * RAYS_PER_WAVE));
+  const int n_rec = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
+  int m = 1;
+  while (m < n_rec && (uint64_t)nb * ((n_rec + m - 1) / m) > slots) ++m;
+  if (forced > 0) m = forced < n_rec ? forced : n_rec;
+  return m;
+}
+
+// mp.seg_blocks > 0 together with `segmented`: the launch is (ray blocks x segments)
 template <typename K>
-static int launch_w(K kernel, size_t lds, const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
+static int launch_w(K kernel, size_t lds, const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream, bool segmented = false) {
   const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-  const unsigned nb = (unsigned)((a.rays.n_rays + WAVES * RAYS_PER_WAVE - 1) / (WAVES * RAYS_PER_WAVE));
+  unsigned nb = (unsigned)((a.rays.n_rays + WAVES * RAYS_PER_WAVE - 1) / (WAVES * RAYS_PER_WAVE));
+  if (segmented) {
+    const int n_rec = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
+    nb *= (unsigned)((n_rec + mp.seg_blocks - 1) / mp.seg_blocks);
+  }
   hipLaunchKernelGGL(kernel, dim3(nb), dim3(256), lds, stream, a, mp);
   return LP_OK;
 }
 
-#define LP_DISPATCH_W(KERNEL, LDS)                                                         \
+#define LP_DISPATCH_W(KERNEL, LDS, SEG)                                                       \
   do {                                                                                     \
     const int gm = grid_mode_w(a);                                                         \
     if (a.grid.channels == 16) {                                                           \
-      if (gm == GM_TRIPLANE) rc = launch_w(KERNEL<16, GM_TRIPLANE, 2>, LDS, a, mp, stream); \
-      else if (gm == GM_VOXEL) rc = launch_w(KERNEL<16, GM_VOXEL, 2>, LDS, a, mp, stream);  \
-      else rc = launch_w(KERNEL<16, GM_GENERIC, 2>, LDS, a, mp, stream);                    \
+      if (gm == GM_TRIPLANE) rc = launch_w(KERNEL<16, GM_TRIPLANE, 2>, LDS, a, mp, stream, SEG); \
+      else if (gm == GM_VOXEL) rc = launch_w(KERNEL<16, GM_VOXEL, 2>, LDS, a, mp, stream, SEG);  \
+      else rc = launch_w(KERNEL<16, GM_GENERIC, 2>, LDS, a, mp, stream, SEG);                    \
     } else {                                                                               \
-      if (gm == GM_TRIPLANE) rc = launch_w(KERNEL<32, GM_TRIPLANE, 2>, LDS, a, mp, stream); \
-      else if (gm == GM_VOXEL) rc = launch_w(KERNEL<32, GM_VOXEL, 2>, LDS, a, mp, stream);  \
-      else rc = launch_w(KERNEL<32, GM_GENERIC, 2>, LDS, a, mp, stream);                    \
+      if (gm == GM_TRIPLANE) rc = launch_w(KERNEL<32, GM_TRIPLANE, 2>, LDS, a, mp, stream, SEG); \
+      else if (gm == GM_VOXEL) rc = launch_w(KERNEL<32, GM_VOXEL, 2>, LDS, a, mp, stream, SEG);  \
+      else rc = launch_w(KERNEL<32, GM_GENERIC, 2>, LDS, a, mp, stream, SEG);                    \
     }                                                                                      \
   } while (0)
 
 int renderer_forward_mfma_wide(const LpRendererArgs& a, hipStream_t stream) {
   if (a.rays.n_rays == 0) return LP_OK;
-  const MfmaParams mp = make_params_w(a, 64);
+  MfmaParams mp = make_params_w(a, 64);
   int rc;
-  LP_DISPATCH_W(renderer_fwd_mfma_w, LdsW<2>::FWD_END * sizeof(float));
+  // small batch with state records: segment march (two workgroups per CU: 512 slots) + combine pass
+  static const bool seg_fwd = getenv("LP_SEG_FWD") == nullptr || atoi(getenv("LP_SEG_FWD")) != 0;
+  const bool segf = a.seg_prefix && seg_fwd && !a.seg_forward_off;
+  if (segf) {
+    mp.seg_blocks = wide_seg_blocks(a, 512);
+    mp.seg_fwd = 1;
+  }
+  LP_DISPATCH_W(renderer_fwd_mfma_w, LdsW<2>::FWD_END * sizeof(float), segf);
   if (rc) return rc;
+  if (segf && (rc = renderer_forward_combine_launch(a, mp.seg_blocks, stream))) return rc;
   return check_launch("renderer_fwd_mfma_w");
 }
 
 int renderer_backward_mfma_wide(const LpRendererArgs& a, hipStream_t stream) {
   if (a.rays.n_rays == 0) return LP_OK;
-  const MfmaParams mp = make_params_w(a, 64);
+  MfmaParams mp = make_params_w(a, 64);
+  const bool segb = a.seg_prefix != nullptr;  // one workgroup per CU: 256 slots
+  if (segb) mp.seg_blocks = wide_seg_blocks(a, 256);
   int rc;
   const bool plain = !(a.noise_sigma > 0.0f) && !a.march.contract_coords && !a.scaffold && a.march.num_samples_inf == 0 &&
                      !(a.stop_neg_log_t > 0.0f);
@@ -777,10 +865,10 @@ int renderer_backward_mfma_wide(const LpRendererArgs& a, hipStream_t stream) {
   static const bool no_nc3 = getenv("LP_MFMA_NO_NC3") != nullptr;
   const bool rgb = a.color_chn <= 3 && !no_nc3;
 #define LP_BW(CV, GMV)                                                                                     \
-  (rgb ? (plain ? launch_w(renderer_bwd_mfma_w<CV, GMV, 2, true, 3>, lds_b, a, mp, stream)                 \
-                : launch_w(renderer_bwd_mfma_w<CV, GMV, 2, false, 3>, lds_b, a, mp, stream))               \
-       : (plain ? launch_w(renderer_bwd_mfma_w<CV, GMV, 2, true>, lds_b, a, mp, stream)                    \
-                : launch_w(renderer_bwd_mfma_w<CV, GMV, 2, false>, lds_b, a, mp, stream)))
+  (rgb ? (plain ? launch_w(renderer_bwd_mfma_w<CV, GMV, 2, true, 3>, lds_b, a, mp, stream, segb)                 \
+                : launch_w(renderer_bwd_mfma_w<CV, GMV, 2, false, 3>, lds_b, a, mp, stream, segb))               \
+       : (plain ? launch_w(renderer_bwd_mfma_w<CV, GMV, 2, true>, lds_b, a, mp, stream, segb)                    \
+                : launch_w(renderer_bwd_mfma_w<CV, GMV, 2, false>, lds_b, a, mp, stream, segb)))
   {
     const int gm = grid_mode_w(a);
     if (a.grid.channels == 16) rc = gm == GM_TRIPLANE ? LP_BW(16, GM_TRIPLANE) : gm == GM_VOXEL ? LP_BW(16, GM_VOXEL) : LP_BW(16, GM_GENERIC);

@@ -169,8 +169,10 @@ def test_renderer_coherent_early_termination_exact_when_off():
     ("voxel20_c32", 72, dict()),                                   # C = 32 instantiations
     ("voxel20_c32", 50, dict(hidden=16)),                          # flex family (fp32-MFMA kernels, run-time segment switch)
     ("two_grid_triplane_c16", 66, dict()),                         # two-grid decoder: second scatter per sample
+    ("triplane_plus_voxel_c16", 50, dict(hidden=64)),              # width-64 family
+    ("voxel20_c32", 40, dict(hidden=64, scaffold=True)),           # width-64 family, C = 32, non-PLAIN
 ], ids=["triplane_s88", "triplane_s64_nomask", "triplane_s33", "mixed_s72", "voxel_b2_rgba_s96", "triplane_scaffold_noise_s70",
-        "triplane_16k_rays_s80", "voxel_c32_s72", "voxel_flex_h16_s50", "two_grid_s66"])
+        "triplane_16k_rays_s80", "voxel_c32_s72", "voxel_flex_h16_s50", "two_grid_s66", "mixed_h64_s50", "voxel_c32_h64_scaffold_s40"])
 def test_segmented_backward(grid, num_samples, kw):
     """4 096-ray image, S > 16: the backward runs one workgroup per (128 rays, block of 16 samples) and has to agree with
     the oracle AND with the one-workgroup-per-128-rays sweep of the same kernel (same recompute, so no ReLU-flip slack:
@@ -268,8 +270,9 @@ def test_segmented_backward_is_not_used_where_it_cannot_be():
     assert lp.backward_segments(d32["rays"], d32["grids"], d32["decoder"], **d32["cfg"]) == 4
     dflex = coherent_renderer_inputs("triplane24_c16", "64x64_axis", num_samples=64, hidden=16)  # flex family: the same
     assert lp.backward_segments(dflex["rays"], dflex["grids"], dflex["decoder"], **dflex["cfg"]) == 4
-    dwide = coherent_renderer_inputs("triplane24_c16", "64x64_axis", num_samples=64, hidden=64)  # width-64 family: not yet
-    assert lp.backward_segments(dwide["rays"], dwide["grids"], dwide["decoder"], **dwide["cfg"]) == 1
+    dwide = coherent_renderer_inputs("triplane24_c16", "64x64_axis", num_samples=64, hidden=64)  # width-64 family: the same
+    assert lp.backward_segments(dwide["rays"], dwide["grids"], dwide["decoder"], **dwide["cfg"]) == 4
+    assert lp.backward_segments(dwide["rays"], dwide["grids"], dwide["decoder"], **dict(dwide["cfg"], num_samples_inf=1)) == 1
     big = pinhole_rays(256, 256, enc_dim=32, gen=torch.Generator().manual_seed(0))      # 65 536 rays fill the chip
     assert lp.backward_segments(big, d["grids"], d["decoder"], **d["cfg"]) == 1
 
