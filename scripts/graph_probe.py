@@ -8,7 +8,7 @@ from tests.synth import grid_sizes_for, pinhole_rays, random_decoder, random_gri
 dev = torch.device("cuda:0")
 lp.config.check_inputs = False
 gen = torch.Generator().manual_seed(0)
-C, S = 16, 64
+C, S = 16, int(os.environ.get("S", "64"))
 rays = pinhole_rays(64, 64, enc_dim=32, gen=gen).to(dev)
 sizes = grid_sizes_for((1, 64, 64, 64, C), True)
 flat = lp.flatten_grid([g.to(dev) for g in random_grids(gen, sizes)])[0]
