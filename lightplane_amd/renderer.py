@@ -215,10 +215,8 @@ class LightplaneFunction(torch.autograd.Function):
         ctx.save_for_backward(nlt, ckpt, seg_for_backward, mlp_params, encoding, directions, origins, grid_idx, near, far, scaffold,
                               bg_color, *grids, *color_grids)
         ctx.cfg = cfg
-        # the backward re-uses the filled argument block (its pointers stay valid: every tensor behind them is saved above)
+        # the backward re-uses the filled argument block (it re-reads the pointers from the saved tensors)
         a.ray_length = a.feature = a.alpha = None
-        if seg_for_backward is None:
-            a.seg_prefix = None
         ctx.args = a
         if not cfg.alpha_mode:
             ctx.mark_non_differentiable(alpha)
@@ -236,7 +234,24 @@ class LightplaneFunction(torch.autograd.Function):
         need_params, need_enc = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         need_g = ctx.needs_input_grad[10: 10 + cfg.n_grid_tensors]
         need_c = ctx.needs_input_grad[10 + cfg.n_grid_tensors:]
-        a = ctx.args  # filled by the forward: rays, grids, decoder, march, neg_log_t, checkpoints, segment states, bg_color
+        # The forward's argument block is re-used: shapes, decoder layout and march are already in it.  Only the pointers
+        # are taken again from the saved tensors (they are the forward's tensors unless a saved-tensor hook -- CPU
+        # offloading, checkpointing -- unpacked them into new storage).
+        a = ctx.args
+        r = a.rays
+        r.directions, r.origins, r.grid_idx = _lib.ptr(directions), _lib.ptr(origins), _lib.ptr(grid_idx)
+        r.near_t, r.far_t, r.encoding = _lib.ptr(near), _lib.ptr(far), _lib.ptr(encoding)
+        a.mlp_params, a.scaffold, a.bg_color = _lib.ptr(mlp_params), _lib.ptr(scaffold), _lib.ptr(bg_color)
+        a.neg_log_t, a.neg_log_t_ckpt, a.seg_prefix = _lib.ptr(nlt), _lib.ptr(ckpt), _lib.ptr(seg)
+        if cfg.grid_is_list:
+            for i, g in enumerate(grids):
+                a.grid.grids[i].data = _lib.ptr(g)
+            for i, g in enumerate(color_grids):
+                a.color_grid.grids[i].data = _lib.ptr(g)
+        else:
+            a.grid.data = _lib.ptr(grids[0])
+            if color_grids:
+                a.color_grid.data = _lib.ptr(color_grids[0])
         g_len = None if g_len is None else g_len.contiguous()
         g_nlt = None if g_nlt is None else g_nlt.contiguous()
         g_feat = None if g_feat is None else g_feat.contiguous()

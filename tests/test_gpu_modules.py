@@ -233,3 +233,18 @@ def test_two_rank_ray_shards_equal_single_process():
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     out = r.stdout.decode()
     assert r.returncode == 0 and "DIST_OK" in out, out[-4000:]
+
+
+def test_backward_with_offloaded_saved_tensors():
+    """Saved-tensor hooks (CPU offloading, checkpointing) hand the backward NEW tensors: the argument block the backward
+    re-uses from the forward must take its pointers from them, not from the forward's addresses."""
+    from tests.synth import RENDERER_CASES
+    from tests.test_gpu_parity import run_hip_renderer
+    dev = torch.device("cuda:0")
+    for name in ("triplane_plus_voxel", "voxel_c32_color1"):  # a grid-list of several tensors; S = 37: segment records saved too
+        d = next(c for c in RENDERER_CASES if c.name == name).build()
+        ref = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO)
+        with torch.autograd.graph.save_on_cpu():
+            got = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO)
+        for a, b in zip([ref[1], ref[2]] + list(ref[3]), [got[1], got[2]] + list(got[3])):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7 * float(a.abs().max()) + 1e-12), name
