@@ -209,6 +209,30 @@ def test_backward_segments_query_without_gpu():
     assert L.lp_renderer_forward(ctypes.byref(a), None) == 0
 
 
+def test_backward_segments_python_query_covers_every_mfma_family():
+    """``lp.backward_segments`` (shapes only, no GPU): the default shape with 16 / 32 channels, the flex and two-grid
+    shapes and the width-64 family march small batches in segments; the shape-generic kernels do not."""
+    from tests.synth import grid_sizes_for, pinhole_rays, random_decoder, random_grids
+    gen = torch.Generator().manual_seed(0)
+    rays = pinhole_rays(32, 32, enc_dim=32, gen=gen)
+
+    def q(C=16, layers=(2, 2, 2), hidden=32, sep=False, **kw):
+        sizes = grid_sizes_for((1, 8, 8, 8, C), True)
+        grids = random_grids(gen, sizes)
+        cgrids = random_grids(gen, sizes) if sep else None
+        dec = random_decoder(gen, *layers, input_chn=C, hidden_chn=hidden, color_chn=3, use_separate_color_grid=sep)
+        return lp.backward_segments(rays, grids, dec, color_grid=cgrids, **dict(dict(num_samples=64), **kw))
+
+    assert q() == 4 and q(C=32) == 4
+    assert q(layers=(1, 1, 1), hidden=16) == 4          # flex
+    assert q(layers=(0, 2, 2), sep=True) == 4           # two-grid decoder
+    assert q(C=32, hidden=64) == 4                      # width-64 family
+    assert q(layers=(3, 2, 2)) == 1                     # shape-generic kernels
+    assert q(num_samples=16) == 1 and q(num_samples_inf=2) == 1 and q(stop_transmittance=0.01) == 1
+    assert lp.kernel_family(rays, random_grids(gen, grid_sizes_for((1, 8, 8, 8, 16), True)),
+                            random_decoder(gen, 3, 2, 2, input_chn=16, hidden_chn=32, color_chn=3)) == 0
+
+
 def _gloo_worker(rank, world_size, port, ret):
     import torch.distributed as dist
     from lightplane_amd import parallel
