@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- Mrays/s fwd+bwd of the Lightplane Renderer / Splatter hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg4|1080p_s128|cfg3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg4|1080p_s128|cfg3|cfg5|small|refbench|refbench_splatter]
 
 Workloads (BASELINE.json `configs`); one step = forward + backward, inputs resident in HBM:
   cfg2        (default, the headline metric) Renderer, 256x256 rays per GPU (pinhole camera looking at the [-1,1]^3
@@ -12,6 +12,17 @@ Workloads (BASELINE.json `configs`); one step = forward + backwa
   1080p_s128  Renderer, one 1920x1080 camera per GPU on the cfg-2 scene (triplane 64^2 x 16 ch, 128 samples):
               the batch north_star asks the Mrays/s report for.
   cfg3        Splatter, 256x256 rays x 32 ch per GPU -> voxel grid 128^3 x 32 ch, 256 samples.
+  cfg5        Joint Splatter -> Renderer (BASELINE configs[4]), weak-scaled: per GPU 13 views of 512x512 rays x 32 ch are
+              splatted into a private 256^3 x 32 ch voxel grid, the un-normalised grids + weights are summed over the GPUs
+              (reduce-scatter + all-gather: 2.15 GB) and normalised, then every GPU renders its 135 x 1920 rows of a
+              1920x1080 camera (x N GPUs) from the replicated grid; end-to-end backward (grid gradient all-reduced, splat
+              backward local).  At 8 GPUs: 104 views and one full 1080p frame, as BASELINE names it.
+  refbench    the reference's OWN speed benchmark (tests/renderer_speed_benchmark.py:228-285): triplane [3,32,32,32,32]
+              (three batch entries, 32^2 planes x 32 ch), hidden 32, 2/2/2 layers, 256 samples, random rays, image sizes
+              16 .. 2048 (x sqrt 2 steps); its protocol: fresh inputs per iteration, 2 warm-up + 5 timed reruns, wall time of
+              the forward / of the backward bracketed by device synchronisation, peak memory over forward + backward.
+  refbench_splatter  tests/splatter_speed_benchmark.py:200-247: 128^2 x num_view random rays x 64 ch -> voxel 160^3 x 64 ch,
+              96 samples, mask_out_of_bounds_samples, same protocol.
 With N > 1 GPUs (one process per GPU, RCCL) every rank works on its own camera (weak scaling), the grid / parameters
 are replicated and the Renderer's grid + MLP gradients (the Splatter's un-normalised output + weight grid) are summed
 with an all-reduce INSIDE the timed step.
@@ -44,6 +55,11 @@ from lightplane_amd import _lib, parallel  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_PEAK = 157.3e12    # fp32 vector = fp32 MFMA peak
+CLOCK_GHZ = 2.4         # MI355X engine clock
+N_SIMD = 256 * 4        # 256 CUs x 4 SIMDs
+ATOMIC_SEGMENTS_PER_S = 21e9  # 64-byte global_atomic_add_f32 segments the chip retires (scripts/atomics_probe2.hip)
+ARITHMETIC = ("fp32-equivalent: decoder products as bf16x3 (three exact bf16 limbs per fp32 operand, six limb products, fp32 "
+              "accumulation) on v_mfma_f32_32x32x16_bf16; weight-gradient products v_mfma_f32_16x16x4_f32; everything else fp32 VALU")
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -182,9 +198,182 @@ class SplatterWorkload:
                 "note": "fwd = splat walk + normalise + torch zero-fill of the 268 MB grid; SURVEY 8(d)'s 532 936 B/ray"}
 
 
+
+# ----------------------------------------------------------------------------------------------------------------
+# the reference's own speed benchmarks (its published axes)
+# ----------------------------------------------------------------------------------------------------------------
+REFBENCH_SIZES = [16, 16 * math.sqrt(2), 32, 32 * math.sqrt(2), 64, 64 * math.sqrt(2), 128, 128 * math.sqrt(2), 256,
+                  256 * math.sqrt(2), 512, 512 * math.sqrt(2), 1024, 1024 * math.sqrt(2), 2048]
+REFBENCH_VIEWS = [1, 2, 4, 8, 16, 32, 64, 128, 256]
+
+
+def _ref_protocol(make_inputs, run, dev, n_reruns=5, n_warmup=2):
+    """tests/renderer_speed_benchmark.py:108-186 / tests/utils.py:33-77: per iteration fresh (re-seeded) inputs; forward timed
+    with wall clock between two device synchronisations; a second forward (untimed) + backward timed the same way; peak memory
+    of forward / of forward + backward over the inputs-only base; averages over the reruns after the warm-up."""
+    rec = []
+    for it in range(n_reruns + n_warmup):
+        inp = make_inputs(it)
+        torch.cuda.synchronize(dev)
+        torch.cuda.reset_peak_memory_stats(dev)
+        base = torch.cuda.memory_allocated(dev)
+        t0 = time.time()
+        out = run(inp)
+        torch.cuda.synchronize(dev)
+        t_fw = time.time() - t0
+        mem_fw = (torch.cuda.max_memory_allocated(dev) - base) / 1024.0 / 1000.0  # the reference's "MB"
+        del out, inp
+        inp = make_inputs(it)
+        torch.cuda.synchronize(dev)
+        torch.cuda.reset_peak_memory_stats(dev)
+        base = torch.cuda.memory_allocated(dev)
+        out = run(inp)
+        outs = out if isinstance(out, (tuple, list)) else (out,)
+        grad_var = sum((o * torch.randn_like(o)).mean() for o in outs)
+        torch.cuda.synchronize(dev)
+        t0 = time.time()
+        grad_var.backward()
+        torch.cuda.synchronize(dev)
+        t_bw = time.time() - t0
+        mem_bw = (torch.cuda.max_memory_allocated(dev) - base) / 1024.0 / 1000.0
+        del out, outs, grad_var, inp
+        if it >= n_warmup:
+            rec.append((t_fw, t_bw, mem_fw, mem_bw))
+    n = len(rec)
+    return {"t_fw_kernel_ms": round(sum(r[0] for r in rec) / n * 1e3, 4), "t_bw_kernel_ms": round(sum(r[1] for r in rec) / n * 1e3, 4),
+            "max_mem_fw_kernel_mb": round(sum(r[2] for r in rec) / n, 3), "max_mem_bw_kernel_mb": round(sum(r[3] for r in rec) / n, 3)}
+
+
+def refbench_renderer(dev, sizes=None, kernel=_lib.LP_KERNEL_AUTO):
+    """tests/renderer_speed_benchmark.py:228-285 on this implementation: grid [3,32,32,32,32] as a triplane (three batch entries),
+    2/2/2 x 32 decoder with N(0, 0.01) parameters (tests/utils.py:349), 256 samples, random rays (tests/utils.py:230-268)."""
+    from tests.synth import grid_sizes_for, random_decoder, random_grids, random_rays
+    rows = []
+    for im in (sizes or REFBENCH_SIZES):
+        n = int(im ** 2)
+
+        def make_inputs(it):
+            gen = torch.Generator().manual_seed(it)
+            gsz = grid_sizes_for((3, 32, 32, 32, 32), True)
+            grids = [g.to(dev).requires_grad_(True) for g in random_grids(gen, gsz)]
+            dec = random_decoder(gen, 2, 2, 2, 32, 32, 3, std=0.01)
+            params = dec.mlp_params.to(dev).requires_grad_(True)
+            rays = random_rays(gen, n, 3, 32).to(dev)
+            rays.encoding.requires_grad_(True)
+            return rays, grids, lp.DecoderParams(params, dec.n_hidden_trunk, dec.n_hidden_opacity, dec.n_hidden_color, 3)
+
+        def run(inp):
+            rays, grids, dec = inp
+            return lp.lightplane_renderer(rays, grids, dec, num_samples=256, gain=1.0, disparity_at_inf=0.01, inject_noise_seed=0,
+                                          kernel=kernel)
+
+        r = _ref_protocol(make_inputs, run, dev)
+        r.update(num_rays=n, image_size=int(n ** 0.5),
+                 Mrays_per_s_fwd_bwd=round(n / (r["t_fw_kernel_ms"] + r["t_bw_kernel_ms"]) / 1e3, 4))
+        rows.append(r)
+    return {"benchmark": "reference tests/renderer_speed_benchmark.py:228-285: triplane [3,32,32,32,32], hidden 32, 2/2/2 layers, S=256, "
+                         "random rays; wall time incl. host side and output / gradient allocation, 2 warm-up + 5 reruns",
+            "published_reference": "SURVEY 6: 256^2 rays fwd ~28 ms / bwd ~0.32 s (figure in the reference's README, A100-class GPU, Triton)",
+            "rows": rows}
+
+
+def refbench_splatter(dev, views=None):
+    """tests/splatter_speed_benchmark.py:200-247: 128^2 x num_view random rays x 64 ch -> voxel [1,160,160,160,64], S = 96,
+    mask_out_of_bounds_samples."""
+    from tests.synth import random_rays
+    rows = []
+    sizes = [[1, 160, 160, 160, 64]]
+    for nv in (views or REFBENCH_VIEWS):
+        n = 128 * 128 * nv
+
+        def make_inputs(it):
+            gen = torch.Generator().manual_seed(it)
+            rays = random_rays(gen, n, 1, None)
+            rays.encoding = torch.rand(n, 64, generator=gen)
+            rays = rays.to(dev)
+            rays.encoding.requires_grad_(True)
+            return rays
+
+        def run(rays):
+            return lp.lightplane_splatter(rays, sizes, num_samples=96, mask_out_of_bounds_samples=True)
+
+        r = _ref_protocol(make_inputs, run, dev)
+        r.update(num_view=nv, num_rays=n, Mrays_per_s_fwd_bwd=round(n / (r["t_fw_kernel_ms"] + r["t_bw_kernel_ms"]) / 1e3, 4))
+        rows.append(r)
+    return {"benchmark": "reference tests/splatter_speed_benchmark.py:200-247: 128^2 x num_view random rays x 64 ch -> voxel "
+                         "[1,160,160,160,64] (1.05 GB), S=96, mask_out_of_bounds_samples; wall time, 2 warm-up + 5 reruns", "rows": rows}
+
+
+class JointWorkload:
+    """cfg 5 (BASELINE configs[4]), weak-scaled per GPU: splat V views -> sum over GPUs -> normalise -> render this GPU's rows of
+    a 1920x1080 camera from the replicated grid -> end-to-end backward.  Sizes from the environment for the two-rank test
+    (CFG5_VIEWS, CFG5_IMG, CFG5_GRID, CFG5_ROWS, CFG5_S)."""
+
+    name = "cfg5"
+    roofline_kernel = "splatter forward walk"
+
+    def __init__(self, rank, world, dev, pg, kernel):
+        from tests.synth import pinhole_rays, random_decoder
+        env = lambda k, d: int(os.environ.get(k, d))  # noqa: E731
+        self.pg, self.kernel = pg, kernel
+        self.V, self.img, self.G, self.rows, self.S, self.C = env("CFG5_VIEWS", 13), env("CFG5_IMG", 512), env("CFG5_GRID", 256), \
+            env("CFG5_ROWS", 135), env("CFG5_S", 256), 32
+        gen = torch.Generator().manual_seed(1000 + rank)
+        tot = self.V * max(world, 1)
+        parts = []
+        for v in range(self.V):
+            k = rank * self.V + v
+            r = pinhole_rays(self.img, self.img, gen=gen, azimuth_deg=360.0 * k / tot, elevation_deg=40.0 * math.sin(2 * math.pi * k / tot))
+            parts.append(r)
+        from tests.synth import cat_rays
+        rays = cat_rays(parts)
+        rays.encoding = torch.rand(rays.n_rays, self.C, generator=gen)
+        self.splat_rays = rays.to(dev)
+        self.splat_rays.encoding.requires_grad_(True)
+        H, W = 1080, 1920
+        cam = pinhole_rays(H, W, enc_dim=32, gen=torch.Generator().manual_seed(5))
+        r0 = (rank * self.rows) % (H - self.rows + 1)
+        self.cam = cam[r0 * W:(r0 + self.rows) * W].to(dev)
+        dec_c = random_decoder(torch.Generator().manual_seed(0), 2, 2, 2, self.C, 32, 3, std=0.15)
+        self.params = dec_c.mlp_params.to(dev).requires_grad_(True)
+        self.dec_c = dec_c
+        self.sizes = [[1, self.G, self.G, self.G, self.C]]
+        self.n_rays = self.splat_rays.n_rays + self.cam.n_rays
+        self.desc = (f"cfg5 per GPU: {self.V} views {self.img}x{self.img} x32ch -> {self.G}^3x32ch voxel (sum over GPUs by reduce-scatter + "
+                     f"all-gather, then normalise), render {self.rows}x1920 rays of a 1080p camera at {self.S} samples, end-to-end backward")
+
+    def zero_grads(self):
+        self.params.grad = self.splat_rays.encoding.grad = None
+
+    def forward(self, replicated=True):
+        pg = self.pg if replicated else None
+        grid = lp.lightplane_splatter(self.splat_rays, self.sizes, num_samples=self.S, return_list=False, process_group=pg)
+        p = self.params
+        if replicated:  # the splatted grid is a replicated tensor consumed by ray shards: its gradient is summed over the GPUs
+            grid, p = parallel.replicate_with_grad_allreduce([grid, self.params], self.pg)
+        d = lp.DecoderParams(p, self.dec_c.n_hidden_trunk, self.dec_c.n_hidden_opacity, self.dec_c.n_hidden_color, 3)
+        return lp.lightplane_renderer(self.cam, grid, d, num_samples=self.S, gain=1.0, grid_sizes=self.sizes, kernel=self.kernel)
+
+    def loss(self, out):
+        return out[0].sum() + out[1].sum() + out[2].sum()
+
+    def step(self):
+        self.zero_grads()
+        self.loss(self.forward()).backward()
+
+    def roofline(self, fwd_ms, bwd_ms):
+        ns, nr, S, C = self.splat_rays.n_rays, self.cam.n_rays, self.S, self.C
+        b = ns * S * (8 * C * 4 + 8 * 4) + ns * S * 8 * C * 4 + nr * (S * 8 * C * 4 * 3 + 500)
+        ach = b / ((fwd_ms + bwd_ms) * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "whole step (splat fwd+bwd, render fwd+bwd)", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": b, "frac_fwd_plus_bwd": round(ach / HBM_PEAK_GBS, 5)}
+
+
 def make_workload(name, rank, dev, pg, kernel):
     if name == "cfg3":
         return SplatterWorkload(rank, dev, pg)
+    if name == "cfg5":
+        return JointWorkload(rank, int(os.environ.get("WORLD_SIZE", "1")), dev, pg, kernel)
     return RendererWorkload(name, rank, dev, pg, kernel)
 
 
@@ -207,9 +396,9 @@ def event_times(wl, reps):
     return fwd_ms, bwd_ms
 
 
-def pmc_traffic(workload, kernel_substr):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r*_pmc_summary.json:
-    (FETCH_SIZE + WRITE_SIZE) * 1024 from separate --pmc runs of `bench.py --workload <w>`).  Not measured in this run."""
+def pmc_entry(workload, kernel_substr):
+    """Per-launch counter averages of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r*_pmc_summary.json,
+    separate --pmc runs of `bench.py --workload <w>`, scripts/gpu_profile.sh).  NOT measured in this run."""
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_summary.json")))
     for f in reversed(files):
         try:
@@ -218,8 +407,61 @@ def pmc_traffic(workload, kernel_substr):
             continue
         for k, v in d.items():
             if k.startswith(workload + ":") and kernel_substr in k and "hbm_bytes_per_launch" in v:
-                return int(v["hbm_bytes_per_launch"]), os.path.relpath(f, REPO)
-    return None, None
+                return v, os.path.relpath(f, REPO), k.split(": ", 1)[1]
+    return None, None, None
+
+
+def pmc_traffic(workload, kernel_substr):
+    v, src, _ = pmc_entry(workload, kernel_substr)
+    return (int(v["hbm_bytes_per_launch"]), src) if v else (None, None)
+
+
+def binding_ceiling(workload, wl, fwd_ms, bwd_ms):
+    """The ceiling that actually binds the dominant kernel, next to the nominal HBM line (whose algorithmic bytes are served
+    by the L2 and by run-merging in registers: fractions above 1 are possible there and say nothing about a hardware limit).
+
+    Renderer backward: INSTRUCTION ISSUE.  A SIMD issues one wave64 VALU instruction per 4 cycles, and the fp32
+    v_mfma_f32_16x16x4_f32 of the weight-gradient quadrants (32 cycles each) do not overlap with VALU work
+    (profiles/r02_mfma_valu_overlap.txt), while the bf16 32x32x16 MFMAs do.  bound = (VALU x 4 + fp32-MFMA x 32) cycles per
+    SIMD / clock; frac_issue = bound / measured time (1.0 = nothing but issue; the rest is waits: barriers, LDS, memory).
+    Splatter forward: ATOMIC SEGMENTS.  frac_segments = 64-byte atomic segments per launch (WRITE_SIZE / 64 B) / time / 21 G/s.
+    Instruction and segment counts come from the committed PMC passes, not from this run."""
+    renderer = isinstance(wl, RendererWorkload)
+    v, src, kname = pmc_entry(workload, "renderer_bwd" if renderer else "splat_fwd_walk")
+    if v is None:
+        return None
+    if renderer:
+        valu, mfma = v.get("SQ_INSTS_VALU"), v.get("SQ_INSTS_MFMA")
+        if not valu or not mfma:
+            return None
+        f32_share = 112.0 / 202.0 if "bf3" in kname else 0.0  # dW: 112 fp32 16x16x4 of the 202 MFMAs per wave-sample
+        cyc = (valu * 4.0 + mfma * f32_share * 32.0) / N_SIMD
+        if "bf3" not in kname:  # fp32-MFMA kernels: every MFMA adds (32x32x2: 64 cycles, 16x16x4: 32 cycles; 120 : 112)
+            cyc = (valu * 4.0 + mfma * (120.0 * 64.0 + 112.0 * 32.0) / 232.0) / N_SIMD
+        bound_ms = cyc / (CLOCK_GHZ * 1e6)
+        return {"kind": "issue", "kernel": kname, "valu_insts_per_launch": valu, "mfma_insts_per_launch": mfma,
+                "issue_cycles_per_simd": round(cyc), "clock_ghz": CLOCK_GHZ, "bound_ms": round(bound_ms, 4),
+                "frac_issue": round(bound_ms / bwd_ms, 4), "source": src + " (committed counter passes, not this run)"}
+    w = v.get("WRITE_SIZE")
+    if not w:
+        return None
+    segs = w * 1024.0 / 64.0
+    return {"kind": "atomic segments", "kernel": kname, "segments_per_launch": round(segs), "peak_segments_per_s": ATOMIC_SEGMENTS_PER_S,
+            "achieved_segments_per_s": round(segs / (fwd_ms * 1e-3)), "frac_segments": round(segs / (fwd_ms * 1e-3) / ATOMIC_SEGMENTS_PER_S, 4),
+            "source": src + " (committed counter passes, not this run); the forward time includes the normalise pass and the grid zero-fill"}
+
+
+def reference_protocol_peak_mb(wl, dev):
+    """Peak memory of one forward + backward the way the reference measures `max_mem_bw_kernel` (tests/utils.py:33-57,
+    tests/renderer_speed_benchmark.py:158-180): inputs exist, NO gradient buffers yet; peak of allocated memory over forward +
+    loss + backward relative to that base -- so outputs, saved state AND the gradient buffers count."""
+    wl.zero_grads()
+    torch.cuda.synchronize(dev)
+    torch.cuda.reset_peak_memory_stats(dev)
+    base = torch.cuda.memory_allocated(dev)
+    wl.loss(wl.forward(replicated=False)).backward()
+    torch.cuda.synchronize(dev)
+    return (torch.cuda.max_memory_allocated(dev) - base) / 2**20
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -245,15 +487,14 @@ def cpu_baseline(wl):
 
     torch.set_num_threads(min(16, os.cpu_count() or 1))  # more threads only thrash on problems this small
     cores = torch.get_num_threads()
-    res = {"unit": "Mrays/s", "cores": cores, "kind": "port"}
+    res = {"unit": "Mrays/s", "cores": cores, "kind": "port",
+           "kind_note": "the reference itself (/root/reference, pure PyTorch) does not exist on the GPU box and cannot travel; the "
+                        "oracle is its restatement, pinned to 49 fixtures the reference's own naive functions produced (tests/golden)"}
 
     # BASELINE configs[0] ("cfg 1"): 1k random rays, 32^3 x 16 voxel grid, 64 samples, 2/2/2 x 32 decoder
-    gen = torch.Generator().manual_seed(0)
-    grids1 = random_grids(gen, [[1, 32, 32, 32, 16]])
-    dec1 = random_decoder(gen, 2, 2, 2, 16, 32, 3, std=0.15)
-    rays1 = random_rays(gen, 1000, 1, 32)
-    rays1.near = torch.full((1000,), 0.1)
-    rays1.far = torch.full((1000,), 3.0)
+    from tests.synth import baseline_cfg1
+    d1 = baseline_cfg1()
+    rays1, dec1, grids1 = d1["rays"], d1["decoder"], d1["grids"]
 
     def one_cfg1():
         rr = copy.copy(rays1)
@@ -269,6 +510,9 @@ def cpu_baseline(wl):
                    f"64 samples, 2/2/2x32 MLPs, fwd+bwd, {reps} reps"}
 
     n_sub = 1024
+    if isinstance(wl, JointWorkload):
+        res["value"], res["sample"] = res["cfg1"]["value"], res["cfg1"]["sample"]
+        return res
     if isinstance(wl, RendererWorkload):
         idx = torch.arange(0, wl.n_rays, wl.n_rays // n_sub)[:n_sub]
         r = wl.rays_c[idx]
@@ -306,14 +550,18 @@ def measure_extra(name, dev, kernel, reps):
     wl = make_workload(name, 0, dev, None, kernel)
     for _ in range(2 if name in ("cfg4", "1080p_s128") else 10):
         wl.step()
+    reps = max(reps, 5)
     torch.cuda.synchronize()
-    torch.cuda.reset_peak_memory_stats(dev)
-    mem0 = torch.cuda.memory_allocated(dev)
     fwd_ms, bwd_ms = event_times(wl, reps)
-    peak_mb = (torch.cuda.max_memory_allocated(dev) - mem0) / 2**20
+    peak_mb = reference_protocol_peak_mb(wl, dev)
+    roof = wl.roofline(fwd_ms, bwd_ms)
+    roof["binding"] = binding_ceiling(name, wl, fwd_ms, bwd_ms)
+    if roof["frac"] > 1.0 or roof["frac_fwd_plus_bwd"] > 1.0:
+        roof["note"] = ("nominal line: SURVEY 8(d)'s algorithmic bytes are served by the L2 / Infinity Cache and merged in registers "
+                        "before they reach the fabric, so a fraction above 1 is not a hardware limit exceeded -- see `binding`")
     out = {"workload": wl.desc, "rays": wl.n_rays, "fwd_ms": round(fwd_ms, 4), "bwd_ms": round(bwd_ms, 4),
            "Mrays_per_s_fwd_bwd": round(wl.n_rays / (fwd_ms + bwd_ms) / 1e3, 4), "reps": reps,
-           "peak_bwd_mem_mb": round(peak_mb, 2), "roofline": wl.roofline(fwd_ms, bwd_ms)}
+           "peak_bwd_mem_mb": round(peak_mb, 2), "roofline": roof}
     if isinstance(wl, RendererWorkload):
         out["mlp_fp32_frac_of_peak"] = round(wl.mlp_flops_fwdbwd() / ((fwd_ms + bwd_ms) * 1e-3) / FP32_PEAK, 5)
     del wl
@@ -396,7 +644,9 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: >= 0.5 s of work: 200 for cfg2 / cfg3, "
                                                             "10 for the 1080p workloads)")
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "1080p_s128", "cfg3", "small"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "1080p_s128", "cfg3", "small", "cfg5", "refbench", "refbench_splatter"])
+    ap.add_argument("--refbench-max", type=float, default=None, help="refbench: largest image size (default 2048) / refbench_splatter: "
+                                                                      "largest num_view (default 256)")
     ap.add_argument("--kernel", type=int, default=_lib.LP_KERNEL_AUTO)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the short runs of the other configurations (N = 1 only)")
@@ -404,8 +654,8 @@ def main():
                                                        "multi-rank code path with several ranks on one GPU)")
     args = ap.parse_args()
     big = args.workload in ("cfg4", "1080p_s128")
-    steps = args.steps if args.steps is not None else (10 if big else 200)
-    warmup = args.warmup if args.warmup is not None else (2 if big else 10)
+    steps = args.steps if args.steps is not None else (2 if args.workload == "cfg5" else 10 if big else 200)
+    warmup = args.warmup if args.warmup is not None else (1 if args.workload == "cfg5" else 2 if big else 10)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -426,6 +676,21 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     lp.config.check_inputs = False  # the grid_idx range check is a host sync, not part of the op
+    if args.workload.startswith("refbench"):  # the reference's own benchmark tables (single GPU, its protocol; no timed-step loop)
+        assert world == 1, "refbench is a single-GPU table"
+        if args.workload == "refbench":
+            tab = refbench_renderer(dev, [x for x in REFBENCH_SIZES if x <= (args.refbench_max or 2048) + 1e-6], args.kernel)
+            r = next((x for x in tab["rows"] if x["image_size"] == 256), tab["rows"][-1])
+        else:
+            tab = refbench_splatter(dev, [v for v in REFBENCH_VIEWS if v <= (args.refbench_max or 256)])
+            r = tab["rows"][0]
+        print(json.dumps({"metric": f"Mrays/sec fwd+bwd ({args.workload}: the reference's speed benchmark, row image_size / num_view = "
+                                    f"{r.get('image_size', r.get('num_view'))}); peak bwd mem (MB)",
+                          "value": r["Mrays_per_s_fwd_bwd"], "unit": "Mrays/s", "n_gpus": 1, "steps": 5, "warmup": 2,
+                          "ms_per_step": round(r["t_fw_kernel_ms"] + r["t_bw_kernel_ms"], 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "arithmetic": ARITHMETIC, "data": "synthetic",
+                          "config": {"workload": tab["benchmark"]}, "peak_bwd_mem_mb": r["max_mem_bw_kernel_mb"], "table": tab}), flush=True)
+        return
     wl = make_workload(args.workload, rank, dev, pg, args.kernel)
 
     def sync():
@@ -436,14 +701,12 @@ def main():
     for _ in range(warmup):
         wl.step()
     sync()
-    torch.cuda.reset_peak_memory_stats(dev)
-    mem0 = torch.cuda.memory_allocated(dev)
     t0 = time.perf_counter()
     for _ in range(steps):
         wl.step()
     sync()
     dt = time.perf_counter() - t0
-    peak_mb = (torch.cuda.max_memory_allocated(dev) - mem0) / 2**20
+    peak_mb = reference_protocol_peak_mb(wl, dev)  # outside the timed region; the reference's max_mem_bw protocol
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -482,6 +745,7 @@ def main():
         roof = wl.roofline(fwd_ms, bwd_ms)
         traffic, src = pmc_traffic(args.workload, "renderer_bwd" if isinstance(wl, RendererWorkload) else "splat_fwd_walk")
         roof["traffic"] = traffic
+        roof["binding"] = binding_ceiling(args.workload, wl, fwd_ms, bwd_ms)
         roof["traffic_source"] = (f"{src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, NOT measured in "
                                   f"this run; L2 -> fabric requests, i.e. one 64 B write request per atomic segment") if src else None
         if isinstance(wl, RendererWorkload) and args.workload in ("cfg2", "1080p_s128"):
@@ -491,11 +755,15 @@ def main():
                        else f"Mrays/sec fwd+bwd ({args.workload}); peak bwd mem (MB)"),
             "value": round(value, 4), "unit": "Mrays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "arithmetic": ARITHMETIC, "data": "synthetic",
             "config": {"workload": wl.desc, "rays_per_gpu": wl.n_rays,
                        "parallelism": f"ray-shard dp{world}, grid replicated, "
-                                      + ("un-normalised splat + weights all-reduced" if args.workload == "cfg3" else "grad all-reduce")},
+                                      + ("un-normalised splat + weights all-reduced" if args.workload == "cfg3" else
+                                         "splat grids summed (reduce-scatter + all-gather), render-grad all-reduce" if args.workload == "cfg5"
+                                         else "grad all-reduce")},
             "peak_bwd_mem_mb": round(peak_mb, 2),
+            "peak_bwd_mem_protocol": "reference max_mem_bw_kernel (tests/utils.py:33-57): inputs resident, no gradient buffers yet; "
+                                     "peak over forward + loss + backward (outputs, saved state and gradient buffers count)",
             "fwd_ms": round(fwd_ms, 4), "bwd_ms": round(bwd_ms, 4),
             "roofline": roof,
         }
@@ -524,9 +792,12 @@ def main():
         if world == 1 and args.workload == "cfg2" and not args.no_extras:
             res["extras"] = {
                 "splatter_cfg3": measure_extra("cfg3", dev, args.kernel, 10),
-                "renderer_1080p_s128": measure_extra("1080p_s128", dev, args.kernel, 4),
-                "renderer_cfg4_shard": measure_extra("cfg4", dev, args.kernel, 3),
+                "renderer_1080p_s128": measure_extra("1080p_s128", dev, args.kernel, 5),
+                "renderer_cfg4_shard": measure_extra("cfg4", dev, args.kernel, 5),
                 "renderer_small_batch": measure_small_batch(dev, args.kernel, 20),
+                # the reference's own benchmark axes (its protocol: wall time incl. host side, fresh inputs per rerun)
+                "refbench_renderer": refbench_renderer(dev, [256, 1024], args.kernel),
+                "refbench_splatter": refbench_splatter(dev, [1, 16]),
             }
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only
             res["cpu_baseline"] = cpu_baseline(wl)

@@ -486,7 +486,9 @@ LP_DEV float epilogue_grad_nlt(const LpRendererArgs& a, int64_t rid, bool valid,
   }
   if (a.bg_color) {
     float s = 0.0f;
-    for (int c = 0; c < n_chn; ++c) s = fmaf(a.bg_color[c], gfeat[c], s);
+    // bg_color holds color_chn floats; the MFMA kernels call this with their 4-wide colour path (gfeat[c >= color_chn] = 0,
+    // but 0 * NaN from a float behind the tensor would poison the ray)
+    for (int c = 0; c < n_chn && c < a.color_chn; ++c) s = fmaf(a.bg_color[c], gfeat[c], s);
     g_nlt -= T * s;
   }
   return g_nlt;

@@ -1,0 +1,1040 @@
+// lp_renderer_loop.hip -- the LAYER-LOOPED bf16x3 MFMA family of the Renderer: any decoder depth the reference sweeps.
+//
+// The tuned kernels (lp_renderer_mfma*.hip) are written for one decoder shape (trunk / opacity / colour of 2 layers, one
+// hidden layer each next to the output layers) and its "flex" subsets.  The reference generates a kernel for ANY layer
+// counts (triton_src/__init__.py:82-125) and its own sweep uses 2 or 4 layers per MLP
+// (tests/test_renderer_with_autograd.py:49-51).  This family covers those shapes on the matrix cores:
+//   trunk 1..MT layers (none with a separate colour grid-list), opacity / colour heads of 1..MH+1 layers (MH hidden layers +
+//   the output layer), ONE hidden width H in {16, 32} (NB = 1; 16 is staged zero-padded) or 64 (NB = 2 blocks of 32
+//   features), grid channels 16 / 32, <= 4 colour channels.
+// Same arithmetic and data layout as the bf16x3 kernels of the default shape (lp_bf3.h): one wave = 32 rays, lane (h, r) owns
+// ray r and 16 of every 32 features, every layer is the six limb products of v_mfma_f32_32x32x16_bf16 on row-major limb
+// images in LDS (one image per 32 x 32 block of a weight matrix, read transposed by the forward and plainly by the dX
+// chains), weight gradients are shared by the four waves of a workgroup through fp32 tiles and v_mfma_f32_16x16x4_f32
+// quadrants (lp_renderer_mfma_bwd.hip), the grid gradient leaves through the run-merged scatter (lp_mfma_common.h).
+// What is different: the layers of an MLP are a LOOP (unrolled to the family's maximum with wave-uniform guards, so every
+// activation keeps a compile-time register name), the backward keeps every hidden activation of the recompute (up to
+// (4 + 3 + 3) x 16 registers) and therefore runs at one wave per SIMD with the 512-register budget.
+#include <type_traits>
+
+#include "lp_bf3.h"
+#include "lp_mfma_common.h"
+
+namespace lp {
+
+typedef float f32x4l __attribute__((ext_vector_type(4)));
+#define LP_MFMA16L(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int LOOP_MAX_T = 4;       // trunk layers
+constexpr int LOOP_MAX_H = 3;       // hidden layers of a head (its output layer comes on top)
+constexpr int LOOP_N_INF = 64;      // beyond-far samples tabulated
+constexpr int LOOP_ST = 32 * RM_LD * 2;   // bytes of one limb of a 32 x 32 block (72-byte rows)
+constexpr int LOOP_BLK = 3 * LOOP_ST;     // bytes of a block image (three limbs)
+constexpr int LT_LD = 36;           // row stride of the feature-major fp32 tiles [32 features][32 rays + 4]
+
+struct LoopLayer {
+  int64_t w, b;   // float offsets inside mlp_params: W [rows_in x cols] row-major, b [cols]
+  int rows_in;    // input width (grid channels or hidden width)
+  int cols;       // output width (hidden width)
+  int img;        // byte offset of the layer's block images in LDS: block (ib, ob) at img + (ib * NB + ob) * LOOP_BLK
+  int bias;       // float index of the bias (zero-padded to 32 * NB) in the small block
+};
+
+struct LoopParams {
+  int n_t, n_o, n_c;   // layers on the matrix cores: every trunk layer, the hidden layers of the heads
+  LoopLayer t[LOOP_MAX_T], o[LOOP_MAX_H], c[LOOP_MAX_H];
+  int64_t w_o2, b_o2, w_c2, b_c2;   // output layers of the heads
+  int ldc2;                         // row stride of the colour output layer (padded colour width)
+  int hid, hin;                     // hidden width; input width of the heads (= width of the ray encoding)
+  int ho_w, hc_w;                   // input widths of the two output layers
+  int wo2, wc2, hb, inf;            // float offsets inside the small block
+  int img_end;                      // bytes before the per-wave tiles
+  int dbg;
+};
+
+// per-wave LDS area behind the images (floats)
+struct LoopTile {
+  static constexpr int XT = 0;                 // X tile [32][36] (also: dx0 tile of the scatter)
+  static constexpr int YT = 32 * LT_LD;        // dY tile [32][36] (also: the scatter's weight table)
+  static constexpr int TS = 2 * 32 * LT_LD;    // [5][32]: d raw_o, d raw_c[0..3] by ray
+  static constexpr int PER_WAVE = TS + 5 * 32;
+};
+
+LP_DEV constexpr int pi16l(int m) { return m < 4 ? 2 * m : (m < 12 ? 2 * (m - 4) + 1 : 2 * (m - 8)); }
+LP_DEV void lds_barrier_l() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// staging
+// ---------------------------------------------------------------------------------------------------------------
+template <int NB>
+LP_DEV void loop_stage_layer(char* lds, float* sm, const float* P, const LoopLayer& L, int tid) {
+  const int in_blocks = (L.rows_in + 31) >> 5;
+  for (int ib = 0; ib < in_blocks; ++ib) {
+    for (int ob = 0; ob < NB; ++ob) {
+      char* blk = lds + L.img + (ib * NB + ob) * LOOP_BLK;
+      for (int i = tid; i < 32 * 32; i += 256) {
+        const int k = i >> 5, m = i & 31;
+        const int row = 32 * ib + k, col = 32 * ob + m;
+        const float w = (row < L.rows_in && col < L.cols) ? P[L.w + (int64_t)row * L.cols + col] : 0.0f;
+        unsigned short l1, l2, l3;
+        split3_scalar(w, l1, l2, l3);
+        char* base = blk + (k * RM_LD + m) * 2;
+        *reinterpret_cast<unsigned short*>(base) = l1;
+        *reinterpret_cast<unsigned short*>(base + LOOP_ST) = l2;
+        *reinterpret_cast<unsigned short*>(base + 2 * LOOP_ST) = l3;
+      }
+    }
+  }
+  for (int i = tid; i < 32 * NB; i += 256) sm[L.bias + i] = (i < L.cols) ? P[L.b + i] : 0.0f;
+}
+
+template <int NB>
+LP_DEV void loop_stage(const LpRendererArgs& a, const LoopParams& lp, float* lds) {
+  const float* P = a.mlp_params;
+  const int tid = threadIdx.x;
+  char* b = reinterpret_cast<char*>(lds);
+  for (int l = 0; l < lp.n_t; ++l) loop_stage_layer<NB>(b, lds, P, lp.t[l], tid);
+  for (int l = 0; l < lp.n_o; ++l) loop_stage_layer<NB>(b, lds, P, lp.o[l], tid);
+  for (int l = 0; l < lp.n_c; ++l) loop_stage_layer<NB>(b, lds, P, lp.c[l], tid);
+  for (int i = tid; i < 32 * NB; i += 256) {
+    lds[lp.wo2 + i] = (i < lp.ho_w) ? P[lp.w_o2 + i] : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lds[lp.wc2 + i * 4 + c] = (i < lp.hc_w && c < a.color_chn) ? P[lp.w_c2 + (int64_t)i * lp.ldc2 + c] : 0.0f;
+  }
+  for (int i = tid; i < LOOP_N_INF; i += 256) lds[lp.inf + i] = (i < a.march.num_samples_inf) ? inf_scale(i, a.march) : 0.0f;
+  if (tid == 0) {
+    lds[lp.hb] = P[lp.b_o2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lds[lp.hb + 1 + c] = (c < a.color_chn) ? P[lp.b_c2 + c] : 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// one layer on the matrix cores
+// ---------------------------------------------------------------------------------------------------------------
+// out = relu(W^T in + b): `in` / `out` are NB blocks of this lane's 16 features; lbase = LDS base (+ the opaque zero)
+template <int NB>
+LP_DEV void loop_layer_fwd(const char* lbase, const float* sm, const LoopLayer& L, int lane, const float (&in)[NB][16],
+                           float (&out)[NB][16]) {
+  const int h = lane >> 5;
+  const int in_chunks = (L.rows_in + 15) >> 4;
+  f32x16 acc[NB];
+#pragma unroll
+  for (int ob = 0; ob < NB; ++ob) {
+    const float4* bsrc = reinterpret_cast<const float4*>(sm + L.bias + 32 * ob + 4 * h);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 v = bsrc[2 * j];
+      acc[ob][4 * j + 0] = v.x; acc[ob][4 * j + 1] = v.y; acc[ob][4 * j + 2] = v.z; acc[ob][4 * j + 3] = v.w;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 2 * NB; ++c) {
+    if (c < in_chunks) {  // wave-uniform
+      u32x4_t l1, l2, l3;
+      split3_chunk(&in[c >> 1][8 * (c & 1)], l1, l2, l3);
+#pragma unroll
+      for (int ob = 0; ob < NB; ++ob)
+        acc[ob] = chunk_bf3(AColsFwd{lbase + L.img + ((c >> 1) * NB + ob) * LOOP_BLK, LOOP_ST}, c & 1, lane, l1, l2, l3, acc[ob]);
+    }
+  }
+#pragma unroll
+  for (int ob = 0; ob < NB; ++ob) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) out[ob][q] = fmaxf(acc[ob][q], 0.0f);
+  }
+}
+
+// dX += W dY (blocks of the layer's INPUT): dy = NB blocks of this lane's 16 output features
+template <int NB>
+LP_DEV void loop_layer_dx(const char* lbase, const LoopLayer& L, int lane, const float (&dy)[NB][16], f32x16 (&dx)[NB]) {
+  const int out_chunks = (L.cols + 15) >> 4;
+  const int in_blocks = (L.rows_in + 31) >> 5;
+#pragma unroll
+  for (int c = 0; c < 2 * NB; ++c) {
+    if (c < out_chunks) {
+      u32x4_t l1, l2, l3;
+      split3_chunk(&dy[c >> 1][8 * (c & 1)], l1, l2, l3);
+#pragma unroll
+      for (int ib = 0; ib < NB; ++ib) {
+        if (ib < in_blocks)
+          dx[ib] = chunk_bf3(ARowsBwd{lbase + L.img + (ib * NB + (c >> 1)) * LOOP_BLK, LOOP_ST, 31}, c & 1, lane, l1, l2, l3, dx[ib]);
+      }
+    }
+  }
+}
+
+LP_DEV void loop_tile_store(float* tile, int r, int h, const float (&v)[16]) {
+#pragma unroll
+  for (int q = 0; q < 16; ++q) tile[featq(q, h) * LT_LD + r] = v[q];
+}
+
+// dW quadrant of one 32 x 32 block over the 128 rays of the workgroup: acc += X^T dY (see lp_renderer_mfma_bwd.hip)
+LP_DEV f32x4l loop_dw_quadrant(const float* wave0, int a_off, int b_off, f32x4l acc, float& db) {
+  float s = 0.0f;
+  for (int v = 0; v < WAVES; ++v) {
+    const float* base = wave0 + v * LoopTile::PER_WAVE;
+    const float4 a0 = *reinterpret_cast<const float4*>(base + a_off);
+    const float4 a1 = *reinterpret_cast<const float4*>(base + a_off + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(base + b_off);
+    const float4 b1 = *reinterpret_cast<const float4*>(base + b_off + 4);
+    acc = LP_MFMA16L(a0.x, b0.x, acc);
+    acc = LP_MFMA16L(a0.y, b0.y, acc);
+    acc = LP_MFMA16L(a0.z, b0.z, acc);
+    acc = LP_MFMA16L(a0.w, b0.w, acc);
+    acc = LP_MFMA16L(a1.x, b1.x, acc);
+    acc = LP_MFMA16L(a1.y, b1.y, acc);
+    acc = LP_MFMA16L(a1.z, b1.z, acc);
+    acc = LP_MFMA16L(a1.w, b1.w, acc);
+    s += ((b0.x + b0.y) + (b0.z + b0.w)) + ((b1.x + b1.y) + (b1.z + b1.w));
+  }
+  db += s;
+  return acc;
+}
+
+// accumulators of one layer's weight gradient: this wave's quadrant of every block + its share of the bias gradient
+template <int NB>
+struct LoopDw {
+  f32x4l q[NB][NB];
+  float db[NB];
+};
+template <int NB>
+LP_DEV void loop_dw_zero(LoopDw<NB>& d) {
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    d.db[i] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) d.q[i][j] = (f32x4l){0, 0, 0, 0};
+  }
+}
+
+// Backward of one layer: dW (workgroup-shared quadrants) and dX.  x = the layer's input activation, dy = upstream gradient
+// (already masked by the layer's own ReLU).  Publishes the X / dY tiles of one block pair, runs the dX chain while the LDS
+// writes land, then barrier -> quadrant -> barrier per block pair.
+template <int NB>
+LP_DEV void loop_layer_bwd(const char* lbase, const LoopLayer& L, int lane, float* xt, float* yt, const float* wave0, int a_off,
+                           int b_off, bool want_params, bool want_dx, const float (&x)[NB][16], const float (&dy)[NB][16],
+                           LoopDw<NB>& dw, f32x16 (&dx)[NB]) {
+  const int h = lane >> 5, r = lane & 31;
+  const int in_blocks = (L.rows_in + 31) >> 5;
+  if (want_params) {
+    loop_tile_store(xt, r, h, x[0]);
+    loop_tile_store(yt, r, h, dy[0]);
+  }
+  if (want_dx) loop_layer_dx<NB>(lbase, L, lane, dy, dx);
+  if (want_params) {
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib) {
+#pragma unroll
+      for (int ob = 0; ob < NB; ++ob) {
+        if (ib < in_blocks) {  // workgroup-uniform
+          if (ib + ob > 0) {
+            loop_tile_store(xt, r, h, x[ib]);
+            loop_tile_store(yt, r, h, dy[ob]);
+          }
+          lds_barrier_l();
+          float db_unused = 0.0f;
+          dw.q[ib][ob] = loop_dw_quadrant(wave0, a_off, b_off, dw.q[ib][ob], ib == 0 ? dw.db[ob] : db_unused);
+          lds_barrier_l();
+        }
+      }
+    }
+  }
+}
+
+// flush this wave's quadrants of one layer
+template <int NB>
+LP_DEV void loop_dw_flush(float* G, const LoopLayer& L, const LoopDw<NB>& dw, int wave, int lane) {
+  const int mi = wave >> 1, ni = wave & 1;
+  const int m16 = lane & 15, ka = lane >> 4;
+#pragma unroll
+  for (int ib = 0; ib < NB; ++ib) {
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) {
+      const int col = 32 * ob + 16 * ni + pi16l(m16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = 32 * ib + 16 * mi + pi16l(4 * ka + i);
+        if (row < L.rows_in && col < L.cols) atomic_add_f32(G + L.w + (int64_t)row * L.cols + col, dw.q[ib][ob][i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int ob = 0; ob < NB; ++ob) {
+    float d = dw.db[ob];
+    d += __shfl_xor(d, 16);
+    d += __shfl_xor(d, 32);
+    const int col = 32 * ob + 16 * ni + pi16l(m16);
+    if (ka == 0 && mi == 0 && col < L.cols) atomic_add_f32(G + L.b + col, d);
+  }
+}
+
+// output layers of the heads on the VALU (N = 1 and N <= 4): each lane covers its 16 features per block, its partner lane
+// (l ^ 32) the other 16
+template <int NB>
+LP_DEV Heads loop_heads_forward(const float* sm, const LoopParams& lp, int h, const float (&ho)[NB][16], const float (&hc)[NB][16]) {
+  float po = 0.0f, pc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 wo = *reinterpret_cast<const float4*>(sm + lp.wo2 + 32 * blk + 8 * j + 4 * h);
+      const float wov[4] = {wo.x, wo.y, wo.z, wo.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = 4 * j + i;
+        po = fmaf(ho[blk][q], wov[i], po);
+        const float4 wc = *reinterpret_cast<const float4*>(sm + lp.wc2 + (32 * blk + 8 * j + 4 * h + i) * 4);
+        pc[0] = fmaf(hc[blk][q], wc.x, pc[0]);
+        pc[1] = fmaf(hc[blk][q], wc.y, pc[1]);
+        pc[2] = fmaf(hc[blk][q], wc.z, pc[2]);
+        pc[3] = fmaf(hc[blk][q], wc.w, pc[3]);
+      }
+    }
+  }
+  Heads o;
+  o.raw_o = (po + __shfl_xor(po, 32)) + sm[lp.hb];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) o.raw_c[c] = (pc[c] + __shfl_xor(pc[c], 32)) + sm[lp.hb + 1 + c];
+  return o;
+}
+
+// this lane's features of the ray encoding, NB blocks (features >= width read as 0)
+template <int NB>
+LP_DEV void loop_load_encoding(const LpRendererArgs& a, int64_t rid, int h, int width, float (&enc)[NB][16]) {
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk) {
+    const float4* src = reinterpret_cast<const float4*>(a.rays.encoding + rid * width + 32 * blk + 4 * h);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 v = (32 * blk + 8 * j + 4 * h < width) ? src[2 * j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      enc[blk][4 * j + 0] = v.x; enc[blk][4 * j + 1] = v.y; enc[blk][4 * j + 2] = v.z; enc[blk][4 * j + 3] = v.w;
+    }
+  }
+}
+
+// sampled feature x0 [C/2 registers] -> NB blocks (zero-padded); RELU: the two-grid decoder's heads read relu(sample)
+template <int C, int NB, bool RELU>
+LP_DEV void loop_pad_input(const float (&x0)[C / 2], float (&out)[NB][16]) {
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const bool in = blk == 0 && q < C / 2;
+      const float v = in ? x0[in ? q : 0] : 0.0f;
+      out[blk][q] = RELU ? fmaxf(v, 0.0f) : v;
+    }
+  }
+}
+
+template <int NB>
+LP_DEV void loop_copy(const float (&src)[NB][16], float (&dst)[NB][16]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dst[b][q] = src[b][q];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------------
+template <int C, int NB, bool TG>
+__global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) renderer_fwd_loop(const LpRendererArgs a, const LoopParams lp) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  loop_stage<NB>(a, lp, lds);
+  __syncthreads();
+  const float* const geo = lds + lp.inf - Lds::INF;  // sample_geometry() reads its beyond-far table at geo + Lds::INF
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, r = lane & 31;
+  const int64_t ray_id = ((int64_t)blockIdx.x * WAVES + wave) * RAYS_PER_WAVE + r;
+  const bool valid = ray_id < a.rays.n_rays;
+  const int64_t rid = valid ? ray_id : 0;
+  const Ray ray = load_ray(a.rays, rid);
+  float enc[NB][16];
+  loop_load_encoding<NB>(a, rid, h, lp.hin, enc);
+  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
+  const int n_ckpt = ckpt_count(a.march);
+  const float delta0 = (a.march.num_samples > 1) ? (ray.far_t - ray.near_t) / (float)(a.march.num_samples - 1) : 1.0f;
+  float nlt = 0.0f, nlt_lo = 0.0f, t_prev = 1.0f, len = 0.0f, depth_prev = 0.0f;
+  int s_last = s_tot - 1;
+  float facc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  Sample<C> nx;
+  for (int s = 0; s < s_tot; ++s) {
+    fetch_sample<C, GM_GENERIC, true>(a, geo, ray, s, h, nx);
+    const float depth = nx.depth, occ = nx.occ;
+    const int zo = opaque_zero();
+    const char* lbase = reinterpret_cast<const char*>(lds) + zo;
+    const float* sm = lds + zo;
+    float cur[NB][16], ho[NB][16], hc[NB][16];
+    loop_pad_input<C, NB, TG>(nx.x0, cur);
+#pragma unroll
+    for (int l = 0; l < LOOP_MAX_T; ++l) {
+      if (!TG && l < lp.n_t) {
+        float nxt[NB][16];
+        loop_layer_fwd<NB>(lbase, sm, lp.t[l], lane, cur, nxt);
+        loop_copy<NB>(nxt, cur);
+      }
+    }
+    // colour head input: trunk output (two-grid decoder: relu(sampled colour feature)) + ray encoding
+    float cin[NB][16];
+    if (TG) {
+      float xc0[C / 2];
+      gather_list<C, false>(a.color_grid, a.march.mask_out_of_bounds != 0, ray, nx.x, nx.y, nx.z, h, xc0);
+      loop_pad_input<C, NB, true>(xc0, cin);
+    } else {
+      loop_copy<NB>(cur, cin);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) cin[b][q] += enc[b][q];
+    }
+    loop_copy<NB>(cur, ho);
+#pragma unroll
+    for (int l = 0; l < LOOP_MAX_H; ++l) {
+      if (l < lp.n_o) {
+        float nxt[NB][16];
+        loop_layer_fwd<NB>(lbase, sm, lp.o[l], lane, ho, nxt);
+        loop_copy<NB>(nxt, ho);
+      }
+    }
+    loop_copy<NB>(cin, hc);
+#pragma unroll
+    for (int l = 0; l < LOOP_MAX_H; ++l) {
+      if (l < lp.n_c) {
+        float nxt[NB][16];
+        loop_layer_fwd<NB>(lbase, sm, lp.c[l], lane, hc, nxt);
+        loop_copy<NB>(nxt, hc);
+      }
+    }
+    const Heads hd = loop_heads_forward<NB>(sm, lp, h, ho, hc);
+    const float delta = (s == 0) ? delta0 : depth - depth_prev;
+    depth_prev = depth;
+    float raw = hd.raw_o;
+    if (a.noise_sigma > 0.0f) raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
+    const float opacity = a.gain * softplus_f(raw) * occ;
+    nlt_add(nlt, nlt_lo, opacity * delta);
+    if (a.neg_log_t_ckpt && valid && h == 0) {
+      const int ck = ckpt_index(s, a.march);
+      if (ck >= 0) *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + ck) * 2) = make_float2(nlt, nlt_lo);
+    }
+    const float tr = __expf(-nlt);
+    const float w = t_prev - tr;
+    t_prev = tr;
+    len = fmaf(w, depth, len);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) facc[c] = fmaf(w, sigmoid_f(hd.raw_c[c]) * occ, facc[c]);
+    if (a.stop_neg_log_t > 0.0f && __ballot(valid && nlt < a.stop_neg_log_t) == 0) {
+      s_last = s;
+      break;
+    }
+  }
+  if (valid && h == 0) {
+    write_ray_outputs(a, ray_id, len, nlt, facc);
+    if (a.neg_log_t_ckpt)
+      *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + n_ckpt - 1) * 2) = make_float2((float)s_last, nlt_lo);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------------------
+// MT / MH: the trunk layers / hidden head layers this instantiation holds registers for (the kernel's loops are unrolled to
+// them; NB = 2 is instantiated for the 2 / 2 / 2 shape only: 64-wide activations are 32 registers each)
+template <int C, int NB, bool TG, int MT, int MH>
+__global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs a, const LoopParams lp) {
+  using T = LoopTile;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  loop_stage<NB>(a, lp, lds);
+  const float* const geo = lds + lp.inf - Lds::INF;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int h = lane >> 5, r = lane & 31;
+  float* const wave0 = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + lp.img_end);
+  float* const wv = wave0 + wave * T::PER_WAVE;
+  float* const xt = wv + T::XT;
+  float* const yt = wv + T::YT;
+  float* const ts = wv + T::TS;
+  const int64_t ray_id = ((int64_t)blockIdx.x * WAVES + wave) * RAYS_PER_WAVE + r;
+  const bool valid = ray_id < a.rays.n_rays;
+  const int64_t rid = valid ? ray_id : 0;
+  const Ray ray = load_ray(a.rays, rid);
+  float enc[NB][16];
+  loop_load_encoding<NB>(a, rid, h, lp.hin, enc);
+  // closing pair of the checkpoint list: last sample the forward marched for this wave (early termination) and the low word
+  // of the final -log T.  The sample loop is workgroup-uniform (barriers): it starts at the largest index of the four waves.
+  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
+  const int n_ckpt = ckpt_count(a.march);
+  int s_last_w = s_tot - 1;
+  float nlt_lo = 0.0f;
+  if (a.neg_log_t_ckpt) {
+    const float2 e2 = *reinterpret_cast<const float2*>(a.neg_log_t_ckpt + (rid * n_ckpt + n_ckpt - 1) * 2);
+    s_last_w = __builtin_amdgcn_readfirstlane((int)e2.x);
+    s_last_w = s_last_w < 0 ? 0 : (s_last_w > s_tot - 1 ? s_tot - 1 : s_last_w);
+    nlt_lo = e2.y;
+  }
+  if (lane == 0) ts[0] = (float)s_last_w;
+  __syncthreads();
+  int s_begin = 0;
+#pragma unroll
+  for (int v = 0; v < WAVES; ++v) {
+    const int sv = (int)wave0[v * T::PER_WAVE + T::TS];
+    s_begin = sv > s_begin ? sv : s_begin;
+  }
+  __syncthreads();  // ts[] is reused by the sample loop
+
+  float denc[NB][16];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) denc[b][q] = 0.0f;
+  }
+  float gfeat[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) gfeat[c] = (valid && a.grad_feature && c < a.color_chn) ? a.grad_feature[rid * a.color_chn + c] : 0.0f;
+  const float g_len = (valid && a.grad_ray_length) ? a.grad_ray_length[rid] : 0.0f;
+  const float g_nlt = epilogue_grad_nlt(a, rid, valid, a.neg_log_t[rid], (valid && a.grad_neg_log_t) ? a.grad_neg_log_t[rid] : 0.0f, gfeat, 4);
+  const bool want_params = a.grad_mlp_params != nullptr;
+  const float delta0 = (a.march.num_samples > 1) ? (ray.far_t - ray.near_t) / (float)(a.march.num_samples - 1) : 1.0f;
+
+  // dW quadrant of this wave inside every 32 x 32 block: rows 16 mi .., columns 16 ni ..; MFMA lane (m16, ka)
+  const int mi = wave >> 1, ni = wave & 1;
+  const int m16 = lane & 15, ka = lane >> 4;
+  const int a_off = T::XT + (16 * mi + pi16l(m16)) * LT_LD + 8 * ka;
+  const int b_off = T::YT + (16 * ni + pi16l(m16)) * LT_LD + 8 * ka;
+  LoopDw<NB> dw_t[MT], dw_o[MH], dw_c[MH];
+#pragma unroll
+  for (int l = 0; l < MT; ++l) loop_dw_zero<NB>(dw_t[l]);
+#pragma unroll
+  for (int l = 0; l < MH; ++l) {
+    loop_dw_zero<NB>(dw_o[l]);
+    loop_dw_zero<NB>(dw_c[l]);
+  }
+  // output layers of the heads: lane (f = l & 31, half h) owns feature 32 blk + f, partial over the 16 rays of its half
+  float dwo2[NB], dwc2[NB][4];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    dwo2[b] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dwc2[b][c] = 0.0f;
+  }
+  float dbo2 = 0.0f, dbc2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  const bool gg = a.grad_grid_list[0] != nullptr;
+  const bool ggc = TG && a.grad_color_grid_list[0] != nullptr;
+
+  float nlt = a.neg_log_t[rid];
+  float suffix = 0.0f, p_next = 0.0f;
+  Sample<C> nx;
+  fetch_sample<C, GM_GENERIC, false>(a, geo, ray, s_begin, h, nx);
+  for (int s = s_begin; s >= 0; --s) {
+    const bool on = s <= s_last_w;  // wave-uniform; false only for samples a sibling wave still marches
+    const float depth = nx.depth, occ = nx.occ, x = nx.x, y = nx.y, z = nx.z;
+    const int zo = opaque_zero();
+    const char* lbase = reinterpret_cast<const char*>(lds) + zo;
+    const float* sm = lds + zo;
+
+    // ---------------- forward recompute: every hidden activation is kept ----------------
+    float xin[NB][16];          // input of the first layer(s): sampled feature (two-grid decoder: its relu)
+    loop_pad_input<C, NB, TG>(nx.x0, xin);
+    float tA[MT][NB][16];       // trunk activations (post-ReLU)
+    float e[NB][16];            // trunk output = input of the heads
+    loop_copy<NB>(xin, e);
+#pragma unroll
+    for (int l = 0; l < MT; ++l) {
+      if (!TG && l < lp.n_t) {
+        loop_layer_fwd<NB>(lbase, sm, lp.t[l], lane, e, tA[l]);
+        loop_copy<NB>(tA[l], e);
+      }
+    }
+    float xc[C / 2];            // two-grid decoder: sampled colour feature of this sample
+    float cin[NB][16];          // input of the colour head
+    if (TG) {
+      gather_list<C, true>(a.color_grid, a.march.mask_out_of_bounds != 0, ray, x, y, z, h, xc);
+      loop_pad_input<C, NB, true>(xc, cin);
+    } else {
+      loop_copy<NB>(e, cin);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) cin[b][q] += enc[b][q];
+    }
+    float oA[MH][NB][16], cA[MH][NB][16];
+    float ho[NB][16], hc[NB][16];
+    loop_copy<NB>(e, ho);
+#pragma unroll
+    for (int l = 0; l < MH; ++l) {
+      if (l < lp.n_o) {
+        loop_layer_fwd<NB>(lbase, sm, lp.o[l], lane, ho, oA[l]);
+        loop_copy<NB>(oA[l], ho);
+      }
+    }
+    loop_copy<NB>(cin, hc);
+#pragma unroll
+    for (int l = 0; l < MH; ++l) {
+      if (l < lp.n_c) {
+        loop_layer_fwd<NB>(lbase, sm, lp.c[l], lane, hc, cA[l]);
+        loop_copy<NB>(cA[l], hc);
+      }
+    }
+    const Heads hd = loop_heads_forward<NB>(sm, lp, h, ho, hc);
+    LP_SCHED_FENCE();
+
+    // ---------------- compositing, backward ----------------
+    const float depth_prev = sample_depth_tab((s > 0) ? s - 1 : 0, a.march, ray.near_t, ray.far_t, lds + lp.inf);
+    const float delta = (s == 0) ? delta0 : depth - depth_prev;
+    float raw = hd.raw_o;
+    if (a.noise_sigma > 0.0f) raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
+    const float opacity = a.gain * softplus_f(raw) * occ;
+    if (on && a.neg_log_t_ckpt) {
+      const int ck = ckpt_index(s, a.march);
+      if (ck >= 0) {
+        const float2 c2 = *reinterpret_cast<const float2*>(a.neg_log_t_ckpt + (rid * n_ckpt + ck) * 2);
+        nlt = c2.x;
+        nlt_lo = c2.y;
+      }
+    }
+    const float t_i = __expf(-nlt);
+    nlt_add(nlt, nlt_lo, on ? -(opacity * delta) : 0.0f);
+    if (!(nlt > 0.0f)) { nlt = 0.0f; nlt_lo = 0.0f; }
+    const float t_im1 = __expf(-nlt);
+    const float w = t_im1 - t_i;
+    float sg[4];
+    float p_i = g_len * depth;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      sg[c] = sigmoid_f(hd.raw_c[c]);
+      p_i = fmaf(gfeat[c], sg[c] * occ, p_i);
+    }
+    suffix = on ? fmaf(t_i, p_i - p_next, suffix) : suffix;
+    p_next = on ? p_i : p_next;
+    const float d_a = suffix + g_nlt;
+    const bool contrib = valid && on;
+    const float dro = contrib ? d_a * delta * a.gain * occ * d_softplus_f(raw) : 0.0f;
+    float drc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) drc[c] = contrib ? w * gfeat[c] * occ * sg[c] * (1.0f - sg[c]) : 0.0f;
+
+    // ---------------- output layers of the heads (VALU) ----------------
+    if (h == 0) {
+      dbo2 += dro;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dbc2[c] += drc[c];
+    }
+    if (want_params) {
+      if (h == 0) {
+        ts[r] = dro;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ts[(1 + c) * 32 + r] = drc[c];
+      }
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk) {
+        // ho / hc of this block -> the (wave-private) tiles; lane (f = r, half h) reads the rays 16h .. 16h+15 of feature f
+        loop_tile_store(xt, r, h, ho[blk]);
+        loop_tile_store(yt, r, h, hc[blk]);
+        const float* xf = xt + r * LT_LD + 16 * h;
+        const float* yf = yt + r * LT_LD + 16 * h;
+        const float* tf = ts + 16 * h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4 hov = *reinterpret_cast<const float4*>(xf + 4 * i);
+          const float4 hcv = *reinterpret_cast<const float4*>(yf + 4 * i);
+          const float4 d0 = *reinterpret_cast<const float4*>(tf + 4 * i);
+          dwo2[blk] = fmaf(hov.x, d0.x, dwo2[blk]); dwo2[blk] = fmaf(hov.y, d0.y, dwo2[blk]);
+          dwo2[blk] = fmaf(hov.z, d0.z, dwo2[blk]); dwo2[blk] = fmaf(hov.w, d0.w, dwo2[blk]);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float4 dc = *reinterpret_cast<const float4*>(tf + (1 + c) * 32 + 4 * i);
+            dwc2[blk][c] = fmaf(hcv.x, dc.x, dwc2[blk][c]); dwc2[blk][c] = fmaf(hcv.y, dc.y, dwc2[blk][c]);
+            dwc2[blk][c] = fmaf(hcv.z, dc.z, dwc2[blk][c]); dwc2[blk][c] = fmaf(hcv.w, dc.w, dwc2[blk][c]);
+          }
+          LP_SCHED_FENCE();
+        }
+        LP_SCHED_FENCE();
+      }
+    }
+    // gradients of the heads' last hidden activations (masked by their ReLU where there is a hidden layer)
+    float g[NB][16];   // running gradient of the head being back-propagated
+    float de[NB][16];  // gradient of the heads' input e (both heads)
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int q = 4 * j + i;
+          const float4 wc = *reinterpret_cast<const float4*>(sm + lp.wc2 + (32 * blk + 8 * j + 4 * h + i) * 4);
+          float v = drc[0] * wc.x;
+          v = fmaf(drc[1], wc.y, v);
+          v = fmaf(drc[2], wc.z, v);
+          v = fmaf(drc[3], wc.w, v);
+          g[blk][q] = (lp.n_c == 0 || hc[blk][q] > 0.0f) ? v : 0.0f;
+        }
+      }
+    }
+    LP_SCHED_FENCE();
+
+    // ---------------- colour head, hidden layers last -> first ----------------
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int l = MH - 1; l >= 0; --l) {
+      if (l < lp.n_c) {
+        f32x16 dx[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) dx[b] = (f32x16){0};
+        if (l > 0) {
+          loop_layer_bwd<NB>(lbase, lp.c[l], lane, xt, yt, wave0, a_off, b_off, want_params, true, cA[l > 0 ? l - 1 : 0], g, dw_c[l], dx);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) g[b][q] = (cA[l > 0 ? l - 1 : 0][b][q] > 0.0f) ? dx[b][q] : 0.0f;
+          }
+        } else {
+          loop_layer_bwd<NB>(lbase, lp.c[0], lane, xt, yt, wave0, a_off, b_off, want_params, true, cin, g, dw_c[0], dx);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) g[b][q] = dx[b][q];
+          }
+        }
+      }
+    }
+    // g = d cin = d (e | relu(colour feature)) and d encoding
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) denc[b][q] += g[b][q];
+    }
+    if (TG) {
+      // two-grid decoder: scatter d relu(colour feature) into the colour grid-list now, while the wave's tiles are idle
+      // between two layer phases; the opacity branch then starts from zero
+      if (ggc && !(lp.dbg & 2)) {
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int q = 0; q < C / 2; ++q) xt[featq(q, h) * DX_LD + r] = (xc[q] > 0.0f) ? g[0][q] : 0.0f;
+        const bool live_c = valid && on && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
+#pragma unroll 1
+        for (int gi = 0; gi < a.color_grid.n_grids; ++gi)
+          scatter_grid<C>(a.grad_color_grid_list[gi], a.color_grid.grids[gi], ray.b, x, y, z, live_c, lane, xt, yt, lp.dbg);
+        __builtin_amdgcn_s_setprio(1);
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) de[b][q] = 0.0f;
+      }
+    } else {
+      loop_copy<NB>(g, de);
+    }
+    // ---------------- opacity head ----------------
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 wo = *reinterpret_cast<const float4*>(sm + lp.wo2 + 32 * blk + 8 * j + 4 * h);
+        const float wov[4] = {wo.x, wo.y, wo.z, wo.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int q = 4 * j + i;
+          g[blk][q] = (lp.n_o == 0 || ho[blk][q] > 0.0f) ? dro * wov[i] : 0.0f;
+        }
+      }
+    }
+#pragma unroll
+    for (int l = MH - 1; l >= 0; --l) {
+      if (l < lp.n_o) {
+        f32x16 dx[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) dx[b] = (f32x16){0};
+        if (l > 0) {
+          loop_layer_bwd<NB>(lbase, lp.o[l], lane, xt, yt, wave0, a_off, b_off, want_params, true, oA[l > 0 ? l - 1 : 0], g, dw_o[l], dx);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) g[b][q] = (oA[l > 0 ? l - 1 : 0][b][q] > 0.0f) ? dx[b][q] : 0.0f;
+          }
+        } else {
+          loop_layer_bwd<NB>(lbase, lp.o[0], lane, xt, yt, wave0, a_off, b_off, want_params, true, e, g, dw_o[0], dx);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) g[b][q] = dx[b][q];
+          }
+        }
+      }
+    }
+    // d e of both heads, through the ReLU that produced e (the trunk's last layer, or relu(sample) of the two-grid decoder)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) g[b][q] = (e[b][q] > 0.0f) ? de[b][q] + g[b][q] : 0.0f;
+    }
+    // ---------------- trunk, last -> first ----------------
+#pragma unroll
+    for (int l = MT - 1; l >= 0; --l) {
+      if (!TG && l < lp.n_t) {
+        f32x16 dx[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) dx[b] = (f32x16){0};
+        if (l > 0) {
+          loop_layer_bwd<NB>(lbase, lp.t[l], lane, xt, yt, wave0, a_off, b_off, want_params, true, tA[l > 0 ? l - 1 : 0], g, dw_t[l], dx);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) g[b][q] = (tA[l > 0 ? l - 1 : 0][b][q] > 0.0f) ? dx[b][q] : 0.0f;
+          }
+        } else {
+          loop_layer_bwd<NB>(lbase, lp.t[0], lane, xt, yt, wave0, a_off, b_off, want_params, gg, xin, g, dw_t[0], dx);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) g[b][q] = dx[b][q];
+          }
+        }
+      }
+    }
+    // g = d (sampled feature) -> LDS [channel][ray] (the X tile is free behind the last barrier)
+    if (gg) {
+#pragma unroll
+      for (int q = 0; q < C / 2; ++q) xt[featq(q, h) * DX_LD + r] = g[0][q];
+    }
+    LP_SCHED_FENCE();
+    // ---------------- next (nearer) sample + grid gradient ----------------
+    __builtin_amdgcn_s_setprio(0);
+    const bool live = valid && on && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
+    if (s > 0) fetch_sample<C, GM_GENERIC, true>(a, geo, ray, s - 1, h, nx);
+    LP_SCHED_FENCE();
+    if (gg && !(lp.dbg & 2)) {
+#pragma unroll 1
+      for (int gi = 0; gi < a.grid.n_grids; ++gi)
+        scatter_grid<C, GM_GENERIC>(a.grad_grid_list[gi], a.grid.grids[gi], ray.b, x, y, z, live, lane, xt, yt, lp.dbg);
+    }
+  }
+
+  // ---------------- epilogue ----------------
+  if (valid && a.grad_encoding) {
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+      float4* dst = reinterpret_cast<float4*>(a.grad_encoding + ray_id * lp.hin + 32 * blk + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (32 * blk + 8 * j + 4 * h < lp.hin)
+          dst[2 * j] = make_float4(denc[blk][4 * j], denc[blk][4 * j + 1], denc[blk][4 * j + 2], denc[blk][4 * j + 3]);
+      }
+    }
+  }
+  if (want_params) {
+    float* G = a.grad_mlp_params;
+    const int j = lane & 31;
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+      const int f = 32 * blk + j;
+      if (f < lp.ho_w) atomic_add_f32(G + lp.w_o2 + f, dwo2[blk]);
+      if (f < lp.hc_w) {
+        for (int c = 0; c < a.color_chn; ++c) atomic_add_f32(G + lp.w_c2 + (int64_t)f * lp.ldc2 + c, dwc2[blk][c]);
+      }
+    }
+    float v = dbo2, c0 = dbc2[0], c1 = dbc2[1], c2 = dbc2[2], c3 = dbc2[3];
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) {
+      v += __shfl_xor(v, m);
+      c0 += __shfl_xor(c0, m);
+      c1 += __shfl_xor(c1, m);
+      c2 += __shfl_xor(c2, m);
+      c3 += __shfl_xor(c3, m);
+    }
+    if (lane == 0) {
+      atomic_add_f32(G + lp.b_o2, v);
+      const float cv[4] = {c0, c1, c2, c3};
+      for (int c = 0; c < a.color_chn; ++c) atomic_add_f32(G + lp.b_c2 + c, cv[c]);
+    }
+#pragma unroll
+    for (int l = 0; l < MT; ++l) {
+      if (!TG && l < lp.n_t) loop_dw_flush<NB>(G, lp.t[l], dw_t[l], wave, lane);
+    }
+#pragma unroll
+    for (int l = 0; l < MH; ++l) {
+      if (l < lp.n_o) loop_dw_flush<NB>(G, lp.o[l], dw_o[l], wave, lane);
+      if (l < lp.n_c) loop_dw_flush<NB>(G, lp.c[l], dw_c[l], wave, lane);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+static int loop_nb(int H) { return H <= 32 ? 1 : 2; }
+
+// Shape family: grid-list(s) with C in {16, 32} channels below 4 GB; trunk of 1..4 layers, or none with a separate colour
+// grid-list; heads of 1..4 layers; every hidden width equal to H in {16, 32} -- or H = 64 with at most 2 trunk layers and
+// heads of at most 2 layers; <= 4 colour channels; <= 64 beyond-far samples.
+bool renderer_loop_supported(const LpRendererArgs& a, const char** why) {
+  *why = "";
+  const int C = a.grid.channels;
+  const bool tg = a.color_grid.n_grids > 0;
+  if (C != 16 && C != 32) { *why = "grid channels not 16 or 32"; return false; }
+  if ((tg && a.trunk.n_layers != 0) || (!tg && a.trunk.n_layers < 1) || a.trunk.n_layers > LOOP_MAX_T || a.opacity.n_layers < 1 ||
+      a.opacity.n_layers > LOOP_MAX_H + 1 || a.color.n_layers < 1 || a.color.n_layers > LOOP_MAX_H + 1) {
+    *why = "layer counts outside trunk 1-4 (0 with a colour grid) / opacity 1-4 / colour 1-4";
+    return false;
+  }
+  int H = 0;
+  bool same = true;
+  auto hidden = [&](int w) { if (H == 0) H = w; else same = same && (w == H); };
+  for (int l = 1; l <= a.trunk.n_layers; ++l) hidden(a.trunk.dims[l]);
+  for (int l = 1; l < a.opacity.n_layers; ++l) hidden(a.opacity.dims[l]);
+  for (int l = 1; l < a.color.n_layers; ++l) hidden(a.color.dims[l]);
+  if (H == 0) H = C;  // two-grid decoder with single-layer heads: no hidden layer at all
+  if (!same) { *why = "hidden widths differ between layers"; return false; }
+  if (H != 16 && H != 32 && H != 64) { *why = "hidden width other than 16 / 32 / 64"; return false; }
+  if (H == 64 && (a.trunk.n_layers > 2 || a.opacity.n_layers > 2 || a.color.n_layers > 2 || tg)) {
+    *why = "hidden width 64 with more than 2 layers per MLP (or a colour grid)";
+    return false;
+  }
+  if (a.color_chn > 4) { *why = "more than 4 colour channels"; return false; }
+  if (a.grid.n_rows * C * 4 >= (int64_t)1 << 32) { *why = "grid-list of 4 GB or more"; return false; }
+  if (tg && a.color_grid.n_rows * C * 4 >= (int64_t)1 << 32) { *why = "colour grid-list of 4 GB or more"; return false; }
+  if (a.march.num_samples_inf > LOOP_N_INF) { *why = "more than 64 beyond-far samples"; return false; }
+  return true;
+}
+
+static LoopParams loop_params(const LpRendererArgs& a) {
+  LoopParams p = {};
+  const int C = a.grid.channels;
+  const bool tg = a.color_grid.n_grids > 0;
+  p.n_t = a.trunk.n_layers;
+  p.n_o = a.opacity.n_layers - 1;
+  p.n_c = a.color.n_layers - 1;
+  const int H = p.n_t > 0 ? a.trunk.dims[1] : (p.n_o > 0 ? a.opacity.dims[1] : (p.n_c > 0 ? a.color.dims[1] : C));
+  const int NB = loop_nb(H);
+  p.hid = H;
+  p.hin = tg ? C : H;
+  p.ho_w = p.n_o > 0 ? H : p.hin;
+  p.hc_w = p.n_c > 0 ? H : p.hin;
+  // small block (floats): biases of the layers, output layers of the heads, beyond-far table
+  int f = 0;
+  int img = 0;  // bytes, relative to the end of the small block (fixed up below)
+  auto layers = [&](const LpMlp& m, int n, LoopLayer* out) {
+    int64_t off = m.offset;
+    // flat layout of an MLP: all weight matrices, then all biases (mlp_utils.py flatten_*)
+    int64_t boff = m.offset;
+    for (int l = 0; l < m.n_layers; ++l) boff += (int64_t)m.dims[l] * m.dims[l + 1];
+    for (int l = 0; l < m.n_layers; ++l) {
+      if (l < n) {
+        out[l].w = off;
+        out[l].b = boff;
+        out[l].rows_in = m.dims[l];
+        out[l].cols = m.dims[l + 1];
+        out[l].bias = f;
+        f += 32 * NB;
+        out[l].img = img;
+        img += ((m.dims[l] + 31) / 32) * NB * LOOP_BLK;
+      }
+      off += (int64_t)m.dims[l] * m.dims[l + 1];
+      boff += m.dims[l + 1];
+    }
+  };
+  layers(a.trunk, p.n_t, p.t);
+  layers(a.opacity, p.n_o, p.o);
+  layers(a.color, p.n_c, p.c);
+  // output layers: the last weight matrix / bias of each head
+  auto last = [&](const LpMlp& m, int64_t& w, int64_t& b) {
+    int64_t off = m.offset, boff = m.offset;
+    for (int l = 0; l < m.n_layers; ++l) boff += (int64_t)m.dims[l] * m.dims[l + 1];
+    for (int l = 0; l + 1 < m.n_layers; ++l) {
+      off += (int64_t)m.dims[l] * m.dims[l + 1];
+      boff += m.dims[l + 1];
+    }
+    w = off;
+    b = boff;
+  };
+  last(a.opacity, p.w_o2, p.b_o2);
+  last(a.color, p.w_c2, p.b_c2);
+  p.ldc2 = a.color.dims[a.color.n_layers];
+  p.wo2 = f; f += 32 * NB;
+  p.wc2 = f; f += 32 * NB * 4;
+  p.hb = f; f += 8;
+  p.inf = f; f += LOOP_N_INF;
+  const int small_bytes = f * 4;  // multiple of 16
+  for (int l = 0; l < p.n_t; ++l) p.t[l].img += small_bytes;
+  for (int l = 0; l < p.n_o; ++l) p.o[l].img += small_bytes;
+  for (int l = 0; l < p.n_c; ++l) p.c[l].img += small_bytes;
+  p.img_end = small_bytes + img;
+  static const int dbg = getenv("LP_MFMA_DEBUG") ? atoi(getenv("LP_MFMA_DEBUG")) : 0;
+  p.dbg = dbg;
+  return p;
+}
+
+static size_t loop_lds_bytes(const LoopParams& p, bool backward) {
+  return (size_t)p.img_end + (backward ? (size_t)WAVES * LoopTile::PER_WAVE * 4 : 0);
+}
+
+bool renderer_loop_fits(const LpRendererArgs& a) {
+  return loop_lds_bytes(loop_params(a), true) <= 160 * 1024;
+}
+
+template <typename K>
+static int loop_set_lds(K kernel, size_t bytes) {
+  const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  return LP_OK;
+}
+
+static unsigned loop_blocks(const LpRendererArgs& a) {
+  return (unsigned)((a.rays.n_rays + WAVES * RAYS_PER_WAVE - 1) / (WAVES * RAYS_PER_WAVE));
+}
+
+int renderer_forward_loop(const LpRendererArgs& a, hipStream_t stream) {
+  const unsigned nb = loop_blocks(a);
+  if (nb == 0) return LP_OK;
+  const LoopParams p = loop_params(a);
+  const size_t lds = loop_lds_bytes(p, false);
+  const bool tg = a.color_grid.n_grids > 0;
+  const int NB = loop_nb(p.hid);
+  int rc = LP_OK;
+#define LP_LOOP_FWD(CV, NBV, TGV)                                                                       \
+  do {                                                                                                  \
+    if ((rc = loop_set_lds(renderer_fwd_loop<CV, NBV, TGV>, lds))) return rc;                           \
+    hipLaunchKernelGGL((renderer_fwd_loop<CV, NBV, TGV>), dim3(nb), dim3(256), lds, stream, a, p);      \
+  } while (0)
+  if (a.grid.channels == 16) {
+    if (NB == 2) LP_LOOP_FWD(16, 2, false);
+    else if (tg) LP_LOOP_FWD(16, 1, true);
+    else LP_LOOP_FWD(16, 1, false);
+  } else {
+    if (NB == 2) LP_LOOP_FWD(32, 2, false);
+    else if (tg) LP_LOOP_FWD(32, 1, true);
+    else LP_LOOP_FWD(32, 1, false);
+  }
+#undef LP_LOOP_FWD
+  return check_launch("renderer_fwd_loop");
+}
+
+int renderer_backward_loop(const LpRendererArgs& a, hipStream_t stream) {
+  const unsigned nb = loop_blocks(a);
+  if (nb == 0) return LP_OK;
+  const LoopParams p = loop_params(a);
+  const size_t lds = loop_lds_bytes(p, true);
+  const bool tg = a.color_grid.n_grids > 0;
+  const int NB = loop_nb(p.hid);
+  int rc = LP_OK;
+#define LP_LOOP_BWD(CV, NBV, TGV, MTV, MHV)                                                                   \
+  do {                                                                                                        \
+    if ((rc = loop_set_lds(renderer_bwd_loop<CV, NBV, TGV, MTV, MHV>, lds))) return rc;                       \
+    hipLaunchKernelGGL((renderer_bwd_loop<CV, NBV, TGV, MTV, MHV>), dim3(nb), dim3(256), lds, stream, a, p);  \
+  } while (0)
+  if (a.grid.channels == 16) {
+    if (NB == 2) LP_LOOP_BWD(16, 2, false, 2, 1);
+    else if (tg) LP_LOOP_BWD(16, 1, true, 1, LOOP_MAX_H);
+    else LP_LOOP_BWD(16, 1, false, LOOP_MAX_T, LOOP_MAX_H);
+  } else {
+    if (NB == 2) LP_LOOP_BWD(32, 2, false, 2, 1);
+    else if (tg) LP_LOOP_BWD(32, 1, true, 1, LOOP_MAX_H);
+    else LP_LOOP_BWD(32, 1, false, LOOP_MAX_T, LOOP_MAX_H);
+  }
+#undef LP_LOOP_BWD
+  return check_launch("renderer_bwd_loop");
+}
+
+}  // namespace lp

@@ -86,7 +86,9 @@ class _RayEmbeddingFunction(torch.autograd.Function):
 
 def _fused_embedding_supported(n_harmonics: int, out_dim: int) -> bool:
     # limits of lp_ray_embedding.hip (LDS staging of the backward)
-    return 0 <= n_harmonics <= 10 and 256 * (6 * n_harmonics + 3 + 1 + out_dim + 1) * 4 <= 150 * 1024
+    # (out_dim: check_ray_embed's LP_MAX_WIDTH; beyond it the PyTorch op chain runs, as the docstring promises)
+    return (0 <= n_harmonics <= 10 and 1 <= out_dim <= 128
+            and 256 * (6 * n_harmonics + 3 + 1 + out_dim + 1) * 4 <= 150 * 1024)
 
 
 class LightplaneRenderer(torch.nn.Module):
@@ -354,8 +356,9 @@ class LightplaneRenderer(torch.nn.Module):
             scaffold=scaffold, color_grid=color_feature_grid, grid_sizes=grid_sizes,
             color_grid_sizes=color_grid_sizes,
         )
-        if config.fused_module_ops:
+        if config.fused_module_ops and not bg.requires_grad:
             # background compositing and alpha inside the render kernel (and its backward): reference :552-561
+            # (a background colour that needs a gradient takes the op chain below: the kernels do not produce one)
             ray_length, _, feature, alpha = _render(r, feature_grid, self.get_decoder_params(),
                                                     bg_color=bg.to(torch.float32), alpha_mode=2 if return_log_t else 1, **kw)
             return ray_length, alpha, feature

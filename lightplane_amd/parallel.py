@@ -25,6 +25,11 @@ import torch.distributed as dist
 BUCKET_BYTES = 64 << 20
 #: above this size use reduce-scatter + all-gather explicitly (uses all 7 xGMI links of a GPU)
 RS_AG_BYTES = 256 << 20
+#: gradients of replicated tensors of at least this size are reduced IN PLACE, in the buffer autograd hands to the
+#: all-reduce node, instead of in a private clone (cfg 5: the 2.15 GB gradient of the 256^3 x 32 grid on a 19 GB peak).
+#: Such a gradient was written by this package's backward kernels into a buffer of its own; what an in-place reduce
+#: changes is that a hook / retain_grad() on the replicated view sees the all-rank sum instead of the local partial sum.
+INPLACE_GRAD_BYTES = RS_AG_BYTES
 
 
 def is_distributed(process_group=None) -> bool:
@@ -44,10 +49,18 @@ def shard_rays(rays, process_group=None):
     return rays.shard(dist.get_rank(process_group), dist.get_world_size(process_group))
 
 
-def _big_allreduce_(t: torch.Tensor, process_group) -> None:
+def _big_allreduce_(t: torch.Tensor, process_group, reduce_scatter=None, all_gather=None) -> None:
     """reduce-scatter + all-gather on a flat tensor, in place and without a padded copy: the part divisible by the
     world size goes through the two collectives (every rank reduces 1/world of it over all its xGMI links), the
-    remainder (< world elements) through a plain all-reduce."""
+    remainder (< world elements) through a plain all-reduce.
+
+    ``reduce_scatter(out_shard, inp, group)`` / ``all_gather(out, in_shard, group)`` default to the torch.distributed
+    tensor collectives; they are parameters so that the view / tail arithmetic can be exercised with other
+    implementations (tests/test_host_logic.py runs it on gloo with the native ones and with an all-reduce emulation)."""
+    if reduce_scatter is None:
+        reduce_scatter = lambda out, inp, group: dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group)  # noqa: E731
+    if all_gather is None:
+        all_gather = lambda out, inp, group: dist.all_gather_into_tensor(out, inp, group=group)  # noqa: E731
     ws = dist.get_world_size(process_group)
     rank = dist.get_rank(process_group)
     flat = t.view(-1)
@@ -56,8 +69,8 @@ def _big_allreduce_(t: torch.Tensor, process_group) -> None:
     if per > 0:
         head = flat[: per * ws]
         shard = head[rank * per : (rank + 1) * per]  # a view: the reduced shard lands where it belongs
-        dist.reduce_scatter_tensor(shard, head, op=dist.ReduceOp.SUM, group=process_group)
-        dist.all_gather_into_tensor(head, shard, group=process_group)
+        reduce_scatter(shard, head, process_group)
+        all_gather(head, shard, process_group)
     if per * ws != n:
         dist.all_reduce(flat[per * ws :], op=dist.ReduceOp.SUM, group=process_group)
 
@@ -70,13 +83,16 @@ def _coalesced_all_reduce_(tensors: List[torch.Tensor], process_group, async_op:
     backend = dist.get_backend(process_group)
     cm = getattr(dist.distributed_c10d, "_coalescing_manager", None)
     if backend == "nccl" and cm is not None and tensors[0].is_cuda:
-        try:
-            with cm(group=process_group, device=tensors[0].device, async_ops=async_op) as handle:
+        try:  # only the call that builds the context may fail softly (private API, its signature has moved before); an
+            # error INSIDE the group call must surface -- retrying tensor by tensor would sum some of them twice
+            group_call = cm(group=process_group, device=tensors[0].device, async_ops=async_op)
+        except TypeError:
+            group_call = None
+        if group_call is not None:
+            with group_call as handle:
                 for t in tensors:
                     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group)
             return [handle] if async_op else [None]
-        except (TypeError, RuntimeError):  # private API moved: keep working, one collective per tensor
-            pass
     return [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group, async_op=async_op) for t in tensors]
 
 
@@ -95,7 +111,7 @@ def allreduce_sum_(tensors: Sequence[Optional[torch.Tensor]], process_group=None
     for t in tensors:
         assert t.is_contiguous(), "all-reduce works in place: tensors have to be contiguous"
         nbytes = t.numel() * t.element_size()
-        if nbytes >= RS_AG_BYTES and _supports_rs(t):
+        if nbytes >= RS_AG_BYTES and _supports_rs(t, process_group):
             _big_allreduce_(t, process_group)
         elif nbytes <= BUCKET_BYTES:
             small.append(t)
@@ -106,9 +122,10 @@ def allreduce_sum_(tensors: Sequence[Optional[torch.Tensor]], process_group=None
     return [w for w in works if w is not None] if async_op else []
 
 
-def _supports_rs(t: torch.Tensor) -> bool:
-    # gloo has no reduce_scatter_tensor; keep the CPU test path on plain all_reduce
-    return t.is_cuda and dist.get_backend() == "nccl"
+def _supports_rs(t: torch.Tensor, process_group=None) -> bool:
+    # the backend of THIS group decides (a gloo sub-group under an nccl default group, or the other way round); the
+    # explicit two-step path only pays on RCCL / xGMI, every other backend keeps its plain all_reduce
+    return t.is_cuda and dist.get_backend(process_group) == "nccl"
 
 
 class _AllReduceGrad(torch.autograd.Function):
@@ -125,8 +142,16 @@ class _AllReduceGrad(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        # never reduce into the buffers autograd handed us (they may be shared with hooks / retain_grad): own copies
-        grads = [None if g is None else g.clone(memory_format=torch.contiguous_format) for g in grads]
+        # never reduce into the buffers autograd handed us (they may be shared with hooks / retain_grad): own copies --
+        # except for gradients of INPLACE_GRAD_BYTES or more, where the clone would double a multi-GB buffer
+        def own(g):
+            if g is None:
+                return None
+            if g.is_contiguous() and g.numel() * g.element_size() >= INPLACE_GRAD_BYTES:
+                return g
+            return g.clone(memory_format=torch.contiguous_format)
+
+        grads = [own(g) for g in grads]
         # Synchronous on the STREAM only (the host does not block).  It cannot be deferred past this node: autograd
         # accumulates the returned tensors into .grad right away, on this stream.  Overlap with the ray-embedding
         # backward comes from the node order instead: wrap the replicated tensors BEFORE the module computes the ray

@@ -237,7 +237,9 @@ class LightplaneFunction(torch.autograd.Function):
         # The forward's argument block is re-used: shapes, decoder layout and march are already in it.  Only the pointers
         # are taken again from the saved tensors (they are the forward's tensors unless a saved-tensor hook -- CPU
         # offloading, checkpointing -- unpacked them into new storage).
-        a = ctx.args
+        # (a private copy of the block: backward calls through one graph may overlap -- multithreaded autograd with
+        # retain_graph -- and must not patch each other's pointers)
+        a = type(ctx.args).from_buffer_copy(ctx.args)
         r = a.rays
         r.directions, r.origins, r.grid_idx = _lib.ptr(directions), _lib.ptr(origins), _lib.ptr(grid_idx)
         r.near_t, r.far_t, r.encoding = _lib.ptr(near), _lib.ptr(far), _lib.ptr(encoding)
@@ -256,7 +258,6 @@ class LightplaneFunction(torch.autograd.Function):
         g_nlt = None if g_nlt is None else g_nlt.contiguous()
         g_feat = None if g_feat is None else g_feat.contiguous()
         a.grad_ray_length, a.grad_neg_log_t, a.grad_feature = _lib.ptr(g_len), _lib.ptr(g_nlt), _lib.ptr(g_feat)
-        # (the block may be re-used by a second backward through the same graph: every gradient field is assigned)
         g_alpha = g_alpha.contiguous() if (cfg.alpha_mode and g_alpha is not None) else None
         a.grad_alpha = _lib.ptr(g_alpha)
         # the kernels scatter into every grid of a list or into none: allocate all buffers if any grid needs one

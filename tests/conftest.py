@@ -15,3 +15,24 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(REPO, "tests", "golden")
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Every use of the ReLU-flip allowance (tests/test_gpu_parity.py assert_grad_close) is reported: which tensor, how many
+    entries missed the 1e-4 bar, how many of those the fp64 oracle explains, the worst miss."""
+    try:
+        from tests.test_gpu_parity import FLIP_EVENTS
+    except Exception:
+        return
+    if not FLIP_EVENTS:
+        return
+    terminalreporter.write_sep("-", f"ReLU-flip allowance taken {len(FLIP_EVENTS)} time(s)")
+    for e in FLIP_EVENTS:
+        terminalreporter.write_line(
+            f"flip-allowance {e['name']}: {e['n_off']} entries above {e['tol']:g} ({e['explained']} agree with the fp64 oracle, "
+            f"{e['unexplained']} unexplained <= {e['allowed']} allowed), worst {e['worst']:.2e}, rel L2 {e['l2']:.2e}")
+    out = os.path.join(REPO, "gpurun_out")
+    if os.path.isdir(out):
+        import json
+        with open(os.path.join(out, "flip_allowance.json"), "w") as f:
+            json.dump(FLIP_EVENTS, f, indent=1)

@@ -101,6 +101,40 @@ def main():
         close("mlp-splatter: grad_input_grid", a, b)
     close("mlp-splatter: grad_encoding (local shard)", e2, e1[lo:hi])
 
+    # ---------------- joint Splatter -> Renderer (BASELINE configs[4]): every rank splats its share of the rays into the
+    # grid (sum over ranks, then normalise), then renders its share of the camera rays from the replicated grid; end to end
+    # backward: the grid gradient is summed over the ranks before it enters the (local) splat backward
+    from tests.synth import pinhole_rays, random_decoder
+    gen = torch.Generator().manual_seed(77)
+    sizes = [[1, 12, 10, 14, 16]]
+    srays = pinhole_rays(20, 24, gen=gen, azimuth_deg=40.0, elevation_deg=20.0)
+    srays.encoding = torch.rand(srays.n_rays, 16, generator=gen)
+    cam = pinhole_rays(16, 24, enc_dim=32, gen=gen, azimuth_deg=-60.0, elevation_deg=35.0)
+    jdec = random_decoder(gen, 2, 2, 2, 16, 32, 3, std=0.2)
+    jup = [torch.randn(cam.n_rays, generator=gen).to(dev), torch.randn(cam.n_rays, generator=gen).to(dev),
+           torch.randn(cam.n_rays, 3, generator=gen).to(dev)]
+
+    def joint(sr, cr, ups, group):
+        r = sr.to(dev)
+        r.encoding = r.encoding.clone().requires_grad_(True)
+        params = jdec.mlp_params.to(dev).clone().requires_grad_(True)
+        grid = lp.lightplane_splatter(r, sizes, num_samples=20, return_list=False, process_group=group)
+        g, p = (grid, params) if group is None else parallel.replicate_with_grad_allreduce([grid, params], group)
+        hdec = lp.DecoderParams(p, jdec.n_hidden_trunk, jdec.n_hidden_opacity, jdec.n_hidden_color, 3)
+        c = cr.to(dev)
+        out = lp.lightplane_renderer(c, g, hdec, num_samples=24, gain=2.0, grid_sizes=sizes)
+        ((out[0] * ups[0]).sum() + (out[1] * ups[1]).sum() + (out[2] * ups[2]).sum()).backward()
+        return out, params.grad, r.encoding.grad
+
+    o1, p1, e1 = joint(srays, cam, jup, None)
+    slo, shi = parallel.shard_bounds(srays.n_rays, rank, world)
+    clo, chi = parallel.shard_bounds(cam.n_rays, rank, world)
+    o2, p2, e2 = joint(srays[slo:shi], cam[clo:chi], [u[clo:chi] for u in jup], pg)
+    for a, b in zip(o2, o1):
+        close("joint: render output (local shard)", a, b[clo:chi])
+    close("joint: grad_mlp_params", p2, p1)
+    close("joint: grad of the splatted features (local shard)", e2, e1[slo:shi], tol=5e-5)
+
     dist.barrier()
     if rank == 0:
         print("DIST_OK", flush=True)

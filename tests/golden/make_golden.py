@@ -154,6 +154,23 @@ def make_module_splatter():
     return rec
 
 
+def make_baseline_cfg1():
+    """BASELINE.json configs[0] exactly (tests/synth.py baseline_cfg1): outputs and gradients only -- the inputs come from
+    the seeded builder; a few input checksums make a generator drift visible."""
+    from tests.synth import baseline_cfg1
+
+    class _Case:
+        def build(self):
+            return baseline_cfg1()
+
+    rec = make_renderer(_Case())
+    keep = {k: v for k, v in rec.items() if k in ("ray_length", "neg_log_t", "feature", "grad_mlp_params", "grad_encoding",
+                                                  "grad_grid0")}
+    keep["checksum_inputs"] = np.array([rec["grid0"].astype(np.float64).sum(), rec["directions"].astype(np.float64).sum(),
+                                        rec["encoding"].astype(np.float64).sum(), rec["mlp_params"].astype(np.float64).sum()])
+    return keep
+
+
 def make_randn():
     rec = {}
     for seed in (0, 5, 123456):
@@ -179,6 +196,10 @@ def main():
     if only == {"modules"}:
         make_modules()
         return
+    if only == {"baseline_cfg1"}:
+        np.savez_compressed(os.path.join(HERE, "renderer__baseline_cfg1.npz"), **make_baseline_cfg1())
+        print("renderer baseline_cfg1")
+        return
     if only:
         for case in RENDERER_CASES:
             if case.name in only:
@@ -198,6 +219,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"splatter__{case.name}.npz"), **rec)
         print("splatter", case.name, rec["out0"].shape)
     np.savez_compressed(os.path.join(HERE, "randn.npz"), **make_randn())
+    np.savez_compressed(os.path.join(HERE, "renderer__baseline_cfg1.npz"), **make_baseline_cfg1())
     make_modules()
     print("done")
 

@@ -260,6 +260,17 @@ RENDERER_CASES = [
                  contract=True, noise_sigma=0.5, noise_seed=77, n_rays=40),
     RendererCase("colorgrid_c32_mixed", seed=26, grid_base=(1, 6, 5, 4, 32), is_triplane=True,
                  separate_color_grid=True, n_layers=(0, 2, 1), mask_oob=True, n_rays=70, num_samples=21),
+    # deep decoders: the layer counts of the reference's own sweep (tests/test_renderer_with_autograd.py:49-51: 2 or 4
+    # layers per MLP), hidden widths 16 / 32 / 64, up to 16 colour channels -- the layer-looped MFMA family
+    RendererCase("triplane_deep444", seed=27, is_triplane=True, n_layers=(4, 4, 4), n_rays=70, num_samples=21),
+    RendererCase("voxel_deep342_h64_c32", seed=28, grid_base=(2, 5, 6, 7, 32), hidden=64, n_layers=(3, 4, 2), n_rays=40,
+                 param_std=0.15, scaffold_size=(6, 4, 5), gain=3.0),
+    RendererCase("colorgrid_deep044", seed=29, is_triplane=True, separate_color_grid=True, n_layers=(0, 4, 4), n_rays=40,
+                 mask_oob=True, num_samples_inf=2),
+    RendererCase("color16_deep323_h16", seed=30, hidden=16, color_chn=16, n_layers=(3, 2, 3), n_rays=33, param_std=0.3,
+                 noise_sigma=0.5, noise_seed=99, contract=True, num_samples_inf=3),
+    RendererCase("triplane_242_c32_color4", seed=31, is_triplane=True, grid_base=(2, 6, 5, 4, 32), n_layers=(2, 4, 2),
+                 color_chn=4, n_rays=130, num_samples=33),
 ]
 
 SPLATTER_CASES = [
@@ -277,7 +288,48 @@ SPLATTER_CASES = [
                  is_triplane=True, in_triplane=True, mask_oob=True, num_samples_inf=2, n_rays=40),
     SplatterCase("mlp2_voxel_in16_out32", seed=9, use_mlp=True, n_layers=2, feat_dim=16, in_base=(2, 4, 6, 5, 16),
                  contract=True, num_samples_inf=3, n_rays=33),
+    # the MLP shapes of the reference's own sweep (tests/test_splatter_with_autograd.py:49-51: hidden 64, 3-4 layers,
+    # feature width 32 / 64) and a 64-channel plain splat (the reference's speed benchmark shape)
+    SplatterCase("mlp3_voxel_h64_f32", seed=10, use_mlp=True, n_layers=3, hidden=64, feat_dim=32, n_rays=70, num_samples=11),
+    SplatterCase("mlp4_voxel_h64_f64_c16", seed=11, use_mlp=True, n_layers=4, hidden=64, feat_dim=64, out_base=(2, 6, 5, 7, 16),
+                 num_samples_inf=2, contract=True, n_rays=40),
+    SplatterCase("voxel_c64", seed=12, out_base=(2, 6, 5, 7, 64), n_rays=70, num_samples=11, mask_oob=True),
+    SplatterCase("triplane_c64", seed=13, out_base=(1, 6, 5, 7, 64), is_triplane=True, n_rays=40),
 ]
+
+
+def baseline_cfg1(seed=0):
+    """BASELINE.json configs[0] (SURVEY 8(d) cfg 1) exactly: 1 000 random rays (the reference's ``random_rays`` recipe with
+    near 0.1 / far 3.0), one 32^3 x 16-channel voxel grid, 64 samples, 2/2/2-layer x 32-hidden decoder, 3 colour channels.
+    Same dictionary as ``RendererCase.build``.  Used by bench.py's ``cpu_baseline`` leg, by the golden generator
+    (tests/golden/renderer__baseline_cfg1.npz) and by the GPU parity test of this configuration."""
+    gen = torch.Generator().manual_seed(seed)
+    sizes = [[1, 32, 32, 32, 16]]
+    grids = random_grids(gen, sizes)
+    dec = random_decoder(gen, 2, 2, 2, 16, 32, 3, std=0.15)
+    rays = random_rays(gen, 1000, 1, 32)
+    rays.near = torch.full((1000,), 0.1)
+    rays.far = torch.full((1000,), 3.0)
+    cfg = dict(num_samples=64, gain=1.0, num_samples_inf=0, mask_out_of_bounds_samples=False, contract_coords=False,
+               inject_noise_sigma=0.0, inject_noise_seed=0)
+    up = (torch.randn(1000, generator=gen), torch.randn(1000, generator=gen), torch.randn(1000, 3, generator=gen))
+    return dict(rays=rays, grids=grids, color_grids=None, decoder=dec, scaffold=None, cfg=cfg, sizes=sizes, upstream=up)
+
+
+def cfg2_inputs(height=256, width=256, channels=16, grid=64, num_samples=128, rank=0):
+    """BASELINE.json configs[1] (cfg 2) as bench.py builds it: pinhole image, canonical triplane grid^2 x channels, 2/2/2 x 32
+    decoder with N(0, 0.15) parameters, 32-wide ray encoding, random upstream gradients."""
+    gen = torch.Generator().manual_seed(0)
+    sizes = grid_sizes_for((1, grid, grid, grid, channels), True)
+    grids = random_grids(gen, sizes)
+    dec = random_decoder(gen, 2, 2, 2, channels, 32, 3, std=0.15)
+    gen_r = torch.Generator().manual_seed(100 + rank)
+    rays = pinhole_rays(height, width, enc_dim=32, gen=gen_r)
+    n = height * width
+    up = (torch.randn(n, generator=gen_r), torch.randn(n, generator=gen_r), torch.randn(n, 3, generator=gen_r))
+    cfg = dict(num_samples=num_samples, gain=1.0, num_samples_inf=0, mask_out_of_bounds_samples=False, contract_coords=False,
+               inject_noise_sigma=0.0, inject_noise_seed=0)
+    return dict(rays=rays, grids=grids, color_grids=None, decoder=dec, scaffold=None, cfg=cfg, sizes=sizes, upstream=up)
 
 
 # ---- Module level (SURVEY row a10): configurations of the reference's LightplaneRenderer module whose outputs and

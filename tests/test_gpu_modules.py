@@ -235,6 +235,25 @@ def test_two_rank_ray_shards_equal_single_process():
     assert r.returncode == 0 and "DIST_OK" in out, out[-4000:]
 
 
+def test_bench_cfg5_two_ranks_on_one_gpu():
+    """bench.py --workload cfg5 (splat shard -> sum over ranks -> normalise -> ray-sharded render -> gradient all-reduce ->
+    splat backward) with two gloo ranks on this GPU, at toy sizes: the line the driver's 2 / 4 / 8-GPU runs would print."""
+    import json
+    port = 29900 + (os.getpid() % 90)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CFG5_VIEWS="2", CFG5_IMG="48", CFG5_GRID="32",
+               CFG5_ROWS="8", CFG5_S="32")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg5", "--backend",
+                        "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode()
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, out[-4000:]
+    res = json.loads(lines[-1])
+    assert res["n_gpus"] == 2 and res["value"] > 0 and "cfg5" in res["config"]["workload"]
+    assert res["config"]["rays_per_gpu"] == 2 * 48 * 48 + 8 * 1920
+
+
 def test_backward_with_offloaded_saved_tensors():
     """Saved-tensor hooks (CPU offloading, checkpointing) hand the backward NEW tensors: the argument block the backward
     re-uses from the forward must take its pointers from them, not from the forward's addresses."""

@@ -40,6 +40,7 @@ def _assert_close(name, got, want, tol=REL_TOL):
 
 
 FLIP_SAMPLES = 4
+FLIP_EVENTS = []  # one record per use of the flip allowance; printed by conftest.pytest_terminal_summary
 
 
 def rel_l2(got, want):
@@ -48,8 +49,13 @@ def rel_l2(got, want):
     return (got - want).norm().item() / max(want.norm().item(), 1e-30)
 
 
-def assert_grad_close(name, got, want, entries_per_sample, tol=1e-4):
-    """Gradient tensor vs the fp32 oracle: the north_star bar, or the ReLU-flip allowance described in tests/test_gpu_coherent.py's docstring."""
+def assert_grad_close(name, got, want, entries_per_sample, tol=1e-4, want64=None, flip_samples=FLIP_SAMPLES):
+    """Gradient tensor vs the fp32 oracle: the north_star bar, or the ReLU-flip allowance described in
+    tests/test_gpu_coherent.py's docstring.  Every use of the allowance is recorded and printed.
+
+    ``want64`` (the same oracle run in fp64): an entry that misses the bar against the fp32 oracle but meets it against the
+    fp64 one is EXPLAINED -- the fp32 oracle took the other branch of a ReLU there, the kernel the exact one -- and does not
+    count; only entries that miss both count against ``flip_samples`` samples' worth of entries."""
     want = torch.as_tensor(np.asarray(want))
     g = got.detach().double().cpu()
     w = want.double()
@@ -61,10 +67,21 @@ def assert_grad_close(name, got, want, entries_per_sample, tol=1e-4):
     if worst <= tol:
         assert l2 <= tol, f"{name}: relative L2 error {l2:.3e} > {tol} (max-norm {worst:.3e})"
         return
-    n_off = int((err > tol).sum())
-    ok = n_off <= FLIP_SAMPLES * entries_per_sample and worst <= 5e-2 and l2 <= 1e-3
-    assert ok, (f"{name}: max err / scale = {worst:.3e} > {tol} and not a ReLU-flip pattern: {n_off} entries above the bar "
-                f"(allowed {FLIP_SAMPLES * entries_per_sample}), relative L2 {l2:.3e} (allowed 1e-3)")
+    off = err > tol
+    n_off = int(off.sum())
+    unexplained = off
+    if want64 is not None:
+        w64 = torch.as_tensor(np.asarray(want64)).double()
+        unexplained = off & ((g - w64).abs() / scale > tol)
+    n_un = int(unexplained.sum())
+    allowed = flip_samples * entries_per_sample
+    FLIP_EVENTS.append(dict(name=name, tol=tol, n_off=n_off, explained=n_off - n_un, unexplained=n_un, allowed=allowed,
+                            worst=worst, l2=l2))
+    print(f"flip-allowance {name}: {n_off} entries above {tol:g}, {n_off - n_un} explained by the fp64 oracle, worst {worst:.3e}, "
+          f"rel L2 {l2:.3e}")
+    ok = n_un <= allowed and worst <= 5e-2 and l2 <= 1e-3
+    assert ok, (f"{name}: max err / scale = {worst:.3e} > {tol} and not a ReLU-flip pattern: {n_un} entries above the bar "
+                f"({n_off - n_un} more explained by the fp64 oracle; allowed {allowed}), relative L2 {l2:.3e} (allowed 1e-3)")
 
 
 def _rays_to(rays, dev, requires_grad=False):

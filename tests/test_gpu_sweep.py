@@ -15,8 +15,8 @@ import lightplane_amd as lp
 from lightplane_amd import _lib
 from oracle import lightplane_oracle as O
 from tests.synth import RendererCase, SplatterCase
-from tests.test_gpu_parity import (_dev, _rel_err, run_hip_mlp_splatter, run_hip_renderer, run_hip_splatter,
-                                   run_oracle_renderer)
+from tests.test_gpu_parity import (_dev, _rel_err, assert_grad_close, run_hip_mlp_splatter, run_hip_renderer,
+                                   run_hip_splatter, run_oracle_renderer)
 
 pytestmark = pytest.mark.gpu
 
@@ -24,15 +24,29 @@ F64 = torch.float64
 TOL = 2e-4
 
 
-def _check(name, got, want64, ref32=None):
-    """Error against the fp64 oracle: within TOL, or -- where the reference's own fp32 path is less accurate than
-    that (beyond-far samples: interval lengths ~1e5 make its gradients cancel catastrophically, 1e-3 .. 6e-3 on some
-    seeds; index arithmetic on a cell boundary) -- within 3x the fp32 oracle's own error."""
+def _check(name, got, want64, ref32=None, inf=False, grad_entries=None):
+    """Error against the fp64 oracle within TOL, or against the fp32 oracle -- the reference's own arithmetic: the cell a
+    sample falls into, the scaffold cell it looks up and the out-of-bounds mask are DEFINED by fp32 coordinate arithmetic,
+    and the fp64 run decides differently for a sample on a boundary -- within north_star's 1e-4.  Two documented escapes,
+    both confined:
+    * ``inf`` (cases with beyond-far samples only: interval lengths ~1e5 make the reference's own fp32 gradients cancel
+      catastrophically, 1e-3 .. 6e-3 on some seeds): within 3x the fp32 oracle's own error;
+    * gradient tensors (``grad_entries`` = entries one sample touches): the ReLU-flip allowance of assert_grad_close --
+      entries that miss the fp64 oracle but meet the fp32 one are explained (the kernel took the fp32 oracle's branch),
+      the rest is counted, bounded and printed."""
     e = _rel_err(got, want64.detach().numpy())
-    bound = TOL
-    if ref32 is not None:
+    if e <= TOL:
+        return
+    if ref32 is not None and _rel_err(got, ref32.detach().numpy()) <= 1e-4:
+        return
+    if inf and ref32 is not None:
         bound = max(TOL, 3.0 * _rel_err(ref32, want64.detach().numpy()))
-    assert e <= bound, f"{name}: max err / scale = {e:.3e} > {bound:.3e}"
+        assert e <= bound, f"{name}: max err / scale = {e:.3e} > {bound:.3e}"
+        return
+    if grad_entries is not None and ref32 is not None:
+        assert_grad_close(name, got, want64.detach().numpy(), grad_entries, tol=TOL, want64=ref32.detach().numpy())
+        return
+    assert e <= TOL, f"{name}: max err / scale = {e:.3e} > {TOL:.3e}"
 
 
 def _rays64(rays):
@@ -97,15 +111,25 @@ def test_renderer_sweep(i):
     out, gp, ge, gg, gc = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO)
     o_out, o_gp, o_ge, o_gg, o_gc = run_oracle_renderer64(d)
     r_out, r_gp, r_ge, r_gg, r_gc = run_oracle_renderer(d)  # the reference's fp32 arithmetic
+    _check_renderer_all(case, d, (out, gp, ge, gg, gc), (o_out, o_gp, o_ge, o_gg, o_gc), (r_out, r_gp, r_ge, r_gg, r_gc))
+
+
+def _check_renderer_all(case, d, got, o64, r32):
+    out, gp, ge, gg, gc = got
+    o_out, o_gp, o_ge, o_gg, o_gc = o64
+    r_out, r_gp, r_ge, r_gg, r_gc = r32
+    inf = case.num_samples_inf > 0
+    C = d["grids"][0].shape[-1]
     for nm, a, b, c in (("ray_length", out[0], o_out[0], r_out[0]), ("neg_log_t", out[1], o_out[1], r_out[1]),
-                        ("feature", out[2], o_out[2], r_out[2]), ("grad_mlp_params", gp, o_gp, r_gp),
-                        ("grad_encoding", ge, o_ge, r_ge)):
-        _check(f"{case}: {nm}", a, b, c)
+                        ("feature", out[2], o_out[2], r_out[2])):
+        _check(f"{case.name}: {nm}", a, b, c, inf=inf)
+    _check(f"{case.name}: grad_mlp_params", gp, o_gp, r_gp, inf=inf, grad_entries=4 * max(case.hidden, C))
+    _check(f"{case.name}: grad_encoding", ge, o_ge, r_ge, inf=inf, grad_entries=ge.shape[1])
     for k, (a, b, c) in enumerate(zip(gg, o_gg, r_gg)):
-        _check(f"{case}: grad_grid{k}", a, b, c)
+        _check(f"{case.name}: grad_grid{k}", a, b, c, inf=inf, grad_entries=8 * C)
     if gc is not None:
         for k, (a, b, c) in enumerate(zip(gc, o_gc, r_gc)):
-            _check(f"{case}: grad_color_grid{k}", a, b, c)
+            _check(f"{case.name}: grad_color_grid{k}", a, b, c, inf=inf, grad_entries=8 * C)
 
 
 def _segmented_case(i):
@@ -134,12 +158,7 @@ def test_renderer_segmented_sweep(i):
     out, gp, ge, gg, _ = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO)
     o_out, o_gp, o_ge, o_gg, _ = run_oracle_renderer64(d)
     r_out, r_gp, r_ge, r_gg, _ = run_oracle_renderer(d)
-    for nm, a, b, c in (("ray_length", out[0], o_out[0], r_out[0]), ("neg_log_t", out[1], o_out[1], r_out[1]),
-                        ("feature", out[2], o_out[2], r_out[2]), ("grad_mlp_params", gp, o_gp, r_gp),
-                        ("grad_encoding", ge, o_ge, r_ge)):
-        _check(f"{case}: {nm}", a, b, c)
-    for k, (a, b, c) in enumerate(zip(gg, o_gg, r_gg)):
-        _check(f"{case}: grad_grid{k}", a, b, c)
+    _check_renderer_all(case, d, (out, gp, ge, gg, None), (o_out, o_gp, o_ge, o_gg, None), (r_out, r_gp, r_ge, r_gg, None))
 
 
 def _splatter_case(i):

@@ -261,10 +261,44 @@ def _gloo_worker(rank, world_size, port, ret):
         ((gv.sum() + 2 * pv.sum()) * float(rank + 1)).backward()
         assert torch.allclose(g.grad, torch.full((7, 3), 3.0)) and torch.allclose(p.grad, torch.full((4,), 6.0))
         assert torch.allclose(seen[0], torch.full((7, 3), float(rank + 1)))
-        # odd-sized payload through the reduce-scatter path's bookkeeping is GPU-only; the flat path handles any size
         odd = torch.full((11,), float(rank + 1))
         parallel.allreduce_sum_([odd])
         assert torch.allclose(odd, torch.full((11,), 3.0))
+        # the reduce-scatter + all-gather path (payloads >= 256 MB on RCCL): its in-place view / tail arithmetic for
+        # n % world in {0, 1, world - 1} and n < world, with gloo's own tensor collectives and with an emulation of the
+        # reduce-scatter by an all-reduce (what a backend without reduce_scatter_tensor would be given)
+        def rs_emulated(out, inp, group):
+            tmp = inp.clone()
+            dist.all_reduce(tmp, group=group)
+            per = out.numel()
+            out.copy_(tmp[dist.get_rank(group) * per:(dist.get_rank(group) + 1) * per])
+
+        for n in (0, 1, world_size, 4 * world_size, 4 * world_size + 1, 5 * world_size - 1, 1000003):
+            for rs in (None, rs_emulated):
+                base = torch.arange(n, dtype=torch.float64) * 0.25
+                t = (base * (rank + 1)).reshape(-1)
+                parallel._big_allreduce_(t, None, reduce_scatter=rs)
+                want = base * sum(r + 1 for r in range(world_size))
+                assert torch.equal(t, want), (n, rs is None)
+        # ... and through allreduce_sum_ when the thresholds select it (the backend check is per process group)
+        old = parallel.RS_AG_BYTES, parallel._supports_rs
+        parallel.RS_AG_BYTES, parallel._supports_rs = 64, (lambda t, pg=None: dist.get_backend(pg) == "gloo")
+        try:
+            big = torch.full((3, 7), float(rank + 1))
+            parallel.allreduce_sum_([big, None, torch.full((2,), 1.0)])
+            assert torch.allclose(big, torch.full((3, 7), 3.0))
+        finally:
+            parallel.RS_AG_BYTES, parallel._supports_rs = old
+        # large gradients of replicated tensors are reduced in place (no clone): the hook sees the reduced buffer
+        old_inplace = parallel.INPLACE_GRAD_BYTES
+        parallel.INPLACE_GRAD_BYTES = 16
+        try:
+            g2 = torch.ones(9, 2, requires_grad=True)
+            (gv2,) = parallel.replicate_with_grad_allreduce([g2])
+            (gv2.sum() * float(rank + 1)).backward()
+            assert torch.allclose(g2.grad, torch.full((9, 2), 3.0))
+        finally:
+            parallel.INPLACE_GRAD_BYTES = old_inplace
         ret[rank] = True
     finally:
         dist.destroy_process_group()

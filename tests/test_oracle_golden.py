@@ -83,6 +83,27 @@ def test_splatter_oracle_matches_reference(case, golden_dir):
             _close(f"grad_in_grid{i}", g.grad, z[f"grad_in_grid{i}"])
 
 
+def test_baseline_cfg1_oracle_matches_reference(golden_dir):
+    """BASELINE.json configs[0] exactly (1 000 random rays, voxel 32^3 x 16, 64 samples, 2/2/2 x 32): the oracle against
+    the outputs / gradients the reference's naive renderer produced for it (tests/golden/make_golden.py baseline_cfg1)."""
+    from tests.synth import baseline_cfg1
+    z = np.load(os.path.join(golden_dir, "renderer__baseline_cfg1.npz"))
+    d = baseline_cfg1()
+    rays, dec = d["rays"], d["decoder"]
+    sums = [d["grids"][0].double().sum().item(), rays.directions.double().sum().item(), rays.encoding.double().sum().item(),
+            dec.mlp_params.double().sum().item()]
+    assert np.allclose(sums, z["checksum_inputs"], rtol=0, atol=1e-9), "seeded inputs drifted from the golden file"
+    rays.encoding = rays.encoding.clone().requires_grad_(True)
+    dec.mlp_params = dec.mlp_params.clone().requires_grad_(True)
+    grids = [g.clone().requires_grad_(True) for g in d["grids"]]
+    out = O.lightplane_renderer_naive(rays, grids, dec, **d["cfg"])
+    g_len, g_nlt, g_feat = d["upstream"]
+    ((out[0] * g_len).sum() + (out[1] * g_nlt).sum() + (out[2] * g_feat).sum()).backward()
+    for nm, a in (("ray_length", out[0]), ("neg_log_t", out[1]), ("feature", out[2]), ("grad_mlp_params", dec.mlp_params.grad),
+                  ("grad_encoding", rays.encoding.grad), ("grad_grid0", grids[0].grad)):
+        _close(nm, a.detach(), z[nm])
+
+
 def test_hash_rng_matches_reference(golden_dir):
     z = np.load(os.path.join(golden_dir, "randn.npz"))
     x1, x2 = torch.from_numpy(z["x1"]), torch.from_numpy(z["x2"])
