@@ -2,6 +2,7 @@
 // Argument validation, kernel selection and error reporting; no device code here.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "lp_host.h"
 #include "lp_mfma_common.h"
@@ -225,13 +226,20 @@ int lp_abi_sizeof(int which) {
   }
 }
 
-// kernel selection: width-32 MFMA family, width-64 MFMA family, else the shape-generic kernel
+// kernel selection: 1 = width-32 MFMA family (tuned default shape + its flex subsets), 2 = width-64 MFMA family (2/2/2 layers),
+// 3 = layer-looped bf16x3 MFMA family (1-4 layers per MLP), 0 = the shape-generic kernel.  LP_LOOP=1 (developer knob, read
+// once): the layer-looped family wherever it applies, also for the shapes families 1 / 2 cover (A/B, test coverage).
 static int select_renderer(const LpRendererArgs& a, const char** why) {
   const char* w32 = "";
   const char* w64 = "";
+  const char* wl = "";
+  static const bool force_loop = getenv("LP_LOOP") != nullptr && atoi(getenv("LP_LOOP")) != 0;
+  const bool loop_ok = renderer_loop_supported(a, &wl) && renderer_loop_fits(a);
+  if (force_loop && loop_ok) return 3;
   if (renderer_mfma_supported(a, &w32)) return 1;
   if (renderer_mfma_wide_supported(a, &w64)) return 2;
-  *why = w32;
+  if (loop_ok) return 3;
+  *why = wl[0] ? wl : "weight images of this decoder exceed the 160 KB LDS";
   return 0;
 }
 
@@ -246,12 +254,22 @@ int lp_renderer_backward_segments(const LpRendererArgs* args) {
   const char* why = "";
   if (args->kernel == LP_KERNEL_GENERIC) return 1;
   const int fam = select_renderer(*args, &why);
-  return fam == 1 ? renderer_mfma_segments(*args) : fam == 2 ? renderer_mfma_wide_segments(*args) : 1;
+  return fam == 1 ? renderer_mfma_segments(*args) : fam == 2 ? renderer_mfma_wide_segments(*args) : 1;  // (family 3: one sweep)
+}
+
+// MLP-Splatter: 2 = [E,32,Cout] fp32-MFMA family, 3 = layer-looped bf16x3 family (2-4 layers, widths 16 / 32 / 64), 0 = generic.
+// LP_LOOP=1 (developer knob): the layer-looped family wherever it applies.
+static int splatter_mlp_family(const LpSplatterArgs& a) {
+  static const bool force_loop = getenv("LP_LOOP") != nullptr && atoi(getenv("LP_LOOP")) != 0;
+  const bool loop_ok = splatter_mlp_loop_supported(a);
+  if (force_loop && loop_ok) return 3;
+  if (splatter_mlp_mfma_supported(a)) return 2;
+  return loop_ok ? 3 : 0;
 }
 
 int lp_splatter_kernel_family(const LpSplatterArgs* args) {
   if (!args) return set_error(LP_ENULL, "args is NULL");
-  if (args->mlp.n_layers > 0) return splatter_mlp_mfma_supported(*args) ? 2 : 0;
+  if (args->mlp.n_layers > 0) return splatter_mlp_family(*args);
   const int C = args->out.channels;
   return ((C == 16 || C == 32) && args->out.n_rows < ((int64_t)1 << 31)) ? 1 : 0;
 }
@@ -288,6 +306,7 @@ int lp_renderer_forward(const LpRendererArgs* args, void* stream) {
     return set_error(LP_EUNSUPPORTED, "MFMA renderer kernel unavailable for this shape: %s", why);
   if (fam == 1 && a.kernel != LP_KERNEL_GENERIC) return renderer_forward_mfma(a, (hipStream_t)stream);
   if (fam == 2 && a.kernel != LP_KERNEL_GENERIC) return renderer_forward_mfma_wide(a, (hipStream_t)stream);
+  if (fam == 3 && a.kernel != LP_KERNEL_GENERIC) return renderer_forward_loop(a, (hipStream_t)stream);
   return renderer_forward_generic(a, (hipStream_t)stream);
 }
 
@@ -302,6 +321,7 @@ int lp_renderer_backward(const LpRendererArgs* args, void* stream) {
     return set_error(LP_EUNSUPPORTED, "MFMA renderer kernel unavailable for this shape: %s", why);
   if (fam == 1 && a.kernel != LP_KERNEL_GENERIC) return renderer_backward_mfma(a, (hipStream_t)stream);
   if (fam == 2 && a.kernel != LP_KERNEL_GENERIC) return renderer_backward_mfma_wide(a, (hipStream_t)stream);
+  if (fam == 3 && a.kernel != LP_KERNEL_GENERIC) return renderer_backward_loop(a, (hipStream_t)stream);
   return renderer_backward_generic(a, (hipStream_t)stream);
 }
 
@@ -335,10 +355,11 @@ int lp_splatter_forward(const LpSplatterArgs* args_, void* stream) {
   if (rc) return rc;
   const LpSplatterArgs* args = &a_;
   if (args->mlp.n_layers > 0) {
-    const bool fast = splatter_mlp_mfma_supported(*args);
-    if (args->kernel == LP_KERNEL_MFMA && !fast)
+    const int fam = splatter_mlp_family(*args);
+    if (args->kernel == LP_KERNEL_MFMA && fam == 0)
       return set_error(LP_EUNSUPPORTED, "MFMA MLP-splatter kernel unavailable for this shape");
-    if (fast && args->kernel != LP_KERNEL_GENERIC) return splatter_mlp_forward_mfma(*args, (hipStream_t)stream);
+    if (fam == 2 && args->kernel != LP_KERNEL_GENERIC) return splatter_mlp_forward_mfma(*args, (hipStream_t)stream);
+    if (fam == 3 && args->kernel != LP_KERNEL_GENERIC) return splatter_mlp_forward_loop(*args, (hipStream_t)stream);
     return splatter_mlp_forward_launch(*args, (hipStream_t)stream);
   }
   return splatter_forward_launch(*args, (hipStream_t)stream);
@@ -357,10 +378,11 @@ int lp_splatter_backward(const LpSplatterArgs* args_, void* stream) {
   if (rc) return rc;
   const LpSplatterArgs* args = &a_;
   if (args->mlp.n_layers > 0) {
-    const bool fast = splatter_mlp_mfma_supported(*args);
-    if (args->kernel == LP_KERNEL_MFMA && !fast)
+    const int fam = splatter_mlp_family(*args);
+    if (args->kernel == LP_KERNEL_MFMA && fam == 0)
       return set_error(LP_EUNSUPPORTED, "MFMA MLP-splatter kernel unavailable for this shape");
-    if (fast && args->kernel != LP_KERNEL_GENERIC) return splatter_mlp_backward_mfma(*args, (hipStream_t)stream);
+    if (fam == 2 && args->kernel != LP_KERNEL_GENERIC) return splatter_mlp_backward_mfma(*args, (hipStream_t)stream);
+    if (fam == 3 && args->kernel != LP_KERNEL_GENERIC) return splatter_mlp_backward_loop(*args, (hipStream_t)stream);
     return splatter_mlp_backward_launch(*args, (hipStream_t)stream);
   }
   return splatter_backward_launch(*args, (hipStream_t)stream);

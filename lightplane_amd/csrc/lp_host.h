@@ -28,6 +28,12 @@ bool renderer_mfma_wide_supported(const LpRendererArgs& a, const char** why);
 int renderer_forward_mfma_wide(const LpRendererArgs& a, hipStream_t stream);
 int renderer_backward_mfma_wide(const LpRendererArgs& a, hipStream_t stream);
 
+// layer-looped bf16x3 MFMA family (1-4 layers per MLP, hidden 16 / 32 / 64): lp_renderer_loop.hip
+bool renderer_loop_supported(const LpRendererArgs& a, const char** why);
+bool renderer_loop_fits(const LpRendererArgs& a);  // its weight images + tiles fit the 160 KB LDS
+int renderer_forward_loop(const LpRendererArgs& a, hipStream_t stream);
+int renderer_backward_loop(const LpRendererArgs& a, hipStream_t stream);
+
 // splatter: lp_splatter.hip
 int splatter_forward_launch(const LpSplatterArgs& a, hipStream_t stream);
 int splatter_backward_launch(const LpSplatterArgs& a, hipStream_t stream);
@@ -38,6 +44,10 @@ int splatter_mlp_backward_launch(const LpSplatterArgs& a, hipStream_t stream);
 bool splatter_mlp_mfma_supported(const LpSplatterArgs& a);
 int splatter_mlp_forward_mfma(const LpSplatterArgs& a, hipStream_t stream);
 int splatter_mlp_backward_mfma(const LpSplatterArgs& a, hipStream_t stream);
+// MLP-Splatter, layer-looped bf16x3 family (2-4 layers, widths 16 / 32 / 64): lp_splatter_mlp_loop.hip
+bool splatter_mlp_loop_supported(const LpSplatterArgs& a);
+int splatter_mlp_forward_loop(const LpSplatterArgs& a, hipStream_t stream);
+int splatter_mlp_backward_loop(const LpSplatterArgs& a, hipStream_t stream);
 int splatter_normalize_launch(float* feature, const float* weight, int64_t n_rows, int channels,
                               hipStream_t stream);
 // ray-direction embedding of the module front-end: lp_ray_embedding.hip

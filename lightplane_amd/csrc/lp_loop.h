@@ -1,0 +1,230 @@
+// lp_loop.h -- building blocks of the LAYER-LOOPED bf16x3 MFMA families (Renderer: lp_renderer_loop.hip, MLP-Splatter:
+// lp_splatter_mlp_loop.hip): one dense layer of any [rows_in x cols] shape up to 64 x 64 as 32 x 32 blocks of row-major limb
+// images in LDS, forward (transposed reads), dX (plain reads) and the workgroup-shared dW quadrants.
+// Lane mapping and arithmetic: lp_bf3.h / lp_renderer_mfma.hip.
+#pragma once
+#include "lp_bf3.h"
+#include "lp_mfma_common.h"
+
+namespace lp {
+
+typedef float f32x4l __attribute__((ext_vector_type(4)));
+#define LP_MFMA16L(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int LOOP_N_INF = 64;      // beyond-far samples tabulated
+constexpr int LOOP_ST = 32 * RM_LD * 2;   // bytes of one limb of a 32 x 32 block (72-byte rows)
+constexpr int LOOP_BLK = 3 * LOOP_ST;     // bytes of a block image (three limbs)
+constexpr int LT_LD = 36;           // row stride of the feature-major fp32 tiles [32 features][32 rays + 4]
+
+struct LoopLayer {
+  int64_t w, b;   // float offsets inside mlp_params: W [rows_in x cols] row-major, b [cols]
+  int rows_in;    // input width (grid channels or hidden width)
+  int cols;       // output width (hidden width)
+  int ob;         // output blocks of 32 features: ceil(cols / 32)
+  int img;        // byte offset of the layer's block images in LDS: block (ib, ob) at img + (ib * ob_count + ob) * LOOP_BLK
+  int bias;       // float index of the bias (zero-padded to 32 * NB) in the small block
+};
+// bytes of a layer's block images
+inline int loop_layer_bytes(int rows_in, int cols) { return ((rows_in + 31) / 32) * ((cols + 31) / 32) * LOOP_BLK; }
+
+LP_DEV constexpr int pi16l(int m) { return m < 4 ? 2 * m : (m < 12 ? 2 * (m - 4) + 1 : 2 * (m - 8)); }
+LP_DEV void lds_barrier_l() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// staging
+// ---------------------------------------------------------------------------------------------------------------
+template <int NB>
+LP_DEV void loop_stage_layer(char* lds, float* sm, const float* P, const LoopLayer& L, int tid) {
+  const int in_blocks = (L.rows_in + 31) >> 5;
+  for (int ib = 0; ib < in_blocks; ++ib) {
+    for (int ob = 0; ob < L.ob; ++ob) {
+      char* blk = lds + L.img + (ib * L.ob + ob) * LOOP_BLK;
+      for (int i = tid; i < 32 * 32; i += 256) {
+        const int k = i >> 5, m = i & 31;
+        const int row = 32 * ib + k, col = 32 * ob + m;
+        const float w = (row < L.rows_in && col < L.cols) ? P[L.w + (int64_t)row * L.cols + col] : 0.0f;
+        unsigned short l1, l2, l3;
+        split3_scalar(w, l1, l2, l3);
+        char* base = blk + (k * RM_LD + m) * 2;
+        *reinterpret_cast<unsigned short*>(base) = l1;
+        *reinterpret_cast<unsigned short*>(base + LOOP_ST) = l2;
+        *reinterpret_cast<unsigned short*>(base + 2 * LOOP_ST) = l3;
+      }
+    }
+  }
+  for (int i = tid; i < 32 * NB; i += 256) sm[L.bias + i] = (i < L.cols) ? P[L.b + i] : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// one layer on the matrix cores
+// ---------------------------------------------------------------------------------------------------------------
+// out = relu(W^T in + b) (RELU = false: the affine map only): `in` / `out` are NB blocks of this lane's 16 features; lbase =
+// LDS base (+ the opaque zero); output blocks beyond the layer's width come out as zeros
+template <int NB, bool RELU = true>
+LP_DEV void loop_layer_fwd(const char* lbase, const float* sm, const LoopLayer& L, int lane, const float (&in)[NB][16],
+                           float (&out)[NB][16]) {
+  const int h = lane >> 5;
+  const int in_chunks = (L.rows_in + 15) >> 4;
+  f32x16 acc[NB];
+#pragma unroll
+  for (int ob = 0; ob < NB; ++ob) {
+    const float4* bsrc = reinterpret_cast<const float4*>(sm + L.bias + 32 * ob + 4 * h);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 v = bsrc[2 * j];
+      acc[ob][4 * j + 0] = v.x; acc[ob][4 * j + 1] = v.y; acc[ob][4 * j + 2] = v.z; acc[ob][4 * j + 3] = v.w;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 2 * NB; ++c) {
+    if (c < in_chunks) {  // wave-uniform
+      u32x4_t l1, l2, l3;
+      split3_chunk(&in[c >> 1][8 * (c & 1)], l1, l2, l3);
+#pragma unroll
+      for (int ob = 0; ob < NB; ++ob) {
+        if (ob < L.ob)  // wave-uniform
+          acc[ob] = chunk_bf3(AColsFwd{lbase + L.img + ((c >> 1) * L.ob + ob) * LOOP_BLK, LOOP_ST}, c & 1, lane, l1, l2, l3, acc[ob]);
+      }
+    }
+  }
+#pragma unroll
+  for (int ob = 0; ob < NB; ++ob) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) out[ob][q] = RELU ? fmaxf(acc[ob][q], 0.0f) : acc[ob][q];
+  }
+}
+
+// dX += W dY (blocks of the layer's INPUT): dy = NB blocks of this lane's 16 output features
+template <int NB>
+LP_DEV void loop_layer_dx(const char* lbase, const LoopLayer& L, int lane, const float (&dy)[NB][16], f32x16 (&dx)[NB]) {
+  const int out_chunks = (L.cols + 15) >> 4;
+  const int in_blocks = (L.rows_in + 31) >> 5;
+#pragma unroll
+  for (int c = 0; c < 2 * NB; ++c) {
+    if (c < out_chunks) {
+      u32x4_t l1, l2, l3;
+      split3_chunk(&dy[c >> 1][8 * (c & 1)], l1, l2, l3);
+#pragma unroll
+      for (int ib = 0; ib < NB; ++ib) {
+        if (ib < in_blocks)
+          dx[ib] = chunk_bf3(ARowsBwd{lbase + L.img + (ib * L.ob + (c >> 1)) * LOOP_BLK, LOOP_ST, 31}, c & 1, lane, l1, l2, l3, dx[ib]);
+      }
+    }
+  }
+}
+
+LP_DEV void loop_tile_store(float* tile, int r, int h, const float (&v)[16]) {
+#pragma unroll
+  for (int q = 0; q < 16; ++q) tile[featq(q, h) * LT_LD + r] = v[q];
+}
+
+// dW quadrant of one 32 x 32 block over the 128 rays of the workgroup: acc += X^T dY (see lp_renderer_mfma_bwd.hip)
+LP_DEV f32x4l loop_dw_quadrant(const float* wave0, int stride, int a_off, int b_off, f32x4l acc, float& db) {
+  float s = 0.0f;
+  for (int v = 0; v < WAVES; ++v) {
+    const float* base = wave0 + v * stride;
+    const float4 a0 = *reinterpret_cast<const float4*>(base + a_off);
+    const float4 a1 = *reinterpret_cast<const float4*>(base + a_off + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(base + b_off);
+    const float4 b1 = *reinterpret_cast<const float4*>(base + b_off + 4);
+    acc = LP_MFMA16L(a0.x, b0.x, acc);
+    acc = LP_MFMA16L(a0.y, b0.y, acc);
+    acc = LP_MFMA16L(a0.z, b0.z, acc);
+    acc = LP_MFMA16L(a0.w, b0.w, acc);
+    acc = LP_MFMA16L(a1.x, b1.x, acc);
+    acc = LP_MFMA16L(a1.y, b1.y, acc);
+    acc = LP_MFMA16L(a1.z, b1.z, acc);
+    acc = LP_MFMA16L(a1.w, b1.w, acc);
+    s += ((b0.x + b0.y) + (b0.z + b0.w)) + ((b1.x + b1.y) + (b1.z + b1.w));
+  }
+  db += s;
+  return acc;
+}
+
+// accumulators of one layer's weight gradient: this wave's quadrant of every block + its share of the bias gradient
+template <int NB>
+struct LoopDw {
+  f32x4l q[NB][NB];
+  float db[NB];
+};
+template <int NB>
+LP_DEV void loop_dw_zero(LoopDw<NB>& d) {
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    d.db[i] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) d.q[i][j] = (f32x4l){0, 0, 0, 0};
+  }
+}
+
+// Backward of one layer: dW (workgroup-shared quadrants) and dX.  x = the layer's input activation, dy = upstream gradient
+// (already masked by the layer's own ReLU).  Publishes the X / dY tiles of one block pair, runs the dX chain while the LDS
+// writes land, then barrier -> quadrant -> barrier per block pair.
+template <int NB>
+LP_DEV void loop_layer_bwd(const char* lbase, const LoopLayer& L, int lane, float* xt, float* yt, const float* wave0, int stride,
+                           int a_off, int b_off, bool want_params, bool want_dx, const float (&x)[NB][16], const float (&dy)[NB][16],
+                           LoopDw<NB>& dw, f32x16 (&dx)[NB]) {
+  const int h = lane >> 5, r = lane & 31;
+  const int in_blocks = (L.rows_in + 31) >> 5;
+  if (want_params) {
+    loop_tile_store(xt, r, h, x[0]);
+    loop_tile_store(yt, r, h, dy[0]);
+  }
+  if (want_dx) loop_layer_dx<NB>(lbase, L, lane, dy, dx);
+  if (want_params) {
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib) {
+#pragma unroll
+      for (int ob = 0; ob < NB; ++ob) {
+        if (ib < in_blocks && ob < L.ob) {  // workgroup-uniform
+          if (ib + ob > 0) {
+            loop_tile_store(xt, r, h, x[ib]);
+            loop_tile_store(yt, r, h, dy[ob]);
+          }
+          lds_barrier_l();
+          float db_unused = 0.0f;
+          dw.q[ib][ob] = loop_dw_quadrant(wave0, stride, a_off, b_off, dw.q[ib][ob], ib == 0 ? dw.db[ob] : db_unused);
+          lds_barrier_l();
+        }
+      }
+    }
+  }
+}
+
+// flush this wave's quadrants of one layer
+template <int NB>
+LP_DEV void loop_dw_flush(float* G, const LoopLayer& L, const LoopDw<NB>& dw, int wave, int lane) {
+  const int mi = wave >> 1, ni = wave & 1;
+  const int m16 = lane & 15, ka = lane >> 4;
+#pragma unroll
+  for (int ib = 0; ib < NB; ++ib) {
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) {
+      const int col = 32 * ob + 16 * ni + pi16l(m16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = 32 * ib + 16 * mi + pi16l(4 * ka + i);
+        if (row < L.rows_in && col < L.cols) atomic_add_f32(G + L.w + (int64_t)row * L.cols + col, dw.q[ib][ob][i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int ob = 0; ob < NB; ++ob) {
+    float d = dw.db[ob];
+    d += __shfl_xor(d, 16);
+    d += __shfl_xor(d, 32);
+    const int col = 32 * ob + 16 * ni + pi16l(m16);
+    if (ka == 0 && mi == 0 && col < L.cols) atomic_add_f32(G + L.b + col, d);
+  }
+}
+
+template <int NB>
+LP_DEV void loop_copy(const float (&src)[NB][16], float (&dst)[NB][16]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dst[b][q] = src[b][q];
+  }
+}
+
+}  // namespace lp

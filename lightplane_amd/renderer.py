@@ -115,9 +115,9 @@ def _warn_if_generic(a, cfg: _RendererCfg) -> None:
         _warned_shapes.add(key)
         warnings.warn(
             "lightplane_amd: this decoder shape runs on the shape-generic Renderer kernels (10-100x slower). The "
-            "MFMA families cover grid channels 16/32, <= 4 colour channels, grid-lists below 4 GB and either trunk 1-2 "
-            "(0 with a separate colour grid) / opacity 1-2 / colour 1-2 layers with one hidden width of 16 or 32, or "
-            "2/2/2 layers with hidden width 64. "
+            "MFMA families cover grid channels 16/32, <= 4 colour channels, grid-lists below 4 GB, trunk 1-4 (0 with a "
+            "separate colour grid) / opacity 1-4 / colour 1-4 layers with ONE hidden width of 16 or 32, or up to 2/2/2 layers "
+            "with hidden width 64. "
             f"Got channels={cfg.channels}, trunk={cfg.dims_trunk}, opacity={cfg.dims_opacity}, "
             f"color={cfg.dims_color}, color_chn={cfg.color_chn}, separate colour grid={cfg.color_descs is not None}.")
 
@@ -144,8 +144,8 @@ def _shape_args(grid, decoder_params: DecoderParams, grid_sizes=None, color_grid
 
 def kernel_family(rays: Rays, grid, decoder_params: DecoderParams, grid_sizes=None, color_grid=None,
                   color_grid_sizes=None) -> int:
-    """Kernel family ``LP_KERNEL_AUTO`` selects for these shapes: 0 generic, 1 MFMA hidden-32, 2 MFMA hidden-64
-    (``lp_renderer_kernel_family``; needs no GPU)."""
+    """Kernel family ``LP_KERNEL_AUTO`` selects for these shapes: 0 generic, 1 MFMA hidden-32 (tuned), 2 MFMA hidden-64,
+    3 layer-looped MFMA (1-4 layers per MLP) (``lp_renderer_kernel_family``; needs no GPU)."""
     a = _shape_args(grid, decoder_params, grid_sizes, color_grid, color_grid_sizes)
     return int(_lib.lib().lp_renderer_kernel_family(ctypes.byref(a)))
 

@@ -227,10 +227,10 @@ def test_backward_segments_python_query_covers_every_mfma_family():
     assert q(layers=(1, 1, 1), hidden=16) == 4          # flex
     assert q(layers=(0, 2, 2), sep=True) == 4           # two-grid decoder
     assert q(C=32, hidden=64) == 4                      # width-64 family
-    assert q(layers=(3, 2, 2)) == 1                     # shape-generic kernels
+    assert q(layers=(3, 2, 2)) == 1                     # layer-looped family: one sweep per ray
     assert q(num_samples=16) == 1 and q(num_samples_inf=2) == 1 and q(stop_transmittance=0.01) == 1
     assert lp.kernel_family(rays, random_grids(gen, grid_sizes_for((1, 8, 8, 8, 16), True)),
-                            random_decoder(gen, 3, 2, 2, input_chn=16, hidden_chn=32, color_chn=3)) == 0
+                            random_decoder(gen, 3, 2, 2, input_chn=16, hidden_chn=32, color_chn=3)) == 3
 
 
 def _gloo_worker(rank, world_size, port, ret):
@@ -358,6 +358,23 @@ def test_mlp_splatter_c_abi_argument_errors():
     assert L.lp_splatter_forward(ctypes.byref(a), None) == -3  # mlp_params NULL
 
 
+def _family_with_color_grid(dec, sizes, csizes):
+    """kernel_family for a flat-tensor colour grid given by its sizes only (no tensors needed for the query)."""
+    from lightplane_amd.grids import make_grid_descs
+    from lightplane_amd.params import mlp_numel
+    from lightplane_amd.renderer import _decoder_dims
+    descs, channels, n_rows = make_grid_descs(sizes)
+    cdescs, _, c_rows = make_grid_descs(csizes)
+    dims_t, dims_o, dims_c = _decoder_dims(dec)
+    a = _lib.LpRendererArgs()
+    a.grid = _lib.make_grid_list(None, descs, channels, n_rows)
+    a.color_grid = _lib.make_grid_list(None, cdescs, channels, c_rows)
+    n_t, n_o = mlp_numel(dims_t), mlp_numel(dims_o)
+    a.trunk, a.opacity, a.color = _lib.make_mlp(dims_t, 0), _lib.make_mlp(dims_o, n_t), _lib.make_mlp(dims_c, n_t + n_o)
+    a.color_chn = int(dec.color_chn)
+    return int(_lib.lib().lp_renderer_kernel_family(ctypes.byref(a)))
+
+
 def test_kernel_family_selection():
     """LP_KERNEL_AUTO picks the MFMA families for the shapes they are built for (no GPU needed): the headline
     configuration must never fall back to the shape-generic kernels silently."""
@@ -365,7 +382,8 @@ def test_kernel_family_selection():
     from tests.synth import RENDERER_CASES, grid_sizes_for, random_decoder
     want = {"voxel_basic": 1, "triplane_basic": 1, "triplane_c32": 1, "voxel_c32_color1": 1, "triplane_h64_c32": 2,
             "voxel_h64_c16_scaffold": 2, "triplane_colorgrid": 1, "colorgrid_c32_h16_voxel": 1, "colorgrid_heads1_inf": 1, "colorgrid_c32_mixed": 1,
-            "voxel_deep": 0, "triplane_h16_c32": 0, "color16": 0,
+            "voxel_deep": 3, "triplane_h16_c32": 3, "color16": 0, "triplane_deep444": 3, "colorgrid_deep044": 3,
+            "triplane_242_c32_color4": 3, "voxel_deep342_h64_c32": 0, "color16_deep323_h16": 0,
             "nb2_like_t2_o1_c1": 1, "nb1_like_h16_111": 1, "flex_121_h16_c32_noise": 1, "flex_212_c32_scaffold": 1}
     for c in RENDERER_CASES:
         if c.name in want:
@@ -376,6 +394,16 @@ def test_kernel_family_selection():
     for C, G in ((16, 64), (32, 128)):
         dec = random_decoder(gen, 2, 2, 2, C, 32, 3)
         assert kernel_family(None, None, dec, grid_sizes=grid_sizes_for((1, G, G, G, C), True)) == 1
+    # every decoder shape of the reference's own sweep (tests/test_renderer_with_autograd.py:35-56: grid [3,16,12,8,16], hidden
+    # 32, 3 colour channels, 2 or 4 layers per MLP, trunk 0 with a separate colour grid [4,3,9]) runs on the matrix cores
+    import itertools
+    for color_grid, tri, nt, no, nc in itertools.product([None, [4, 3, 9]], [False, True], [2, 4], [2, 4], [2, 4]):
+        sep = color_grid is not None
+        dec = random_decoder(gen, 0 if sep else nt, no, nc, 16, 32, 3, use_separate_color_grid=sep)
+        sizes = grid_sizes_for((3, 16, 12, 8, 16), tri)
+        csizes = grid_sizes_for((3, *color_grid, 16), tri) if sep else None
+        fam = _family_with_color_grid(dec, sizes, csizes) if sep else kernel_family(None, None, dec, grid_sizes=sizes)
+        assert fam in (1, 3), (color_grid, tri, nt, no, nc, fam)
     # splatter families through the C ABI
     L = _lib.lib()
     from lightplane_amd.grids import make_grid_descs
@@ -388,6 +416,16 @@ def test_kernel_family_selection():
     a.input_grid = _lib.make_grid_list(None, in_descs, Ci, rows_i)
     assert L.lp_splatter_kernel_family(ctypes.byref(a)) == 2
     a.mlp = _lib.make_mlp([32, 64, 64, 32], 0)
+    assert L.lp_splatter_kernel_family(ctypes.byref(a)) == 3  # layer-looped family
+    # every MLP shape of the reference's own Splatter sweep (tests/test_splatter_with_autograd.py:38-53: hidden 64, 3 / 4 layers,
+    # 32 / 64 input features, 32 output channels) runs on the matrix cores
+    for n_layers in (3, 4):
+        for feat in (32, 64):
+            a.mlp = _lib.make_mlp([feat] + [64] * (n_layers - 1) + [32], 0)
+            in_descs, Ci, rows_i = make_grid_descs([[2, 10, 14, 16, feat]])
+            a.input_grid = _lib.make_grid_list(None, in_descs, Ci, rows_i)
+            assert L.lp_splatter_kernel_family(ctypes.byref(a)) == 3, (n_layers, feat)
+    a.mlp = _lib.make_mlp([32, 64, 48, 32], 0)  # hidden widths differ: shape-generic kernels
     assert L.lp_splatter_kernel_family(ctypes.byref(a)) == 0
 
 
