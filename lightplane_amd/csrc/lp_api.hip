@@ -271,7 +271,7 @@ int lp_splatter_kernel_family(const LpSplatterArgs* args) {
   if (!args) return set_error(LP_ENULL, "args is NULL");
   if (args->mlp.n_layers > 0) return splatter_mlp_family(*args);
   const int C = args->out.channels;
-  return ((C == 16 || C == 32) && args->out.n_rows < ((int64_t)1 << 31)) ? 1 : 0;
+  return ((C == 16 || C == 32 || C == 64) && args->out.n_rows < ((int64_t)1 << 31)) ? 1 : 0;
 }
 
 // copy of the caller's arguments with every per-grid pointer made explicit (what the kernels read)

@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256) splat_bwd_kernel(const LpSplatterArgs a) 
 // lane groups at the end.  (The per-ray kernel below re-derives the geometry in every lane and reads eight rows
 // per ray and sample.)
 template <int C, int B>
-__global__ void __launch_bounds__(256, B == 4 ? 3 : 2) splat_bwd_walk_kernel(const LpSplatterArgs a, int n_seg) {
+__global__ void __launch_bounds__(256, (B == 4 && C < 64) ? 3 : 2) splat_bwd_walk_kernel(const LpSplatterArgs a, int n_seg) {
   constexpr int RPW = 16, CPL = C / 16, NQ = 4, SPQ = 2;
   __shared__ __attribute__((aligned(16))) float lds[4][8 * RPW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -462,14 +462,17 @@ static int splat_segments(const LpSplatterArgs& a, unsigned ray_blocks) {
 int splatter_forward_launch(const LpSplatterArgs& a, hipStream_t stream) {
   const int Cw = a.out.channels;
   static const bool no_walk = getenv("LP_SPLAT_NO_WALK") != nullptr;  // A/B timing knob
-  if ((Cw == 16 || Cw == 32) && a.out.n_rows < ((int64_t)1 << 31) && !no_walk) {
+  if ((Cw == 16 || Cw == 32 || Cw == 64) && a.out.n_rows < ((int64_t)1 << 31) && !no_walk) {
     static const int rpw = getenv("LP_SPLAT_RPW") ? atoi(getenv("LP_SPLAT_RPW")) : 16;
     static const int dbg = getenv("LP_SPLAT_DEBUG") ? atoi(getenv("LP_SPLAT_DEBUG")) : 0;  // timing experiments
-    const unsigned ray_blocks = (unsigned)((a.rays.n_rays + 4 * rpw - 1) / (4 * rpw));
+    const int rpw_eff = Cw == 64 ? 16 : rpw;
+    const unsigned ray_blocks = (unsigned)((a.rays.n_rays + 4 * rpw_eff - 1) / (4 * rpw_eff));
     if (ray_blocks == 0) return LP_OK;
     const int n_seg = splat_segments(a, ray_blocks);
     const unsigned blocks = ray_blocks * (unsigned)n_seg;
-    if (Cw == 16 && rpw == 32) hipLaunchKernelGGL((splat_fwd_walk_kernel<16, 32>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg);
+    // (64 channels -- the reference's own speed benchmark splats into [1,160,160,160,64] -- : four channels per lane)
+    if (Cw == 64) hipLaunchKernelGGL((splat_fwd_walk_kernel<64, 16>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg);
+    else if (Cw == 16 && rpw == 32) hipLaunchKernelGGL((splat_fwd_walk_kernel<16, 32>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg);
     else if (Cw == 16) hipLaunchKernelGGL((splat_fwd_walk_kernel<16, 16>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg);
     else if (rpw == 32) hipLaunchKernelGGL((splat_fwd_walk_kernel<32, 32>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg);
     else hipLaunchKernelGGL((splat_fwd_walk_kernel<32, 16>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg);
@@ -482,10 +485,10 @@ int splatter_forward_launch(const LpSplatterArgs& a, hipStream_t stream) {
 int splatter_backward_launch(const LpSplatterArgs& a, hipStream_t stream) {
   const int Cw = a.out.channels;
   static const bool no_walk = getenv("LP_SPLAT_NO_WALK") != nullptr;  // A/B timing knob
-  bool voxels = a.out.n_grids > 0;
-  for (int g = 0; g < a.out.n_grids; ++g)
-    voxels = voxels && a.out.grids[g].D > 1 && a.out.grids[g].H > 1 && a.out.grids[g].W > 1;
-  if ((Cw == 16 || Cw == 32) && voxels && a.out.n_rows < ((int64_t)1 << 31) && !no_walk) {
+  // (plane grids take the same walk: their tap sets have four slots, so the two lane groups of the second z layer see
+  // validity bits and weights of zero and contribute nothing -- half the lanes idle, but a run of rays still reads its
+  // rows once instead of once per ray)
+  if ((Cw == 16 || Cw == 32 || Cw == 64) && a.out.n_grids > 0 && a.out.n_rows < ((int64_t)1 << 31) && !no_walk) {
     const unsigned ray_blocks = (unsigned)((a.rays.n_rays + 63) / 64);
     if (ray_blocks == 0) return LP_OK;
     const int n_seg = splat_segments(a, ray_blocks);
@@ -496,7 +499,8 @@ int splatter_backward_launch(const LpSplatterArgs& a, hipStream_t stream) {
     const unsigned blocks = ray_blocks * (unsigned)n_seg;
     // batches of 8 rays; batches of 4 at three waves/SIMD measured the same (cfg 3)
     if (Cw == 16) hipLaunchKernelGGL((splat_bwd_walk_kernel<16, 8>), dim3(blocks), dim3(256), 0, stream, a, n_seg);
-    else hipLaunchKernelGGL((splat_bwd_walk_kernel<32, 8>), dim3(blocks), dim3(256), 0, stream, a, n_seg);
+    else if (Cw == 32) hipLaunchKernelGGL((splat_bwd_walk_kernel<32, 8>), dim3(blocks), dim3(256), 0, stream, a, n_seg);
+    else hipLaunchKernelGGL((splat_bwd_walk_kernel<64, 4>), dim3(blocks), dim3(256), 0, stream, a, n_seg);  // (batches of 8: 300 B of scratch)
     return check_launch("splat_bwd_walk_kernel");
   }
   LP_SPLAT_DISPATCH(splat_bwd_kernel);

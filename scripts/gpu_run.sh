@@ -6,7 +6,7 @@
 # Every step writes gpurun_out/<TAG>_<step>.log (merged back into the build container) and prints its tail.  Steps:
 #   tests[=<pytest -k expression>]     pytest -m gpu (-x), optionally narrowed
 #   testsall[=<-k expression>]         the same without -x (every failure is listed)
-#   pytest=<arguments>                 pytest -m gpu with these arguments (files, -k ..., -x ...)
+#   pytest=<arguments>                 pytest -m gpu with these arguments (files, -k ..., -x ...); eval'ed: -k \"a or b\" works
 #   testfile=<tests/file.py[::test]>   one test file / test
 #   bench[=<bench.py arguments>]       python bench.py <arguments>            (default: the driver's command, no flags)
 #   ab[=<bench.py arguments>]          every ab/lib*.so through bench.py, two alternating rounds (A/B of library builds)
@@ -30,7 +30,7 @@ for step in "$@"; do
     tests) if [ -n "$arg" ]; then timeout 1500 python -m pytest tests -m gpu -q -x --tb=short -p no:cacheprovider -k "$arg" > "$log" 2>&1;
            else timeout 1500 python -m pytest tests -m gpu -q -x --tb=short -p no:cacheprovider > "$log" 2>&1; fi; echo "rc=$?" >> "$log" ;;
     testsall) timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider ${arg:+-k "$arg"} > "$log" 2>&1; echo "rc=$?" >> "$log" ;;
-    pytest) timeout 2400 python -m pytest $arg -m gpu -q --tb=short -p no:cacheprovider > "$log" 2>&1; echo "rc=$?" >> "$log" ;;
+    pytest) eval "timeout 2400 python -m pytest $arg -m gpu -q --tb=short -p no:cacheprovider" > "$log" 2>&1; echo "rc=$?" >> "$log" ;;
     testfile) timeout 1500 python -m pytest $arg -m gpu -q -x --tb=short -p no:cacheprovider > "$log" 2>&1; echo "rc=$?" >> "$log" ;;
     bench) timeout 900 python bench.py $arg > "$log" 2>&1; echo "rc=$?" >> "$log" ;;
     ab) for round in 1 2; do for f in ab/lib*.so; do

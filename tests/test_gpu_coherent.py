@@ -79,11 +79,17 @@ GRIDS = {
     "two_grid_triplane_c16": ((1, 24, 24, 24, 16), True, False, True, (0, 2, 2), 1),
     "voxel18_c16_b2": ((2, 18, 16, 20, 16), False, False, False, (2, 2, 2), 2),
 }
+# deep decoders (layer-looped MFMA family, lp_renderer_loop.hip): test_renderer_coherent_deep
+DEEP_GRIDS = {
+    "triplane24_c16_deep444": ((1, 24, 24, 24, 16), True, False, False, (4, 4, 4), 1),
+    "voxel20_c32_deep342": ((1, 20, 20, 20, 32), False, False, False, (3, 4, 2), 1),
+    "two_grid_mixed_c16_deep044": ((1, 24, 24, 24, 16), True, True, True, (0, 4, 4), 1),
+}
 
 
 def coherent_renderer_inputs(grid_name, image_name, mask_oob=True, num_samples=24, seed=0, hidden=32, color_chn=3,
                              scaffold=False):
-    base, tri, extra, sep, n_layers, batch = GRIDS[grid_name]
+    base, tri, extra, sep, n_layers, batch = {**GRIDS, **DEEP_GRIDS}[grid_name]
     height, width, az, el = {**IMAGES, **BIG_IMAGE}[image_name]
     gen = torch.Generator().manual_seed(seed)
     B, C = base[0], base[-1]
@@ -145,6 +151,31 @@ def test_renderer_coherent_image(grid, image, kernel):
 def test_renderer_coherent_variants(grid, kw):
     d = coherent_renderer_inputs(grid, "48x80_az30_el45", seed=3, **kw)
     check_renderer(d, _dev(), _lib.LP_KERNEL_AUTO, f"{grid}/{kw}")
+
+
+@pytest.mark.parametrize("grid,kw", [
+    ("triplane24_c16_deep444", dict()),
+    ("voxel20_c32_deep342", dict(mask_oob=False, color_chn=4)),
+    ("two_grid_mixed_c16_deep044", dict(scaffold=True)),
+    ("triplane24_c16_deep444", dict(hidden=16, mask_oob=False)),
+], ids=["triplane_444", "voxel_342_rgba", "two_grid_044_scaffold", "triplane_444_h16"])
+def test_renderer_coherent_deep(grid, kw):
+    """Whole pinhole images through the layer-looped MFMA family (3-4 layers per MLP): run-merged scatter, workgroup-shared dW
+    of ten layers, the two-grid decoder's colour-grid scatter."""
+    d = coherent_renderer_inputs(grid, "48x80_az30_el45", seed=5, **kw)
+    assert lp.kernel_family(d["rays"], d["grids"], d["decoder"], color_grid=d["color_grids"]) == 3
+    check_renderer(d, _dev(), _lib.LP_KERNEL_AUTO, f"{grid}/{kw}")
+
+
+def test_loop_family_on_the_shapes_of_the_other_families():
+    """LP_LOOP=1 (read once per process) sends every shape the layer-looped family supports through it -- also the default
+    2/2/2 x 32 shape, the flex shapes, hidden 64 and the two-layer MLP-Splatter: the golden suite and a coherent image in a
+    child process."""
+    env = dict(os.environ, LP_LOOP="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "renderer_matches or mlp_splatter_matches or test_renderer_coherent_image"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
 
 
 def test_renderer_coherent_early_termination_exact_when_off():
