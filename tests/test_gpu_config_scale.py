@@ -178,3 +178,52 @@ def test_hot_kernel_touched_rows_equal_oracle(name):
         assert torch.equal(touched, o_touched), (f"{name} grid {g}: touched-row sets differ in "
                                                   f"{int((touched != o_touched).sum())} of {touched.numel()} rows")
         assert int(touched.sum()) > 0.3 * touched.numel() and int((~named).sum()) >= 0
+
+
+@pytest.mark.parametrize("which", ["ref_fixture_std0.01", "grid_1e3_weights_1e-3", "mixed_magnitudes_deep"])
+def test_bf16x3_operand_dynamic_range(which):
+    """The decoder products run as bf16x3 (three bf16 limbs per fp32 operand) -- exact splits, so the accuracy must not
+    depend on operand magnitudes.  The parity cases draw weights from N(0, 0.15-0.3) and grids from N(0, 1); here: the
+    reference fixture's own N(0, 0.01) parameters (tests/utils.py:349), grid features of ~1e3 against weights of ~1e-3, and a
+    deep decoder (layer-looped family) whose layers alternate between scales 8 and 1/8 with per-channel grid scales over six
+    decades -- all held to the fp32 oracle at the 1e-4 bar."""
+    dev = _dev()
+    gen = torch.Generator().manual_seed(11)
+    C, H = 16, 32
+    layers = (4, 3, 4) if which == "mixed_magnitudes_deep" else (2, 2, 2)
+    sizes = grid_sizes_for((1, 12, 14, 10, C), True)
+    grids = random_grids(gen, sizes)
+    std = 0.01 if which == "ref_fixture_std0.01" else 0.2
+    dec = random_decoder(gen, *layers, C, H, 3, std=std)
+    if which == "grid_1e3_weights_1e-3":
+        grids = [g * 1e3 for g in grids]
+        p = dec.mlp_params.clone()
+        p[: C * H] *= 1e-3  # first trunk layer's weights
+        dec.mlp_params = p
+    if which == "mixed_magnitudes_deep":
+        scale = 10.0 ** torch.linspace(-3, 3, C)
+        grids = [g * scale for g in grids]
+        p = dec.mlp_params.clone()
+        p[: C * H] = p[: C * H].reshape(C, H) .div(scale[:, None]).reshape(-1)  # undo the channel scales in the first layer
+        off = C * H
+        for l in range(3):  # the three hidden trunk layers: x8, /8, x8 (the next layer's weights compensate)
+            f = 8.0 if l % 2 == 0 else 0.125
+            p[off: off + H * H] *= f
+            off += H * H
+        dec.mlp_params = p
+    rays = pinhole_rays(40, 48, cam_dist=2.4, enc_dim=H, gen=gen, azimuth_deg=25.0, elevation_deg=15.0)
+    n = rays.n_rays
+    up = (torch.randn(n, generator=gen), torch.randn(n, generator=gen), torch.randn(n, 3, generator=gen))
+    cfg = dict(num_samples=24, gain=1.0 if which != "ref_fixture_std0.01" else 3.0, num_samples_inf=0, mask_out_of_bounds_samples=False,
+               contract_coords=False, inject_noise_sigma=0.0, inject_noise_seed=0)
+    d = dict(rays=rays, grids=grids, color_grids=None, decoder=dec, scaffold=None, cfg=cfg, sizes=sizes, upstream=up)
+    assert lp.kernel_family(rays, grids, dec) in (1, 3)
+    out, gp, ge, gg, _ = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO)
+    o_out, o_gp, o_ge, o_gg = oracle_chunked(d)
+    _, q_gp, q_ge, q_gg = oracle_chunked(d, dtype=F64)
+    for nm, a, b in (("ray_length", out[0], o_out[0]), ("neg_log_t", out[1], o_out[1]), ("feature", out[2], o_out[2])):
+        _assert_close(f"{which}: {nm}", a, b.numpy())
+    assert_grad_close(f"{which}: grad_mlp_params", gp, o_gp.numpy(), 4 * H, want64=q_gp.numpy())
+    assert_grad_close(f"{which}: grad_encoding", ge, o_ge.numpy(), H, want64=q_ge.numpy())
+    for i, (a, b, c) in enumerate(zip(gg, o_gg, q_gg)):
+        assert_grad_close(f"{which}: grad_grid{i}", a, b.numpy(), 8 * C, want64=c.numpy())
