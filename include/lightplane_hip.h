@@ -257,7 +257,7 @@ int lp_renderer_backward_segments(const LpRendererArgs* args);
 /* Which kernel family LP_KERNEL_AUTO selects for these arguments (no launch; shapes only):
  *   lp_renderer_kernel_family: 0 shape-generic VALU kernels, 1 MFMA hidden-32 family (tuned default shape and its subsets),
  *                              2 MFMA hidden-64 family (2/2/2 layers), 3 layer-looped bf16x3 MFMA family (1-4 layers per
- *                              MLP, one hidden width of 16 / 32 -- or 64 with at most 2 layers per MLP --, <= 4 colour channels)
+ *                              MLP, one hidden width of 16 / 32 and <= 32 colour channels -- or 64 with at most 2 layers per MLP and <= 4 colour channels)
  *   lp_splatter_kernel_family: 0 shape-generic kernels, 1 run-merged walk (plain Splatter, C in {16,32,64}),
  *                              2 MFMA MLP-Splatter ([E,32,Cout] family), 3 layer-looped bf16x3 MFMA MLP-Splatter (2-4
  *                              layers, widths 16 / 32 / 64, Cout 16 / 32)

@@ -20,6 +20,7 @@ struct LoopLayer {
   int64_t w, b;   // float offsets inside mlp_params: W [rows_in x cols] row-major, b [cols]
   int rows_in;    // input width (grid channels or hidden width)
   int cols;       // output width (hidden width)
+  int ld;         // row stride of W inside mlp_params (= cols, except for a padded output layer)
   int ob;         // output blocks of 32 features: ceil(cols / 32)
   int img;        // byte offset of the layer's block images in LDS: block (ib, ob) at img + (ib * ob_count + ob) * LOOP_BLK
   int bias;       // float index of the bias (zero-padded to 32 * NB) in the small block
@@ -42,7 +43,7 @@ LP_DEV void loop_stage_layer(char* lds, float* sm, const float* P, const LoopLay
       for (int i = tid; i < 32 * 32; i += 256) {
         const int k = i >> 5, m = i & 31;
         const int row = 32 * ib + k, col = 32 * ob + m;
-        const float w = (row < L.rows_in && col < L.cols) ? P[L.w + (int64_t)row * L.cols + col] : 0.0f;
+        const float w = (row < L.rows_in && col < L.cols) ? P[L.w + (int64_t)row * L.ld + col] : 0.0f;
         unsigned short l1, l2, l3;
         split3_scalar(w, l1, l2, l3);
         char* base = blk + (k * RM_LD + m) * 2;
@@ -204,7 +205,7 @@ LP_DEV void loop_dw_flush(float* G, const LoopLayer& L, const LoopDw<NB>& dw, in
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = 32 * ib + 16 * mi + pi16l(4 * ka + i);
-        if (row < L.rows_in && col < L.cols) atomic_add_f32(G + L.w + (int64_t)row * L.cols + col, dw.q[ib][ob][i]);
+        if (row < L.rows_in && col < L.cols) atomic_add_f32(G + L.w + (int64_t)row * L.ld + col, dw.q[ib][ob][i]);
       }
     }
   }

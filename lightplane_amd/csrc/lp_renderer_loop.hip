@@ -27,6 +27,7 @@ constexpr int LOOP_MAX_H = 3;       // hidden layers of a head (its output layer
 struct LoopParams {
   int n_t, n_o, n_c;   // layers on the matrix cores: every trunk layer, the hidden layers of the heads
   LoopLayer t[LOOP_MAX_T], o[LOOP_MAX_H], c[LOOP_MAX_H];
+  LoopLayer co;                     // WC (5..32 colour channels): the colour output layer, on the matrix cores as well
   int64_t w_o2, b_o2, w_c2, b_c2;   // output layers of the heads
   int ldc2;                         // row stride of the colour output layer (padded colour width)
   int hid, hin;                     // hidden width; input width of the heads (= width of the ray encoding)
@@ -53,6 +54,7 @@ LP_DEV void loop_stage(const LpRendererArgs& a, const LoopParams& lp, float* lds
   for (int l = 0; l < lp.n_t; ++l) loop_stage_layer<NB>(b, lds, P, lp.t[l], tid);
   for (int l = 0; l < lp.n_o; ++l) loop_stage_layer<NB>(b, lds, P, lp.o[l], tid);
   for (int l = 0; l < lp.n_c; ++l) loop_stage_layer<NB>(b, lds, P, lp.c[l], tid);
+  if (a.color_chn > 4) loop_stage_layer<NB>(b, lds, P, lp.co, tid);
   for (int i = tid; i < 32 * NB; i += 256) {
     lds[lp.wo2 + i] = (i < lp.ho_w) ? P[lp.w_o2 + i] : 0.0f;
 #pragma unroll
@@ -97,6 +99,24 @@ LP_DEV Heads loop_heads_forward(const float* sm, const LoopParams& lp, int h, co
   return o;
 }
 
+// WC: only the opacity head ends on the VALU
+template <int NB>
+LP_DEV float loop_opacity_forward(const float* sm, const LoopParams& lp, int h, const float (&ho)[NB][16]) {
+  float po = 0.0f;
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 wo = *reinterpret_cast<const float4*>(sm + lp.wo2 + 32 * blk + 8 * j + 4 * h);
+      po = fmaf(ho[blk][4 * j + 0], wo.x, po);
+      po = fmaf(ho[blk][4 * j + 1], wo.y, po);
+      po = fmaf(ho[blk][4 * j + 2], wo.z, po);
+      po = fmaf(ho[blk][4 * j + 3], wo.w, po);
+    }
+  }
+  return (po + __shfl_xor(po, 32)) + sm[lp.hb];
+}
+
 // this lane's features of the ray encoding, NB blocks (features >= width read as 0)
 template <int NB>
 LP_DEV void loop_load_encoding(const LpRendererArgs& a, int64_t rid, int h, int width, float (&enc)[NB][16]) {
@@ -128,7 +148,9 @@ LP_DEV void loop_pad_input(const float (&x0)[C / 2], float (&out)[NB][16]) {
 // ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
-template <int C, int NB, bool TG>
+// WC: 5..32 colour channels -- the colour output layer runs on the matrix cores like a hidden layer (without ReLU), lane
+// (h, r) composites the 16 channels feat(q, h) of its ray
+template <int C, int NB, bool TG, bool WC = false>
 __global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) renderer_fwd_loop(const LpRendererArgs a, const LoopParams lp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   loop_stage<NB>(a, lp, lds);
@@ -147,7 +169,10 @@ __global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) renderer_fwd_loop(const 
   const float delta0 = (a.march.num_samples > 1) ? (ray.far_t - ray.near_t) / (float)(a.march.num_samples - 1) : 1.0f;
   float nlt = 0.0f, nlt_lo = 0.0f, t_prev = 1.0f, len = 0.0f, depth_prev = 0.0f;
   int s_last = s_tot - 1;
-  float facc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  constexpr int NCH = WC ? 16 : 4;  // colour channels this lane composites
+  float facc[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) facc[c] = 0.0f;
   Sample<C> nx;
   for (int s = 0; s < s_tot; ++s) {
     fetch_sample<C, GM_GENERIC, true>(a, geo, ray, s, h, nx);
@@ -197,10 +222,21 @@ __global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) renderer_fwd_loop(const 
         loop_copy<NB>(nxt, hc);
       }
     }
-    const Heads hd = loop_heads_forward<NB>(sm, lp, h, ho, hc);
+    float raw, raw_c[NCH];
+    if constexpr (WC) {
+      raw = loop_opacity_forward<NB>(sm, lp, h, ho);
+      float cv[NB][16];
+      loop_layer_fwd<NB, false>(lbase, sm, lp.co, lane, hc, cv);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) raw_c[c] = cv[0][c];
+    } else {
+      const Heads hd = loop_heads_forward<NB>(sm, lp, h, ho, hc);
+      raw = hd.raw_o;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) raw_c[c] = hd.raw_c[c];
+    }
     const float delta = (s == 0) ? delta0 : depth - depth_prev;
     depth_prev = depth;
-    float raw = hd.raw_o;
     if (a.noise_sigma > 0.0f) raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
     const float opacity = a.gain * softplus_f(raw) * occ;
     nlt_add(nlt, nlt_lo, opacity * delta);
@@ -213,17 +249,36 @@ __global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) renderer_fwd_loop(const 
     t_prev = tr;
     len = fmaf(w, depth, len);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) facc[c] = fmaf(w, sigmoid_f(hd.raw_c[c]) * occ, facc[c]);
+    for (int c = 0; c < NCH; ++c) facc[c] = fmaf(w, sigmoid_f(raw_c[c]) * occ, facc[c]);
     if (a.stop_neg_log_t > 0.0f && __ballot(valid && nlt < a.stop_neg_log_t) == 0) {
       s_last = s;
       break;
     }
   }
-  if (valid && h == 0) {
+  if constexpr (WC) {
+    if (valid) {  // both lanes of a ray write their channels; lane h = 0 the per-ray scalars (write_ray_outputs, lp_device.h)
+      const bool epi = a.bg_color != nullptr || a.alpha != nullptr;
+      const float T = epi ? expf(-nlt) : 0.0f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int ch = featq(q, h);
+        if (ch < a.color_chn) {
+          float f = facc[q];
+          if (a.bg_color) f = f + T * a.bg_color[ch];
+          a.feature[ray_id * a.color_chn + ch] = f;
+        }
+      }
+      if (h == 0) {
+        a.ray_length[ray_id] = len;
+        a.neg_log_t[ray_id] = nlt;
+        if (a.alpha) a.alpha[ray_id] = (a.alpha_mode == 2) ? -nlt : 1.0f - T;
+      }
+    }
+  } else if (valid && h == 0) {
     write_ray_outputs(a, ray_id, len, nlt, facc);
-    if (a.neg_log_t_ckpt)
-      *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + n_ckpt - 1) * 2) = make_float2((float)s_last, nlt_lo);
   }
+  if (valid && h == 0 && a.neg_log_t_ckpt)
+    *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + n_ckpt - 1) * 2) = make_float2((float)s_last, nlt_lo);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -231,7 +286,7 @@ __global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) renderer_fwd_loop(const 
 // ---------------------------------------------------------------------------------------------------------------
 // MT / MH: the trunk layers / hidden head layers this instantiation holds registers for (the kernel's loops are unrolled to
 // them; NB = 2 is instantiated for the 2 / 2 / 2 shape only: 64-wide activations are 32 registers each)
-template <int C, int NB, bool TG, int MT, int MH>
+template <int C, int NB, bool TG, int MT, int MH, bool WC = false>
 __global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs a, const LoopParams lp) {
   using T = LoopTile;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -279,11 +334,37 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs
 #pragma unroll
     for (int q = 0; q < 16; ++q) denc[b][q] = 0.0f;
   }
-  float gfeat[4];
+  constexpr int NCH = WC ? 16 : 4;  // colour channels of this lane: 0..3 (both lanes of a ray alike), or the 16 channels feat(q, h)
+  float gfeat[NCH];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) gfeat[c] = (valid && a.grad_feature && c < a.color_chn) ? a.grad_feature[rid * a.color_chn + c] : 0.0f;
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = WC ? featq(c, h) : c;
+    gfeat[c] = (valid && a.grad_feature && ch < a.color_chn) ? a.grad_feature[rid * a.color_chn + (ch < a.color_chn ? ch : 0)] : 0.0f;
+  }
   const float g_len = (valid && a.grad_ray_length) ? a.grad_ray_length[rid] : 0.0f;
-  const float g_nlt = epilogue_grad_nlt(a, rid, valid, a.neg_log_t[rid], (valid && a.grad_neg_log_t) ? a.grad_neg_log_t[rid] : 0.0f, gfeat, 4);
+  float g_nlt;
+  if constexpr (WC) {  // epilogue_grad_nlt (lp_device.h) with the background sum taken over both lanes of the ray
+    g_nlt = (valid && a.grad_neg_log_t) ? a.grad_neg_log_t[rid] : 0.0f;
+    if (a.bg_color != nullptr || a.grad_alpha != nullptr) {
+      const float T = expf(-a.neg_log_t[rid]);
+      if (a.grad_alpha && valid) {
+        const float ga = a.grad_alpha[rid];
+        g_nlt += (a.alpha_mode == 2) ? -ga : ga * T;
+      }
+      if (a.bg_color) {
+        float sb = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int ch = featq(q, h);
+          if (ch < a.color_chn) sb = fmaf(a.bg_color[ch], gfeat[q], sb);
+        }
+        sb += __shfl_xor(sb, 32);
+        g_nlt -= T * sb;
+      }
+    }
+  } else {
+    g_nlt = epilogue_grad_nlt(a, rid, valid, a.neg_log_t[rid], (valid && a.grad_neg_log_t) ? a.grad_neg_log_t[rid] : 0.0f, gfeat, 4);
+  }
   const bool want_params = a.grad_mlp_params != nullptr;
   const float delta0 = (a.march.num_samples > 1) ? (ray.far_t - ray.near_t) / (float)(a.march.num_samples - 1) : 1.0f;
 
@@ -292,7 +373,8 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs
   const int m16 = lane & 15, ka = lane >> 4;
   const int a_off = T::XT + (16 * mi + pi16l(m16)) * LT_LD + 8 * ka;
   const int b_off = T::YT + (16 * ni + pi16l(m16)) * LT_LD + 8 * ka;
-  LoopDw<NB> dw_t[MT], dw_o[MH], dw_c[MH];
+  LoopDw<NB> dw_t[MT], dw_o[MH], dw_c[MH], dw_co;
+  loop_dw_zero<NB>(dw_co);
 #pragma unroll
   for (int l = 0; l < MT; ++l) loop_dw_zero<NB>(dw_t[l]);
 #pragma unroll
@@ -367,13 +449,24 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs
         loop_copy<NB>(cA[l], hc);
       }
     }
-    const Heads hd = loop_heads_forward<NB>(sm, lp, h, ho, hc);
+    float raw, raw_c[NCH];
+    if constexpr (WC) {
+      raw = loop_opacity_forward<NB>(sm, lp, h, ho);
+      float cv[NB][16];
+      loop_layer_fwd<NB, false>(lbase, sm, lp.co, lane, hc, cv);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) raw_c[c] = cv[0][c];
+    } else {
+      const Heads hd = loop_heads_forward<NB>(sm, lp, h, ho, hc);
+      raw = hd.raw_o;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) raw_c[c] = hd.raw_c[c];
+    }
     LP_SCHED_FENCE();
 
     // ---------------- compositing, backward ----------------
     const float depth_prev = sample_depth_tab((s > 0) ? s - 1 : 0, a.march, ray.near_t, ray.far_t, lds + lp.inf);
     const float delta = (s == 0) ? delta0 : depth - depth_prev;
-    float raw = hd.raw_o;
     if (a.noise_sigma > 0.0f) raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
     const float opacity = a.gain * softplus_f(raw) * occ;
     if (on && a.neg_log_t_ckpt) {
@@ -389,39 +482,53 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs
     if (!(nlt > 0.0f)) { nlt = 0.0f; nlt_lo = 0.0f; }
     const float t_im1 = __expf(-nlt);
     const float w = t_im1 - t_i;
-    float sg[4];
+    float sg[NCH];
     float p_i = g_len * depth;
+    if constexpr (WC) {
+      float pc = 0.0f;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      sg[c] = sigmoid_f(hd.raw_c[c]);
-      p_i = fmaf(gfeat[c], sg[c] * occ, p_i);
+      for (int c = 0; c < 16; ++c) {
+        sg[c] = sigmoid_f(raw_c[c]);
+        pc = fmaf(gfeat[c], sg[c] * occ, pc);
+      }
+      p_i += pc + __shfl_xor(pc, 32);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        sg[c] = sigmoid_f(raw_c[c]);
+        p_i = fmaf(gfeat[c], sg[c] * occ, p_i);
+      }
     }
     suffix = on ? fmaf(t_i, p_i - p_next, suffix) : suffix;
     p_next = on ? p_i : p_next;
     const float d_a = suffix + g_nlt;
     const bool contrib = valid && on;
     const float dro = contrib ? d_a * delta * a.gain * occ * d_softplus_f(raw) : 0.0f;
-    float drc[4];
+    float drc[NCH];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) drc[c] = contrib ? w * gfeat[c] * occ * sg[c] * (1.0f - sg[c]) : 0.0f;
+    for (int c = 0; c < NCH; ++c) drc[c] = contrib ? w * gfeat[c] * occ * sg[c] * (1.0f - sg[c]) : 0.0f;
 
     // ---------------- output layers of the heads (VALU) ----------------
     if (h == 0) {
       dbo2 += dro;
+      if constexpr (!WC) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) dbc2[c] += drc[c];
+        for (int c = 0; c < 4; ++c) dbc2[c] += drc[c];
+      }
     }
     if (want_params) {
       if (h == 0) {
         ts[r] = dro;
+        if constexpr (!WC) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) ts[(1 + c) * 32 + r] = drc[c];
+          for (int c = 0; c < 4; ++c) ts[(1 + c) * 32 + r] = drc[c];
+        }
       }
 #pragma unroll
       for (int blk = 0; blk < NB; ++blk) {
         // ho / hc of this block -> the (wave-private) tiles; lane (f = r, half h) reads the rays 16h .. 16h+15 of feature f
         loop_tile_store(xt, r, h, ho[blk]);
-        loop_tile_store(yt, r, h, hc[blk]);
+        if constexpr (!WC) loop_tile_store(yt, r, h, hc[blk]);
         const float* xf = xt + r * LT_LD + 16 * h;
         const float* yf = yt + r * LT_LD + 16 * h;
         const float* tf = ts + 16 * h;
@@ -432,11 +539,13 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs
           const float4 d0 = *reinterpret_cast<const float4*>(tf + 4 * i);
           dwo2[blk] = fmaf(hov.x, d0.x, dwo2[blk]); dwo2[blk] = fmaf(hov.y, d0.y, dwo2[blk]);
           dwo2[blk] = fmaf(hov.z, d0.z, dwo2[blk]); dwo2[blk] = fmaf(hov.w, d0.w, dwo2[blk]);
+          if constexpr (!WC) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float4 dc = *reinterpret_cast<const float4*>(tf + (1 + c) * 32 + 4 * i);
-            dwc2[blk][c] = fmaf(hcv.x, dc.x, dwc2[blk][c]); dwc2[blk][c] = fmaf(hcv.y, dc.y, dwc2[blk][c]);
-            dwc2[blk][c] = fmaf(hcv.z, dc.z, dwc2[blk][c]); dwc2[blk][c] = fmaf(hcv.w, dc.w, dwc2[blk][c]);
+            for (int c = 0; c < 4; ++c) {
+              const float4 dc = *reinterpret_cast<const float4*>(tf + (1 + c) * 32 + 4 * i);
+              dwc2[blk][c] = fmaf(hcv.x, dc.x, dwc2[blk][c]); dwc2[blk][c] = fmaf(hcv.y, dc.y, dwc2[blk][c]);
+              dwc2[blk][c] = fmaf(hcv.z, dc.z, dwc2[blk][c]); dwc2[blk][c] = fmaf(hcv.w, dc.w, dwc2[blk][c]);
+            }
           }
           LP_SCHED_FENCE();
         }
@@ -446,19 +555,39 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs
     // gradients of the heads' last hidden activations (masked by their ReLU where there is a hidden layer)
     float g[NB][16];   // running gradient of the head being back-propagated
     float de[NB][16];  // gradient of the heads' input e (both heads)
+    if constexpr (WC) {
+      // the colour output layer as a layer phase of its own: dW = hc^T d raw_c (workgroup-shared), d hc = W d raw_c
+      __builtin_amdgcn_s_setprio(1);
+      float dyc[NB][16];
 #pragma unroll
-    for (int blk = 0; blk < NB; ++blk) {
+      for (int b = 0; b < NB; ++b) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+        for (int q = 0; q < 16; ++q) dyc[b][q] = (b == 0) ? drc[q] : 0.0f;
+      }
+      f32x16 dxc[NB];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int q = 4 * j + i;
-          const float4 wc = *reinterpret_cast<const float4*>(sm + lp.wc2 + (32 * blk + 8 * j + 4 * h + i) * 4);
-          float v = drc[0] * wc.x;
-          v = fmaf(drc[1], wc.y, v);
-          v = fmaf(drc[2], wc.z, v);
-          v = fmaf(drc[3], wc.w, v);
-          g[blk][q] = (lp.n_c == 0 || hc[blk][q] > 0.0f) ? v : 0.0f;
+      for (int b = 0; b < NB; ++b) dxc[b] = (f32x16){0};
+      loop_layer_bwd<NB>(lbase, lp.co, lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, true, hc, dyc, dw_co, dxc);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) g[b][q] = (lp.n_c == 0 || hc[b][q] > 0.0f) ? dxc[b][q] : 0.0f;
+      }
+    } else {
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int q = 4 * j + i;
+            const float4 wc = *reinterpret_cast<const float4*>(sm + lp.wc2 + (32 * blk + 8 * j + 4 * h + i) * 4);
+            float v = drc[0] * wc.x;
+            v = fmaf(drc[1], wc.y, v);
+            v = fmaf(drc[2], wc.z, v);
+            v = fmaf(drc[3], wc.w, v);
+            g[blk][q] = (lp.n_c == 0 || hc[blk][q] > 0.0f) ? v : 0.0f;
+          }
         }
       }
     }
@@ -620,7 +749,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs
     for (int blk = 0; blk < NB; ++blk) {
       const int f = 32 * blk + j;
       if (f < lp.ho_w) atomic_add_f32(G + lp.w_o2 + f, dwo2[blk]);
-      if (f < lp.hc_w) {
+      if (!WC && f < lp.hc_w) {
         for (int c = 0; c < a.color_chn; ++c) atomic_add_f32(G + lp.w_c2 + (int64_t)f * lp.ldc2 + c, dwc2[blk][c]);
       }
     }
@@ -636,8 +765,11 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs
     if (lane == 0) {
       atomic_add_f32(G + lp.b_o2, v);
       const float cv[4] = {c0, c1, c2, c3};
-      for (int c = 0; c < a.color_chn; ++c) atomic_add_f32(G + lp.b_c2 + c, cv[c]);
+      if (!WC) {
+        for (int c = 0; c < a.color_chn; ++c) atomic_add_f32(G + lp.b_c2 + c, cv[c]);
+      }
     }
+    if (WC) loop_dw_flush<NB>(G, lp.co, dw_co, wave, lane);
 #pragma unroll
     for (int l = 0; l < MT; ++l) {
       if (!TG && l < lp.n_t) loop_dw_flush<NB>(G, lp.t[l], dw_t[l], wave, lane);
@@ -681,7 +813,8 @@ bool renderer_loop_supported(const LpRendererArgs& a, const char** why) {
     *why = "hidden width 64 with more than 2 layers per MLP (or a colour grid)";
     return false;
   }
-  if (a.color_chn > 4) { *why = "more than 4 colour channels"; return false; }
+  if (a.color_chn > 32) { *why = "more than 32 colour channels"; return false; }
+  if (a.color_chn > 4 && H == 64) { *why = "more than 4 colour channels with hidden width 64"; return false; }
   if (a.grid.n_rows * C * 4 >= (int64_t)1 << 32) { *why = "grid-list of 4 GB or more"; return false; }
   if (tg && a.color_grid.n_rows * C * 4 >= (int64_t)1 << 32) { *why = "colour grid-list of 4 GB or more"; return false; }
   if (a.march.num_samples_inf > LOOP_N_INF) { *why = "more than 64 beyond-far samples"; return false; }
@@ -715,6 +848,7 @@ static LoopParams loop_params(const LpRendererArgs& a) {
         out[l].b = boff;
         out[l].rows_in = m.dims[l];
         out[l].cols = m.dims[l + 1];
+        out[l].ld = m.dims[l + 1];
         out[l].ob = (m.dims[l + 1] + 31) / 32;
         out[l].bias = f;
         f += 32 * NB;
@@ -742,6 +876,18 @@ static LoopParams loop_params(const LpRendererArgs& a) {
   last(a.opacity, p.w_o2, p.b_o2);
   last(a.color, p.w_c2, p.b_c2);
   p.ldc2 = a.color.dims[a.color.n_layers];
+  if (a.color_chn > 4) {  // the colour output layer on the matrix cores: its color_chn real columns, row stride = padded width
+    p.co.w = p.w_c2;
+    p.co.b = p.b_c2;
+    p.co.rows_in = p.hc_w;
+    p.co.cols = a.color_chn;
+    p.co.ld = p.ldc2;
+    p.co.ob = 1;
+    p.co.bias = f;
+    f += 32 * NB;
+    p.co.img = img;
+    img += loop_layer_bytes(p.hc_w, a.color_chn);
+  }
   p.wo2 = f; f += 32 * NB;
   p.wc2 = f; f += 32 * NB * 4;
   p.hb = f; f += 8;
@@ -750,6 +896,7 @@ static LoopParams loop_params(const LpRendererArgs& a) {
   for (int l = 0; l < p.n_t; ++l) p.t[l].img += small_bytes;
   for (int l = 0; l < p.n_o; ++l) p.o[l].img += small_bytes;
   for (int l = 0; l < p.n_c; ++l) p.c[l].img += small_bytes;
+  p.co.img += small_bytes;
   p.img_end = small_bytes + img;
   static const int dbg = getenv("LP_MFMA_DEBUG") ? atoi(getenv("LP_MFMA_DEBUG")) : 0;
   p.dbg = dbg;
@@ -783,19 +930,24 @@ int renderer_forward_loop(const LpRendererArgs& a, hipStream_t stream) {
   const bool tg = a.color_grid.n_grids > 0;
   const int NB = loop_nb(p.hid);
   int rc = LP_OK;
-#define LP_LOOP_FWD(CV, NBV, TGV)                                                                       \
+#define LP_LOOP_FWD(CV, NBV, TGV, WCV)                                                                  \
   do {                                                                                                  \
-    if ((rc = loop_set_lds(renderer_fwd_loop<CV, NBV, TGV>, lds))) return rc;                           \
-    hipLaunchKernelGGL((renderer_fwd_loop<CV, NBV, TGV>), dim3(nb), dim3(256), lds, stream, a, p);      \
+    if ((rc = loop_set_lds(renderer_fwd_loop<CV, NBV, TGV, WCV>, lds))) return rc;                      \
+    hipLaunchKernelGGL((renderer_fwd_loop<CV, NBV, TGV, WCV>), dim3(nb), dim3(256), lds, stream, a, p); \
   } while (0)
+  const bool wc = a.color_chn > 4;
   if (a.grid.channels == 16) {
-    if (NB == 2) LP_LOOP_FWD(16, 2, false);
-    else if (tg) LP_LOOP_FWD(16, 1, true);
-    else LP_LOOP_FWD(16, 1, false);
+    if (NB == 2) LP_LOOP_FWD(16, 2, false, false);
+    else if (tg && wc) LP_LOOP_FWD(16, 1, true, true);
+    else if (tg) LP_LOOP_FWD(16, 1, true, false);
+    else if (wc) LP_LOOP_FWD(16, 1, false, true);
+    else LP_LOOP_FWD(16, 1, false, false);
   } else {
-    if (NB == 2) LP_LOOP_FWD(32, 2, false);
-    else if (tg) LP_LOOP_FWD(32, 1, true);
-    else LP_LOOP_FWD(32, 1, false);
+    if (NB == 2) LP_LOOP_FWD(32, 2, false, false);
+    else if (tg && wc) LP_LOOP_FWD(32, 1, true, true);
+    else if (tg) LP_LOOP_FWD(32, 1, true, false);
+    else if (wc) LP_LOOP_FWD(32, 1, false, true);
+    else LP_LOOP_FWD(32, 1, false, false);
   }
 #undef LP_LOOP_FWD
   return check_launch("renderer_fwd_loop");
@@ -809,19 +961,24 @@ int renderer_backward_loop(const LpRendererArgs& a, hipStream_t stream) {
   const bool tg = a.color_grid.n_grids > 0;
   const int NB = loop_nb(p.hid);
   int rc = LP_OK;
-#define LP_LOOP_BWD(CV, NBV, TGV, MTV, MHV)                                                                   \
-  do {                                                                                                        \
-    if ((rc = loop_set_lds(renderer_bwd_loop<CV, NBV, TGV, MTV, MHV>, lds))) return rc;                       \
-    hipLaunchKernelGGL((renderer_bwd_loop<CV, NBV, TGV, MTV, MHV>), dim3(nb), dim3(256), lds, stream, a, p);  \
+#define LP_LOOP_BWD(CV, NBV, TGV, MTV, MHV, WCV)                                                                   \
+  do {                                                                                                             \
+    if ((rc = loop_set_lds(renderer_bwd_loop<CV, NBV, TGV, MTV, MHV, WCV>, lds))) return rc;                       \
+    hipLaunchKernelGGL((renderer_bwd_loop<CV, NBV, TGV, MTV, MHV, WCV>), dim3(nb), dim3(256), lds, stream, a, p);  \
   } while (0)
+  const bool wc = a.color_chn > 4;
   if (a.grid.channels == 16) {
-    if (NB == 2) LP_LOOP_BWD(16, 2, false, 2, 1);
-    else if (tg) LP_LOOP_BWD(16, 1, true, 1, LOOP_MAX_H);
-    else LP_LOOP_BWD(16, 1, false, LOOP_MAX_T, LOOP_MAX_H);
+    if (NB == 2) LP_LOOP_BWD(16, 2, false, 2, 1, false);
+    else if (tg && wc) LP_LOOP_BWD(16, 1, true, 1, LOOP_MAX_H, true);
+    else if (tg) LP_LOOP_BWD(16, 1, true, 1, LOOP_MAX_H, false);
+    else if (wc) LP_LOOP_BWD(16, 1, false, LOOP_MAX_T, LOOP_MAX_H, true);
+    else LP_LOOP_BWD(16, 1, false, LOOP_MAX_T, LOOP_MAX_H, false);
   } else {
-    if (NB == 2) LP_LOOP_BWD(32, 2, false, 2, 1);
-    else if (tg) LP_LOOP_BWD(32, 1, true, 1, LOOP_MAX_H);
-    else LP_LOOP_BWD(32, 1, false, LOOP_MAX_T, LOOP_MAX_H);
+    if (NB == 2) LP_LOOP_BWD(32, 2, false, 2, 1, false);
+    else if (tg && wc) LP_LOOP_BWD(32, 1, true, 1, LOOP_MAX_H, true);
+    else if (tg) LP_LOOP_BWD(32, 1, true, 1, LOOP_MAX_H, false);
+    else if (wc) LP_LOOP_BWD(32, 1, false, LOOP_MAX_T, LOOP_MAX_H, true);
+    else LP_LOOP_BWD(32, 1, false, LOOP_MAX_T, LOOP_MAX_H, false);
   }
 #undef LP_LOOP_BWD
   return check_launch("renderer_bwd_loop");

@@ -393,6 +393,7 @@ static SplatLoopParams sloop_params(const LpSplatterArgs& a, int NB) {
     p.l[l].b = boff;
     p.l[l].rows_in = m.dims[l];
     p.l[l].cols = m.dims[l + 1];
+    p.l[l].ld = m.dims[l + 1];
     p.l[l].ob = (m.dims[l + 1] + 31) / 32;
     p.l[l].bias = f;
     f += 32 * NB;

@@ -507,3 +507,54 @@ def test_hip_graph_capture_of_forward_backward():
             _assert_close(f"graph replay grad_{nm}", t.grad, r.cpu().numpy(), 1e-5)
     finally:
         lp.config.check_inputs = old
+
+
+@pytest.mark.parametrize("color_chn,layers,sep,C,hidden", [(5, (2, 2, 2), False, 16, 32), (16, (4, 2, 3), False, 32, 32), (32, (1, 1, 1), False, 16, 16),
+                                                      (12, (0, 3, 2), True, 16, 32), (8, (2, 1, 1), False, 32, 32)],
+                         ids=["c5_222", "c16_423_C32", "c32_111_h16", "c12_two_grid_032", "c8_211_C32"])
+def test_wide_colour_on_the_matrix_cores(color_chn, layers, sep, C, hidden):
+    """5 .. 32 colour channels (feature rendering): the colour output layer runs as an MFMA layer of the layer-looped family,
+    each lane composites 16 of the channels.  Outputs and all gradients against the oracle, and the fused background / alpha
+    epilogue (whose background sum crosses the two lanes of a ray) against the PyTorch ops."""
+    from tests.synth import RendererCase
+    dev = _dev()
+    case = RendererCase(f"wide{color_chn}", seed=400 + color_chn, n_rays=70, grid_base=(2, 5, 6, 7, C), is_triplane=not sep, n_layers=layers,
+                        hidden=hidden, color_chn=color_chn, num_samples=13, num_samples_inf=2, gain=2.0, separate_color_grid=sep,
+                        mask_oob=True, param_std=0.25)
+    d = case.build()
+    assert lp.kernel_family(d["rays"], d["grids"], d["decoder"], color_grid=d["color_grids"]) == 3
+    out, gp, ge, gg, gc = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO)
+    o_out, o_gp, o_ge, o_gg, o_gc = run_oracle_renderer(d)
+    for nm, a, b in (("ray_length", out[0], o_out[0]), ("neg_log_t", out[1], o_out[1]), ("feature", out[2], o_out[2]),
+                     ("grad_mlp_params", gp, o_gp), ("grad_encoding", ge, o_ge)):
+        _assert_close(f"{case.name}: {nm}", a, b.detach().numpy())
+    for i, (a, b) in enumerate(zip(gg, o_gg)):
+        _assert_close(f"{case.name}: grad_grid{i}", a, b.numpy())
+    if gc is not None:
+        for i, (a, b) in enumerate(zip(gc, o_gc)):
+            _assert_close(f"{case.name}: grad_color_grid{i}", a, b.numpy())
+    # fused epilogue (feature + T * bg, alpha = 1 - T) against the op chain on the kernel's own outputs
+    from lightplane_amd.renderer import _render
+    gen = torch.Generator().manual_seed(9)
+    bg = torch.rand(color_chn, generator=gen).to(dev)
+    g_alpha = torch.randn(case.n_rays, generator=gen).to(dev)
+    g_feat = torch.randn(case.n_rays, color_chn, generator=gen).to(dev)
+
+    def run(fused):
+        rays = _rays_to(d["rays"], dev, True)
+        dec = d["decoder"]
+        params = dec.mlp_params.to(dev).clone().requires_grad_(True)
+        hdec = lp.DecoderParams(params, dec.n_hidden_trunk, dec.n_hidden_opacity, dec.n_hidden_color, dec.color_chn)
+        grids = [g.to(dev).clone().requires_grad_(True) for g in d["grids"]]
+        cgrids = None if d["color_grids"] is None else [g.to(dev) for g in d["color_grids"]]
+        if fused:
+            _, _, feat, alpha = _render(rays, grids, hdec, color_grid=cgrids, bg_color=bg, alpha_mode=1, **d["cfg"])
+        else:
+            _, nlt, feat = lp.lightplane_renderer(rays, grids, hdec, color_grid=cgrids, **d["cfg"])
+            T = torch.exp(-nlt)
+            feat, alpha = feat + T[:, None] * bg, 1 - T
+        ((feat * g_feat).sum() + (alpha * g_alpha).sum()).backward()
+        return feat, alpha, params.grad, rays.encoding.grad, grids[0].grad
+
+    for nm, a, b in zip(("feature", "alpha", "grad_mlp_params", "grad_encoding", "grad_grid0"), run(True), run(False)):
+        _assert_close(f"{case.name}: fused epilogue {nm}", a, b.detach().cpu().numpy(), tol=2e-5)
