@@ -549,7 +549,7 @@ def test_forward_variants_agree(grid, variant, tmp_path):
 
 
 def test_1080p_c16_batch_uses_variant4_and_matches_oracle_subsample():
-    """A real 1080p x C = 16 batch (2 073 600 rays > 98 304: the launcher picks renderer_fwd_mfma_np<16, GM, 4>): a block
+    """A real 1080p x C = 16 batch (2 073 600 rays: the launcher picks the three-waves-per-SIMD bf16x3 forward, renderer_fwd_bf3<16, GM, 3, 3>): a block
     of 24 x 40 neighbouring pixels of the full-size launch equals the oracle of those rays (per-ray outputs do not
     depend on the batch), S = 32 to keep the launch short."""
     dev = _dev()
@@ -581,8 +581,8 @@ sys.exit(pytest.main([{root!r} + "/tests/test_gpu_parity.py", "-m", "gpu", "-q",
 @pytest.mark.parametrize("env", [{"LP_MFMA_F32": "1"}, {"LP_MFMA_F32_BWD": "1"}], ids=["fp32_mfma_kernels", "fp32_mfma_backward_only"])
 def test_golden_suite_on_the_other_kernel_families(env):
     """The default decoder shape runs the bf16x3 forward and (C = 16) the bf16x3 backward; this runs the golden /
-    cfg-2-sized / early-termination Renderer tests once more on the fp32-MFMA kernels they replace (still what C = 32
-    backward passes and LP_MFMA_F32 select), so that every kernel that can be launched is held to the oracle."""
+    cfg-2-sized / early-termination Renderer tests once more on the fp32-MFMA kernels they replace (still what the flex / two-grid shapes, LP_BF3_C32=0
+    and LP_MFMA_F32 select), so that every kernel that can be launched is held to the oracle."""
     r = subprocess.run([sys.executable, "-c", _GOLDEN_CHILD.format(root=ROOT)], cwd=ROOT, env=dict(os.environ, **env),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
     assert r.returncode == 0, r.stdout.decode()[-3000:]

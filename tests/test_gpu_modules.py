@@ -235,6 +235,51 @@ def test_two_rank_ray_shards_equal_single_process():
     assert r.returncode == 0 and "DIST_OK" in out, out[-4000:]
 
 
+def test_graphed_renderer_replays_the_module_step():
+    """lightplane_amd.graphs.graphed_renderer: forward + backward of a LightplaneRenderer call captured into HIP graphs
+    (torch.cuda.make_graphed_callables) and replayed on NEW ray / grid values: outputs and gradients of the grids and of
+    the module's parameters equal the eager call's."""
+    from lightplane_amd.graphs import graphed_renderer
+    from tests.synth import grid_sizes_for, random_grids, random_rays
+    dev = torch.device("cuda:0")
+    old = lp.config.check_inputs
+    lp.config.check_inputs = False
+    try:
+        torch.manual_seed(0)
+        mod = lp.LightplaneRenderer(num_samples=24, color_chn=3, grid_chn=16, mlp_hidden_chn=32, gain=2.0, opacity_init_bias=-1.0,
+                                    ray_embedding_num_harmonics=3, bg_color=0.2).to(dev)
+        with torch.no_grad():
+            mod.mlp_params.mul_(4.0)
+        gen = torch.Generator().manual_seed(3)
+        sizes = grid_sizes_for((2, 8, 9, 10, 16), True)
+
+        def inputs(seed):
+            g = torch.Generator().manual_seed(seed)
+            grids = [x.to(dev).requires_grad_(True) for x in random_grids(g, sizes)]
+            rays = random_rays(g, 300, 2, None).to(dev)
+            up = [torch.randn(300, generator=g).to(dev), torch.randn(300, generator=g).to(dev), torch.randn(300, 3, generator=g).to(dev)]
+            return rays, grids, up
+
+        rays0, grids0, _ = inputs(1)
+        fn = graphed_renderer(mod, rays0, grids0)
+        for seed in (2, 3):
+            rays, grids, up = inputs(seed)
+            mod.zero_grad()
+            out = fn(rays, grids)
+            sum((o * u).sum() for o, u in zip(out, up)).backward()
+            got = [o.detach().clone() for o in out] + [g.grad.clone() for g in grids] + [p.grad.clone() for p in mod.parameters()]
+            grids_e = [g.detach().clone().requires_grad_(True) for g in grids]
+            mod.zero_grad()
+            out_e = mod(rays, grids_e)
+            sum((o * u).sum() for o, u in zip(out_e, up)).backward()
+            want = [o.detach() for o in out_e] + [g.grad for g in grids_e] + [p.grad for p in mod.parameters()]
+            for i, (a, b) in enumerate(zip(got, want)):
+                scale = float(b.abs().max()) + 1e-30
+                assert float((a - b).abs().max()) / scale <= 2e-5, (seed, i)
+    finally:
+        lp.config.check_inputs = old
+
+
 def test_bench_cfg5_two_ranks_on_one_gpu():
     """bench.py --workload cfg5 (splat shard -> sum over ranks -> normalise -> ray-sharded render -> gradient all-reduce ->
     splat backward) with two gloo ranks on this GPU, at toy sizes: the line the driver's 2 / 4 / 8-GPU runs would print."""
