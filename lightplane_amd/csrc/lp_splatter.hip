@@ -451,10 +451,14 @@ __global__ void __launch_bounds__(256) hash_randn_kernel(const int32_t* x1, cons
 // into a 128^3 x 32 grid (scripts/bench_small_batch.py --splatter, profiles/r02_small_batch.txt): 4 096 rays forward
 // 1.31 -> 0.28 ms, backward 1.19 -> 0.23 ms; 16 384 rays 1.29 -> 0.89 / 1.16 -> 0.81 ms; at 32 768 rays (512 ray blocks)
 // two segments no longer pay for the backward (1.17 -> 1.29 ms), hence the 768.
-static int splat_segments(const LpSplatterArgs& a, unsigned ray_blocks) {
+// The FORWARD also gains from a few segments on mid-sized batches (more waves in flight behind the atomics): cfg 3 (1 024 ray
+// blocks, 256 samples) forward 2.42 ms with one segment, 2.35 with two, 2.26 with three, 2.33 with four; its backward loses
+// (2.33 -> 2.43 .. 2.69 ms) -- hence `forward`: up to three segments while the launch stays within 3 072 workgroups.
+static int splat_segments(const LpSplatterArgs& a, unsigned ray_blocks, bool forward = false) {
   static const int forced = getenv("LP_SPLAT_SEGMENTS") ? atoi(getenv("LP_SPLAT_SEGMENTS")) : 0;
   const int s_tot = a.march.num_samples + a.march.num_samples_inf;
   int n = forced > 0 ? forced : (int)(768u / (ray_blocks ? ray_blocks : 1u));
+  if (forced <= 0 && forward && n <= 1) n = (int)(3072u / (ray_blocks ? ray_blocks : 1u));
   if (n > s_tot / 16) n = s_tot / 16;
   return n < 1 ? 1 : n;
 }
@@ -468,7 +472,7 @@ int splatter_forward_launch(const LpSplatterArgs& a, hipStream_t stream) {
     const int rpw_eff = Cw == 64 ? 16 : rpw;
     const unsigned ray_blocks = (unsigned)((a.rays.n_rays + 4 * rpw_eff - 1) / (4 * rpw_eff));
     if (ray_blocks == 0) return LP_OK;
-    const int n_seg = splat_segments(a, ray_blocks);
+    const int n_seg = splat_segments(a, ray_blocks, true);
     const unsigned blocks = ray_blocks * (unsigned)n_seg;
     // (64 channels -- the reference's own speed benchmark splats into [1,160,160,160,64] -- : four channels per lane)
     if (Cw == 64) hipLaunchKernelGGL((splat_fwd_walk_kernel<64, 16>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg);

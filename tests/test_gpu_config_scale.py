@@ -33,6 +33,16 @@ F64 = torch.float64
 
 def oracle_chunked(d, idx=None, dtype=torch.float32, chunk=2048):
     """Oracle forward + backward over the rays ``idx`` (default: all) in chunks, gradients of the replicated inputs summed."""
+    # (a problem of this size thrashes on the box's 100+ host cores: bench.py's cpu_baseline leg measured 16 threads as the knee)
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    try:
+        return _oracle_chunked(d, idx, dtype, chunk)
+    finally:
+        torch.set_num_threads(old_threads)
+
+
+def _oracle_chunked(d, idx, dtype, chunk):
     rays = d["rays"] if idx is None else d["rays"][idx]
     up = d["upstream"] if idx is None else tuple(u[idx] for u in d["upstream"])
     n = rays.n_rays
