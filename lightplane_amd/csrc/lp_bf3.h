@@ -382,18 +382,18 @@ LP_DEV Heads decode_bf3(const float* sm, const char* fimg_, int lane, const floa
   const char* fimg = fimg_ + zo;
   f32x16 acc = layer_bf3v<C / 16>(fimg, L::CH_T1, lane, t.x0, load_bias_bf3(sm, 0, h, zo));
 #pragma unroll
-  for (int q = 0; q < 16; ++q) t.h1[q] = fmaxf(acc[q], 0.0f);
+  for (int q = 0; q < 16; ++q) t.h1[q] = relu_f(acc[q]);
   acc = layer_bf3v<2>(fimg, L::CH_T2, lane, t.h1, load_bias_bf3(sm, 1, h, zo));
 #pragma unroll
-  for (int q = 0; q < 16; ++q) t.e[q] = fmaxf(acc[q], 0.0f);
+  for (int q = 0; q < 16; ++q) t.e[q] = relu_f(acc[q]);
   f32x16 acc_o = load_bias_bf3(sm, 2, h, zo), acc_c;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc_c[q] = cb[q];
   layer2_bf3v<2>(fimg, L::CH_O1, L::CH_C1, lane, t.e, acc_o, acc_c);
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
-    t.ho[q] = fmaxf(acc_o[q], 0.0f);
-    t.hc[q] = fmaxf(acc_c[q], 0.0f);
+    t.ho[q] = relu_f(acc_o[q]);
+    t.hc[q] = relu_f(acc_c[q]);
   }
   return heads_forward<NC>(sm, h, t.ho, t.hc, zo);
 }

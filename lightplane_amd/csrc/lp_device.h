@@ -420,6 +420,40 @@ LP_DEV float softplus_f(float x) {
   const float sp = (e < 0.015625f) ? series : lg;
   return (x > 20.0f) ? x : sp;
 }
+// ReLU on the integer unit.  fmaxf(x, 0) costs TWO instructions here: in IEEE mode v_max_f32 has to be preceded by a
+// canonicalising v_max_f32 x, x, x whenever the compiler cannot prove x is not a signalling NaN (MFMA results never qualify).
+// The sign-magnitude encoding makes max over the bit patterns the same function: negative floats are negative integers,
+// -0 -> +0, positive values and +NaN pass through (one v_max_i32).
+LP_DEV float relu_f(float x) {
+#ifdef LP_X_RELU_F
+  return fmaxf(x, 0.0f);
+#else
+  const int i = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, i > 0 ? i : 0);
+#endif
+}
+
+// ReLU masks as bits of one register (the backward keeps 16 activations' masks in 16 bits instead of 16 registers).
+// mask_bit: post-ReLU value -> bit q.  mask_apply: v if bit q is set else 0: v_bfe_i32 (sign-extends the bit to all ones) +
+// v_and_b32 instead of and + compare + select.
+LP_DEV unsigned mask_bit(unsigned m, float relu_value, int q) {
+#ifdef LP_X_MASK_BIT_INT  // two integer ops (v_min_i32, v_lshl_or_b32) -- but with it the allocator of the dominant backward
+  // kernel spills 19 values inside the sample loop instead of 2 (scripts/isa_loop_scratch.py): off
+  const int i = __builtin_bit_cast(int, relu_value);
+  return m | ((unsigned)(i < 1 ? i : 1) << q);
+#else
+  return m | ((relu_value > 0.0f) ? (1u << q) : 0u);
+#endif
+}
+LP_DEV float mask_apply(unsigned m, int q, float v) {
+#ifdef LP_X_MASK_APPLY
+  return (m & (1u << q)) ? v : 0.0f;
+#else
+  const int all = ((int)(m << (31 - q))) >> 31;
+  return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & all);
+#endif
+}
+
 // 1 / (1 + e^-x) with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division (ten instructions):
 // the forward evaluates it 3-4 times per ray and sample, the backward once more for d softplus
 LP_DEV float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }

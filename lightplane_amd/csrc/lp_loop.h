@@ -91,7 +91,7 @@ LP_DEV void loop_layer_fwd(const char* lbase, const float* sm, const LoopLayer& 
 #pragma unroll
   for (int ob = 0; ob < NB; ++ob) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) out[ob][q] = RELU ? fmaxf(acc[ob][q], 0.0f) : acc[ob][q];
+    for (int q = 0; q < 16; ++q) out[ob][q] = RELU ? relu_f(acc[ob][q]) : acc[ob][q];
   }
 }
 

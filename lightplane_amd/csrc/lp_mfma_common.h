@@ -406,7 +406,7 @@ LP_DEV Heads decode_prefetch(const LpRendererArgs& a, const float* lds, const Ra
   LP_SCHED_FENCE();
   f32x16 acc = layer<C / 2>(wl + M::WT1, t.x0, load_bias(lds, 0, h, zo));
 #pragma unroll
-  for (int q = 0; q < 16; ++q) t.h1[q] = fmaxf(acc[q], 0.0f);
+  for (int q = 0; q < 16; ++q) t.h1[q] = relu_f(acc[q]);
   LP_SCHED_FENCE();
   // ---- group 1: trunk layer 2  ||  plane 0 / voxel taps 0-3 ----
   if (GM == GM_TRIPLANE || GM == GM_VOXEL) {
@@ -415,7 +415,7 @@ LP_DEV Heads decode_prefetch(const LpRendererArgs& a, const float* lds, const Ra
   }
   acc = layer<16>(wl + M::WT2, t.h1, load_bias(lds, 1, h, zo));
 #pragma unroll
-  for (int q = 0; q < 16; ++q) t.e[q] = fmaxf(acc[q], 0.0f);
+  for (int q = 0; q < 16; ++q) t.e[q] = relu_f(acc[q]);
   if (GM == GM_TRIPLANE || GM == GM_VOXEL) interleave_hint<16, 5, 2>();
   LP_SCHED_FENCE();
   // ---- group 2: opacity hidden layer  ||  plane 1 / voxel taps 4-7 ----
@@ -428,7 +428,7 @@ LP_DEV Heads decode_prefetch(const LpRendererArgs& a, const float* lds, const Ra
   }
   acc = layer<16>(wl + M::WO1, t.e, load_bias(lds, 2, h, zo));
 #pragma unroll
-  for (int q = 0; q < 16; ++q) t.ho[q] = fmaxf(acc[q], 0.0f);
+  for (int q = 0; q < 16; ++q) t.ho[q] = relu_f(acc[q]);
   if (GM == GM_TRIPLANE || GM == GM_VOXEL) interleave_hint<16, 5, 2>();
   LP_SCHED_FENCE();
   // ---- group 3: colour hidden layer  ||  plane 2 ----
@@ -441,7 +441,7 @@ LP_DEV Heads decode_prefetch(const LpRendererArgs& a, const float* lds, const Ra
   for (int q = 0; q < 16; ++q) ein[q] = t.e[q] + enc[q];
   acc = layer<16>(wl + M::WC1, ein, load_bias(lds, 3, h, zo));
 #pragma unroll
-  for (int q = 0; q < 16; ++q) t.hc[q] = fmaxf(acc[q], 0.0f);
+  for (int q = 0; q < 16; ++q) t.hc[q] = relu_f(acc[q]);
   if (GM == GM_TRIPLANE) interleave_hint<16, 6, 2>();
   LP_SCHED_FENCE();
   return heads_forward<NC>(lds, h, t.ho, t.hc, zo);

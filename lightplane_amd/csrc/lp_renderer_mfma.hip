@@ -108,7 +108,7 @@ LP_DEV Heads decode_flex(const float* lds, int lane, const float (&enc)[16], Act
   if (t1) {
     const f32x16 acc = layer<C / 2>(wl + M::WT1, t.x0, load_bias(lds, 0, h, zo));
 #pragma unroll
-    for (int q = 0; q < 16; ++q) t.h1[q] = fmaxf(acc[q], 0.0f);
+    for (int q = 0; q < 16; ++q) t.h1[q] = relu_f(acc[q]);
   } else {  // two-grid decoder: the opacity head sees relu(sampled feature)
 #pragma unroll
     for (int q = 0; q < 16; ++q) t.h1[q] = (q < C / 2) ? fmaxf(t.x0[q < C / 2 ? q : 0], 0.0f) : 0.0f;
@@ -117,7 +117,7 @@ LP_DEV Heads decode_flex(const float* lds, int lane, const float (&enc)[16], Act
   if (t2) {
     acc = layer<16>(wl + M::WT2, t.h1, load_bias(lds, 1, h, zo));
 #pragma unroll
-    for (int q = 0; q < 16; ++q) t.e[q] = fmaxf(acc[q], 0.0f);
+    for (int q = 0; q < 16; ++q) t.e[q] = relu_f(acc[q]);
   } else {
 #pragma unroll
     for (int q = 0; q < 16; ++q) t.e[q] = t.h1[q];
@@ -125,7 +125,7 @@ LP_DEV Heads decode_flex(const float* lds, int lane, const float (&enc)[16], Act
   if (oh) {
     acc = layer<16>(wl + M::WO1, t.e, load_bias(lds, 2, h, zo));
 #pragma unroll
-    for (int q = 0; q < 16; ++q) t.ho[q] = fmaxf(acc[q], 0.0f);
+    for (int q = 0; q < 16; ++q) t.ho[q] = relu_f(acc[q]);
   } else {
 #pragma unroll
     for (int q = 0; q < 16; ++q) t.ho[q] = t.e[q];
@@ -141,7 +141,7 @@ LP_DEV Heads decode_flex(const float* lds, int lane, const float (&enc)[16], Act
   if (ch) {
     acc = layer<16>(wl + M::WC1, ein, load_bias(lds, 3, h, zo));
 #pragma unroll
-    for (int q = 0; q < 16; ++q) t.hc[q] = fmaxf(acc[q], 0.0f);
+    for (int q = 0; q < 16; ++q) t.hc[q] = relu_f(acc[q]);
   } else {
 #pragma unroll
     for (int q = 0; q < 16; ++q) t.hc[q] = ein[q];

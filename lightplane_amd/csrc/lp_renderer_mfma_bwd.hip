@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     if (t1) {
       acc = layer<C / 2>(wl + M::WT1, x0, load_bias(lds, 0, h, zo));
 #pragma unroll
-      for (int q = 0; q < 16; ++q) h1[q] = fmaxf(acc[q], 0.0f);
+      for (int q = 0; q < 16; ++q) h1[q] = relu_f(acc[q]);
     } else {  // the opacity head reads relu(sampled feature)
 #pragma unroll
       for (int q = 0; q < 16; ++q) h1[q] = (q < C / 2) ? fmaxf(x0[q < C / 2 ? q : 0], 0.0f) : 0.0f;
@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     if (t2) {
       acc = layer<16>(wl + M::WT2, h1, load_bias(lds, 1, h, zo));
 #pragma unroll
-      for (int q = 0; q < 16; ++q) e[q] = fmaxf(acc[q], 0.0f);
+      for (int q = 0; q < 16; ++q) e[q] = relu_f(acc[q]);
     } else {
 #pragma unroll
       for (int q = 0; q < 16; ++q) e[q] = h1[q];
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
     if (oh) {
       acc = layer<16>(wl + M::WO1, e, load_bias(lds, 2, h, zo));
 #pragma unroll
-      for (int q = 0; q < 16; ++q) ho[q] = fmaxf(acc[q], 0.0f);
+      for (int q = 0; q < 16; ++q) ho[q] = relu_f(acc[q]);
     } else {
 #pragma unroll
       for (int q = 0; q < 16; ++q) ho[q] = e[q];
@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArg
       if (ch) {
         acc = layer<16>(wl + M::WC1, ein, load_bias(lds, 3, h, zo));
 #pragma unroll
-        for (int q = 0; q < 16; ++q) hc[q] = fmaxf(acc[q], 0.0f);
+        for (int q = 0; q < 16; ++q) hc[q] = relu_f(acc[q]);
       } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q) hc[q] = ein[q];
@@ -845,12 +845,12 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
       {
         acc = layer_bf3v<C / 16>(Af(I0{}), lane, x0, load_bias(sm, 0, h, zo));
 #pragma unroll
-        for (int q = 0; q < 16; ++q) h1[q] = fmaxf(acc[q], 0.0f);
+        for (int q = 0; q < 16; ++q) h1[q] = relu_f(acc[q]);
       }
       {
         acc = layer_bf3v<2>(Af(I1{}), lane, h1, load_bias(sm, 1, h, zo));
 #pragma unroll
-        for (int q = 0; q < 16; ++q) e[q] = fmaxf(acc[q], 0.0f);
+        for (int q = 0; q < 16; ++q) e[q] = relu_f(acc[q]);
       }
       float ho[16], hc[16];
       {
@@ -868,15 +868,15 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
         layer2_bf3v<2>(Af(I2{}), Af(I3{}), lane, e, acc_o, acc_c);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          ho[q] = fmaxf(acc_o[q], 0.0f);
-          hc[q] = fmaxf(acc_c[q], 0.0f);
+          ho[q] = relu_f(acc_o[q]);
+          hc[q] = relu_f(acc_c[q]);
         }
       }
       hd = heads_forward<NC>(sm, h, ho, hc, zo);
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        ho_mask |= (ho[q] > 0.0f) ? (1u << q) : 0u;
-        hc_mask |= (hc[q] > 0.0f) ? (1u << q) : 0u;
+        ho_mask = mask_bit(ho_mask, ho[q], q);
+        hc_mask = mask_bit(hc_mask, hc[q], q);
       }
       LP_SCHED_FENCE();
       // ho / hc go to the (wave-private) tiles: the output layers' dW reads them from there
@@ -942,7 +942,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
           v = fmaf(drc[1], wc.y, v);
           v = fmaf(drc[2], wc.z, v);
           if (NC > 3) v = fmaf(drc[3], wc.w, v);
-          dhc[q] = (hc_mask & (1u << q)) ? v : 0.0f;
+          dhc[q] = mask_apply(hc_mask, q, v);
         }
         LP_SCHED_FENCE();
       }
@@ -1007,10 +1007,10 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 wo = *reinterpret_cast<const float4*>(ldz + M::WO2 + 8 * j + 4 * h);
-        dho[4 * j + 0] = (ho_mask & (1u << (4 * j + 0))) ? dro * wo.x : 0.0f;
-        dho[4 * j + 1] = (ho_mask & (1u << (4 * j + 1))) ? dro * wo.y : 0.0f;
-        dho[4 * j + 2] = (ho_mask & (1u << (4 * j + 2))) ? dro * wo.z : 0.0f;
-        dho[4 * j + 3] = (ho_mask & (1u << (4 * j + 3))) ? dro * wo.w : 0.0f;
+        dho[4 * j + 0] = mask_apply(ho_mask, 4 * j + 0, dro * wo.x);
+        dho[4 * j + 1] = mask_apply(ho_mask, 4 * j + 1, dro * wo.y);
+        dho[4 * j + 2] = mask_apply(ho_mask, 4 * j + 2, dro * wo.z);
+        dho[4 * j + 3] = mask_apply(ho_mask, 4 * j + 3, dro * wo.w);
       }
       if (want_params) tile_store_fm(yt, r, h, dho);  // the X tile still holds e
       acc = layer_bf3v<2>(Ab(I2{}), lane, dho, acc);

@@ -104,7 +104,7 @@ LP_DEV void layer_w(const float* w, const float* bias, const float* in, float* o
         acc = LP_MFMA(w[(32 * ib + featq(kk, 0)) * WLD + 32 * ob], in[16 * ib + kk], acc);
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) out[16 * ob + q] = relu ? fmaxf(acc[q], 0.0f) : acc[q];
+    for (int q = 0; q < 16; ++q) out[16 * ob + q] = relu ? relu_f(acc[q]) : acc[q];
   }
 }
 

@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256, 2) splat_mlp_fwd_mfma(const LpSplatterArg
     for (int q = 0; q < E / 2; ++q) xin[q] = sm.x0[q] + enc[q];
     f32x16 acc = layer<E / 2>(wl + M::W1, xin, bias16(lds + M::B1 + 4 * h + zo));
 #pragma unroll
-    for (int q = 0; q < 16; ++q) h1[q] = fmaxf(acc[q], 0.0f);
+    for (int q = 0; q < 16; ++q) h1[q] = relu_f(acc[q]);
     acc = layer<16>(wl + M::W2, h1, bias16(lds + M::B2 + 4 * h + zo));
     LP_SCHED_FENCE();
     // output vector -> [channel][ray]
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(256, 2) splat_mlp_bwd_mfma(const LpSplatterArg
     for (int q = 0; q < 16; ++q) xin[q] = (q < E / 2) ? sm.x0[q < E / 2 ? q : 0] + enc[q < E / 2 ? q : 0] : 0.0f;
     f32x16 acc = layer<E / 2>(wl + M::W1, xin, bias16(lds + M::B1 + 4 * h + zo));
 #pragma unroll
-    for (int q = 0; q < 16; ++q) h1[q] = fmaxf(acc[q], 0.0f);
+    for (int q = 0; q < 16; ++q) h1[q] = relu_f(acc[q]);
     LP_SCHED_FENCE();
     // ---- d v: gather of grad_out / clamp(weight) at the output taps (Splatter interpolation) ----
     float dv[16];
