@@ -254,7 +254,7 @@ int lp_renderer_backward_segments(const LpRendererArgs* args) {
   const char* why = "";
   if (args->kernel == LP_KERNEL_GENERIC) return 1;
   const int fam = select_renderer(*args, &why);
-  return fam == 1 ? renderer_mfma_segments(*args) : fam == 2 ? renderer_mfma_wide_segments(*args) : 1;  // (family 3: one sweep)
+  return fam == 1 ? renderer_mfma_segments(*args) : fam == 2 ? renderer_mfma_wide_segments(*args) : fam == 3 ? renderer_loop_segments(*args) : 1;
 }
 
 // MLP-Splatter: 2 = [E,32,Cout] fp32-MFMA family, 3 = layer-looped bf16x3 family (2-4 layers, widths 16 / 32 / 64), 0 = generic.

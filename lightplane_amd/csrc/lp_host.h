@@ -31,6 +31,7 @@ int renderer_backward_mfma_wide(const LpRendererArgs& a, hipStream_t stream);
 // layer-looped bf16x3 MFMA family (1-4 layers per MLP, hidden 16 / 32 / 64): lp_renderer_loop.hip
 bool renderer_loop_supported(const LpRendererArgs& a, const char** why);
 bool renderer_loop_fits(const LpRendererArgs& a);  // its weight images + tiles fit the 160 KB LDS
+int renderer_loop_segments(const LpRendererArgs& a);  // segments of the segment-parallel march (1 = none)
 int renderer_forward_loop(const LpRendererArgs& a, hipStream_t stream);
 int renderer_backward_loop(const LpRendererArgs& a, hipStream_t stream);
 

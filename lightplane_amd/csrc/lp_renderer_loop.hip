@@ -35,6 +35,9 @@ struct LoopParams {
   int wo2, wc2, hb, inf;            // float offsets inside the small block
   int img_end;                      // bytes before the per-wave tiles
   int dbg;
+  // segment-parallel march of a small batch (LpRendererArgs.seg_prefix): LP_SEG_LEN-sample blocks per workgroup;
+  // seg_fwd: this forward launch marches segments (segment-local state records, chained by renderer_fwd_combine)
+  int seg_blocks, seg_fwd;
 };
 
 // per-wave LDS area behind the images (floats)
@@ -158,7 +161,14 @@ __global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) renderer_fwd_loop(const 
   const float* const geo = lds + lp.inf - Lds::INF;  // sample_geometry() reads its beyond-far table at geo + Lds::INF
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, r = lane & 31;
-  const int64_t ray_id = ((int64_t)blockIdx.x * WAVES + wave) * RAYS_PER_WAVE + r;
+  // small batch (lp.seg_fwd): a workgroup marches ONE segment of its 128 rays from transmittance 1 and leaves segment-local
+  // state records; renderer_fwd_combine chains them (lp_renderer_mfma.hip)
+  const bool segf = !WC && lp.seg_fwd != 0;
+  const int seg_len = LP_SEG_LEN * lp.seg_blocks;
+  const int n_seg = segf ? (a.march.num_samples + seg_len - 1) / seg_len : 1;
+  const int blk = segf ? (int)blockIdx.x / n_seg : (int)blockIdx.x;
+  const int seg = segf ? (int)blockIdx.x - blk * n_seg : 0;
+  const int64_t ray_id = ((int64_t)blk * WAVES + wave) * RAYS_PER_WAVE + r;
   const bool valid = ray_id < a.rays.n_rays;
   const int64_t rid = valid ? ray_id : 0;
   const Ray ray = load_ray(a.rays, rid);
@@ -174,7 +184,13 @@ __global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) renderer_fwd_loop(const 
 #pragma unroll
   for (int c = 0; c < NCH; ++c) facc[c] = 0.0f;
   Sample<C> nx;
-  for (int s = 0; s < s_tot; ++s) {
+  const int s_lo = segf ? seg * seg_len : 0;
+  const int s_hi = segf ? ((s_lo + seg_len < s_tot) ? s_lo + seg_len : s_tot) : s_tot;
+  if (segf && s_lo > 0) {  // interval length of the segment's first sample
+    sample_geometry<C>(a, geo, ray, s_lo - 1, nx);
+    depth_prev = nx.depth;
+  }
+  for (int s = s_lo; s < s_hi; ++s) {
     fetch_sample<C, GM_GENERIC, true>(a, geo, ray, s, h, nx);
     const float depth = nx.depth, occ = nx.occ;
     const int zo = opaque_zero();
@@ -240,7 +256,7 @@ __global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) renderer_fwd_loop(const 
     if (a.noise_sigma > 0.0f) raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
     const float opacity = a.gain * softplus_f(raw) * occ;
     nlt_add(nlt, nlt_lo, opacity * delta);
-    if (a.neg_log_t_ckpt && valid && h == 0) {
+    if (!segf && a.neg_log_t_ckpt && valid && h == 0) {
       const int ck = ckpt_index(s, a.march);
       if (ck >= 0) *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + ck) * 2) = make_float2(nlt, nlt_lo);
     }
@@ -250,6 +266,12 @@ __global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) renderer_fwd_loop(const 
     len = fmaf(w, depth, len);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) facc[c] = fmaf(w, sigmoid_f(raw_c[c]) * occ, facc[c]);
+    // state records of the segment-parallel backward (absolute; segf: relative to the segment's start)
+    if (!WC && a.seg_prefix && valid && h == 0 && (((s + 1) % LP_SEG_LEN) == 0 || s == a.march.num_samples - 1)) {
+      float4* dst = reinterpret_cast<float4*>(a.seg_prefix + (ray_id * segment_count(a.march) + s / LP_SEG_LEN) * 8);
+      dst[0] = make_float4(len, facc[0], facc[1], facc[2]);
+      dst[1] = make_float4(facc[3], nlt, nlt_lo, 0.0f);
+    }
     if (a.stop_neg_log_t > 0.0f && __ballot(valid && nlt < a.stop_neg_log_t) == 0) {
       s_last = s;
       break;
@@ -274,10 +296,10 @@ __global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) renderer_fwd_loop(const 
         if (a.alpha) a.alpha[ray_id] = (a.alpha_mode == 2) ? -nlt : 1.0f - T;
       }
     }
-  } else if (valid && h == 0) {
+  } else if (valid && h == 0 && !segf) {
     write_ray_outputs(a, ray_id, len, nlt, facc);
   }
-  if (valid && h == 0 && a.neg_log_t_ckpt)
+  if (valid && h == 0 && a.neg_log_t_ckpt && !segf)
     *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + n_ckpt - 1) * 2) = make_float2((float)s_last, nlt_lo);
 }
 
@@ -300,7 +322,15 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs
   float* const xt = wv + T::XT;
   float* const yt = wv + T::YT;
   float* const ts = wv + T::TS;
-  const int64_t ray_id = ((int64_t)blockIdx.x * WAVES + wave) * RAYS_PER_WAVE + r;
+  // segment-parallel sweep of a small batch (LpRendererArgs.seg_prefix): workgroup = (128 rays, lp.seg_blocks blocks of
+  // LP_SEG_LEN samples), see renderer_bwd_bf3 (lp_renderer_mfma_bwd.hip)
+  const bool seg_on = !WC && a.seg_prefix != nullptr;
+  const int n_rec = seg_on ? segment_count(a.march) : 1;
+  const int seg_len = LP_SEG_LEN * lp.seg_blocks;
+  const int n_seg = seg_on ? (a.march.num_samples + seg_len - 1) / seg_len : 1;
+  const int blk = seg_on ? (int)blockIdx.x / n_seg : (int)blockIdx.x;
+  const int seg = seg_on ? (int)blockIdx.x - blk * n_seg : 0;
+  const int64_t ray_id = ((int64_t)blk * WAVES + wave) * RAYS_PER_WAVE + r;
   const bool valid = ray_id < a.rays.n_rays;
   const int64_t rid = valid ? ray_id : 0;
   const Ray ray = load_ray(a.rays, rid);
@@ -327,6 +357,8 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs
     s_begin = sv > s_begin ? sv : s_begin;
   }
   __syncthreads();  // ts[] is reused by the sample loop
+  const int s_lo = seg_on ? seg * seg_len : 0;
+  if (seg_on) s_begin = (s_lo + seg_len - 1 < s_tot - 1) ? s_lo + seg_len - 1 : s_tot - 1;
 
   float denc[NB][16];
 #pragma unroll
@@ -396,9 +428,26 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs
 
   float nlt = a.neg_log_t[rid];
   float suffix = 0.0f, p_next = 0.0f;
+  if constexpr (!WC) {
+    if (seg_on) {  // start of a segment: -log T and the sums behind its last sample, from the forward's state records
+      const float4* pj = reinterpret_cast<const float4*>(a.seg_prefix + (rid * n_rec + s_begin / LP_SEG_LEN) * 8);
+      const float4* pt = reinterpret_cast<const float4*>(a.seg_prefix + (rid * n_rec + n_rec - 1) * 8);
+      const float4 j0 = pj[0], j1 = pj[1], t0 = pt[0];
+      nlt = j1.y;
+      nlt_lo = j1.z;
+      if (seg < n_seg - 1) {
+        float rest = g_len * (t0.x - j0.x);
+        rest = fmaf(gfeat[0], t0.y - j0.y, rest);
+        rest = fmaf(gfeat[1], t0.z - j0.z, rest);
+        rest = fmaf(gfeat[2], t0.w - j0.w, rest);
+        rest = fmaf(gfeat[3], pt[1].x - j1.x, rest);
+        suffix = -rest;
+      }
+    }
+  }
   Sample<C> nx;
   fetch_sample<C, GM_GENERIC, false>(a, geo, ray, s_begin, h, nx);
-  for (int s = s_begin; s >= 0; --s) {
+  for (int s = s_begin; s >= s_lo; --s) {
     const bool on = s <= s_last_w;  // wave-uniform; false only for samples a sibling wave still marches
     const float depth = nx.depth, occ = nx.occ, x = nx.x, y = nx.y, z = nx.z;
     const int zo = opaque_zero();
@@ -721,7 +770,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs
     // ---------------- next (nearer) sample + grid gradient ----------------
     __builtin_amdgcn_s_setprio(0);
     const bool live = valid && on && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
-    if (s > 0) fetch_sample<C, GM_GENERIC, true>(a, geo, ray, s - 1, h, nx);
+    if (s > s_lo) fetch_sample<C, GM_GENERIC, true>(a, geo, ray, s - 1, h, nx);
     LP_SCHED_FENCE();
     if (gg && !(lp.dbg & 2)) {
 #pragma unroll 1
@@ -731,7 +780,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs
   }
 
   // ---------------- epilogue ----------------
-  if (valid && a.grad_encoding) {
+  if (valid && a.grad_encoding && !seg_on) {
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
       float4* dst = reinterpret_cast<float4*>(a.grad_encoding + ray_id * lp.hin + 32 * blk + 4 * h);
@@ -739,6 +788,18 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs
       for (int j = 0; j < 4; ++j) {
         if (32 * blk + 8 * j + 4 * h < lp.hin)
           dst[2 * j] = make_float4(denc[blk][4 * j], denc[blk][4 * j + 1], denc[blk][4 * j + 2], denc[blk][4 * j + 3]);
+      }
+    }
+  } else if (valid && a.grad_encoding) {  // the segments of a ray add up (the caller zero-fills)
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+      float* dst = a.grad_encoding + ray_id * lp.hin + 32 * blk + 4 * h;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (32 * blk + 8 * j + 4 * h < lp.hin) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) atomic_add_f32(dst + 8 * j + i, denc[blk][4 * j + i]);
+        }
       }
     }
   }
@@ -900,7 +961,32 @@ static LoopParams loop_params(const LpRendererArgs& a) {
   p.img_end = small_bytes + img;
   static const int dbg = getenv("LP_MFMA_DEBUG") ? atoi(getenv("LP_MFMA_DEBUG")) : 0;
   p.dbg = dbg;
+  p.seg_blocks = 1;
+  p.seg_fwd = 0;
   return p;
+}
+
+// Segment-parallel march of a small batch (same rules as renderer_mfma_segments, lp_renderer_mfma.hip): the looped kernels
+// run one four-wave workgroup per CU, so 256 workgroups = 32 768 rays fill the chip once; below that a workgroup per
+// (128 rays, segment) fills it.  Not with 5..32 colour channels (the state records hold four colour sums).
+int renderer_loop_segments(const LpRendererArgs& a) {
+  static const int forced = getenv("LP_SEGMENTS") ? atoi(getenv("LP_SEGMENTS")) : -1;
+  if (forced == 0 || a.march.num_samples_inf != 0 || a.stop_neg_log_t > 0.0f || a.color_chn > 4) return 1;
+  const int n_seg = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
+  if (n_seg < 2) return 1;
+  if (forced < 0 && a.rays.n_rays > 24576) return 1;
+  return n_seg;
+}
+
+// LP_SEG_LEN-sample blocks per segment: as many segments as keep the launch within one round of resident workgroups (every
+// workgroup stages up to 69 KB of limb images and flushes its dW once)
+static int loop_seg_blocks(const LpRendererArgs& a, unsigned ray_blocks) {
+  static const int forced = getenv("LP_SEG_BLOCKS") ? atoi(getenv("LP_SEG_BLOCKS")) : 0;
+  const int n_rec = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
+  int m = 1;
+  while (m < n_rec && (uint64_t)ray_blocks * ((n_rec + m - 1) / m) > 256u) ++m;
+  if (forced > 0) m = forced < n_rec ? forced : n_rec;
+  return m;
 }
 
 static size_t loop_lds_bytes(const LoopParams& p, bool backward) {
@@ -923,9 +1009,17 @@ static unsigned loop_blocks(const LpRendererArgs& a) {
 }
 
 int renderer_forward_loop(const LpRendererArgs& a, hipStream_t stream) {
-  const unsigned nb = loop_blocks(a);
+  unsigned nb = loop_blocks(a);
   if (nb == 0) return LP_OK;
-  const LoopParams p = loop_params(a);
+  LoopParams p = loop_params(a);
+  static const bool seg_fwd = getenv("LP_SEG_FWD") == nullptr || atoi(getenv("LP_SEG_FWD")) != 0;
+  const bool segf = a.seg_prefix && seg_fwd && !a.seg_forward_off && a.color_chn <= 4;
+  if (segf) {
+    const int n_rec = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
+    p.seg_blocks = loop_seg_blocks(a, nb);
+    p.seg_fwd = 1;
+    nb *= (unsigned)((n_rec + p.seg_blocks - 1) / p.seg_blocks);
+  }
   const size_t lds = loop_lds_bytes(p, false);
   const bool tg = a.color_grid.n_grids > 0;
   const int NB = loop_nb(p.hid);
@@ -950,13 +1044,19 @@ int renderer_forward_loop(const LpRendererArgs& a, hipStream_t stream) {
     else LP_LOOP_FWD(32, 1, false, false);
   }
 #undef LP_LOOP_FWD
+  if (segf && (rc = renderer_forward_combine_launch(a, p.seg_blocks, stream))) return rc;
   return check_launch("renderer_fwd_loop");
 }
 
 int renderer_backward_loop(const LpRendererArgs& a, hipStream_t stream) {
-  const unsigned nb = loop_blocks(a);
+  unsigned nb = loop_blocks(a);
   if (nb == 0) return LP_OK;
-  const LoopParams p = loop_params(a);
+  LoopParams p = loop_params(a);
+  if (a.seg_prefix && a.color_chn <= 4) {  // small batch: one workgroup per (128 rays, segment)
+    const int n_rec = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
+    p.seg_blocks = loop_seg_blocks(a, nb);
+    nb *= (unsigned)((n_rec + p.seg_blocks - 1) / p.seg_blocks);
+  }
   const size_t lds = loop_lds_bytes(p, true);
   const bool tg = a.color_grid.n_grids > 0;
   const int NB = loop_nb(p.hid);

@@ -202,8 +202,12 @@ def test_renderer_coherent_early_termination_exact_when_off():
     ("two_grid_triplane_c16", 66, dict()),                         # two-grid decoder: second scatter per sample
     ("triplane_plus_voxel_c16", 50, dict(hidden=64)),              # width-64 family
     ("voxel20_c32", 40, dict(hidden=64, scaffold=True)),           # width-64 family, C = 32, non-PLAIN
+    ("triplane24_c16_deep444", 72, dict()),                        # layer-looped family: ragged last segment
+    ("voxel20_c32_deep342", 50, dict(scaffold=True, noise=True, color_chn=4)),  # layer-looped family, C = 32, fourth colour sum
+    ("two_grid_mixed_c16_deep044", 66, dict()),                    # layer-looped two-grid decoder
 ], ids=["triplane_s88", "triplane_s64_nomask", "triplane_s33", "mixed_s72", "voxel_b2_rgba_s96", "triplane_scaffold_noise_s70",
-        "triplane_16k_rays_s80", "voxel_c32_s72", "voxel_flex_h16_s50", "two_grid_s66", "mixed_h64_s50", "voxel_c32_h64_scaffold_s40"])
+        "triplane_16k_rays_s80", "voxel_c32_s72", "voxel_flex_h16_s50", "two_grid_s66", "mixed_h64_s50", "voxel_c32_h64_scaffold_s40",
+        "deep444_s72", "deep342_c32_scaffold_noise_s50", "deep_two_grid_s66"])
 def test_segmented_backward(grid, num_samples, kw):
     """4 096-ray image, S > 16: the backward runs one workgroup per (128 rays, block of 16 samples) and has to agree with
     the oracle AND with the one-workgroup-per-128-rays sweep of the same kernel (same recompute, so no ReLU-flip slack:

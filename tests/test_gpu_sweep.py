@@ -133,15 +133,17 @@ def _check_renderer_all(case, d, got, o64, r32):
 
 
 def _segmented_case(i):
-    """Default decoder shape, 17 .. 130 samples, no beyond-far samples: the segment-parallel forward + backward (ragged
-    last segments, partial waves, several grid batch entries, the non-PLAIN instantiations)."""
+    """Default decoder shape (every fourth case: a 3-4 layer decoder of the layer-looped family), 17 .. 130 samples, no
+    beyond-far samples: the segment-parallel forward + backward (ragged last segments, partial waves, several grid batch
+    entries, the non-PLAIN instantiations)."""
     rnd = random.Random(3000 + i)
     C = rnd.choice([16, 32])
     tri = rnd.random() < 0.5
     B = rnd.choice([1, 2, 3])
     contract = rnd.random() < 0.3
     kw = dict(seed=9000 + i, n_rays=rnd.choice([1, 33, 130, 300, 1000]), grid_base=(B, rnd.randint(3, 9), rnd.randint(3, 9), rnd.randint(3, 9), C),
-              is_triplane=tri, extra_voxel=tri and rnd.random() < 0.3, n_layers=(2, 2, 2), hidden=32,
+              is_triplane=tri, extra_voxel=tri and rnd.random() < 0.3,
+              n_layers=(2, 2, 2) if i % 4 else rnd.choice([(4, 2, 3), (3, 4, 2), (1, 3, 3)]), hidden=32,  # every fourth: layer-looped family
               color_chn=rnd.choice([1, 3, 3, 4]), num_samples=rnd.choice([17, 31, 32, 33, 48, 65, 100, 130]), num_samples_inf=0,
               gain=rnd.choice([1.0, 3.0]), mask_oob=(not contract) and rnd.random() < 0.4, contract=contract,
               scaffold_size=(rnd.randint(2, 6), rnd.randint(2, 6), rnd.randint(2, 6)) if rnd.random() < 0.3 else None,

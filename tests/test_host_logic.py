@@ -227,7 +227,7 @@ def test_backward_segments_python_query_covers_every_mfma_family():
     assert q(layers=(1, 1, 1), hidden=16) == 4          # flex
     assert q(layers=(0, 2, 2), sep=True) == 4           # two-grid decoder
     assert q(C=32, hidden=64) == 4                      # width-64 family
-    assert q(layers=(3, 2, 2)) == 1                     # layer-looped family: one sweep per ray
+    assert q(layers=(3, 2, 2)) == 4                     # layer-looped family
     assert q(num_samples=16) == 1 and q(num_samples_inf=2) == 1 and q(stop_transmittance=0.01) == 1
     assert lp.kernel_family(rays, random_grids(gen, grid_sizes_for((1, 8, 8, 8, 16), True)),
                             random_decoder(gen, 3, 2, 2, input_chn=16, hidden_chn=32, color_chn=3)) == 3
