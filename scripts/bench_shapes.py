@@ -29,7 +29,10 @@ if what == "renderer":
     shapes = [(2, 2, 2, 32, 16, 64, False), (4, 4, 4, 32, 16, 64, False), (4, 2, 4, 32, 16, 64, False), (2, 4, 2, 32, 16, 64, False),
               (3, 3, 3, 16, 16, 64, False), (0, 4, 4, 32, 16, 64, True), (0, 2, 2, 32, 16, 64, True), (4, 4, 4, 32, 32, 128, False),
               (2, 2, 2, 64, 32, 128, False), (1, 1, 1, 16, 16, 64, False)]
+    only = os.environ.get("SHAPES")  # e.g. SHAPES="4/2/4,4/4/4": only these layer triples
     for (nt, no, nc, H, C, G, sep) in shapes:
+        if only and f"{nt}/{no}/{nc}" not in only.split(","):
+            continue
         gen = torch.Generator().manual_seed(0)
         d = random_decoder(gen, nt, no, nc, C, H, 3, use_separate_color_grid=sep, std=0.1)
         enc_dim = int(d.n_hidden_color[0])
