@@ -68,7 +68,11 @@ LP_DEV constexpr int pi16(int m) { return m < 4 ? 2 * m : (m < 12 ? 2 * (m - 4) 
 
 // workgroup barrier that only drains LDS traffic (a __syncthreads() would also wait for the
 // outstanding global atomics of the gradient scatter)
+#ifdef LP_X_NO_BARRIER  // timing experiment only (wrong weight gradients): what do the barriers of the layer phases cost?
+LP_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
 LP_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 // 16-register activation (accumulator order) -> feature-major tile
 LP_DEV void tile_store_fm(float* tile, int r, int h, const float (&v)[16]) {
