@@ -59,6 +59,18 @@ LP_DEV void loop_stage_layer(char* lds, float* sm, const float* P, const LoopLay
 // ---------------------------------------------------------------------------------------------------------------
 // one layer on the matrix cores
 // ---------------------------------------------------------------------------------------------------------------
+// issue order "1 MFMA, 1 LDS operand read, a few VALU" for the 6 NB MFMAs of a chunk and the 44 VALU instructions of the next
+// chunk's limb split (see bf3_interleave_hint, lp_bf3.h)
+template <int NB>
+LP_DEV void loop_interleave_hint() {
+#pragma unroll
+  for (int i = 0; i < 6 * NB; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               // DS read (A operand)
+    __builtin_amdgcn_sched_group_barrier(0x002, NB == 1 ? 8 : 4, 0);  // VALU
+  }
+}
+
 // out = relu(W^T in + b) (RELU = false: the affine map only): `in` / `out` are NB blocks of this lane's 16 features; lbase =
 // LDS base (+ the opaque zero); output blocks beyond the layer's width come out as zeros
 template <int NB, bool RELU = true>
@@ -76,15 +88,38 @@ LP_DEV void loop_layer_fwd(const char* lbase, const float* sm, const LoopLayer& 
       acc[ob][4 * j + 0] = v.x; acc[ob][4 * j + 1] = v.y; acc[ob][4 * j + 2] = v.z; acc[ob][4 * j + 3] = v.w;
     }
   }
+  if constexpr (NB == 1) {
+    // (32-wide layers: the plain form measured faster -- 4/4/4 x 32: 8.90 vs 9.12 ms fwd+bwd -- the compiler's own interleaving
+    // of the two chunks is better than the forced one)
 #pragma unroll
-  for (int c = 0; c < 2 * NB; ++c) {
-    if (c < in_chunks) {  // wave-uniform
-      u32x4_t l1, l2, l3;
-      split3_chunk(&in[c >> 1][8 * (c & 1)], l1, l2, l3);
+    for (int c = 0; c < 2; ++c) {
+      if (c < in_chunks) {  // wave-uniform
+        u32x4_t l1, l2, l3;
+        split3_chunk(&in[0][8 * c], l1, l2, l3);
+        acc[0] = chunk_bf3(AColsFwd{lbase + L.img, LOOP_ST}, c, lane, l1, l2, l3, acc[0]);
+      }
+    }
+  } else {
+    // 64-wide layers, software pipeline over the K-chunks: the limbs of chunk c + 1 are split (44 VALU instructions) in the
+    // shadow of chunk c's 12 dependent MFMAs -- these kernels run ONE wave per SIMD, there is no other wave to fill the matrix
+    // pipe's latency (2/2/2 x 64: 13.97 -> 13.11 ms fwd+bwd).  The next chunk is split unconditionally inside chunk c's block, so
+    // that block stays one scheduling region; a chunk beyond the layer's input width holds zeros and its block is skipped.
+    u32x4_t l1, l2, l3;
+    split3_chunk(&in[0][0], l1, l2, l3);
 #pragma unroll
-      for (int ob = 0; ob < NB; ++ob) {
-        if (ob < L.ob)  // wave-uniform
-          acc[ob] = chunk_bf3(AColsFwd{lbase + L.img + ((c >> 1) * L.ob + ob) * LOOP_BLK, LOOP_ST}, c & 1, lane, l1, l2, l3, acc[ob]);
+    for (int c = 0; c < 2 * NB; ++c) {
+      if (c < in_chunks) {  // wave-uniform
+        u32x4_t n1 = l1, n2 = l2, n3 = l3;
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) {
+          if (ob == 0 || ob < L.ob)  // wave-uniform (a layer has at least one output block)
+            acc[ob] = chunk_bf3(AColsFwd{lbase + L.img + ((c >> 1) * L.ob + ob) * LOOP_BLK, LOOP_ST}, c & 1, lane, l1, l2, l3, acc[ob]);
+        }
+        if (c + 1 < 2 * NB) {
+          split3_chunk(&in[(c + 1) >> 1][8 * ((c + 1) & 1)], n1, n2, n3);
+          loop_interleave_hint<NB>();
+        }
+        l1 = n1; l2 = n2; l3 = n3;
       }
     }
   }
@@ -100,15 +135,32 @@ template <int NB>
 LP_DEV void loop_layer_dx(const char* lbase, const LoopLayer& L, int lane, const float (&dy)[NB][16], f32x16 (&dx)[NB]) {
   const int out_chunks = (L.cols + 15) >> 4;
   const int in_blocks = (L.rows_in + 31) >> 5;
+  if constexpr (NB == 1) {
 #pragma unroll
-  for (int c = 0; c < 2 * NB; ++c) {
-    if (c < out_chunks) {
-      u32x4_t l1, l2, l3;
-      split3_chunk(&dy[c >> 1][8 * (c & 1)], l1, l2, l3);
+    for (int c = 0; c < 2; ++c) {
+      if (c < out_chunks) {
+        u32x4_t l1, l2, l3;
+        split3_chunk(&dy[0][8 * c], l1, l2, l3);
+        dx[0] = chunk_bf3(ARowsBwd{lbase + L.img, LOOP_ST, 31}, c, lane, l1, l2, l3, dx[0]);
+      }
+    }
+  } else {
+    u32x4_t l1, l2, l3;
+    split3_chunk(&dy[0][0], l1, l2, l3);
 #pragma unroll
-      for (int ib = 0; ib < NB; ++ib) {
-        if (ib < in_blocks)
-          dx[ib] = chunk_bf3(ARowsBwd{lbase + L.img + (ib * L.ob + (c >> 1)) * LOOP_BLK, LOOP_ST, 31}, c & 1, lane, l1, l2, l3, dx[ib]);
+    for (int c = 0; c < 2 * NB; ++c) {
+      if (c < out_chunks) {  // wave-uniform; software-pipelined like loop_layer_fwd
+        u32x4_t n1 = l1, n2 = l2, n3 = l3;
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib) {
+          if (ib == 0 || ib < in_blocks)
+            dx[ib] = chunk_bf3(ARowsBwd{lbase + L.img + (ib * L.ob + (c >> 1)) * LOOP_BLK, LOOP_ST, 31}, c & 1, lane, l1, l2, l3, dx[ib]);
+        }
+        if (c + 1 < 2 * NB) {
+          split3_chunk(&dy[(c + 1) >> 1][8 * ((c + 1) & 1)], n1, n2, n3);
+          loop_interleave_hint<NB>();
+        }
+        l1 = n1; l2 = n2; l3 = n3;
       }
     }
   }
