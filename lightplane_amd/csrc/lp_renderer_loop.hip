@@ -153,7 +153,8 @@ LP_DEV void loop_pad_input(const float (&x0)[C / 2], float (&out)[NB][16]) {
 // ---------------------------------------------------------------------------------------------------------------
 // WC: 5..32 colour channels -- the colour output layer runs on the matrix cores like a hidden layer (without ReLU), lane
 // (h, r) composites the 16 channels feat(q, h) of its ray
-template <int C, int NB, bool TG, bool WC = false>
+// GM: GM_TRIPLANE (canonical triplane: shared axis computations, border re-expression in the scatter) or GM_GENERIC
+template <int C, int NB, bool TG, bool WC = false, int GM = GM_GENERIC>
 __global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) renderer_fwd_loop(const LpRendererArgs a, const LoopParams lp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   loop_stage<NB>(a, lp, lds);
@@ -191,7 +192,7 @@ __global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) renderer_fwd_loop(const 
     depth_prev = nx.depth;
   }
   for (int s = s_lo; s < s_hi; ++s) {
-    fetch_sample<C, GM_GENERIC, true>(a, geo, ray, s, h, nx);
+    fetch_sample<C, GM, true>(a, geo, ray, s, h, nx);
     const float depth = nx.depth, occ = nx.occ;
     const int zo = opaque_zero();
     const char* lbase = reinterpret_cast<const char*>(lds) + zo;
@@ -308,7 +309,7 @@ __global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) renderer_fwd_loop(const 
 // ---------------------------------------------------------------------------------------------------------------
 // MT / MH: the trunk layers / hidden head layers this instantiation holds registers for (the kernel's loops are unrolled to
 // them; NB = 2 is instantiated for the 2 / 2 / 2 shape only: 64-wide activations are 32 registers each)
-template <int C, int NB, bool TG, int MT, int MH, bool WC = false>
+template <int C, int NB, bool TG, int MT, int MH, bool WC = false, int GM = GM_GENERIC>
 __global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs a, const LoopParams lp) {
   using T = LoopTile;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -446,7 +447,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs
     }
   }
   Sample<C> nx;
-  fetch_sample<C, GM_GENERIC, false>(a, geo, ray, s_begin, h, nx);
+  fetch_sample<C, GM, false>(a, geo, ray, s_begin, h, nx);
   for (int s = s_begin; s >= s_lo; --s) {
     const bool on = s <= s_last_w;  // wave-uniform; false only for samples a sibling wave still marches
     const float depth = nx.depth, occ = nx.occ, x = nx.x, y = nx.y, z = nx.z;
@@ -770,12 +771,13 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs
     // ---------------- next (nearer) sample + grid gradient ----------------
     __builtin_amdgcn_s_setprio(0);
     const bool live = valid && on && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
-    if (s > s_lo) fetch_sample<C, GM_GENERIC, true>(a, geo, ray, s - 1, h, nx);
+    if (s > s_lo) fetch_sample<C, GM, true>(a, geo, ray, s - 1, h, nx);
     LP_SCHED_FENCE();
     if (gg && !(lp.dbg & 2)) {
+      const int ng = (GM == GM_TRIPLANE) ? 3 : a.grid.n_grids;
 #pragma unroll 1
-      for (int gi = 0; gi < a.grid.n_grids; ++gi)
-        scatter_grid<C, GM_GENERIC>(a.grad_grid_list[gi], a.grid.grids[gi], ray.b, x, y, z, live, lane, xt, yt, lp.dbg);
+      for (int gi = 0; gi < ng; ++gi)
+        scatter_grid<C, GM>(a.grad_grid_list[gi], a.grid.grids[gi], ray.b, x, y, z, live, lane, xt, yt, lp.dbg);
     }
   }
 
@@ -1008,6 +1010,43 @@ static unsigned loop_blocks(const LpRendererArgs& a) {
   return (unsigned)((a.rays.n_rays + WAVES * RAYS_PER_WAVE - 1) / (WAVES * RAYS_PER_WAVE));
 }
 
+// (two-grid decoder: always the run-time-loop grid-list form -- with two gathers per sample its triplane form spills ~150
+// registers; `if constexpr` inside a template keeps those instantiations from being compiled at all)
+template <int C, int NB, bool TG, bool WC>
+static int launch_fwd_loop(const LpRendererArgs& a, const LoopParams& p, unsigned nb, size_t lds, bool tri, hipStream_t stream) {
+  int rc;
+  if constexpr (!TG) {
+    if (tri) {
+      if ((rc = loop_set_lds(renderer_fwd_loop<C, NB, TG, WC, GM_TRIPLANE>, lds))) return rc;
+      hipLaunchKernelGGL((renderer_fwd_loop<C, NB, TG, WC, GM_TRIPLANE>), dim3(nb), dim3(256), lds, stream, a, p);
+      return LP_OK;
+    }
+  }
+  if ((rc = loop_set_lds(renderer_fwd_loop<C, NB, TG, WC, GM_GENERIC>, lds))) return rc;
+  hipLaunchKernelGGL((renderer_fwd_loop<C, NB, TG, WC, GM_GENERIC>), dim3(nb), dim3(256), lds, stream, a, p);
+  return LP_OK;
+}
+
+template <int C, int NB, bool TG, int MT, int MH, bool WC>
+static int launch_bwd_loop(const LpRendererArgs& a, const LoopParams& p, unsigned nb, size_t lds, bool tri, hipStream_t stream) {
+  int rc;
+  if constexpr (!TG) {
+    if (tri) {
+      if ((rc = loop_set_lds(renderer_bwd_loop<C, NB, TG, MT, MH, WC, GM_TRIPLANE>, lds))) return rc;
+      hipLaunchKernelGGL((renderer_bwd_loop<C, NB, TG, MT, MH, WC, GM_TRIPLANE>), dim3(nb), dim3(256), lds, stream, a, p);
+      return LP_OK;
+    }
+  }
+  if ((rc = loop_set_lds(renderer_bwd_loop<C, NB, TG, MT, MH, WC, GM_GENERIC>, lds))) return rc;
+  hipLaunchKernelGGL((renderer_bwd_loop<C, NB, TG, MT, MH, WC, GM_GENERIC>), dim3(nb), dim3(256), lds, stream, a, p);
+  return LP_OK;
+}
+
+static bool loop_triplane(const LpRendererArgs& a) {
+  static const bool generic_grids = getenv("LP_MFMA_GENERIC_GRIDS") != nullptr;  // debugging aid
+  return !generic_grids && is_canonical_triplane(a.grid);
+}
+
 int renderer_forward_loop(const LpRendererArgs& a, hipStream_t stream) {
   unsigned nb = loop_blocks(a);
   if (nb == 0) return LP_OK;
@@ -1021,15 +1060,10 @@ int renderer_forward_loop(const LpRendererArgs& a, hipStream_t stream) {
     nb *= (unsigned)((n_rec + p.seg_blocks - 1) / p.seg_blocks);
   }
   const size_t lds = loop_lds_bytes(p, false);
-  const bool tg = a.color_grid.n_grids > 0;
+  const bool tg = a.color_grid.n_grids > 0, wc = a.color_chn > 4, tri = loop_triplane(a);
   const int NB = loop_nb(p.hid);
   int rc = LP_OK;
-#define LP_LOOP_FWD(CV, NBV, TGV, WCV)                                                                  \
-  do {                                                                                                  \
-    if ((rc = loop_set_lds(renderer_fwd_loop<CV, NBV, TGV, WCV>, lds))) return rc;                      \
-    hipLaunchKernelGGL((renderer_fwd_loop<CV, NBV, TGV, WCV>), dim3(nb), dim3(256), lds, stream, a, p); \
-  } while (0)
-  const bool wc = a.color_chn > 4;
+#define LP_LOOP_FWD(CV, NBV, TGV, WCV) rc = launch_fwd_loop<CV, NBV, TGV, WCV>(a, p, nb, lds, tri, stream)
   if (a.grid.channels == 16) {
     if (NB == 2) LP_LOOP_FWD(16, 2, false, false);
     else if (tg && wc) LP_LOOP_FWD(16, 1, true, true);
@@ -1044,6 +1078,7 @@ int renderer_forward_loop(const LpRendererArgs& a, hipStream_t stream) {
     else LP_LOOP_FWD(32, 1, false, false);
   }
 #undef LP_LOOP_FWD
+  if (rc) return rc;
   if (segf && (rc = renderer_forward_combine_launch(a, p.seg_blocks, stream))) return rc;
   return check_launch("renderer_fwd_loop");
 }
@@ -1058,15 +1093,10 @@ int renderer_backward_loop(const LpRendererArgs& a, hipStream_t stream) {
     nb *= (unsigned)((n_rec + p.seg_blocks - 1) / p.seg_blocks);
   }
   const size_t lds = loop_lds_bytes(p, true);
-  const bool tg = a.color_grid.n_grids > 0;
+  const bool tg = a.color_grid.n_grids > 0, wc = a.color_chn > 4, tri = loop_triplane(a);
   const int NB = loop_nb(p.hid);
   int rc = LP_OK;
-#define LP_LOOP_BWD(CV, NBV, TGV, MTV, MHV, WCV)                                                                   \
-  do {                                                                                                             \
-    if ((rc = loop_set_lds(renderer_bwd_loop<CV, NBV, TGV, MTV, MHV, WCV>, lds))) return rc;                       \
-    hipLaunchKernelGGL((renderer_bwd_loop<CV, NBV, TGV, MTV, MHV, WCV>), dim3(nb), dim3(256), lds, stream, a, p);  \
-  } while (0)
-  const bool wc = a.color_chn > 4;
+#define LP_LOOP_BWD(CV, NBV, TGV, MTV, MHV, WCV) rc = launch_bwd_loop<CV, NBV, TGV, MTV, MHV, WCV>(a, p, nb, lds, tri, stream)
   if (a.grid.channels == 16) {
     if (NB == 2) LP_LOOP_BWD(16, 2, false, 2, 1, false);
     else if (tg && wc) LP_LOOP_BWD(16, 1, true, 1, LOOP_MAX_H, true);
@@ -1081,6 +1111,7 @@ int renderer_backward_loop(const LpRendererArgs& a, hipStream_t stream) {
     else LP_LOOP_BWD(32, 1, false, LOOP_MAX_T, LOOP_MAX_H, false);
   }
 #undef LP_LOOP_BWD
+  if (rc) return rc;
   return check_launch("renderer_bwd_loop");
 }
 
