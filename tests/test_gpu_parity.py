@@ -126,7 +126,13 @@ def test_renderer_matches_oracle_and_golden(case, kernel, golden_dir):
     dev = _dev()
     d = case.build()
     z = np.load(os.path.join(golden_dir, f"renderer__{case.name}.npz"))
-    out, gp, ge, gg, gc = run_hip_renderer(d, dev, kernel)
+    import warnings
+    with warnings.catch_warnings():
+        if lp.kernel_family(d["rays"], d["grids"], d["decoder"], color_grid=d["color_grids"]) == 0:
+            # a shape no MFMA family covers (hidden 64 with more than 2 layers per MLP): the shape-generic kernels are what is
+            # under test here, their "10-100x slower" warning is expected
+            warnings.simplefilter("ignore", UserWarning)
+        out, gp, ge, gg, gc = run_hip_renderer(d, dev, kernel)
     o_out, o_gp, o_ge, o_gg, o_gc = run_oracle_renderer(d)
     # vs golden (numbers the reference itself produced)
     _assert_close("ray_length/golden", out[0], z["ray_length"])
