@@ -206,3 +206,38 @@ def test_splatter_sweep(i):
     for k, o in enumerate(out):
         _check(f"{case}: out{k}", o, o_out[k])
     _check(f"{case}: grad_encoding", ge, rays.encoding.grad)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the reference's OWN sweep axes (tests/test_renderer_with_autograd.py:35-56), sampled
+# ---------------------------------------------------------------------------------------------------------------------
+def _reference_axes_case(i):
+    """One combination of the reference's test_sweep dictionary: grid [3,16,12,8,16] (voxel or triplane), optional separate
+    colour grid [4,3,9] (then no trunk), scaffold [6,4,5] or none, 16 samples + 11 or 0 beyond-far samples, 128 or 3 rays, gain 1 or
+    3, mask / contraction on or off, noise 1.0 or 0, 2 or 4 layers per MLP, hidden 32, 3 colour channels.  Parameters N(0, 0.01)
+    like the reference's fixture (tests/utils.py:349) for every second combination, N(0, 0.2) for the others."""
+    rnd = random.Random(4242 + i)
+    sep = rnd.random() < 0.5
+    tri = rnd.random() < 0.5
+    layers = (0 if sep else rnd.choice([2, 4]), rnd.choice([2, 4]), rnd.choice([2, 4]))
+    kw = dict(seed=12000 + i, n_rays=rnd.choice([128, 3]), grid_base=(3, 16, 12, 8, 16), is_triplane=tri, n_layers=layers, hidden=32,
+              color_chn=3, num_samples=16, num_samples_inf=rnd.choice([11, 0]), gain=rnd.choice([1.0, 3.0]),
+              mask_oob=rnd.random() < 0.5, contract=rnd.random() < 0.5,
+              scaffold_size=(6, 4, 5) if rnd.random() < 0.5 else None, separate_color_grid=sep,
+              noise_sigma=rnd.choice([1.0, 0.0]), noise_seed=rnd.randint(0, 2 ** 20), param_std=0.01 if i % 2 == 0 else 0.2)
+    if sep:
+        kw["color_grid_base"] = (3, 4, 3, 9, 16)
+        kw["color_is_triplane"] = tri
+    return RendererCase(f"refsweep{i}", **kw)
+
+
+@pytest.mark.filterwarnings("ignore:The renderer has been configured to contract")  # the reference's own sweep combines the two switches
+@pytest.mark.parametrize("i", range(40))
+def test_reference_sweep_axes(i):
+    """Every sampled combination runs on an MFMA family (never the shape-generic kernels) and matches the oracle."""
+    case = _reference_axes_case(i)
+    d = case.build()
+    assert lp.kernel_family(d["rays"], d["grids"], d["decoder"], color_grid=d["color_grids"]) in (1, 3), case
+    dev = _dev()
+    got = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO)
+    _check_renderer_all(case, d, got, run_oracle_renderer64(d), run_oracle_renderer(d))
