@@ -241,3 +241,47 @@ def test_reference_sweep_axes(i):
     dev = _dev()
     got = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO)
     _check_renderer_all(case, d, got, run_oracle_renderer64(d), run_oracle_renderer(d))
+
+
+def _reference_splatter_axes_case(i):
+    """One valid combination of the reference's Splatter sweep (tests/test_splatter_with_autograd.py:38-53): output grid
+    [2,16,12,8,32] (voxel / triplane), plain splat of 32 features or an MLP of 3 / 4 layers x 64 hidden reading an input grid
+    [2,10,14,16,feat] with feat in {64, 32}, 16 + 11 samples, 1 or 128 rays, mask / contraction on or off."""
+    rnd = random.Random(777 + i)
+    tri = rnd.random() < 0.5
+    use_mlp = rnd.random() < 0.7
+    kw = dict(seed=13000 + i, n_rays=rnd.choice([1, 128]), out_base=(2, 16, 12, 8, 32), is_triplane=tri, num_samples=16, num_samples_inf=11,
+              mask_oob=rnd.random() < 0.5, contract=rnd.random() < 0.5)
+    if use_mlp:
+        feat = rnd.choice([64, 32])
+        kw.update(use_mlp=True, n_layers=rnd.choice([3, 4]), hidden=64, feat_dim=feat, in_base=(2, 10, 14, 16, feat), in_triplane=tri)
+    return SplatterCase(f"refsplat{i}", **kw)
+
+
+@pytest.mark.filterwarnings("ignore:The splatter has been configured")
+@pytest.mark.parametrize("i", range(24))
+def test_reference_splatter_sweep_axes(i):
+    """Every sampled combination runs on the walk / MFMA families and matches the fp32 oracle (the cell a sample falls into is
+    defined by fp32 index arithmetic)."""
+    case = _reference_splatter_axes_case(i)
+    d = case.build()
+    dev = _dev()
+    rays = copy.copy(d["rays"])
+    rays.encoding = rays.encoding.clone().requires_grad_(True)
+    if case.use_mlp:
+        out, ge, gp, gin = run_hip_mlp_splatter(d, dev)
+        mlp = copy.copy(d["mlp"])
+        mlp.mlp_params = mlp.mlp_params.clone().requires_grad_(True)
+        in_grids = [g.clone().requires_grad_(True) for g in d["in_grids"]]
+        o_out = O.lightplane_mlp_splatter_naive(rays, d["out_sizes"], mlp, in_grids, **d["cfg"])
+        sum((o * u).sum() for o, u in zip(o_out, d["upstream"])).backward()
+        _check(f"{case.name}: grad_mlp_params", gp, mlp.mlp_params.grad)
+        for k, (a, b) in enumerate(zip(gin, in_grids)):
+            _check(f"{case.name}: grad_input_grid{k}", a, b.grad)
+    else:
+        out, ge = run_hip_splatter(d, dev)
+        o_out = O.lightplane_splatter_naive(rays, d["out_sizes"], **d["cfg"])
+        sum((o * u).sum() for o, u in zip(o_out, d["upstream"])).backward()
+    for k, o in enumerate(out):
+        _check(f"{case.name}: out{k}", o, o_out[k])
+    _check(f"{case.name}: grad_encoding", ge, rays.encoding.grad)
