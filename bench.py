@@ -42,6 +42,7 @@ import glob
 import json
 import math
 import os
+import re
 import sys
 import time
 
@@ -57,6 +58,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_PEAK = 157.3e12    # fp32 vector = fp32 MFMA peak
 CLOCK_GHZ = 2.4         # MI355X engine clock
 N_SIMD = 256 * 4        # 256 CUs x 4 SIMDs
+N_SE = 32               # shader engines SQ_BUSY_CYCLES is summed over (8 XCDs x 4)
+LOAD_LATENCY_NS = 800.0 # HBM-miss gather latency used for the loads-in-flight estimate (MI355X_MICROARCH.md: ~0.7-0.9 us)
 ATOMIC_SEGMENTS_PER_S = 21e9  # 64-byte global_atomic_add_f32 segments the chip retires (scripts/atomics_probe2.hip)
 ARITHMETIC = ("fp32-equivalent: decoder products as bf16x3 (three exact bf16 limbs per fp32 operand, six limb products, fp32 "
               "accumulation) on v_mfma_f32_32x32x16_bf16; weight-gradient products v_mfma_f32_16x16x4_f32; everything else fp32 VALU")
@@ -120,6 +123,12 @@ class RendererWorkload:
     def mlp_flops_fwdbwd(self):
         mac = self.C * HIDDEN + HIDDEN * HIDDEN + HIDDEN * HIDDEN + HIDDEN + HIDDEN * HIDDEN + HIDDEN * COLOR
         return 2 * mac * self.S * 4 * self.n_rays  # forward + (recompute + dX + dW)
+
+    def dw_f32_mfma_per_launch(self):
+        """v_mfma_f32_16x16x4_f32 of the weight-gradient quadrants per backward launch: 32 rays x (in x out) MACs of every hidden
+        layer / 1 024 MACs per instruction, per wave-sample (C=16: 112, C=32: 128); output layers run on the VALU."""
+        per_wave_sample = (self.C * HIDDEN + 3 * HIDDEN * HIDDEN) // 32
+        return (self.n_rays // 32) * self.S * per_wave_sample
 
     def zero_grads(self):
         self.flat.grad = self.params.grad = self.rays.encoding.grad = None
@@ -350,7 +359,7 @@ class JointWorkload:
         grid = lp.lightplane_splatter(self.splat_rays, self.sizes, num_samples=self.S, return_list=False, process_group=pg)
         p = self.params
         if replicated:  # the splatted grid is a replicated tensor consumed by ray shards: its gradient is summed over the GPUs
-            grid, p = parallel.replicate_with_grad_allreduce([grid, self.params], self.pg)
+            grid, p = parallel.replicate_with_grad_allreduce([grid, self.params], self.pg, exclusive_grads=True)  # consumed by the Renderer only
         d = lp.DecoderParams(p, self.dec_c.n_hidden_trunk, self.dec_c.n_hidden_opacity, self.dec_c.n_hidden_color, 3)
         return lp.lightplane_renderer(self.cam, grid, d, num_samples=self.S, gain=1.0, grid_sizes=self.sizes, kernel=self.kernel)
 
@@ -396,27 +405,88 @@ def event_times(wl, reps):
     return fwd_ms, bwd_ms
 
 
-def pmc_entry(workload, kernel_substr):
-    """Per-launch counter averages of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r*_pmc_summary.json,
-    separate --pmc runs of `bench.py --workload <w>`, scripts/gpu_profile.sh).  NOT measured in this run."""
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_summary.json")))
-    for f in reversed(files):
+_PMC_FILE = re.compile(r"r(\d+)_pmc_summary\.json$")  # the per-round summaries of the DEFAULT command; r03loop_* etc. are experiments
+
+
+def observed_kernels(wl, reps=3):
+    """Names and mean device time (ms per launch) of the lp:: kernels ONE step of this workload launches, from
+    torch.profiler's device timeline -- so that committed counters are looked up by the kernel that ran here."""
+    from torch.profiler import ProfilerActivity, profile
+
+    def local_step():  # no collective: only rank 0 runs this pass
+        wl.zero_grads()
+        wl.loss(wl.forward(replicated=False)).backward()
+
+    local_step()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(reps):
+            local_step()
+        torch.cuda.synchronize()
+    acc = {}
+    for e in prof.events():
+        if e.device_type != torch.autograd.DeviceType.CUDA or "lp::" not in e.name:
+            continue
+        acc.setdefault(e.name.split("(")[0].replace("void ", "").strip(), []).append(e.device_time_total)
+    return {k: {"launches_per_step": len(v) / reps, "mean_ms": sum(v) / len(v) / 1e3} for k, v in acc.items()}
+
+
+def dominant_kernel(observed, substr):
+    """The observed kernel whose name contains `substr` with the largest device time per step (None if none ran)."""
+    best = None
+    for k, v in (observed or {}).items():
+        if substr in k and (best is None or v["mean_ms"] * v["launches_per_step"] > best[1]):
+            best = (k, v["mean_ms"] * v["launches_per_step"])
+    return best[0] if best else None
+
+
+def pmc_entry(workload, kernel_name, profiles_dir=None):
+    """Per-launch counter averages of `kernel_name` (the EXACT instantiation that ran, e.g.
+    "lp::renderer_bwd_bf3<16, 1, true, 3, 4, false>") from the committed rocprofv3 PMC passes of the default command
+    (profiles/rNN_pmc_summary.json, newest round first; separate --pmc runs of `bench.py --workload <w>`,
+    scripts/gpu_profile.sh).  NOT measured in this run.  Never falls back to another kernel's counters."""
+    if not kernel_name:
+        return None, None, None
+    d0 = profiles_dir or os.path.join(REPO, "profiles")
+    files = [f for f in glob.glob(os.path.join(d0, "r*_pmc_summary.json")) if _PMC_FILE.search(os.path.basename(f))]
+    files.sort(key=lambda f: int(_PMC_FILE.search(os.path.basename(f)).group(1)), reverse=True)
+    want = kernel_name.replace(" ", "")
+    for f in files:
         try:
             d = json.load(open(f))
         except Exception:
             continue
         for k, v in d.items():
-            if k.startswith(workload + ":") and kernel_substr in k and "hbm_bytes_per_launch" in v:
+            if k.startswith(workload + ":") and k.split(": ", 1)[1].replace(" ", "") == want and "hbm_bytes_per_launch" in v:
                 return v, os.path.relpath(f, REPO), k.split(": ", 1)[1]
     return None, None, None
 
 
-def pmc_traffic(workload, kernel_substr):
-    v, src, _ = pmc_entry(workload, kernel_substr)
+def pmc_traffic(workload, kernel_name):
+    v, src, _ = pmc_entry(workload, kernel_name)
     return (int(v["hbm_bytes_per_launch"]), src) if v else (None, None)
 
 
-def binding_ceiling(workload, wl, fwd_ms, bwd_ms):
+def counter_clock_ghz(v):
+    """Shader clock during the counter pass: SQ_BUSY_CYCLES is summed over the 32 shader engines, the pass's own kernel
+    duration is recorded next to it (scripts/summarize_profiles.py).  None when the summary predates that field."""
+    busy, dur = v.get("SQ_BUSY_CYCLES"), v.get("pmc_duration_ns") or v.get("trace_duration_ns")
+    if not busy or not dur:
+        return None
+    return busy / N_SE / dur
+
+
+def issue_bound(v, kname, dw_f32_mfma=None):
+    """Issue cycles per SIMD of one launch from its instruction counts (see binding_ceiling)."""
+    valu, mfma = v["SQ_INSTS_VALU"], v["SQ_INSTS_MFMA"]
+    if "bf3" in kname or "_loop" in kname:  # bf16x3 families: only the fp32 16x16x4 dW MFMAs serialise with the VALU
+        f32 = min(dw_f32_mfma, mfma) if dw_f32_mfma else mfma * 112.0 / 202.0
+        return (valu * 4.0 + f32 * 32.0) / N_SIMD
+    # fp32-MFMA kernels: every MFMA adds (32x32x2: 64 cycles, 16x16x4: 32 cycles; 120 : 112 per wave-sample)
+    return (valu * 4.0 + mfma * (120.0 * 64.0 + 112.0 * 32.0) / 232.0) / N_SIMD
+
+
+def binding_ceiling(workload, wl, fwd_ms, bwd_ms, observed=None):
     """The ceiling that actually binds the dominant kernel, next to the nominal HBM line (whose algorithmic bytes are served
     by the L2 and by run-merging in registers: fractions above 1 are possible there and say nothing about a hardware limit).
 
@@ -424,31 +494,55 @@ def binding_ceiling(workload, wl, fwd_ms, bwd_ms):
     v_mfma_f32_16x16x4_f32 of the weight-gradient quadrants (32 cycles each) do not overlap with VALU work
     (profiles/r02_mfma_valu_overlap.txt), while the bf16 32x32x16 MFMAs do.  bound = (VALU x 4 + fp32-MFMA x 32) cycles per
     SIMD / clock; frac_issue = bound / measured time (1.0 = nothing but issue; the rest is waits: barriers, LDS, memory).
+    The clock is the one the counters saw (SQ_BUSY_CYCLES / 32 SEs / duration), not the nominal 2.4 GHz.
     Splatter forward: ATOMIC SEGMENTS.  frac_segments = 64-byte atomic segments per launch (WRITE_SIZE / 64 B) / time / 21 G/s.
-    Instruction and segment counts come from the committed PMC passes, not from this run."""
+    Splatter backward walk: issue bound as above + the loads in flight its latency-bound gather sustains.
+    Instruction and segment counts come from the committed PMC passes of the SAME kernel instantiation that ran here (looked
+    up by exact name), not from this run; when that instantiation has no committed counters the block is null."""
     renderer = isinstance(wl, RendererWorkload)
-    v, src, kname = pmc_entry(workload, "renderer_bwd" if renderer else "splat_fwd_walk")
+    kname = dominant_kernel(observed, "renderer_bwd" if renderer else "splat_fwd_walk")
+    v, src, kname = pmc_entry(workload, kname)
     if v is None:
         return None
     if renderer:
-        valu, mfma = v.get("SQ_INSTS_VALU"), v.get("SQ_INSTS_MFMA")
-        if not valu or not mfma:
+        if not v.get("SQ_INSTS_VALU") or not v.get("SQ_INSTS_MFMA"):
             return None
-        f32_share = 112.0 / 202.0 if "bf3" in kname else 0.0  # dW: 112 fp32 16x16x4 of the 202 MFMAs per wave-sample
-        cyc = (valu * 4.0 + mfma * f32_share * 32.0) / N_SIMD
-        if "bf3" not in kname:  # fp32-MFMA kernels: every MFMA adds (32x32x2: 64 cycles, 16x16x4: 32 cycles; 120 : 112)
-            cyc = (valu * 4.0 + mfma * (120.0 * 64.0 + 112.0 * 32.0) / 232.0) / N_SIMD
-        bound_ms = cyc / (CLOCK_GHZ * 1e6)
-        return {"kind": "issue", "kernel": kname, "valu_insts_per_launch": valu, "mfma_insts_per_launch": mfma,
-                "issue_cycles_per_simd": round(cyc), "clock_ghz": CLOCK_GHZ, "bound_ms": round(bound_ms, 4),
-                "frac_issue": round(bound_ms / bwd_ms, 4), "source": src + " (committed counter passes, not this run)"}
+        cyc = issue_bound(v, kname, wl.dw_f32_mfma_per_launch())
+        clk = counter_clock_ghz(v)
+        bound_ms = cyc / ((clk or CLOCK_GHZ) * 1e6)
+        t_ms = observed[kname]["mean_ms"] if observed and kname in observed else bwd_ms
+        return {"kind": "issue", "kernel": kname, "valu_insts_per_launch": v["SQ_INSTS_VALU"], "mfma_insts_per_launch": v["SQ_INSTS_MFMA"],
+                "issue_cycles_per_simd": round(cyc), "clock_ghz": round(clk or CLOCK_GHZ, 3),
+                "clock_source": "SQ_BUSY_CYCLES / 32 SEs / kernel duration of the counter pass" if clk else "nominal (summary has no duration)",
+                "bound_ms": round(bound_ms, 4), "kernel_ms": round(t_ms, 4),
+                "frac_issue": round(bound_ms / t_ms, 4), "source": src + " (committed counter passes, not this run)"}
     w = v.get("WRITE_SIZE")
     if not w:
         return None
     segs = w * 1024.0 / 64.0
-    return {"kind": "atomic segments", "kernel": kname, "segments_per_launch": round(segs), "peak_segments_per_s": ATOMIC_SEGMENTS_PER_S,
-            "achieved_segments_per_s": round(segs / (fwd_ms * 1e-3)), "frac_segments": round(segs / (fwd_ms * 1e-3) / ATOMIC_SEGMENTS_PER_S, 4),
-            "source": src + " (committed counter passes, not this run); the forward time includes the normalise pass and the grid zero-fill"}
+    t_ms = observed[kname]["mean_ms"] if observed and kname in observed else fwd_ms
+    out = {"kind": "atomic segments", "kernel": kname, "segments_per_launch": round(segs), "peak_segments_per_s": ATOMIC_SEGMENTS_PER_S,
+           "kernel_ms": round(t_ms, 4),
+           "achieved_segments_per_s": round(segs / (t_ms * 1e-3)), "frac_segments": round(segs / (t_ms * 1e-3) / ATOMIC_SEGMENTS_PER_S, 4),
+           "source": src + " (committed counter passes, not this run)"}
+    # the backward walk: a latency-bound gather -- issue bound and loads in flight
+    kb = dominant_kernel(observed, "splat_bwd_walk")
+    vb, srcb, kb = pmc_entry(workload, kb)
+    if vb and vb.get("SQ_INSTS_VALU"):
+        clk = counter_clock_ghz(vb)
+        cyc = vb["SQ_INSTS_VALU"] * 4.0 / N_SIMD
+        bms = cyc / ((clk or CLOCK_GHZ) * 1e6)
+        tb = observed[kb]["mean_ms"] if observed and kb in observed else bwd_ms
+        vm = vb.get("SQ_INSTS_VMEM")
+        out["backward"] = {"kind": "issue + loads in flight", "kernel": kb, "valu_insts_per_launch": vb["SQ_INSTS_VALU"],
+                           "clock_ghz": round(clk or CLOCK_GHZ, 3), "bound_ms": round(bms, 4), "kernel_ms": round(tb, 4),
+                           "frac_issue": round(bms / tb, 4),
+                           "vmem_insts_per_launch": vm,
+                           "wave_loads_in_flight_per_simd": (round(vm * LOAD_LATENCY_NS * 1e-6 / tb / N_SIMD, 2) if vm else None),
+                           "note": f"loads in flight = wave-level VMEM instructions x {LOAD_LATENCY_NS:.0f} ns (L2-miss gather latency, "
+                                   "MI355X_MICROARCH.md) / kernel time / 1024 SIMDs (Little's law)",
+                           "source": srcb + " (committed counter passes, not this run)"}
+    return out
 
 
 def reference_protocol_peak_mb(wl, dev):
@@ -555,7 +649,8 @@ def measure_extra(name, dev, kernel, reps):
     fwd_ms, bwd_ms = event_times(wl, reps)
     peak_mb = reference_protocol_peak_mb(wl, dev)
     roof = wl.roofline(fwd_ms, bwd_ms)
-    roof["binding"] = binding_ceiling(name, wl, fwd_ms, bwd_ms)
+    observed = observed_kernels(wl, 2)
+    roof["binding"] = binding_ceiling(name, wl, fwd_ms, bwd_ms, observed)
     if roof["frac"] > 1.0 or roof["frac_fwd_plus_bwd"] > 1.0:
         roof["note"] = ("nominal line: SURVEY 8(d)'s algorithmic bytes are served by the L2 / Infinity Cache and merged in registers "
                         "before they reach the fabric, so a fraction above 1 is not a hardware limit exceeded -- see `binding`")
@@ -715,6 +810,7 @@ def main():
     value = wl.n_rays * world / (ms_per_step * 1e-3) / 1e6
 
     fwd_ms, bwd_ms = event_times(wl, max(5, min(steps, 20)))
+    observed = observed_kernels(wl, 3) if rank == 0 and not isinstance(wl, JointWorkload) else {}
 
     # N > 1, default workload: north_star's reporting batches (1920x1080 rays per GPU) through the same sharded step, so
     # that the driver's scaling runs carry them.  A watchdog bounds the leg: if it has not finished in time, rank 0
@@ -743,9 +839,13 @@ def main():
 
     def headline():
         roof = wl.roofline(fwd_ms, bwd_ms)
-        traffic, src = pmc_traffic(args.workload, "renderer_bwd" if isinstance(wl, RendererWorkload) else "splat_fwd_walk")
+        dom = dominant_kernel(observed, "renderer_bwd" if isinstance(wl, RendererWorkload) else "splat_fwd_walk")
+        traffic, src = pmc_traffic(args.workload, dom)
         roof["traffic"] = traffic
-        roof["binding"] = binding_ceiling(args.workload, wl, fwd_ms, bwd_ms)
+        roof["dominant_kernel"] = dom
+        if dom and dom in observed:
+            roof["dominant_kernel_ms"] = round(observed[dom]["mean_ms"], 4)
+        roof["binding"] = binding_ceiling(args.workload, wl, fwd_ms, bwd_ms, observed)
         roof["traffic_source"] = (f"{src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, NOT measured in "
                                   f"this run; L2 -> fabric requests, i.e. one 64 B write request per atomic segment") if src else None
         if isinstance(wl, RendererWorkload) and args.workload in ("cfg2", "1080p_s128"):

@@ -245,7 +245,7 @@ typedef struct LpRayEmbedArgs {
   float* grad_bias;         /* [E] */
 } LpRayEmbedArgs;
 
-int lp_version(void);
+int lp_version(void); /* LP_VERSION; negative = built with -DLP_EXPERIMENTS (A/B timing switches), not a product build */
 const char* lp_last_error(void);
 /* sizeof() of the ABI structs as compiled into the library, for binding self-checks:
  * which = 0 LpGrid, 1 LpGridList, 2 LpRays, 3 LpMarch, 4 LpMlp, 5 LpRendererArgs,

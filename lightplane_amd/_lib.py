@@ -128,6 +128,9 @@ def lib() -> C.CDLL:
         )
     L = C.CDLL(LIB_PATH)
     L.lp_version.restype = C.c_int
+    if L.lp_version() < 0 and os.environ.get("LIGHTPLANE_AMD_ALLOW_EXPERIMENTAL") != "1":
+        raise LightplaneHipError(f"{LIB_PATH} was built with -DLP_EXPERIMENTS (A/B timing switches, lp_version() = {L.lp_version()}): "
+                                 "not a product build; set LIGHTPLANE_AMD_ALLOW_EXPERIMENTAL=1 to time it anyway")
     L.lp_last_error.restype = C.c_char_p
     for name in ("lp_renderer_forward", "lp_renderer_backward"):
         fn = getattr(L, name)

@@ -208,7 +208,11 @@ using namespace lp;
 
 extern "C" {
 
+#ifdef LP_EXPERIMENTS  // a build with experiment switches (LP_X_*) identifies itself: negative version, refused by the binding
+int lp_version(void) { return -LP_VERSION; }
+#else
 int lp_version(void) { return LP_VERSION; }
+#endif
 
 const char* lp_last_error(void) { return g_err; }
 

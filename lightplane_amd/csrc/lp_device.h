@@ -413,6 +413,11 @@ LP_DEV float scaffold_lookup(const float* scaffold, const LpGrid& s, int b, floa
 
 // softplus (torch: beta 1, linear above 20).  log1p(e) through the hardware log for e >= 2^-6 and
 // through its series below (|error| < 3e-8 there): a handful of VALU ops instead of libm's log1pf.
+#if defined(LP_X_RELU_F) || defined(LP_X_MASK_BIT_INT) || defined(LP_X_MASK_APPLY)
+#ifndef LP_EXPERIMENTS
+#error "LP_X_* are A/B timing switches: build them with -DLP_EXPERIMENTS (LP_BUILD_FLAGS), which makes lp_version() negative so that the binding refuses the library unless LIGHTPLANE_AMD_ALLOW_EXPERIMENTAL=1"
+#endif
+#endif
 LP_DEV float softplus_f(float x) {
   const float e = __expf(x);
   const float series = e * fmaf(e, fmaf(e, 0.333333343f, -0.5f), 1.0f);
@@ -424,6 +429,11 @@ LP_DEV float softplus_f(float x) {
 // canonicalising v_max_f32 x, x, x whenever the compiler cannot prove x is not a signalling NaN (MFMA results never qualify).
 // The sign-magnitude encoding makes max over the bit patterns the same function: negative floats are negative integers,
 // -0 -> +0, positive values and +NaN pass through (one v_max_i32).
+// NaN contract of every MFMA family (all their ReLU sites use this helper): a NaN with the sign bit clear propagates (as in
+// torch.relu), a NaN with the sign bit set becomes 0 (torch.relu would propagate it); the mask bit of a NaN activation is
+// clear (`relu_value > 0` is false), so no gradient flows through it.  Non-finite activations are outside the parity contract
+// -- the reference asserts isfinite on its gradients after every backward (lightplane_renderer.py:713-722) -- the kernels only
+// promise not to fault on them.  The shape-generic kernels use fmaxf (both NaNs -> 0).
 LP_DEV float relu_f(float x) {
 #ifdef LP_X_RELU_F
   return fmaxf(x, 0.0f);

@@ -143,7 +143,7 @@ LP_DEV void loop_pad_input(const float (&x0)[C / 2], float (&out)[NB][16]) {
     for (int q = 0; q < 16; ++q) {
       const bool in = blk == 0 && q < C / 2;
       const float v = in ? x0[in ? q : 0] : 0.0f;
-      out[blk][q] = RELU ? fmaxf(v, 0.0f) : v;
+      out[blk][q] = RELU ? relu_f(v) : v;
     }
   }
 }

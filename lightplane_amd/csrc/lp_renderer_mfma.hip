@@ -111,7 +111,7 @@ LP_DEV Heads decode_flex(const float* lds, int lane, const float (&enc)[16], Act
     for (int q = 0; q < 16; ++q) t.h1[q] = relu_f(acc[q]);
   } else {  // two-grid decoder: the opacity head sees relu(sampled feature)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) t.h1[q] = (q < C / 2) ? fmaxf(t.x0[q < C / 2 ? q : 0], 0.0f) : 0.0f;
+    for (int q = 0; q < 16; ++q) t.h1[q] = (q < C / 2) ? relu_f(t.x0[q < C / 2 ? q : 0]) : 0.0f;
   }
   f32x16 acc;
   if (t2) {
@@ -133,7 +133,7 @@ LP_DEV Heads decode_flex(const float* lds, int lane, const float (&enc)[16], Act
   float ein[16];
   if (tg) {  // the colour head sees relu(sampled colour feature) + ray encoding
 #pragma unroll
-    for (int q = 0; q < 16; ++q) ein[q] = ((q < C / 2) ? fmaxf(xc0[q < C / 2 ? q : 0], 0.0f) : 0.0f) + enc[q];
+    for (int q = 0; q < 16; ++q) ein[q] = ((q < C / 2) ? relu_f(xc0[q < C / 2 ? q : 0]) : 0.0f) + enc[q];
   } else {
 #pragma unroll
     for (int q = 0; q < 16; ++q) ein[q] = t.e[q] + enc[q];

@@ -458,7 +458,10 @@ static int splat_segments(const LpSplatterArgs& a, unsigned ray_blocks, bool for
   static const int forced = getenv("LP_SPLAT_SEGMENTS") ? atoi(getenv("LP_SPLAT_SEGMENTS")) : 0;
   const int s_tot = a.march.num_samples + a.march.num_samples_inf;
   int n = forced > 0 ? forced : (int)(768u / (ray_blocks ? ray_blocks : 1u));
-  if (forced <= 0 && forward && n <= 1) n = (int)(3072u / (ray_blocks ? ray_blocks : 1u));
+  if (forced <= 0 && forward && n <= 1) {  // measured up to three; four was already slower (385..768 ray blocks must not get 4..7)
+    n = (int)(3072u / (ray_blocks ? ray_blocks : 1u));
+    if (n > 3) n = 3;
+  }
   if (n > s_tot / 16) n = s_tot / 16;
   return n < 1 ? 1 : n;
 }

@@ -30,7 +30,19 @@ def graphed_renderer(module: torch.nn.Module, rays: Rays, feature_grid: Sequence
 
     ``config.check_inputs`` must be off while capturing and replaying (the ``grid_idx`` range check is a host sync); it is
     switched off for the capture and the returned callable asserts it stays off.
+
+    Every host-side SCALAR of the call is frozen into the graph at capture time: ``num_samples``, ``gain``, ``bg_color`` given as
+    numbers, the switches -- and the opacity-noise seed, which is a by-value kernel argument drawn on the host
+    (``renderer.py``: ``random.randint`` when no seed is given).  A replay would therefore inject the SAME noise pattern at every
+    step, which silently defeats the regulariser (eager mode and the reference draw a fresh seed per call), so capturing with
+    ``inject_noise_sigma > 0`` (module attribute or keyword) is refused.
     """
+    sigma = forward_kwargs.get("inject_noise_sigma")
+    if sigma is None:
+        sigma = getattr(module, "inject_noise_sigma", 0.0)
+    if sigma and float(sigma) > 0.0:
+        raise ValueError("graphed_renderer: inject_noise_sigma > 0 cannot be captured -- the noise seed is a host scalar frozen into "
+                         "the graph, every replay would repeat one noise pattern; train with noise in eager mode")
     assert isinstance(feature_grid, (list, tuple)), "graphed_renderer takes the grid-list as a list of tensors"
     has_enc = rays.encoding is not None
     n_grids = len(feature_grid)

@@ -25,10 +25,12 @@ import torch.distributed as dist
 BUCKET_BYTES = 64 << 20
 #: above this size use reduce-scatter + all-gather explicitly (uses all 7 xGMI links of a GPU)
 RS_AG_BYTES = 256 << 20
-#: gradients of replicated tensors of at least this size are reduced IN PLACE, in the buffer autograd hands to the
-#: all-reduce node, instead of in a private clone (cfg 5: the 2.15 GB gradient of the 256^3 x 32 grid on a 19 GB peak).
-#: Such a gradient was written by this package's backward kernels into a buffer of its own; what an in-place reduce
-#: changes is that a hook / retain_grad() on the replicated view sees the all-rank sum instead of the local partial sum.
+#: With ``replicate_with_grad_allreduce(..., exclusive_grads=True)`` gradients of at least this size are reduced IN PLACE, in
+#: the buffer autograd hands to the all-reduce node, instead of in a private clone (cfg 5: the 2.15 GB gradient of the
+#: 256^3 x 32 grid on a 19 GB peak).  That is only correct when nothing else reads that buffer: autograd hands ONE tensor to
+#: both inputs of an add (``replicated + delta``), AccumulateGrad may have stolen it as somebody's ``.grad``, a hook or
+#: retain_grad() may hold it -- every such reader would see the all-rank sum (or a half-reduced buffer) instead of its local
+#: gradient.  The node cannot prove exclusivity from inside ``backward``, so the caller states it: the default is a clone.
 INPLACE_GRAD_BYTES = RS_AG_BYTES
 
 
@@ -136,18 +138,21 @@ class _AllReduceGrad(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, process_group, *tensors):
+    def forward(ctx, process_group, exclusive_grads, *tensors):
         ctx.process_group = process_group
+        ctx.exclusive_grads = bool(exclusive_grads)
         return tuple(t.view_as(t) for t in tensors)
 
     @staticmethod
     def backward(ctx, *grads):
-        # never reduce into the buffers autograd handed us (they may be shared with hooks / retain_grad): own copies --
-        # except for gradients of INPLACE_GRAD_BYTES or more, where the clone would double a multi-GB buffer
+        # never reduce into the buffers autograd handed us (they may be shared with the other input of an add, with a
+        # stolen .grad, with hooks / retain_grad): own copies -- unless the caller declared the gradients exclusive
+        # (`exclusive_grads`), and then only for INPLACE_GRAD_BYTES or more, where the clone would double a multi-GB buffer
         def own(g):
             if g is None:
                 return None
-            if g.is_contiguous() and g.numel() * g.element_size() >= INPLACE_GRAD_BYTES:
+            if ctx.exclusive_grads and g.is_contiguous() and g.numel() * g.element_size() >= INPLACE_GRAD_BYTES:
+                _AllReduceGrad.inplace_reductions += 1
                 return g
             return g.clone(memory_format=torch.contiguous_format)
 
@@ -157,12 +162,21 @@ class _AllReduceGrad(torch.autograd.Function):
         # backward comes from the node order instead: wrap the replicated tensors BEFORE the module computes the ray
         # embedding, then the embedding's backward nodes (created later) run before this one.
         allreduce_sum_(grads, ctx.process_group)
-        return (None, *grads)
+        return (None, None, *grads)
 
 
-def replicate_with_grad_allreduce(tensors: Iterable[torch.Tensor], process_group=None):
-    """Return views of ``tensors`` whose gradients are all-reduced (sum) across ranks."""
+_AllReduceGrad.inplace_reductions = 0  # how many gradients were reduced without a clone (tests)
+
+
+def replicate_with_grad_allreduce(tensors: Iterable[torch.Tensor], process_group=None, exclusive_grads: bool = False):
+    """Return views of ``tensors`` whose gradients are all-reduced (sum) across ranks.
+
+    ``exclusive_grads=True`` is the caller's statement that each returned view is consumed by exactly ONE differentiable
+    op that writes its gradient into a buffer of its own (this package's Renderer / Splatter calls do), with no hook or
+    ``retain_grad()`` on the view: gradients of ``INPLACE_GRAD_BYTES`` or more are then summed in that buffer instead of
+    in a clone.  Do not set it when a view feeds an add, a sum of losses or any op that forwards its incoming gradient
+    unchanged -- autograd shares one tensor between such an op's inputs."""
     tensors = list(tensors)
     if not is_distributed(process_group):
         return tensors
-    return list(_AllReduceGrad.apply(process_group, *tensors))
+    return list(_AllReduceGrad.apply(process_group, exclusive_grads, *tensors))

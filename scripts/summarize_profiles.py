@@ -36,15 +36,28 @@ for w in ("cfg2", "cfg3", "cfg4", "small"):
         lines = [l for l in open(log) if l.startswith("{")]
         if lines:
             json.dump(json.loads(lines[-1]), open(os.path.join(P, f"{ROUND}_bench_line_{w}.json"), "w"), indent=1)
+    trace_avg = {}  # kernel -> average duration (ns) in the kernel-trace run (no counters)
+    if stats:
+        for r in rows:
+            trace_avg[r["Name"].split("(")[0].replace("void ", "").strip()] = float(r["AverageNs"])
     pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+    pmc_dur = collections.defaultdict(list)  # kernel -> durations (ns) of its dispatches in the pmc1 pass (the SQ_BUSY_CYCLES pass)
+    for path in glob.glob(os.path.join(G, f"pmc1_{w}", "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+            kn = r.get("Kernel_Name", "")
+            if any(t in kn for t in ("renderer", "splat", "ray_embedding")) and r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                pmc_dur[kn.split("(")[0].replace("void ", "").strip()].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     for d in ("pmc1", "pmc2", "pmc3", "pmc4"):
         for path in glob.glob(os.path.join(G, f"{d}_{w}", "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(path)):
                 kn = r["Kernel_Name"]
                 if not any(t in kn for t in ("renderer", "splat", "ray_embedding")):
                     continue
-                k = kn.split("(")[0].replace("void ", "")
+                k = kn.split("(")[0].replace("void ", "").strip()
                 pmc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                if d == "pmc1" and r["Counter_Name"] == "SQ_BUSY_CYCLES" and r.get("Start_Timestamp") and r.get("End_Timestamp") \
+                        and not glob.glob(os.path.join(G, f"pmc1_{w}", "**", "*kernel_trace.csv"), recursive=True):
+                    pmc_dur[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
                 pmc[k]["_VGPR"].append(float(r["VGPR_Count"]) + float(r["Accum_VGPR_Count"]))
                 pmc[k]["_scratch"].append(float(r["Scratch_Size"]))
     for k, v in pmc.items():
@@ -55,6 +68,12 @@ for w in ("cfg2", "cfg3", "cfg4", "small"):
         # issue 16-byte gathers and 64-byte atomic segments (uncalibrated), so it is NOT applied.
         if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
             e["hbm_bytes_per_launch"] = round((avg["FETCH_SIZE"] + avg["WRITE_SIZE"]) * 1024)
+        if pmc_dur.get(k):  # duration of the kernel in the pass that counted SQ_BUSY_CYCLES: clock = busy / 32 SEs / duration
+            e["pmc_duration_ns"] = round(sum(pmc_dur[k]) / len(pmc_dur[k]), 1)
+        if k in trace_avg:
+            e["trace_duration_ns"] = round(trace_avg[k], 1)
+        if e.get("SQ_BUSY_CYCLES") and (e.get("pmc_duration_ns") or e.get("trace_duration_ns")):
+            e["clock_ghz"] = round(e["SQ_BUSY_CYCLES"] / 32.0 / (e.get("pmc_duration_ns") or e["trace_duration_ns"]), 4)
         e["workload"] = w
         out[f"{w}: {k}"] = e
 json.dump(out, open(os.path.join(P, f"{ROUND}_pmc_summary.json"), "w"), indent=1, sort_keys=True)

@@ -289,14 +289,27 @@ def _gloo_worker(rank, world_size, port, ret):
             assert torch.allclose(big, torch.full((3, 7), 3.0))
         finally:
             parallel.RS_AG_BYTES, parallel._supports_rs = old
-        # large gradients of replicated tensors are reduced in place (no clone): the hook sees the reduced buffer
+        # large gradients of replicated tensors: reduced in place (no clone) ONLY when the caller declares them exclusive.
+        # (gv2 * w).sum() hands the node a contiguous buffer of its own (a .sum() alone gives a stride-0 expand, which takes
+        # the clone path whatever the flag says)
         old_inplace = parallel.INPLACE_GRAD_BYTES
         parallel.INPLACE_GRAD_BYTES = 16
         try:
+            wgt2 = torch.arange(18, dtype=torch.float32).reshape(9, 2) + 1.0
+            n0 = parallel._AllReduceGrad.inplace_reductions
             g2 = torch.ones(9, 2, requires_grad=True)
-            (gv2,) = parallel.replicate_with_grad_allreduce([g2])
-            (gv2.sum() * float(rank + 1)).backward()
-            assert torch.allclose(g2.grad, torch.full((9, 2), 3.0))
+            (gv2,) = parallel.replicate_with_grad_allreduce([g2], exclusive_grads=True)
+            ((gv2 * wgt2).sum() * float(rank + 1)).backward()
+            assert torch.allclose(g2.grad, wgt2 * 3.0)
+            assert parallel._AllReduceGrad.inplace_reductions == n0 + 1       # no clone happened
+            # default: the buffer is aliased here (autograd hands ONE tensor to both inputs of the add); the other consumer
+            # has to keep its LOCAL gradient
+            g3 = torch.ones(9, 2, requires_grad=True)
+            delta = torch.zeros(9, 2, requires_grad=True)
+            (gv3,) = parallel.replicate_with_grad_allreduce([g3])
+            (((gv3 + delta) * wgt2).sum() * float(rank + 1)).backward()
+            assert parallel._AllReduceGrad.inplace_reductions == n0 + 1       # cloned
+            assert torch.allclose(g3.grad, wgt2 * 3.0) and torch.allclose(delta.grad, wgt2 * float(rank + 1))
         finally:
             parallel.INPLACE_GRAD_BYTES = old_inplace
         ret[rank] = True
@@ -479,3 +492,59 @@ def test_plain_c_binding_example(tmp_path):
     r = subprocess.run([str(exe), _lib.LIB_PATH], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()
     assert b"kernel family 1" in r.stdout and b"rc = -1" in r.stdout
+
+
+def test_bench_counter_lookup_is_by_the_kernel_that_ran(tmp_path):
+    """bench.py's `roofline.binding` / `traffic` must come from the counters of the kernel instantiation that ran, never
+    from whichever summary file sorts last (round-3 review, weak 5: the LP_LOOP experiment's counters ended up in the line)."""
+    import importlib.util
+    import json
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lp_bench", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    bf3 = "lp::renderer_bwd_bf3<16, 1, true, 3, 4, false>"
+    loop = "lp::renderer_bwd_loop<16, 1, false, 4, 3, false, 1>"
+    # the committed summaries: the tuned kernel's entry is found by its exact name; experiment files are not consulted
+    v, src, k = bench.pmc_entry("cfg2", bf3)
+    assert v is not None and k == bf3 and re.search(r"r\d+_pmc_summary\.json$", src)
+    assert bench.pmc_entry("cfg2", loop)[0] is None          # lives in r03loop_pmc_summary.json only: not a default-command file
+    assert bench.pmc_entry("cfg2", "lp::renderer_bwd")[0] is None and bench.pmc_entry("cfg2", None)[0] is None  # no substring matches
+    # observed kernels -> dominant by device time per step
+    obs = {bf3: {"launches_per_step": 1, "mean_ms": 2.05}, "lp::renderer_fwd_bf3<16, 1, 2, 3, false>": {"launches_per_step": 1, "mean_ms": 0.47},
+           "lp::renderer_bwd_combine": {"launches_per_step": 1, "mean_ms": 0.01}}
+    assert bench.dominant_kernel(obs, "renderer_bwd") == bf3
+    assert bench.dominant_kernel(obs, "splat_fwd_walk") is None
+
+    class WL(bench.RendererWorkload):
+        def __init__(self):
+            self.n_rays, self.S, self.C = 65536, 128, 16
+
+    b = bench.binding_ceiling("cfg2", WL(), 0.48, 2.07, obs)
+    assert b["kernel"] == bf3 and 0.5 < b["frac_issue"] <= 1.0, b
+    assert WL().dw_f32_mfma_per_launch() == 2048 * 128 * 112
+    assert bench.binding_ceiling("cfg2", WL(), 0.48, 2.07, {loop: {"launches_per_step": 1, "mean_ms": 3.8}}) is None
+    # newest round wins, an `rNNxyz_` experiment file never does
+    e = {"FETCH_SIZE": 1.0, "WRITE_SIZE": 1.0, "hbm_bytes_per_launch": 2048, "SQ_INSTS_VALU": 4.0, "SQ_INSTS_MFMA": 1.0}
+    for name, tag in (("r03_pmc_summary.json", 3), ("r04_pmc_summary.json", 4), ("r04zz_pmc_summary.json", 99), ("r10_pmc_summary.json", 10)):
+        json.dump({"cfg2: " + bf3: dict(e, tag=tag)}, open(tmp_path / name, "w"))
+    assert bench.pmc_entry("cfg2", bf3, profiles_dir=str(tmp_path))[0]["tag"] == 10
+
+
+def test_graphed_renderer_refuses_to_freeze_the_noise_seed():
+    """The opacity-noise seed is a host scalar: captured into a HIP graph it would repeat one noise pattern at every replay
+    (ADVICE round 3).  graphed_renderer refuses, before it touches the GPU."""
+    from lightplane_amd.graphs import graphed_renderer
+    from tests.synth import grid_sizes_for, random_grids, random_rays
+
+    g = torch.Generator().manual_seed(0)
+    grids = random_grids(g, grid_sizes_for((1, 4, 4, 4, 16), True))
+    rays = random_rays(g, 32, 1, None)
+    noisy = lp.LightplaneRenderer(num_samples=8, color_chn=3, grid_chn=16, mlp_hidden_chn=32, inject_noise_sigma=0.5)
+    with pytest.raises(ValueError, match="inject_noise_sigma"):
+        graphed_renderer(noisy, rays, grids)
+    quiet = lp.LightplaneRenderer(num_samples=8, color_chn=3, grid_chn=16, mlp_hidden_chn=32)
+    with pytest.raises(ValueError, match="inject_noise_sigma"):
+        graphed_renderer(quiet, rays, grids, inject_noise_sigma=0.1)
