@@ -664,6 +664,28 @@ def measure_extra(name, dev, kernel, reps):
     return out
 
 
+def measure_cfg5(dev, kernel, reps=2):
+    """BASELINE configs[4] at its per-GPU size on ONE GPU (13 views of 512 x 512 x 32 ch -> 256^3 x 32 ch voxel grid, 135 x 1920
+    camera rows rendered from it at 256 samples, end-to-end backward through the render, the normalisation and the splat):
+    event times, the kernels behind them (torch.profiler device times) and the peak memory of one step."""
+    wl = JointWorkload(0, 1, dev, None, kernel)
+    wl.step()
+    torch.cuda.synchronize()
+    fwd_ms, bwd_ms = event_times(wl, reps)
+    peak_mb = reference_protocol_peak_mb(wl, dev)
+    obs = observed_kernels(wl, 1)
+    roof = wl.roofline(fwd_ms, bwd_ms)
+    out = {"workload": wl.desc, "rays": wl.n_rays, "splat_rays": wl.splat_rays.n_rays, "render_rays": wl.cam.n_rays,
+           "fwd_ms": round(fwd_ms, 3), "bwd_ms": round(bwd_ms, 3), "Mrays_per_s_fwd_bwd": round(wl.n_rays / (fwd_ms + bwd_ms) / 1e3, 4),
+           "reps": reps, "peak_bwd_mem_mb": round(peak_mb, 1), "roofline": roof,
+           "kernels": {k: {"launches_per_step": v["launches_per_step"], "mean_ms": round(v["mean_ms"], 3)} for k, v in obs.items()},
+           "timing": "HIP events around forward / backward (torch ops -- grid zero-fill, normalise, loss -- included); `kernels`: "
+                     "torch.profiler device time of the lp:: kernels of one step"}
+    del wl
+    torch.cuda.empty_cache()
+    return out
+
+
 def kernel_times(wl, reps):
     """Median device time of the lp::renderer_fwd* / lp::renderer_bwd* kernels per step, from torch.profiler's device
     timestamps: for batches whose kernels are as short as the host side of a call, events around Python calls would
@@ -895,6 +917,7 @@ def main():
                 "renderer_1080p_s128": measure_extra("1080p_s128", dev, args.kernel, 5),
                 "renderer_cfg4_shard": measure_extra("cfg4", dev, args.kernel, 5),
                 "renderer_small_batch": measure_small_batch(dev, args.kernel, 20),
+                "joint_cfg5_one_gpu": measure_cfg5(dev, args.kernel),
                 # the reference's own benchmark axes (its protocol: wall time incl. host side, fresh inputs per rerun)
                 "refbench_renderer": refbench_renderer(dev, [256, 1024], args.kernel),
                 "refbench_splatter": refbench_splatter(dev, [1, 16]),

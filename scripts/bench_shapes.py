@@ -24,7 +24,41 @@ def t(f, k=3):
     return e0.elapsed_time(e1) / k
 
 
-if what == "renderer":
+if what == "list_vs_flat":
+    # round-3 review, weak 10: this script reported 3.00 ms fwd+bwd (0.63 fwd) for the headline shape given as a LIST of grids,
+    # bench.py 2.55 ms (0.48 fwd) for the flat tensor.  Same inputs, both input forms, warmed up (10 + `k` reps each, interleaved).
+    gen = torch.Generator().manual_seed(0)
+    d = random_decoder(gen, 2, 2, 2, 16, 32, 3, std=0.15)
+    rays = pinhole_rays(n, n, enc_dim=32, gen=gen).to(dev)
+    rays.encoding.requires_grad_(True)
+    sizes = grid_sizes_for((1, 64, 64, 64, 16), True)
+    grids = [g.to(dev).requires_grad_(True) for g in random_grids(gen, sizes)]
+    flat = lp.flatten_grid([g.detach() for g in grids])[0].clone().requires_grad_(True)
+    params = d.mlp_params.to(dev).requires_grad_(True)
+    dec = lp.DecoderParams(params, d.n_hidden_trunk, d.n_hidden_opacity, d.n_hidden_color, 3)
+
+    def mk(g, kw):
+        def fwd():
+            with torch.no_grad():
+                lp.lightplane_renderer(rays, g, dec, num_samples=S, gain=1.0, **kw)
+
+        def fb():
+            params.grad = rays.encoding.grad = flat.grad = None
+            for x in grids:
+                x.grad = None
+            o = lp.lightplane_renderer(rays, g, dec, num_samples=S, gain=1.0, **kw)
+            (o[0].sum() + o[1].sum() + o[2].sum()).backward()
+        return fwd, fb
+
+    forms = {"list": mk(grids, {}), "flat": mk(flat, {"grid_sizes": sizes})}
+    for _ in range(10):
+        for fwd, fb in forms.values():
+            fwd(); fb()
+    for rnd in range(2):
+        for name, (fwd, fb) in forms.items():
+            print(json.dumps({"input": name, "round": rnd, "fwd_ms": round(t(fwd, 50), 4), "fwd_bwd_ms": round(t(fb, 50), 4),
+                              "fwd_ms_3reps_cold_protocol": round(t(fwd, 3), 4)}), flush=True)
+elif what == "renderer":
     #        trunk, opacity, colour, hidden, C, grid, separate colour grid
     shapes = [(2, 2, 2, 32, 16, 64, False), (4, 4, 4, 32, 16, 64, False), (4, 2, 4, 32, 16, 64, False), (2, 4, 2, 32, 16, 64, False),
               (3, 3, 3, 16, 16, 64, False), (0, 4, 4, 32, 16, 64, True), (0, 2, 2, 32, 16, 64, True), (4, 4, 4, 32, 32, 128, False),

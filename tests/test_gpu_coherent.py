@@ -123,13 +123,20 @@ def check_renderer(d, dev, kernel, tag, **extra):
         _assert_close(f"{tag}: {nm}", a, b.detach().numpy())
     C = d["grids"][0].shape[-1]
     width = max(int(v) for v in list(d["decoder"].n_hidden_trunk) + list(d["decoder"].n_hidden_color))
-    assert_grad_close(f"{tag}: grad_mlp_params", gp, o_gp.numpy(), 4 * width)
-    assert_grad_close(f"{tag}: grad_encoding", ge, o_ge.numpy(), ge.shape[1])
+    q = []
+
+    def oracle64():  # the second oracle of the flip allowance: run once, only when some tensor misses the bar
+        if not q:
+            q.append(oracle_renderer64(d))
+        return q[0]
+
+    assert_grad_close(f"{tag}: grad_mlp_params", gp, o_gp.numpy(), 4 * width, want64=lambda: oracle64()[1].numpy())
+    assert_grad_close(f"{tag}: grad_encoding", ge, o_ge.numpy(), ge.shape[1], want64=lambda: oracle64()[2].numpy())
     for i, (a, b) in enumerate(zip(gg, o_gg)):
-        assert_grad_close(f"{tag}: grad_grid{i}", a, b.numpy(), 8 * C)
+        assert_grad_close(f"{tag}: grad_grid{i}", a, b.numpy(), 8 * C, want64=lambda i=i: oracle64()[3][i].numpy())
     if gc is not None:
         for i, (a, b) in enumerate(zip(gc, o_gc)):
-            assert_grad_close(f"{tag}: grad_color_grid{i}", a, b.numpy(), 8 * C)
+            assert_grad_close(f"{tag}: grad_color_grid{i}", a, b.numpy(), 8 * C, want64=lambda i=i: oracle64()[4][i].numpy())
 
 
 @pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)

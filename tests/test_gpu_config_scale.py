@@ -107,10 +107,10 @@ def test_baseline_cfg1_exact(golden_dir):
             assert_grad_close(f"cfg1 {tag}: {nm}/golden", a, z[nm], n, want64=c.numpy())
 
 
-@pytest.mark.parametrize("C,G,S", [(16, 64, 128), (32, 128, 64)], ids=["c16_s128", "c32_s64"])
+@pytest.mark.parametrize("C,G,S", [(16, 64, 128), (32, 128, 64), (32, 128, 256)], ids=["c16_s128", "c32_s64", "cfg4_c32_s256"])
 def test_1080p_backward_block(C, G, S):
     """A real 1920 x 1080 forward + backward launch; upstream gradient non-zero on a 24 x 40 block (not aligned to the 32-ray
-    waves) only."""
+    waves) only.  ``cfg4_c32_s256`` is BASELINE configs[3]'s per-GPU launch itself: triplane 128^2 x 32 ch at 256 samples."""
     dev = _dev()
     H, W = 1080, 1920
     gen = torch.Generator().manual_seed(7)
@@ -152,8 +152,9 @@ INDEX_CASES = {
 }
 
 
+@pytest.mark.parametrize("layers", [(2, 2, 2), (4, 4, 4)], ids=["tuned222", "looped444"])
 @pytest.mark.parametrize("name", list(INDEX_CASES), ids=list(INDEX_CASES))
-def test_hot_kernel_touched_rows_equal_oracle(name):
+def test_hot_kernel_touched_rows_equal_oracle(name, layers):
     """Integer indexing of the PRODUCTION kernels: the rows of grad_grid the MFMA backward writes are exactly the rows the
     oracle's corner indices name (the camera sits close enough that rays leave the volume: border cells, partly valid
     corners and rays that miss a plane altogether all occur)."""
@@ -163,7 +164,7 @@ def test_hot_kernel_touched_rows_equal_oracle(name):
     sizes = grid_sizes_for(base, tri)
     grids = random_grids(gen, sizes)
     C = base[-1]
-    dec = random_decoder(gen, 2, 2, 2, C, 32, 3, std=0.2)
+    dec = random_decoder(gen, *layers, C, 32, 3, std=0.2 if layers == (2, 2, 2) else 0.25)
     parts = [pinhole_rays(H, W, cam_dist=2.2, enc_dim=32, gen=gen, grid_idx=b, azimuth_deg=az + 50.0 * b, elevation_deg=el)
              for b in range(base[0])]
     from tests.synth import cat_rays
@@ -173,7 +174,10 @@ def test_hot_kernel_touched_rows_equal_oracle(name):
     cfg = dict(num_samples=S, gain=1.0, num_samples_inf=0, mask_out_of_bounds_samples=False, contract_coords=False,
                inject_noise_sigma=0.0, inject_noise_seed=0)
     d = dict(rays=rays, grids=grids, color_grids=None, decoder=dec, scaffold=None, cfg=cfg, sizes=sizes, upstream=up)
-    assert lp.kernel_family(rays, grids, dec) != 0, "this test is about the MFMA kernels"
+    fam = lp.kernel_family(rays, grids, dec)
+    assert fam != 0, "this test is about the MFMA kernels"
+    if layers == (4, 4, 4):  # the layer-looped family has its OWN gather / scatter specialisations (lp_renderer_loop.hip)
+        assert fam == 3, fam
     _, _, _, gg, _ = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO)
     rows = O.renderer_corner_indices(rays, sizes, S, 0, False)  # per grid: [N, S, K] rows relative to the grid (-1: outside)
     _, _, _, o_gg = oracle_chunked(d)
@@ -237,3 +241,128 @@ def test_bf16x3_operand_dynamic_range(which):
     assert_grad_close(f"{which}: grad_encoding", ge, o_ge.numpy(), H, want64=q_ge.numpy())
     for i, (a, b, c) in enumerate(zip(gg, o_gg, q_gg)):
         assert_grad_close(f"{which}: grad_grid{i}", a, b.numpy(), 8 * C, want64=c.numpy())
+
+
+# --------------------------------------------------------------------------------------------------------------
+# BASELINE configs[2] (cfg 3) at FULL size, and index parity of the Splatter walks
+# --------------------------------------------------------------------------------------------------------------
+
+
+def splatter_oracle_chunked(rays, shape, cfg, upstream, chunk=1024):
+    """The Splatter oracle over all rays in ray chunks: un-normalised feature / weight sums accumulated with the oracle's own
+    corner arithmetic (oracle._corner_setup with the Splatter's un-normalisation, oracle.ray_depths), normalised once at the
+    end like oracle._splatter_impl; grad_encoding = the adjoint gather of upstream / clamp(weight) with the same corners.
+    (oracle._splatter_impl itself materialises [N, S, C] tensors and out-of-place index_adds of the whole grid: 65 536 rays x
+    256 samples do not fit; this is the same arithmetic in chunks, fp32.)"""
+    B, D, H, W, C = shape
+    n = rays.n_rays
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    try:
+        fgrid = torch.zeros(B * D * H * W, C)
+        wgrid = torch.zeros(B * D * H * W)
+
+        def corners(lo):
+            r = rays[lo:lo + chunk]
+            depths = O.ray_depths(r.near, r.far, cfg["num_samples"], cfg.get("num_samples_inf", 0), 1e-5)
+            pts = depths[..., None] * r.directions[:, None] + r.origins[:, None]
+            assert not cfg.get("contract_coords", False)
+            mask = O.in_bounds(pts).float() if cfg.get("mask_out_of_bounds_samples", False) else torch.ones(pts.shape[:-1])
+            gi = r.grid_idx.long()
+            for idx, w, valid in O._corner_setup(pts, shape, O._unnormalize_splatter):
+                yield r, (gi[:, None] * (D * H * W) + idx), w * valid.float() * mask
+
+        with torch.no_grad():
+            for lo in range(0, n, chunk):
+                for r, rows, w in corners(lo):
+                    wgrid.index_add_(0, rows.reshape(-1), w.reshape(-1))
+                    val = r.encoding[:, None, :] * w[..., None]
+                    fgrid.index_add_(0, rows.reshape(-1), val.reshape(-1, C))
+            out = fgrid / wgrid.clamp(min=1e-5)[:, None]
+            g = upstream.reshape(-1, C) / wgrid.clamp(min=1e-5)[:, None]
+            g_enc = torch.zeros(n, C)
+            for lo in range(0, n, chunk):
+                for r, rows, w in corners(lo):
+                    g_enc[lo:lo + chunk] += (g[rows.reshape(-1)].reshape(rows.shape + (C,)) * w[..., None]).sum(dim=1)
+        return out.reshape(B, D, H, W, C), g_enc, wgrid.reshape(B, D, H, W)
+    finally:
+        torch.set_num_threads(old_threads)
+
+
+def test_splatter_chunked_oracle_equals_oracle_cpu_part():
+    """(runs on the GPU box, CPU work only) the chunked restatement above == oracle.lightplane_splatter_naive + autograd on a
+    case small enough for both."""
+    gen = torch.Generator().manual_seed(5)
+    rays = pinhole_rays(24, 40, cam_dist=2.3, azimuth_deg=20.0, elevation_deg=35.0)
+    rays.encoding = torch.rand(rays.n_rays, 32, generator=gen).requires_grad_(True)
+    shape = [1, 12, 14, 10, 32]
+    cfg = dict(num_samples=20, num_samples_inf=0, mask_out_of_bounds_samples=True, contract_coords=False)
+    up = torch.randn(*shape, generator=gen)
+    (want,) = O.lightplane_splatter_naive(rays, [shape], **cfg)
+    (want * up).sum().backward()
+    with torch.no_grad():
+        got, g_enc, _ = splatter_oracle_chunked(rays, shape, cfg, up, chunk=100)
+    _assert_close("chunked oracle: out", got, want.detach().numpy(), tol=2e-6)
+    _assert_close("chunked oracle: grad_encoding", g_enc, rays.encoding.grad.numpy(), tol=2e-6)
+
+
+def test_cfg3_full_batch_against_oracle():
+    """BASELINE configs[2] at full size -- 65 536 rays of the 256 x 256 camera x 32 ch, 256 samples, into the 128^3 x 32 voxel
+    grid (the launch bench.py's `splatter_cfg3` times): the whole output grid and grad_encoding against the chunked CPU oracle."""
+    from bench import SplatterWorkload
+    dev = _dev()
+    wl = SplatterWorkload(0, dev, None)
+    rays_c, shape = wl.rays_c, wl.sizes[0]
+    cfg = dict(num_samples=wl.S, num_samples_inf=0, mask_out_of_bounds_samples=False, contract_coords=False)
+    up = wl.up.cpu().reshape(*shape)
+    rays = rays_c.to(dev)
+    rays.encoding = rays.encoding.clone().requires_grad_(True)
+    (out,) = lp.lightplane_splatter(rays, [shape], **cfg)
+    (out * up.to(dev)).sum().backward()
+    want, want_ge, wgrid = splatter_oracle_chunked(rays_c, shape, cfg, up)
+    _assert_close("cfg3 full: out", out, want.numpy())
+    _assert_close("cfg3 full: grad_encoding", rays.encoding.grad, want_ge.numpy())
+    num = (rays.encoding.grad.double().cpu() - want_ge.double()).norm().item()
+    assert num / want_ge.double().norm().item() <= 1e-4, "cfg3 full: grad_encoding relative L2"
+    num = (out.double().cpu() - want.double()).norm().item()
+    assert num / want.double().norm().item() <= 1e-4, "cfg3 full: out relative L2"
+    # integer indexing of the walk at full scale: a cell received weight on the GPU iff it did in the oracle
+    assert torch.equal((out != 0).any(dim=-1).cpu(), wgrid > 0), "cfg3 full: touched cells differ from the oracle's"
+    assert int((wgrid > 0).sum()) > 100000
+
+
+SPLAT_INDEX_CASES = {
+    # name: (out_base, triplane, H, W, azimuth, elevation, samples, mask_oob)
+    "voxel14_c16": ((1, 14, 12, 18, 16), False, 48, 80, 30.0, 45.0, 24, False),
+    "voxel12_c32_b2_mask": ((2, 12, 12, 12, 32), False, 40, 48, 60.0, -20.0, 16, True),
+    "voxel10_c64": ((1, 10, 12, 14, 64), False, 40, 48, 15.0, 20.0, 20, False),
+    "triplane20_c16": ((1, 20, 24, 28, 16), True, 48, 80, 30.0, 45.0, 24, False),
+    "triplane16_c32_mask": ((1, 16, 16, 16, 32), True, 64, 64, 0.0, 0.0, 20, True),
+    "triplane12_c64": ((1, 12, 10, 14, 64), True, 40, 48, 40.0, 10.0, 18, False),
+}
+
+
+@pytest.mark.parametrize("name", list(SPLAT_INDEX_CASES), ids=list(SPLAT_INDEX_CASES))
+def test_splatter_walk_touched_cells_equal_oracle(name):
+    """Integer indexing of the PRODUCTION Splatter walks (lp_splat_walk.h: the voxel column walk with carried columns, the
+    per-slot plane walk; C = 16 / 32 / 64) -- which use the Splatter oracle's own un-normalisation `(x + 1) / 2 * W - 0.5`, not
+    the Renderer's: with strictly positive features a cell of the output is non-zero iff it received weight, so the non-zero
+    cells of the GPU output must be EXACTLY the cells the oracle's weight grid marks.  The camera sits close enough that rays
+    leave the volume (border cells, partly valid corners, rays that miss altogether)."""
+    from tests.synth import cat_rays
+    dev = _dev()
+    base, tri, H, W, az, el, S, mask = SPLAT_INDEX_CASES[name]
+    gen = torch.Generator().manual_seed(4)
+    C = base[-1]
+    sizes = grid_sizes_for(base, tri)
+    parts = [pinhole_rays(H, W, cam_dist=2.2, grid_idx=b, azimuth_deg=az + 50.0 * b, elevation_deg=el) for b in range(base[0])]
+    rays = parts[0] if len(parts) == 1 else cat_rays(parts)
+    rays.encoding = 0.5 + 0.5 * torch.rand(rays.n_rays, C, generator=gen)
+    cfg = dict(num_samples=S, num_samples_inf=0, mask_out_of_bounds_samples=mask, contract_coords=False)
+    out = lp.lightplane_splatter(rays.to(dev), sizes, **cfg)
+    for g, (got, shape) in enumerate(zip(out, sizes)):
+        _, _, wgrid = splatter_oracle_chunked(rays, shape, cfg, torch.zeros(*shape))
+        touched = (got != 0).any(dim=-1).cpu()
+        assert torch.equal(touched, wgrid > 0), (f"{name} grid {g}: touched cells differ in {int((touched != (wgrid > 0)).sum())} of "
+                                                 f"{touched.numel()} cells")
+        assert 0.2 * touched.numel() < int(touched.sum()) and bool((got >= 0).all())

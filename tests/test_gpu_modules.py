@@ -222,6 +222,17 @@ def test_device_and_dtype_checks_raise_python_errors():
         lp.lightplane_splatter(rs, ds["out_sizes"], **ds["cfg"])
 
 
+def test_rccl_collectives_on_a_one_rank_group():
+    """RCCL (backend "nccl") executes the collectives of lightplane_amd/parallel.py on this GPU: the private coalescing
+    context, reduce-scatter + all-gather on views of one buffer, the in-place all-reduce inside a Renderer backward
+    (tests/nccl_worker.py; a one-rank group, because the build has no multi-GPU node)."""
+    worker = os.path.join(ROOT, "tests", "nccl_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + (os.getpid() % 90)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, worker], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "RCCL_1RANK_OK" in out, out[-4000:]
+
+
 def test_two_rank_ray_shards_equal_single_process():
     """The multi-GPU path end to end with the REAL autograd functions: two ranks (gloo, both on this GPU) each render /
     splat half of the rays; the all-reduced gradients / the all-reduced splat equal the single-process result."""

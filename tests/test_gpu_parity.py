@@ -49,13 +49,19 @@ def rel_l2(got, want):
     return (got - want).norm().item() / max(want.norm().item(), 1e-30)
 
 
+UNEXPLAINED_MAX = 5e-3  # an entry that misses the bar against BOTH oracles may not be further off than this
+
+
 def assert_grad_close(name, got, want, entries_per_sample, tol=1e-4, want64=None, flip_samples=FLIP_SAMPLES):
     """Gradient tensor vs the fp32 oracle: the north_star bar, or the ReLU-flip allowance described in
     tests/test_gpu_coherent.py's docstring.  Every use of the allowance is recorded and printed.
 
-    ``want64`` (the same oracle run in fp64): an entry that misses the bar against the fp32 oracle but meets it against the
-    fp64 one is EXPLAINED -- the fp32 oracle took the other branch of a ReLU there, the kernel the exact one -- and does not
-    count; only entries that miss both count against ``flip_samples`` samples' worth of entries."""
+    ``want64`` (the same oracle run in fp64; an array or a zero-argument callable that is only evaluated when the bar is
+    missed): an entry that misses the bar against the fp32 oracle but meets it against the fp64 one is EXPLAINED -- the
+    fp32 oracle took the other branch of a ReLU there, the kernel the exact one -- and does not count; only entries that
+    miss both count against ``flip_samples`` samples' worth of entries, and none of those may be off by more than
+    UNEXPLAINED_MAX of the largest entry.  The allowance is NOT available without the second oracle (round-3 review,
+    weak 1): a tensor that misses the bar with ``want64=None`` fails."""
     want = torch.as_tensor(np.asarray(want))
     g = got.detach().double().cpu()
     w = want.double()
@@ -67,22 +73,26 @@ def assert_grad_close(name, got, want, entries_per_sample, tol=1e-4, want64=None
     if worst <= tol:
         assert l2 <= tol, f"{name}: relative L2 error {l2:.3e} > {tol} (max-norm {worst:.3e})"
         return
+    assert want64 is not None, (f"{name}: max err / scale = {worst:.3e} > {tol} (relative L2 {l2:.3e}) and no second (fp64) oracle "
+                                f"was given -- the ReLU-flip allowance needs one")
+    if callable(want64):
+        want64 = want64()
     off = err > tol
     n_off = int(off.sum())
-    unexplained = off
-    if want64 is not None:
-        w64 = torch.as_tensor(np.asarray(want64)).double()
-        unexplained = off & ((g - w64).abs() / scale > tol)
+    w64 = torch.as_tensor(np.asarray(want64)).double()
+    err64 = (g - w64).abs() / scale
+    unexplained = off & (err64 > tol)
     n_un = int(unexplained.sum())
+    worst_un = float(torch.minimum(err, err64)[unexplained].max()) if n_un else 0.0
     allowed = flip_samples * entries_per_sample
-    FLIP_EVENTS.append(dict(name=name, tol=tol, n_off=n_off, explained=(n_off - n_un) if want64 is not None else None,
-                            unexplained=n_un, allowed=allowed, worst=worst, l2=l2))
-    print(f"flip-allowance {name}: {n_off} entries above {tol:g}, "
-          + (f"{n_off - n_un} explained by the second oracle, " if want64 is not None else "no second oracle given, ")
-          + f"worst {worst:.3e}, rel L2 {l2:.3e}")
-    ok = n_un <= allowed and worst <= 5e-2 and l2 <= 1e-3
-    assert ok, (f"{name}: max err / scale = {worst:.3e} > {tol} and not a ReLU-flip pattern: {n_un} entries above the bar "
-                f"({n_off - n_un} more explained by the fp64 oracle; allowed {allowed}), relative L2 {l2:.3e} (allowed 1e-3)")
+    FLIP_EVENTS.append(dict(name=name, tol=tol, n_off=n_off, explained=n_off - n_un, unexplained=n_un, allowed=allowed, worst=worst,
+                            worst_unexplained=worst_un, l2=l2))
+    print(f"flip-allowance {name}: {n_off} entries above {tol:g}, {n_off - n_un} explained by the second oracle, "
+          f"worst {worst:.3e}, worst unexplained {worst_un:.3e}, rel L2 {l2:.3e}")
+    ok = n_un <= allowed and worst <= 5e-2 and l2 <= 1e-3 and worst_un <= UNEXPLAINED_MAX
+    assert ok, (f"{name}: max err / scale = {worst:.3e} > {tol} and not a ReLU-flip pattern: {n_un} entries above the bar against "
+                f"both oracles, the worst by {worst_un:.3e} (allowed {UNEXPLAINED_MAX:g}; {n_off - n_un} more explained by the fp64 "
+                f"oracle; allowed count {allowed}), relative L2 {l2:.3e} (allowed 1e-3)")
 
 
 def _rays_to(rays, dev, requires_grad=False):
@@ -405,11 +415,28 @@ def test_cfg2_sized_properties():
     (o[0].sum() + o[1].sum() + o[2].sum()).backward()
     for name, a, b in (("len", sub_out[0], o[0]), ("nlt", sub_out[1], o[1]), ("feat", sub_out[2], o[2])):
         _assert_close("cfg2-sub " + name, a, b.detach().numpy())
-    # 65 536 samples x 128 hidden units: a ReLU flip between two fp32 evaluations is likely (see test_gpu_coherent.py)
-    assert_grad_close("cfg2-sub gparams", sub_gp, d2.mlp_params.grad.numpy(), 4 * 32)
-    assert_grad_close("cfg2-sub genc", sub_ge, r.encoding.grad.numpy(), 32)
-    for a, b in zip(sub_gg, gs):
-        assert_grad_close("cfg2-sub ggrid", a, b.grad.numpy(), 8 * 16)
+    # 65 536 samples x 128 hidden units: a ReLU flip between two fp32 evaluations is likely (see test_gpu_coherent.py);
+    # the allowance needs the fp64 oracle to tell a flip from an error
+    q = {}
+
+    def oracle64():
+        if not q:
+            r64 = rays[idx]
+            for f in ("directions", "origins", "near", "far", "encoding"):
+                setattr(r64, f, getattr(r64, f).double())
+            r64.encoding = r64.encoding.clone().requires_grad_(True)
+            d64 = copy.copy(dec)
+            d64.mlp_params = dec.mlp_params.double().clone().requires_grad_(True)
+            g64 = [g.double().clone().requires_grad_(True) for g in grids]
+            o64 = O.lightplane_renderer_naive(r64, g64, d64, num_samples=S, gain=1.0)
+            (o64[0].sum() + o64[1].sum() + o64[2].sum()).backward()
+            q.update(gp=d64.mlp_params.grad.numpy(), ge=r64.encoding.grad.numpy(), gg=[g.grad.numpy() for g in g64])
+        return q
+
+    assert_grad_close("cfg2-sub gparams", sub_gp, d2.mlp_params.grad.numpy(), 4 * 32, want64=lambda: oracle64()["gp"])
+    assert_grad_close("cfg2-sub genc", sub_ge, r.encoding.grad.numpy(), 32, want64=lambda: oracle64()["ge"])
+    for i, (a, b) in enumerate(zip(sub_gg, gs)):
+        assert_grad_close("cfg2-sub ggrid", a, b.grad.numpy(), 8 * 16, want64=lambda i=i: oracle64()["gg"][i])
     for a, b in zip(out1, sub_out):
         assert torch.allclose(a[idx.to(dev)], b, rtol=1e-5, atol=1e-6), "ray results depend on batch composition"
 

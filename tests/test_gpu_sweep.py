@@ -57,6 +57,69 @@ def _rays64(rays):
     return r
 
 
+def _splatter_oracle(case, d, dtype):
+    """The Splatter / MLP-Splatter oracle on the case's inputs in ``dtype``: (outputs, grad_encoding, grad_mlp_params | None,
+    grad_input_grids | None)."""
+    rays = copy.copy(d["rays"])
+    for f in ("directions", "origins", "near", "far", "encoding"):
+        setattr(rays, f, getattr(rays, f).to(dtype))
+    rays.encoding = rays.encoding.clone().requires_grad_(True)
+    up = [u.to(dtype) for u in d["upstream"]]
+    if case.use_mlp:
+        mlp = copy.copy(d["mlp"])
+        mlp.mlp_params = mlp.mlp_params.to(dtype).clone().requires_grad_(True)
+        in_grids = [g.to(dtype).clone().requires_grad_(True) for g in d["in_grids"]]
+        o_out = O.lightplane_mlp_splatter_naive(rays, d["out_sizes"], mlp, in_grids, **d["cfg"])
+        sum((o * u).sum() for o, u in zip(o_out, up)).backward()
+        return [o.detach() for o in o_out], rays.encoding.grad, mlp.mlp_params.grad, [g.grad for g in in_grids]
+    o_out = O.lightplane_splatter_naive(rays, d["out_sizes"], **d["cfg"])
+    sum((o * u).sum() for o, u in zip(o_out, up)).backward()
+    return [o.detach() for o in o_out], rays.encoding.grad, None, None
+
+
+SPLAT_TOL = 1e-4  # north_star's bar; the Splatter sweeps held 2e-4 until round 3 (review, weak 2)
+
+
+def _check_splatter_all(case, name, d, dev):
+    """HIP Splatter / MLP-Splatter against the fp32 oracle at north_star's 1e-4 (the cell a sample falls into is DEFINED by the
+    fp32 index arithmetic).  A tensor that misses it may instead meet 1e-4 against the fp64 oracle (the fp32 oracle's own
+    scatter_add order carries error of that size on some seeds); gradients downstream of the MLP's ReLUs get the counted
+    ReLU-flip allowance of assert_grad_close with the fp64 oracle as second opinion.  Outputs never get an allowance."""
+    if case.use_mlp:
+        out, ge, gp, gin = run_hip_mlp_splatter(d, dev)
+    else:
+        out, ge = run_hip_splatter(d, dev)
+        gp = gin = None
+    o32 = _splatter_oracle(case, d, torch.float32)
+    q = []
+
+    def o64():
+        if not q:
+            q.append(_splatter_oracle(case, d, F64))
+        return q[0]
+
+    def one(nm, got, want32, pick64, grad_entries=None):
+        if _rel_err(got, want32.numpy()) <= SPLAT_TOL:
+            return
+        want64 = pick64(o64())
+        if _rel_err(got, want64.numpy()) <= SPLAT_TOL:
+            return
+        if grad_entries is not None:
+            assert_grad_close(f"{name}: {nm}", got, want32.numpy(), grad_entries, tol=SPLAT_TOL, want64=want64.numpy())
+            return
+        raise AssertionError(f"{name}: {nm}: max err / scale = {_rel_err(got, want32.numpy()):.3e} (fp32 oracle), "
+                             f"{_rel_err(got, want64.numpy()):.3e} (fp64 oracle) > {SPLAT_TOL}")
+
+    for k, o in enumerate(out):
+        one(f"out{k}", o, o32[0][k], lambda r, k=k: r[0][k])
+    width = int(max(d["mlp"].n_hidden)) if case.use_mlp else None
+    one("grad_encoding", ge, o32[1], lambda r: r[1], grad_entries=(ge.shape[1] if case.use_mlp else None))
+    if case.use_mlp:
+        one("grad_mlp_params", gp, o32[2], lambda r: r[2], grad_entries=4 * width)
+        for k, (a, b) in enumerate(zip(gin, o32[3])):
+            one(f"grad_input_grid{k}", a, b, lambda r, k=k: r[3][k], grad_entries=8 * a.shape[-1])
+
+
 def run_oracle_renderer64(d):
     rays = _rays64(d["rays"])
     dec = copy.copy(d["decoder"])
@@ -185,27 +248,7 @@ def _splatter_case(i):
 @pytest.mark.parametrize("i", range(32))
 def test_splatter_sweep(i):
     case = _splatter_case(i)
-    d = case.build()
-    dev = _dev()
-    rays = copy.copy(d["rays"])  # fp32 oracle: the cell a sample falls into is defined by the fp32 index arithmetic
-    rays.encoding = rays.encoding.clone().requires_grad_(True)
-    if case.use_mlp:
-        out, ge, gp, gin = run_hip_mlp_splatter(d, dev)
-        mlp = copy.copy(d["mlp"])
-        mlp.mlp_params = mlp.mlp_params.clone().requires_grad_(True)
-        in_grids = [g.clone().requires_grad_(True) for g in d["in_grids"]]
-        o_out = O.lightplane_mlp_splatter_naive(rays, d["out_sizes"], mlp, in_grids, **d["cfg"])
-        sum((o * u).sum() for o, u in zip(o_out, d["upstream"])).backward()
-        _check(f"{case}: grad_mlp_params", gp, mlp.mlp_params.grad)
-        for k, (a, b) in enumerate(zip(gin, in_grids)):
-            _check(f"{case}: grad_input_grid{k}", a, b.grad)
-    else:
-        out, ge = run_hip_splatter(d, dev)
-        o_out = O.lightplane_splatter_naive(rays, d["out_sizes"], **d["cfg"])
-        sum((o * u).sum() for o, u in zip(o_out, d["upstream"])).backward()
-    for k, o in enumerate(out):
-        _check(f"{case}: out{k}", o, o_out[k])
-    _check(f"{case}: grad_encoding", ge, rays.encoding.grad)
+    _check_splatter_all(case, str(case.name), case.build(), _dev())
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -264,24 +307,4 @@ def test_reference_splatter_sweep_axes(i):
     """Every sampled combination runs on the walk / MFMA families and matches the fp32 oracle (the cell a sample falls into is
     defined by fp32 index arithmetic)."""
     case = _reference_splatter_axes_case(i)
-    d = case.build()
-    dev = _dev()
-    rays = copy.copy(d["rays"])
-    rays.encoding = rays.encoding.clone().requires_grad_(True)
-    if case.use_mlp:
-        out, ge, gp, gin = run_hip_mlp_splatter(d, dev)
-        mlp = copy.copy(d["mlp"])
-        mlp.mlp_params = mlp.mlp_params.clone().requires_grad_(True)
-        in_grids = [g.clone().requires_grad_(True) for g in d["in_grids"]]
-        o_out = O.lightplane_mlp_splatter_naive(rays, d["out_sizes"], mlp, in_grids, **d["cfg"])
-        sum((o * u).sum() for o, u in zip(o_out, d["upstream"])).backward()
-        _check(f"{case.name}: grad_mlp_params", gp, mlp.mlp_params.grad)
-        for k, (a, b) in enumerate(zip(gin, in_grids)):
-            _check(f"{case.name}: grad_input_grid{k}", a, b.grad)
-    else:
-        out, ge = run_hip_splatter(d, dev)
-        o_out = O.lightplane_splatter_naive(rays, d["out_sizes"], **d["cfg"])
-        sum((o * u).sum() for o, u in zip(o_out, d["upstream"])).backward()
-    for k, o in enumerate(out):
-        _check(f"{case.name}: out{k}", o, o_out[k])
-    _check(f"{case.name}: grad_encoding", ge, rays.encoding.grad)
+    _check_splatter_all(case, case.name, case.build(), _dev())
