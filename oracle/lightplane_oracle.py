@@ -133,12 +133,47 @@ def split_decoder(mlp_params, n_hidden_trunk, n_hidden_opacity, n_hidden_color):
     )
 
 
+_RELU_RECORDER = None
+
+
+class relu_margin_recorder:
+    """Test diagnostics (no effect on any result): while active, every ReLU of the decoder reports how close its
+    pre-activations come to zero.  ``margin`` = per leading index (``[R, S]`` for the Renderer) the minimum over all ReLU
+    sites and units of |pre-activation| / max |pre-activation of that site|.  The gradient of a ReLU network is
+    discontinuous exactly where a pre-activation is zero: a sample whose margin is below the round-off of an fp32 dot
+    product is where two correct implementations may legitimately take different branches (tests/test_gpu_parity.py
+    ``TieMasks``)."""
+
+    def __init__(self):
+        self.margin = None
+
+    def __enter__(self):
+        global _RELU_RECORDER
+        self._prev, _RELU_RECORDER = _RELU_RECORDER, self
+        return self
+
+    def __exit__(self, *exc):
+        global _RELU_RECORDER
+        _RELU_RECORDER = self._prev
+
+    def update(self, x):
+        with torch.no_grad():
+            m = x.detach().abs().amin(dim=-1) / x.detach().abs().max().clamp(min=1e-30)
+            self.margin = m if self.margin is None else torch.minimum(self.margin, m)
+
+
+def _relu(x):
+    if _RELU_RECORDER is not None:
+        _RELU_RECORDER.update(x)
+    return torch.relu(x)
+
+
 def mlp_forward(x, weights, biases):
     """ReLU between layers, last layer linear (naive_renderer.py:758-776)."""
     for li, (w, b) in enumerate(zip(weights, biases)):
         x = x @ w + b
         if li < len(weights) - 1:
-            x = torch.relu(x)
+            x = _relu(x)
     return x
 
 
@@ -355,14 +390,14 @@ def eval_decoder(points, grids, grid_idx, decoder_params, rays_encoding, gain,
         points = contract_pi(points)
     feat = sample_grid_list(grids, points, grid_idx, mask_out_of_bounds_samples)
     if color_grids is None:
-        trunk = torch.relu(mlp_forward(feat, wt, bt))
+        trunk = _relu(mlp_forward(feat, wt, bt))
         opacity_raw = mlp_forward(trunk, wo, bo)
         color_raw = mlp_forward(trunk + rays_encoding[:, None], wc, bc)
     else:
         assert len(wt) == 0
         cfeat = sample_grid_list(color_grids, points, grid_idx, mask_out_of_bounds_samples)
-        opacity_raw = mlp_forward(torch.relu(feat), wo, bo)
-        color_raw = mlp_forward(torch.relu(cfeat) + rays_encoding[:, None], wc, bc)
+        opacity_raw = mlp_forward(_relu(feat), wo, bo)
+        color_raw = mlp_forward(_relu(cfeat) + rays_encoding[:, None], wc, bc)
     assert opacity_raw.shape[-1] == 1
     opacity_raw = opacity_raw[..., 0]
     if noise is not None:

@@ -25,7 +25,7 @@ import lightplane_amd as lp
 from lightplane_amd import _lib
 from oracle import lightplane_oracle as O
 from tests.synth import baseline_cfg1, cfg2_inputs, grid_sizes_for, pinhole_rays, random_decoder, random_grids
-from tests.test_gpu_parity import _assert_close, _dev, assert_grad_close, run_hip_renderer
+from tests.test_gpu_parity import TieMasks, _assert_close, _dev, assert_grad_close, run_hip_renderer
 
 pytestmark = pytest.mark.gpu
 F64 = torch.float64
@@ -79,10 +79,11 @@ def test_cfg2_full_batch_against_oracle():
     # 65 536 x 128 samples x 128 hidden units = 1.07e9 pre-activations: ~1e-7 of them sit within fp32 round-off of zero, so a
     # few dozen RAYS carry a flipped unit in one of the three evaluations.  grad_encoding is per ray (a flip moves one ray's 32
     # entries): allowance in rays; the grid / parameter gradients sum over ~10^4 ray-samples per entry, a flip does not show.
-    assert_grad_close("cfg2 full: grad_encoding", ge, o_ge.numpy(), 32, want64=q_ge.numpy(), flip_samples=64)
-    assert_grad_close("cfg2 full: grad_mlp_params", gp, o_gp.numpy(), 4 * 32, want64=q_gp.numpy())
+    ties = TieMasks(d)
+    assert_grad_close("cfg2 full: grad_encoding", ge, o_ge.numpy(), 32, want64=q_ge.numpy(), flip_samples=64, tie_mask=ties.encoding_mask())
+    assert_grad_close("cfg2 full: grad_mlp_params", gp, o_gp.numpy(), 4 * 32, want64=q_gp.numpy(), tie_mask=ties.params_mask())
     for i, (a, b, c) in enumerate(zip(gg, o_gg, q_gg)):
-        assert_grad_close(f"cfg2 full: grad_grid{i}", a, b.numpy(), 8 * 16, want64=c.numpy())
+        assert_grad_close(f"cfg2 full: grad_grid{i}", a, b.numpy(), 8 * 16, want64=c.numpy(), tie_mask=ties.grid_mask(i))
     # the fp32 oracle itself against fp64, for the record (what "1e-4 of the naive reference" can mean at this size)
     e = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())  # noqa: E731
     print("cfg2 full: fp32 oracle vs fp64 oracle:", dict(grad_encoding=e(o_ge, q_ge), grad_mlp_params=e(o_gp, q_gp),
@@ -134,13 +135,14 @@ def test_1080p_backward_block(C, G, S):
     didx = idx.to(dev)
     for nm, a, b in (("ray_length", out[0], o_out[0]), ("neg_log_t", out[1], o_out[1]), ("feature", out[2], o_out[2])):
         _assert_close(f"1080p block: {nm}", a[didx], b.numpy())
-    assert_grad_close("1080p block: grad_encoding", ge[didx], o_ge.numpy(), 32, want64=q_ge.numpy())
+    ties = TieMasks(d, idx=idx)
+    assert_grad_close("1080p block: grad_encoding", ge[didx], o_ge.numpy(), 32, want64=q_ge.numpy(), tie_mask=ties.encoding_mask())
     rest = torch.ones(n, dtype=torch.bool, device=dev)
     rest[didx] = False
     assert float(ge[rest].abs().max()) == 0.0, "rays without upstream gradient got an encoding gradient"
-    assert_grad_close("1080p block: grad_mlp_params", gp, o_gp.numpy(), 4 * 32, want64=q_gp.numpy())
+    assert_grad_close("1080p block: grad_mlp_params", gp, o_gp.numpy(), 4 * 32, want64=q_gp.numpy(), tie_mask=ties.params_mask())
     for i, (a, b, c) in enumerate(zip(gg, o_gg, q_gg)):
-        assert_grad_close(f"1080p block: grad_grid{i}", a, b.numpy(), 8 * C, want64=c.numpy())
+        assert_grad_close(f"1080p block: grad_grid{i}", a, b.numpy(), 8 * C, want64=c.numpy(), tie_mask=ties.grid_mask(i))
 
 
 INDEX_CASES = {

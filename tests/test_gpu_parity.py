@@ -49,19 +49,98 @@ def rel_l2(got, want):
     return (got - want).norm().item() / max(want.norm().item(), 1e-30)
 
 
-UNEXPLAINED_MAX = 5e-3  # an entry that misses the bar against BOTH oracles may not be further off than this
+UNEXPLAINED_MAX = 5e-3  # without a tie mask: an entry that misses the bar against BOTH oracles may not be further off than this
+TIE_EPS = 5e-6          # a ReLU pre-activation below this fraction of its layer's largest one counts as a near tie
 
 
-def assert_grad_close(name, got, want, entries_per_sample, tol=1e-4, want64=None, flip_samples=FLIP_SAMPLES):
+class TieMasks:
+    """WHERE may two correct fp32 evaluations of the gradient differ?  Only where a ReLU pre-activation is within round-off of
+    zero: the forward value is continuous there, the gradient is not, and which branch an implementation takes depends on
+    its summation order.  A flipped unit of sample (r, s) changes the gradient of the grid rows that sample's taps touch, of
+    ray r's encoding and of rows / columns of the weight matrices -- nothing else.  The fp64 oracle's forward is run with
+    oracle.relu_margin_recorder; samples whose smallest relative |pre-activation| is below TIE_EPS (~5x the round-off of an
+    fp32 dot product of this size) are near ties, and their tap rows (oracle.renderer_corner_indices in fp32 -- the index
+    arithmetic the kernels reproduce bit for bit) form the mask.  Computed lazily, once per test, only when some tensor misses
+    the bar."""
+
+    def __init__(self, d, idx=None, chunk=2048):
+        self.d, self.idx, self.chunk, self._done = d, idx, chunk, False
+
+    def _compute(self):
+        if self._done:
+            return
+        import copy
+        d = self.d
+        rays = d["rays"] if self.idx is None else d["rays"][self.idx]
+        cfg = d["cfg"]
+        F64 = torch.float64
+        dec = copy.copy(d["decoder"])
+        dec.mlp_params = dec.mlp_params.detach().to(F64)
+        grids = [g.detach().to(F64) for g in d["grids"]]
+        cgrids = None if d.get("color_grids") is None else [g.detach().to(F64) for g in d["color_grids"]]
+        scaffold = None if d.get("scaffold") is None else d["scaffold"].to(F64)
+        margins = []
+        old_threads = torch.get_num_threads()
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        try:
+            with torch.no_grad():
+                for lo in range(0, rays.n_rays, self.chunk):
+                    r = rays[lo:lo + self.chunk]
+                    for f in ("directions", "origins", "near", "far", "encoding"):
+                        setattr(r, f, getattr(r, f).detach().to(F64))
+                    with O.relu_margin_recorder() as rec:
+                        O.lightplane_renderer_naive(r, grids, dec, scaffold=scaffold, color_grid=cgrids, **cfg)
+                    margins.append(rec.margin)
+        finally:
+            torch.set_num_threads(old_threads)
+        near = torch.cat(margins) < TIE_EPS                      # [R, S_tot]
+        self.n_near = int(near.sum())
+        self.ray = near.any(dim=1)
+        r32 = rays
+
+        def row_masks(tensors):
+            sizes = [list(g.shape) for g in tensors]
+            rows = O.renderer_corner_indices(r32, sizes, cfg["num_samples"], cfg.get("num_samples_inf", 0), cfg.get("contract_coords", False))
+            out = []
+            for g, rr in zip(tensors, rows):
+                m = torch.zeros(g.numel() // g.shape[-1], dtype=torch.bool)
+                hit = rr[near].reshape(-1)
+                m[hit[hit >= 0]] = True
+                out.append(m.reshape(g.shape[:-1] + (1,)))
+            return out
+
+        self.grid = row_masks(d["grids"])
+        self.color_grid = None if d.get("color_grids") is None else row_masks(d["color_grids"])
+        self._done = True
+
+    def grid_mask(self, i):
+        return lambda: (self._compute(), self.grid[i])[1]
+
+    def color_grid_mask(self, i):
+        return lambda: (self._compute(), self.color_grid[i])[1]
+
+    def encoding_mask(self):
+        return lambda: (self._compute(), self.ray[:, None])[1]
+
+    def params_mask(self):  # a flipped unit moves a row / a column of weight matrices and bias entries: any entry may move
+        return lambda: (self._compute(), torch.tensor(self.n_near > 0))[1]
+
+
+def assert_grad_close(name, got, want, entries_per_sample, tol=1e-4, want64=None, flip_samples=FLIP_SAMPLES, tie_mask=None):
     """Gradient tensor vs the fp32 oracle: the north_star bar, or the ReLU-flip allowance described in
     tests/test_gpu_coherent.py's docstring.  Every use of the allowance is recorded and printed.
 
     ``want64`` (the same oracle run in fp64; an array or a zero-argument callable that is only evaluated when the bar is
     missed): an entry that misses the bar against the fp32 oracle but meets it against the fp64 one is EXPLAINED -- the
-    fp32 oracle took the other branch of a ReLU there, the kernel the exact one -- and does not count; only entries that
-    miss both count against ``flip_samples`` samples' worth of entries, and none of those may be off by more than
-    UNEXPLAINED_MAX of the largest entry.  The allowance is NOT available without the second oracle (round-3 review,
-    weak 1): a tensor that misses the bar with ``want64=None`` fails."""
+    fp32 oracle took the other branch of a ReLU there, the kernel the exact one -- and does not count.  The entries that
+    miss BOTH oracles (the kernel's own summation order took a branch neither oracle took) count against ``flip_samples``
+    samples' worth of entries, and
+    * with ``tie_mask`` (TieMasks: a callable returning a boolean tensor broadcastable to the gradient): every one of them
+      has to lie where a near-tie ReLU can reach -- an entry outside the mask that misses both oracles FAILS, whatever
+      its size;
+    * without one (or when the mask covers more than half of the tensor, as it does at config scale), none may be off by more
+      than UNEXPLAINED_MAX of the largest entry.
+    The allowance is NOT available without the second oracle (round-3 review, weak 1)."""
     want = torch.as_tensor(np.asarray(want))
     g = got.detach().double().cpu()
     w = want.double()
@@ -83,16 +162,30 @@ def assert_grad_close(name, got, want, entries_per_sample, tol=1e-4, want64=None
     err64 = (g - w64).abs() / scale
     unexplained = off & (err64 > tol)
     n_un = int(unexplained.sum())
-    worst_un = float(torch.minimum(err, err64)[unexplained].max()) if n_un else 0.0
+    both = torch.minimum(err, err64)
+    worst_un = float(both[unexplained].max()) if n_un else 0.0
+    n_outside, worst_outside, dense = None, 0.0, False
+    if tie_mask is not None and n_un:
+        tm = torch.as_tensor(tie_mask()).expand_as(unexplained)
+        outside = unexplained & ~tm
+        n_outside = int(outside.sum())
+        worst_outside = float(both[outside].max()) if n_outside else 0.0
+        dense = float(tm.float().mean()) > 0.5  # (config-scale batches: near ties reach most rows, the mask says little)
     allowed = flip_samples * entries_per_sample
     FLIP_EVENTS.append(dict(name=name, tol=tol, n_off=n_off, explained=n_off - n_un, unexplained=n_un, allowed=allowed, worst=worst,
-                            worst_unexplained=worst_un, l2=l2))
+                            worst_unexplained=worst_un, outside_tie_mask=n_outside, l2=l2))
     print(f"flip-allowance {name}: {n_off} entries above {tol:g}, {n_off - n_un} explained by the second oracle, "
-          f"worst {worst:.3e}, worst unexplained {worst_un:.3e}, rel L2 {l2:.3e}")
-    ok = n_un <= allowed and worst <= 5e-2 and l2 <= 1e-3 and worst_un <= UNEXPLAINED_MAX
+          f"worst {worst:.3e}, worst unexplained {worst_un:.3e}, outside the near-tie mask: {n_outside}, rel L2 {l2:.3e}")
+    ok = n_un <= allowed and worst <= 5e-2 and l2 <= 1e-3
+    if tie_mask is not None:
+        ok = ok and not n_outside
+    if tie_mask is None or dense:
+        ok = ok and worst_un <= UNEXPLAINED_MAX
     assert ok, (f"{name}: max err / scale = {worst:.3e} > {tol} and not a ReLU-flip pattern: {n_un} entries above the bar against "
-                f"both oracles, the worst by {worst_un:.3e} (allowed {UNEXPLAINED_MAX:g}; {n_off - n_un} more explained by the fp64 "
-                f"oracle; allowed count {allowed}), relative L2 {l2:.3e} (allowed 1e-3)")
+                f"both oracles, the worst by {worst_un:.3e}"
+                + (f"; {n_outside} of them where no near-tie ReLU reaches (worst {worst_outside:.3e})" if tie_mask is not None
+                   else f" (allowed {UNEXPLAINED_MAX:g} without a tie mask)")
+                + f"; {n_off - n_un} more explained by the fp64 oracle; allowed count {allowed}; relative L2 {l2:.3e} (allowed 1e-3)")
 
 
 def _rays_to(rays, dev, requires_grad=False):
@@ -433,10 +526,12 @@ def test_cfg2_sized_properties():
             q.update(gp=d64.mlp_params.grad.numpy(), ge=r64.encoding.grad.numpy(), gg=[g.grad.numpy() for g in g64])
         return q
 
-    assert_grad_close("cfg2-sub gparams", sub_gp, d2.mlp_params.grad.numpy(), 4 * 32, want64=lambda: oracle64()["gp"])
-    assert_grad_close("cfg2-sub genc", sub_ge, r.encoding.grad.numpy(), 32, want64=lambda: oracle64()["ge"])
+    ties = TieMasks(dict(rays=rays, grids=grids, decoder=dec, cfg=dict(num_samples=S, gain=1.0)), idx=idx)
+    assert_grad_close("cfg2-sub gparams", sub_gp, d2.mlp_params.grad.numpy(), 4 * 32, want64=lambda: oracle64()["gp"],
+                      tie_mask=ties.params_mask())
+    assert_grad_close("cfg2-sub genc", sub_ge, r.encoding.grad.numpy(), 32, want64=lambda: oracle64()["ge"], tie_mask=ties.encoding_mask())
     for i, (a, b) in enumerate(zip(sub_gg, gs)):
-        assert_grad_close("cfg2-sub ggrid", a, b.grad.numpy(), 8 * 16, want64=lambda i=i: oracle64()["gg"][i])
+        assert_grad_close("cfg2-sub ggrid", a, b.grad.numpy(), 8 * 16, want64=lambda i=i: oracle64()["gg"][i], tie_mask=ties.grid_mask(i))
     for a, b in zip(out1, sub_out):
         assert torch.allclose(a[idx.to(dev)], b, rtol=1e-5, atol=1e-6), "ray results depend on batch composition"
 
