@@ -45,7 +45,8 @@ struct LoopTile {
   static constexpr int XT = 0;                 // X tile [32][36] (also: dx0 tile of the scatter)
   static constexpr int YT = 32 * LT_LD;        // dY tile [32][36] (also: the scatter's weight table)
   static constexpr int TS = 2 * 32 * LT_LD;    // [5][32]: d raw_o, d raw_c[0..3] by ray
-  static constexpr int PER_WAVE = TS + 5 * 32;
+  static constexpr int WT = TS + 5 * 32;       // [8][32]: the scatter's weight table when C = 64 (its dx0 tile [64][36] spans X and dY)
+  static constexpr int PER_WAVE = WT + 8 * 32;
 };
 
 
@@ -135,14 +136,16 @@ LP_DEV void loop_load_encoding(const LpRendererArgs& a, int64_t rid, int h, int 
 }
 
 // sampled feature x0 [C/2 registers] -> NB blocks (zero-padded); RELU: the two-grid decoder's heads read relu(sample)
+// (C = 64: register 16 blk + q of the gather holds channel 32 blk + featq(q, h), as in the MLP-Splatter's sloop_input)
 template <int C, int NB, bool RELU>
 LP_DEV void loop_pad_input(const float (&x0)[C / 2], float (&out)[NB][16]) {
+  static_assert(C <= 32 * NB, "a 64-channel grid needs the two-block instantiation");
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const bool in = blk == 0 && q < C / 2;
-      const float v = in ? x0[in ? q : 0] : 0.0f;
+      const bool in = 16 * blk + q < C / 2;
+      const float v = in ? x0[in ? 16 * blk + q : 0] : 0.0f;
       out[blk][q] = RELU ? relu_f(v) : v;
     }
   }
@@ -763,9 +766,9 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs
       }
     }
     // g = d (sampled feature) -> LDS [channel][ray] (the X tile is free behind the last barrier)
-    if (gg) {
+    if (gg) {  // (C = 64: rows 32 .. 63 of the [channel][ray] tile lie in the dY tile; the weight table moves behind the tiles)
 #pragma unroll
-      for (int q = 0; q < C / 2; ++q) xt[featq(q, h) * DX_LD + r] = g[0][q];
+      for (int q = 0; q < C / 2; ++q) xt[(32 * (q >> 4) + featq(q & 15, h)) * DX_LD + r] = g[q >> 4][q & 15];
     }
     LP_SCHED_FENCE();
     // ---------------- next (nearer) sample + grid gradient ----------------
@@ -775,9 +778,10 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs
     LP_SCHED_FENCE();
     if (gg && !(lp.dbg & 2)) {
       const int ng = (GM == GM_TRIPLANE) ? 3 : a.grid.n_grids;
+      float* const wtab = (C == 64) ? wv + T::WT : yt;
 #pragma unroll 1
       for (int gi = 0; gi < ng; ++gi)
-        scatter_grid<C, GM>(a.grad_grid_list[gi], a.grid.grids[gi], ray.b, x, y, z, live, lane, xt, yt, lp.dbg);
+        scatter_grid<C, GM>(a.grad_grid_list[gi], a.grid.grids[gi], ray.b, x, y, z, live, lane, xt, wtab, lp.dbg);
     }
   }
 
@@ -848,16 +852,17 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_loop(const LpRendererArgs
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-static int loop_nb(int H) { return H <= 32 ? 1 : 2; }
+static int loop_nb(int H, int C = 16) { return (H <= 32 && C <= 32) ? 1 : 2; }
 
 // Shape family: grid-list(s) with C in {16, 32} channels below 4 GB; trunk of 1..4 layers, or none with a separate colour
-// grid-list; heads of 1..4 layers; every hidden width equal to H in {16, 32} -- or H = 64 with at most 2 trunk layers and
-// heads of at most 2 layers; <= 4 colour channels; <= 64 beyond-far samples.
+// grid-list; heads of 1..4 layers; every hidden width equal to H in {16, 32} -- or, on the two-block instantiation (H = 64, or
+// C = 64 grid channels with any of the three widths): at most 2 trunk layers, heads of at most 2 layers, no colour grid,
+// <= 4 colour channels; <= 64 beyond-far samples.
 bool renderer_loop_supported(const LpRendererArgs& a, const char** why) {
   *why = "";
   const int C = a.grid.channels;
   const bool tg = a.color_grid.n_grids > 0;
-  if (C != 16 && C != 32) { *why = "grid channels not 16 or 32"; return false; }
+  if (C != 16 && C != 32 && C != 64) { *why = "grid channels not 16, 32 or 64"; return false; }
   if ((tg && a.trunk.n_layers != 0) || (!tg && a.trunk.n_layers < 1) || a.trunk.n_layers > LOOP_MAX_T || a.opacity.n_layers < 1 ||
       a.opacity.n_layers > LOOP_MAX_H + 1 || a.color.n_layers < 1 || a.color.n_layers > LOOP_MAX_H + 1) {
     *why = "layer counts outside trunk 1-4 (0 with a colour grid) / opacity 1-4 / colour 1-4";
@@ -872,12 +877,12 @@ bool renderer_loop_supported(const LpRendererArgs& a, const char** why) {
   if (H == 0) H = C;  // two-grid decoder with single-layer heads: no hidden layer at all
   if (!same) { *why = "hidden widths differ between layers"; return false; }
   if (H != 16 && H != 32 && H != 64) { *why = "hidden width other than 16 / 32 / 64"; return false; }
-  if (H == 64 && (a.trunk.n_layers > 2 || a.opacity.n_layers > 2 || a.color.n_layers > 2 || tg)) {
-    *why = "hidden width 64 with more than 2 layers per MLP (or a colour grid)";
+  if ((H == 64 || C == 64) && (a.trunk.n_layers > 2 || a.opacity.n_layers > 2 || a.color.n_layers > 2 || tg)) {
+    *why = "hidden width 64 / 64 grid channels with more than 2 layers per MLP (or a colour grid)";
     return false;
   }
   if (a.color_chn > 32) { *why = "more than 32 colour channels"; return false; }
-  if (a.color_chn > 4 && H == 64) { *why = "more than 4 colour channels with hidden width 64"; return false; }
+  if (a.color_chn > 4 && (H == 64 || C == 64)) { *why = "more than 4 colour channels with hidden width 64 / 64 grid channels"; return false; }
   if (a.grid.n_rows * C * 4 >= (int64_t)1 << 32) { *why = "grid-list of 4 GB or more"; return false; }
   if (tg && a.color_grid.n_rows * C * 4 >= (int64_t)1 << 32) { *why = "colour grid-list of 4 GB or more"; return false; }
   if (a.march.num_samples_inf > LOOP_N_INF) { *why = "more than 64 beyond-far samples"; return false; }
@@ -892,7 +897,7 @@ static LoopParams loop_params(const LpRendererArgs& a) {
   p.n_o = a.opacity.n_layers - 1;
   p.n_c = a.color.n_layers - 1;
   const int H = p.n_t > 0 ? a.trunk.dims[1] : (p.n_o > 0 ? a.opacity.dims[1] : (p.n_c > 0 ? a.color.dims[1] : C));
-  const int NB = loop_nb(H);
+  const int NB = loop_nb(H, C);
   p.hid = H;
   p.hin = tg ? C : H;
   p.ho_w = p.n_o > 0 ? H : p.hin;
@@ -1015,7 +1020,7 @@ static unsigned loop_blocks(const LpRendererArgs& a) {
 template <int C, int NB, bool TG, bool WC>
 static int launch_fwd_loop(const LpRendererArgs& a, const LoopParams& p, unsigned nb, size_t lds, bool tri, hipStream_t stream) {
   int rc;
-  if constexpr (!TG) {
+  if constexpr (!TG && C <= 32) {  // (64 channels: the run-time grid-list form only)
     if (tri) {
       if ((rc = loop_set_lds(renderer_fwd_loop<C, NB, TG, WC, GM_TRIPLANE>, lds))) return rc;
       hipLaunchKernelGGL((renderer_fwd_loop<C, NB, TG, WC, GM_TRIPLANE>), dim3(nb), dim3(256), lds, stream, a, p);
@@ -1030,7 +1035,7 @@ static int launch_fwd_loop(const LpRendererArgs& a, const LoopParams& p, unsigne
 template <int C, int NB, bool TG, int MT, int MH, bool WC>
 static int launch_bwd_loop(const LpRendererArgs& a, const LoopParams& p, unsigned nb, size_t lds, bool tri, hipStream_t stream) {
   int rc;
-  if constexpr (!TG) {
+  if constexpr (!TG && C <= 32) {
     if (tri) {
       if ((rc = loop_set_lds(renderer_bwd_loop<C, NB, TG, MT, MH, WC, GM_TRIPLANE>, lds))) return rc;
       hipLaunchKernelGGL((renderer_bwd_loop<C, NB, TG, MT, MH, WC, GM_TRIPLANE>), dim3(nb), dim3(256), lds, stream, a, p);
@@ -1061,10 +1066,12 @@ int renderer_forward_loop(const LpRendererArgs& a, hipStream_t stream) {
   }
   const size_t lds = loop_lds_bytes(p, false);
   const bool tg = a.color_grid.n_grids > 0, wc = a.color_chn > 4, tri = loop_triplane(a);
-  const int NB = loop_nb(p.hid);
+  const int NB = loop_nb(p.hid, a.grid.channels);
   int rc = LP_OK;
 #define LP_LOOP_FWD(CV, NBV, TGV, WCV) rc = launch_fwd_loop<CV, NBV, TGV, WCV>(a, p, nb, lds, tri, stream)
-  if (a.grid.channels == 16) {
+  if (a.grid.channels == 64) {
+    LP_LOOP_FWD(64, 2, false, false);
+  } else if (a.grid.channels == 16) {
     if (NB == 2) LP_LOOP_FWD(16, 2, false, false);
     else if (tg && wc) LP_LOOP_FWD(16, 1, true, true);
     else if (tg) LP_LOOP_FWD(16, 1, true, false);
@@ -1094,10 +1101,12 @@ int renderer_backward_loop(const LpRendererArgs& a, hipStream_t stream) {
   }
   const size_t lds = loop_lds_bytes(p, true);
   const bool tg = a.color_grid.n_grids > 0, wc = a.color_chn > 4, tri = loop_triplane(a);
-  const int NB = loop_nb(p.hid);
+  const int NB = loop_nb(p.hid, a.grid.channels);
   int rc = LP_OK;
 #define LP_LOOP_BWD(CV, NBV, TGV, MTV, MHV, WCV) rc = launch_bwd_loop<CV, NBV, TGV, MTV, MHV, WCV>(a, p, nb, lds, tri, stream)
-  if (a.grid.channels == 16) {
+  if (a.grid.channels == 64) {
+    LP_LOOP_BWD(64, 2, false, 2, 1, false);
+  } else if (a.grid.channels == 16) {
     if (NB == 2) LP_LOOP_BWD(16, 2, false, 2, 1, false);
     else if (tg && wc) LP_LOOP_BWD(16, 1, true, 1, LOOP_MAX_H, true);
     else if (tg) LP_LOOP_BWD(16, 1, true, 1, LOOP_MAX_H, false);

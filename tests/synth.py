@@ -271,6 +271,12 @@ RENDERER_CASES = [
                  noise_sigma=0.5, noise_seed=99, contract=True, num_samples_inf=3),
     RendererCase("triplane_242_c32_color4", seed=31, is_triplane=True, grid_base=(2, 6, 5, 4, 32), n_layers=(2, 4, 2),
                  color_chn=4, n_rays=130, num_samples=33),
+    # 64 grid channels (the reference takes any power of two >= 16, lightplane_renderer.py:411-416): the two-block
+    # instantiation of the layer-looped family, hidden 32 and the reference example's 1/1/2 x 64 decoder depth
+    RendererCase("triplane_c64_h32", seed=32, is_triplane=True, grid_base=(2, 6, 5, 4, 64), n_rays=70, num_samples=21,
+                 mask_oob=True, param_std=0.15),
+    RendererCase("voxel_c64_h64_112_scaffold", seed=33, grid_base=(2, 5, 6, 7, 64), hidden=64, n_layers=(1, 1, 2), n_rays=40,
+                 scaffold_size=(6, 4, 5), gain=3.0, num_samples_inf=2, param_std=0.1),
 ]
 
 SPLATTER_CASES = [

@@ -520,7 +520,7 @@ def test_bench_counter_lookup_is_by_the_kernel_that_ran(tmp_path):
 
     class WL(bench.RendererWorkload):
         def __init__(self):
-            self.n_rays, self.S, self.C = 65536, 128, 16
+            self.n_rays, self.S, self.C, self.hidden, self.layers = 65536, 128, 16, 32, (2, 2, 2)
 
     b = bench.binding_ceiling("cfg2", WL(), 0.48, 2.07, obs)
     assert b["kernel"] == bf3 and 0.5 < b["frac_issue"] <= 1.0, b
