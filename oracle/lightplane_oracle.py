@@ -139,7 +139,7 @@ _RELU_RECORDER = None
 class relu_margin_recorder:
     """Test diagnostics (no effect on any result): while active, every ReLU of the decoder reports how close its
     pre-activations come to zero.  ``margin`` = per leading index (``[R, S]`` for the Renderer) the minimum over all ReLU
-    sites and units of |pre-activation| / max |pre-activation of that site|.  The gradient of a ReLU network is
+    sites and non-zero units of |pre-activation| / max |pre-activation of that site|.  The gradient of a ReLU network is
     discontinuous exactly where a pre-activation is zero: a sample whose margin is below the round-off of an fp32 dot
     product is where two correct implementations may legitimately take different branches (tests/test_gpu_parity.py
     ``TieMasks``)."""
@@ -158,7 +158,9 @@ class relu_margin_recorder:
 
     def update(self, x):
         with torch.no_grad():
-            m = x.detach().abs().amin(dim=-1) / x.detach().abs().max().clamp(min=1e-30)
+            ax = x.detach().abs()
+            # (an EXACT zero -- a masked / out-of-range sample, a dead input -- is no tie: every implementation gets exactly 0)
+            m = torch.where(ax == 0, torch.full_like(ax, float("inf")), ax).amin(dim=-1) / ax.max().clamp(min=1e-30)
             self.margin = m if self.margin is None else torch.minimum(self.margin, m)
 
 

@@ -78,6 +78,9 @@ GRIDS = {
     "triplane_plus_voxel_c16": ((1, 24, 24, 24, 16), True, True, False, (2, 2, 2), 1),
     "two_grid_triplane_c16": ((1, 24, 24, 24, 16), True, False, True, (0, 2, 2), 1),
     "voxel18_c16_b2": ((2, 18, 16, 20, 16), False, False, False, (2, 2, 2), 2),
+    # 64 grid channels: the looped family's two-block instantiation, four channels per lane in the run-merged scatter
+    "triplane24_c64": ((1, 24, 24, 24, 64), True, False, False, (2, 2, 2), 1),
+    "voxel16_c64": ((1, 16, 16, 16, 64), False, False, False, (2, 1, 2), 1),
 }
 # deep decoders (layer-looped MFMA family, lp_renderer_loop.hip): test_renderer_coherent_deep
 DEEP_GRIDS = {
