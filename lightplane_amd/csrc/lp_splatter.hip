@@ -273,9 +273,14 @@ __global__ void __launch_bounds__(256) splat_bwd_kernel(const LpSplatterArgs a) 
 // eight rays are issued before the first one is used.  The four corner pairs of a ray are summed across the
 // lane groups at the end.  (The per-ray kernel below re-derives the geometry in every lane and reads eight rows
 // per ray and sample.)
-template <int C, int B>
-__global__ void __launch_bounds__(256, (B == 4 && C < 64) ? 3 : 2) splat_bwd_walk_kernel(const LpSplatterArgs a, int n_seg) {
-  constexpr int RPW = 16, CPL = C / 16, NQ = 4, SPQ = 2;
+// RPW = rays per wave: 16 (default), or 8 -- half the per-lane accumulators and batch buffers, so twice the waves fit a SIMD
+// and twice the gathers are in flight, for the price of the per-sample geometry being amortised over 8 rays instead of 16
+// (LP_SPLAT_BWD_RPW, measured in DESIGN.md 4.4).
+template <int C, int B, int RPW = 16>
+__global__ void __launch_bounds__(256, RPW == 8 ? (C < 32 ? 4 : 3) : ((B == 4 && C < 64) ? 3 : 2))
+splat_bwd_walk_kernel(const LpSplatterArgs a, int n_seg) {
+  static_assert(RPW == 16 || (RPW == 8 && B == 8), "rays per wave: 16, or 8 with one batch of 8");
+  constexpr int CPL = C / 16, NQ = 64 / RPW, SPQ = 8 / NQ;
   __shared__ __attribute__((aligned(16))) float lds[4][8 * RPW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane / RPW, r = lane % RPW, sub = lane & 15, grp = lane >> 4;
@@ -320,7 +325,8 @@ __global__ void __launch_bounds__(256, (B == 4 && C < 64) ? 3 : 2) splat_bwd_wal
       const int ok = (int)tp.ok;
       const int prow_ = lane_prev(row0), pok_ = lane_prev(ok);  // all lanes enabled: see run_head()
       const bool head = run_head(r, row0, prow_, ok, pok_);
-      const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head)) | (B == 8 ? 0x101u : 0x1111u);
+      const unsigned mask = ((unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head)) | (B == 8 ? 0x101u : 0x1111u)) &
+                            ((1u << RPW) - 1u);
       const int koff = (grp & 1) * tp.sv + (grp >> 1) * tp.st;
       const unsigned bit_lo = 1u << (2 * grp), bit_hi = 2u << (2 * grp);
       const float4* wlo = reinterpret_cast<const float4*>(wT + (2 * grp) * RPW);
@@ -496,16 +502,22 @@ int splatter_backward_launch(const LpSplatterArgs& a, hipStream_t stream) {
   // validity bits and weights of zero and contribute nothing -- half the lanes idle, but a run of rays still reads its
   // rows once instead of once per ray)
   if ((Cw == 16 || Cw == 32 || Cw == 64) && a.out.n_grids > 0 && a.out.n_rows < ((int64_t)1 << 31) && !no_walk) {
-    const unsigned ray_blocks = (unsigned)((a.rays.n_rays + 63) / 64);
+    // 8 rays per wave (round 4): cfg 3 backward 2.32 -> 2.01 ms -- 146 instead of 210 registers (C = 32), three waves per SIMD
+    // instead of two, i.e. 1.5x the gathers in flight of a latency-bound walk; LP_SPLAT_BWD_RPW=16 selects the 16-ray waves
+    static const int rpw = getenv("LP_SPLAT_BWD_RPW") ? atoi(getenv("LP_SPLAT_BWD_RPW")) : 8;
+    const int rpw_eff = (rpw == 8 && Cw != 64) ? 8 : 16;
+    const unsigned ray_blocks = (unsigned)((a.rays.n_rays + 4 * rpw_eff - 1) / (4 * rpw_eff));
     if (ray_blocks == 0) return LP_OK;
-    const int n_seg = splat_segments(a, ray_blocks);
+    const int n_seg = splat_segments(a, rpw_eff == 8 ? (ray_blocks + 1) / 2 : ray_blocks);
     if (n_seg > 1) {  // the segments accumulate into grad_encoding
       const hipError_t e = hipMemsetAsync(a.grad_encoding, 0, (size_t)a.rays.n_rays * Cw * sizeof(float), stream);
       if (e != hipSuccess) return set_error((int)e, "hipMemsetAsync(grad_encoding): %s", hipGetErrorString(e));
     }
     const unsigned blocks = ray_blocks * (unsigned)n_seg;
     // batches of 8 rays; batches of 4 at three waves/SIMD measured the same (cfg 3)
-    if (Cw == 16) hipLaunchKernelGGL((splat_bwd_walk_kernel<16, 8>), dim3(blocks), dim3(256), 0, stream, a, n_seg);
+    if (Cw == 16 && rpw_eff == 8) hipLaunchKernelGGL((splat_bwd_walk_kernel<16, 8, 8>), dim3(blocks), dim3(256), 0, stream, a, n_seg);
+    else if (Cw == 32 && rpw_eff == 8) hipLaunchKernelGGL((splat_bwd_walk_kernel<32, 8, 8>), dim3(blocks), dim3(256), 0, stream, a, n_seg);
+    else if (Cw == 16) hipLaunchKernelGGL((splat_bwd_walk_kernel<16, 8>), dim3(blocks), dim3(256), 0, stream, a, n_seg);
     else if (Cw == 32) hipLaunchKernelGGL((splat_bwd_walk_kernel<32, 8>), dim3(blocks), dim3(256), 0, stream, a, n_seg);
     else hipLaunchKernelGGL((splat_bwd_walk_kernel<64, 4>), dim3(blocks), dim3(256), 0, stream, a, n_seg);  // (batches of 8: 300 B of scratch)
     return check_launch("splat_bwd_walk_kernel");

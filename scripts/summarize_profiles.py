@@ -10,6 +10,7 @@ import os
 import sys
 
 ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 else None  # workloads profiled in THIS run (gpurun_out keeps older rounds' directories)
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(REPO, "gpurun_out")
 P = os.path.join(REPO, "profiles")
@@ -20,6 +21,8 @@ CMD = {"cfg2": "python bench.py --workload cfg2 --no-cpu-baseline --no-extras --
        "small": "python bench.py --workload small --no-cpu-baseline --no-extras --steps 200 --warmup 3"}
 out = {}
 for w in ("cfg2", "cfg3", "cfg4", "small"):
+    if ONLY and w not in ONLY:
+        continue
     stats = glob.glob(os.path.join(G, f"prof_{w}", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
         rows = list(csv.DictReader(open(stats[0])))

