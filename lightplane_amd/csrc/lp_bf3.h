@@ -374,7 +374,7 @@ LP_DEV void color_prebias_bf3(const float* sm, const char* fimg, int lane, const
   color_prebias_bf3(sm, ASlots{fimg, LdsBf3<C>::CH_C1}, lane, enc, cb);
 }
 
-// Decoder of one sample, default shape.  t.x0 in; fills t.h1 / t.e / t.ho / t.hc (post-ReLU) like decode_prefetch.
+// Decoder of one sample, default shape.  t.x0 in; fills t.h1 / t.e / t.ho / t.hc (post-ReLU).
 template <int C, int NC>
 LP_DEV Heads decode_bf3(const float* sm, const char* fimg_, int lane, const float (&cb)[16], Act<C>& t, int zo) {
   using L = LdsBf3<C>;

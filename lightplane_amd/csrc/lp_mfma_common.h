@@ -70,47 +70,9 @@ struct Lds {
   static constexpr int FWD_END = INF + MAX_INF;
 };
 
-template <int C, bool FLEX = false>
-LP_DEV void stage_weights(const LpRendererArgs& a, const MfmaParams& mp, float* lds) {
-  using M = Lds;
-  const float* P = a.mlp_params;
-  const int tid = threadIdx.x;
-  const int H = FLEX ? mp.hid : HID;
-  const bool t2 = FLEX ? (mp.t2 != 0) : true, oh = FLEX ? (mp.oh != 0) : true, ch = FLEX ? (mp.ch != 0) : true;
-  const bool t1 = FLEX ? (mp.t1 != 0) : true;
-  const int hin = FLEX ? mp.hin : HID;                     // input width of the heads
-  const int ho_w = oh ? H : hin, hc_w = ch ? H : hin;      // input width of the heads' output layers
-  // matrices are staged zero-padded to 32 x 32; absent layers (mp.t1 / t2 / oh / ch == 0) are staged as zeros
-  for (int i = tid; i < 32 * 32; i += 256) {
-    const int row = i >> 5, col = i & 31;
-    const int d = row * W_LD + col;
-    const bool in_h = row < H && col < H;
-    const bool in_head = row < hin && col < H;
-    lds[M::WT1 + d] = (t1 && row < C && col < H) ? P[mp.w_t1 + row * H + col] : 0.0f;
-    lds[M::WT2 + d] = (t2 && in_h) ? P[mp.w_t2 + row * H + col] : 0.0f;
-    lds[M::WO1 + d] = (oh && in_head) ? P[mp.w_o1 + row * H + col] : 0.0f;
-    lds[M::WC1 + d] = (ch && in_head) ? P[mp.w_c1 + row * H + col] : 0.0f;
-  }
-  for (int i = tid; i < 32; i += 256) {
-    const bool in_h = i < H;
-    lds[M::BIAS + i] = (t1 && in_h) ? P[mp.b_t1 + i] : 0.0f;
-    lds[M::BIAS + 32 + i] = (t2 && in_h) ? P[mp.b_t2 + i] : 0.0f;
-    lds[M::BIAS + 64 + i] = (oh && in_h) ? P[mp.b_o1 + i] : 0.0f;
-    lds[M::BIAS + 96 + i] = (ch && in_h) ? P[mp.b_c1 + i] : 0.0f;
-    lds[M::WO2 + i] = (i < ho_w) ? P[mp.w_o2 + i] : 0.0f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      lds[M::WC2 + i * 4 + c] = (i < hc_w && c < a.color_chn) ? P[mp.w_c2 + (int64_t)i * mp.ldc2 + c] : 0.0f;
-  }
-  for (int i = tid; i < MAX_INF; i += 256)
-    lds[M::INF + i] = (i < a.march.num_samples_inf) ? inf_scale(i, a.march) : 0.0f;
-  if (tid == 0) {
-    lds[M::HB + 0] = P[mp.b_o2];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) lds[M::HB + 1 + c] = (c < a.color_chn) ? P[mp.b_c2 + c] : 0.0f;
-  }
-}
-
+// (stage_weights, the fp32 [32][33] images of the first-generation Renderer kernels, went with them in round 4; the layout
+// constants above stay: the bf16x3 kernels address their small fp32 block -- biases, output layers, beyond-far table --
+// through them, and the width-64 family / the MLP-Splatter's two-layer family keep fp32 images of their own.)
 // bias of layer `which` (0 t1, 1 t2, 2 o1, 3 c1) in accumulator-register order for half h
 LP_DEV f32x16 load_bias(const float* lds, int which, int h, int zo) {
   const float4* b = reinterpret_cast<const float4*>(lds + Lds::BIAS + which * 32 + 4 * h + zo);
@@ -371,80 +333,6 @@ template <int C, int GM, bool FENCED = false, bool PLAIN = false>
 LP_DEV void fetch_sample(const LpRendererArgs& a, const float* lds, const Ray& ray, int s, int h, Sample<C>& o) {
   sample_geometry<C, PLAIN>(a, lds, ray, s, o);
   gather_features<C, GM, FENCED>(a, ray, o.x, o.y, o.z, h, o.x0);
-}
-
-// Decoder of the CURRENT sample (input t.x0; fills t.h1 / t.e / t.ho / t.hc) interleaved with the
-// gather of sample `s_next` into `nx` (software pipeline).  Triplane: plane g is gathered next to
-// hidden layer g+1; voxel: taps 0-3 / 4-7 next to layers 2 / 3; generic grid-lists: whole gather
-// first.
-template <int C, int GM_, bool PREFETCH = true, int NC = 4>
-LP_DEV Heads decode_prefetch(const LpRendererArgs& a, const float* lds, const Ray& ray, int lane,
-                             const float (&enc)[16], Act<C>& t, int s_next, Sample<C>& nx, int zo) {
-  using M = Lds;
-  // without prefetch this is the plain decoder (GM = -1 disables every gather below)
-  constexpr int GM = PREFETCH ? GM_ : -1;
-  const int h = lane >> 5;
-  // operand base of this lane; `zo` (always 0) keeps the weight reads inside the sample loop
-  const float* wl = lds + (4 * h) * W_LD + (lane & 31) + zo;
-  float keep = 1.0f;
-  if (PREFETCH) {
-    sample_geometry<C>(a, lds, ray, s_next, nx);
-    keep = (a.march.mask_out_of_bounds && !point_in_bounds(nx.x, nx.y, nx.z)) ? 0.0f : 1.0f;
-  }
-  Taps tp[3];  // one entry per plane (single-voxel grid-lists use the first)
-  if (GM == GM_TRIPLANE) {
-    triplane_taps<false>(a.grid.grids, ray.b, nx.x, nx.y, nx.z, tp);
-  } else if (GM == GM_VOXEL) {
-    voxel_taps<false>(a.grid.grids[0], ray.b, nx.x, nx.y, nx.z, tp[0]);
-  } else if (GM == GM_GENERIC) {
-    gather_features<C, GM_GENERIC>(a, ray, nx.x, nx.y, nx.z, h, nx.x0);
-  }
-  if (GM == GM_TRIPLANE || GM == GM_VOXEL) {
-#pragma unroll
-    for (int q = 0; q < C / 2; ++q) nx.x0[q] = 0.0f;
-  }
-  LP_SCHED_FENCE();
-  f32x16 acc = layer<C / 2>(wl + M::WT1, t.x0, load_bias(lds, 0, h, zo));
-#pragma unroll
-  for (int q = 0; q < 16; ++q) t.h1[q] = relu_f(acc[q]);
-  LP_SCHED_FENCE();
-  // ---- group 1: trunk layer 2  ||  plane 0 / voxel taps 0-3 ----
-  if (GM == GM_TRIPLANE || GM == GM_VOXEL) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.grids[0].data, tp[0].row[k], tp[0].w[k] * keep, h, nx.x0);
-  }
-  acc = layer<16>(wl + M::WT2, t.h1, load_bias(lds, 1, h, zo));
-#pragma unroll
-  for (int q = 0; q < 16; ++q) t.e[q] = relu_f(acc[q]);
-  if (GM == GM_TRIPLANE || GM == GM_VOXEL) interleave_hint<16, 5, 2>();
-  LP_SCHED_FENCE();
-  // ---- group 2: opacity hidden layer  ||  plane 1 / voxel taps 4-7 ----
-  if (GM == GM_TRIPLANE) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.grids[1].data, tp[1].row[k], tp[1].w[k] * keep, h, nx.x0);
-  } else if (GM == GM_VOXEL) {
-#pragma unroll
-    for (int k = 4; k < 8; ++k) gather_tap<C>(a.grid.grids[0].data, tp[0].row[k], tp[0].w[k] * keep, h, nx.x0);
-  }
-  acc = layer<16>(wl + M::WO1, t.e, load_bias(lds, 2, h, zo));
-#pragma unroll
-  for (int q = 0; q < 16; ++q) t.ho[q] = relu_f(acc[q]);
-  if (GM == GM_TRIPLANE || GM == GM_VOXEL) interleave_hint<16, 5, 2>();
-  LP_SCHED_FENCE();
-  // ---- group 3: colour hidden layer  ||  plane 2 ----
-  if (GM == GM_TRIPLANE) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) gather_tap<C>(a.grid.grids[2].data, tp[2].row[k], tp[2].w[k] * keep, h, nx.x0);
-  }
-  float ein[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) ein[q] = t.e[q] + enc[q];
-  acc = layer<16>(wl + M::WC1, ein, load_bias(lds, 3, h, zo));
-#pragma unroll
-  for (int q = 0; q < 16; ++q) t.hc[q] = relu_f(acc[q]);
-  if (GM == GM_TRIPLANE) interleave_hint<16, 6, 2>();
-  LP_SCHED_FENCE();
-  return heads_forward<NC>(lds, h, t.ho, t.hc, zo);
 }
 
 // Gradient scatter, row-contiguous and run-length merged.

@@ -1,9 +1,9 @@
 // lp_renderer_mfma.hip -- Renderer forward on the CDNA4 matrix cores (gfx950) + host dispatch of the
 // MFMA kernels (the backward kernel lives in lp_renderer_mfma_bwd.hip).
 //
-// Shape family (anything else falls back to lp_renderer_generic.hip): single grid-list with
-// C in {16, 32} channels, trunk [C,32,32], opacity [32,32,1], colour [32,32,>=Cc] with Cc <= 4.
-// That covers every BASELINE.json configuration.
+// Shape family = the TUNED default shape: single grid-list with C in {16, 32} channels, trunk [C,32,32],
+// opacity [32,32,1], colour [32,32,>=Cc] with Cc <= 4 -- every BASELINE.json configuration.  Everything else runs the
+// layer-looped family (lp_renderer_loop*.hip), the width-64 family or lp_renderer_generic.hip.
 //
 // Mapping.  One wave = 32 rays.  Lane l = (h = l>>5, r = l&31) works on ray r and on the
 // feature subset F_h = { feat(q,h) = (q&3) + 8*(q>>2) + 4*h : q = 0..15 } of every 32-wide
@@ -36,203 +36,12 @@ namespace lp {
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
+// (Rounds 1-3 kept a first generation here -- renderer_fwd_mfma / renderer_fwd_mfma_np on v_mfma_f32_32x32x2_f32, with FLEX and
+// two-grid instantiations for the decoders that are not the default shape.  Round 4 retired it: the default shape runs the
+// bf16x3 kernels below, every other shallow decoder the layer-looped family's two-waves-per-SIMD instantiations
+// (lp_renderer_loop_shallow.hip), which measured faster on every flex shape and within 5 % on the two-grid ones --
+// profiles/r04_loop_shallow_ab.txt.)
 // NC = 3: at most three colour channels (RGB), the fourth lane of the colour path is compiled out
-template <int C, int GM, int NC = 4>
-__global__ void __launch_bounds__(256, 2) renderer_fwd_mfma(const LpRendererArgs a, const MfmaParams mp) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_weights<C>(a, mp, lds);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int h = lane >> 5, r = lane & 31;
-  const int64_t ray_id = ((int64_t)blockIdx.x * WAVES + wave) * RAYS_PER_WAVE + r;
-  const bool valid = ray_id < a.rays.n_rays;
-  const int64_t rid = valid ? ray_id : 0;
-  const Ray ray = load_ray(a.rays, rid);
-  float enc[16];
-  load_encoding(a, rid, h, enc);
-  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
-  const int n_ckpt = ckpt_count(a.march);
-  const float delta0 = (a.march.num_samples > 1) ? (ray.far_t - ray.near_t) / (float)(a.march.num_samples - 1) : 1.0f;
-  float nlt = 0.0f, nlt_lo = 0.0f, t_prev = 1.0f, len = 0.0f, depth_prev = 0.0f;
-  int s_last = s_tot - 1;  // last sample marched
-  float facc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  Sample<C> nx;
-  fetch_sample<C, GM>(a, lds, ray, 0, h, nx);
-  Act<C> t;
-  for (int s = 0; s < s_tot; ++s) {
-    const float depth = nx.depth, occ = nx.occ;
-#pragma unroll
-    for (int q = 0; q < C / 2; ++q) t.x0[q] = nx.x0[q];
-    // software pipeline: the next sample's gather is interleaved with this sample's MFMA chain
-    const int zo = opaque_zero();
-    const Heads hd = decode_prefetch<C, GM, true, NC>(a, lds, ray, lane, enc, t, (s + 1 < s_tot) ? s + 1 : s, nx, zo);
-    const float delta = (s == 0) ? delta0 : depth - depth_prev;
-    depth_prev = depth;
-    float raw = hd.raw_o;
-    if (a.noise_sigma > 0.0f) raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
-    const float opacity = a.gain * softplus_f(raw) * occ;
-    nlt_add(nlt, nlt_lo, opacity * delta);
-    if (a.neg_log_t_ckpt && valid && h == 0) {
-      const int ck = ckpt_index(s, a.march);
-      if (ck >= 0) *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + ck) * 2) = make_float2(nlt, nlt_lo);
-    }
-    const float tr = __expf(-nlt);
-    const float w = t_prev - tr;
-    t_prev = tr;
-    len = fmaf(w, depth, len);
-#pragma unroll
-    for (int c = 0; c < NC; ++c) facc[c] = fmaf(w, sigmoid_f(hd.raw_c[c]) * occ, facc[c]);
-    // early termination (off unless stop_neg_log_t > 0): every ray of this wave is opaque
-    if (a.stop_neg_log_t > 0.0f && __ballot(valid && nlt < a.stop_neg_log_t) == 0) {
-      s_last = s;
-      break;
-    }
-  }
-  if (valid && h == 0) {
-    write_ray_outputs(a, ray_id, len, nlt, facc);
-    if (a.neg_log_t_ckpt)
-      *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + n_ckpt - 1) * 2) = make_float2((float)s_last, nlt_lo);
-  }
-}
-
-// Variant without the software-pipelined gather, register-allocated for OCC waves per SIMD: with
-// C = 32 the pipelined kernel needs >256 registers (94 spilled) and is 2.3x slower than this one at
-// three waves/SIMD; with C = 16 it wins once there are more than two waves of rays per SIMD.
-// flexible decoder of the width-32 family: 1-2 trunk layers, heads with or without a hidden layer
-template <int C>
-LP_DEV Heads decode_flex(const float* lds, int lane, const float (&enc)[16], Act<C>& t, int zo, bool t1, bool t2, bool oh,
-                         bool ch, bool tg, const float (&xc0)[C / 2]) {
-  using M = Lds;
-  const int h = lane >> 5;
-  const float* wl = lds + (4 * h) * W_LD + (lane & 31) + zo;
-  if (t1) {
-    const f32x16 acc = layer<C / 2>(wl + M::WT1, t.x0, load_bias(lds, 0, h, zo));
-#pragma unroll
-    for (int q = 0; q < 16; ++q) t.h1[q] = relu_f(acc[q]);
-  } else {  // two-grid decoder: the opacity head sees relu(sampled feature)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) t.h1[q] = (q < C / 2) ? relu_f(t.x0[q < C / 2 ? q : 0]) : 0.0f;
-  }
-  f32x16 acc;
-  if (t2) {
-    acc = layer<16>(wl + M::WT2, t.h1, load_bias(lds, 1, h, zo));
-#pragma unroll
-    for (int q = 0; q < 16; ++q) t.e[q] = relu_f(acc[q]);
-  } else {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) t.e[q] = t.h1[q];
-  }
-  if (oh) {
-    acc = layer<16>(wl + M::WO1, t.e, load_bias(lds, 2, h, zo));
-#pragma unroll
-    for (int q = 0; q < 16; ++q) t.ho[q] = relu_f(acc[q]);
-  } else {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) t.ho[q] = t.e[q];
-  }
-  float ein[16];
-  if (tg) {  // the colour head sees relu(sampled colour feature) + ray encoding
-#pragma unroll
-    for (int q = 0; q < 16; ++q) ein[q] = ((q < C / 2) ? relu_f(xc0[q < C / 2 ? q : 0]) : 0.0f) + enc[q];
-  } else {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) ein[q] = t.e[q] + enc[q];
-  }
-  if (ch) {
-    acc = layer<16>(wl + M::WC1, ein, load_bias(lds, 3, h, zo));
-#pragma unroll
-    for (int q = 0; q < 16; ++q) t.hc[q] = relu_f(acc[q]);
-  } else {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) t.hc[q] = ein[q];
-  }
-  return heads_forward(lds, h, t.ho, t.hc, zo);
-}
-
-template <int C, int GM, int OCC, bool FLEX = false, bool TG = false, int NC = 4>
-__global__ void __launch_bounds__(256, OCC) renderer_fwd_mfma_np(const LpRendererArgs a, const MfmaParams mp) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_weights<C, FLEX>(a, mp, lds);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int h = lane >> 5, r = lane & 31;
-  // flex / two-grid shapes, small batch (mp.seg_fwd, see renderer_fwd_bf3 SEGF): a workgroup marches one segment from
-  // transmittance 1 and leaves segment-local state records for renderer_fwd_combine
-  const bool segf = FLEX && mp.seg_fwd != 0;
-  const int seg_len = LP_SEG_LEN * mp.seg_blocks;
-  const int n_seg = segf ? (a.march.num_samples + seg_len - 1) / seg_len : 1;
-  const int blk = segf ? (int)blockIdx.x / n_seg : (int)blockIdx.x;
-  const int seg = segf ? (int)blockIdx.x - blk * n_seg : 0;
-  const int64_t ray_id = ((int64_t)blk * WAVES + wave) * RAYS_PER_WAVE + r;
-  const bool valid = ray_id < a.rays.n_rays;
-  const int64_t rid = valid ? ray_id : 0;
-  const Ray ray = load_ray(a.rays, rid);
-  float enc[16];
-  load_encoding(a, rid, h, enc, FLEX ? mp.hin : HID);
-  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
-  const int n_ckpt = ckpt_count(a.march);
-  const float delta0 = (a.march.num_samples > 1) ? (ray.far_t - ray.near_t) / (float)(a.march.num_samples - 1) : 1.0f;
-  float nlt = 0.0f, nlt_lo = 0.0f, t_prev = 1.0f, len = 0.0f, depth_prev = 0.0f;
-  int s_last = s_tot - 1;  // last sample marched
-  float facc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  Sample<C> nx;
-  Act<C> t;
-  const int s_lo = segf ? seg * seg_len : 0;
-  const int s_hi = segf ? ((s_lo + seg_len < s_tot) ? s_lo + seg_len : s_tot) : s_tot;
-  if (segf && s_lo > 0) {  // interval length of the segment's first sample
-    sample_geometry<C>(a, lds, ray, s_lo - 1, nx);
-    depth_prev = nx.depth;
-  }
-  for (int s = s_lo; s < s_hi; ++s) {
-    fetch_sample<C, GM, true>(a, lds, ray, s, h, nx);
-    const float depth = nx.depth, occ = nx.occ;
-#pragma unroll
-    for (int q = 0; q < C / 2; ++q) t.x0[q] = nx.x0[q];
-    // software pipeline: the next sample's gather is interleaved with this sample's MFMA chain
-    const int zo = opaque_zero();
-    float xc0[C / 2];
-    if (FLEX && TG)
-      gather_list<C, false>(a.color_grid, a.march.mask_out_of_bounds != 0, ray, nx.x, nx.y, nx.z, h, xc0);
-    const Heads hd = FLEX ? decode_flex<C>(lds, lane, enc, t, zo, !TG, mp.t2 != 0, mp.oh != 0, mp.ch != 0, TG, xc0)
-                          : decode_prefetch<C, GM, false, NC>(a, lds, ray, lane, enc, t, s, nx, zo);
-    const float delta = (s == 0) ? delta0 : depth - depth_prev;
-    depth_prev = depth;
-    float raw = hd.raw_o;
-    if (a.noise_sigma > 0.0f) raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
-    const float opacity = a.gain * softplus_f(raw) * occ;
-    nlt_add(nlt, nlt_lo, opacity * delta);
-    if (!segf && a.neg_log_t_ckpt && valid && h == 0) {
-      const int ck = ckpt_index(s, a.march);
-      if (ck >= 0) *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + ck) * 2) = make_float2(nlt, nlt_lo);
-    }
-    const float tr = __expf(-nlt);
-    const float w = t_prev - tr;
-    t_prev = tr;
-    len = fmaf(w, depth, len);
-#pragma unroll
-    for (int c = 0; c < NC; ++c) facc[c] = fmaf(w, sigmoid_f(hd.raw_c[c]) * occ, facc[c]);
-    // state records of the segment-parallel backward (absolute; segf: relative to the segment's start)
-    if (FLEX && a.seg_prefix && valid && h == 0 && (((s + 1) % LP_SEG_LEN) == 0 || s == a.march.num_samples - 1)) {
-      float4* dst = reinterpret_cast<float4*>(a.seg_prefix + (ray_id * segment_count(a.march) + s / LP_SEG_LEN) * 8);
-      dst[0] = make_float4(len, facc[0], facc[1], facc[2]);
-      dst[1] = make_float4(NC == 4 ? facc[3] : 0.0f, nlt, nlt_lo, 0.0f);
-    }
-    // early termination (off unless stop_neg_log_t > 0): every ray of this wave is opaque
-    if (a.stop_neg_log_t > 0.0f && __ballot(valid && nlt < a.stop_neg_log_t) == 0) {
-      s_last = s;
-      break;
-    }
-  }
-  if (!segf && valid && h == 0) {
-    write_ray_outputs(a, ray_id, len, nlt, facc);
-    if (a.neg_log_t_ckpt)
-      *reinterpret_cast<float2*>(a.neg_log_t_ckpt + (ray_id * n_ckpt + n_ckpt - 1) * 2) = make_float2((float)s_last, nlt_lo);
-  }
-}
-
-// Forward of the default shape (trunk [C,32,32], heads [32,32,.]) with the matrix products on the bf16 matrix cores at
-// fp32 accuracy (lp_bf3.h: exact 3-limb splits, six limb products): the MFMA time all but disappears behind the VALU
-// work (interpolation, splits, activations, compositing) instead of adding to it as the fp32 MFMA's does.
 // SEGF (small batches, LpRendererArgs.seg_prefix): a workgroup marches ONE segment (mp.seg_blocks blocks of LP_SEG_LEN
 // samples) of its 128 rays, starting from transmittance 1, and only writes the segment-local running sums into the ray's
 // state records; renderer_fwd_combine chains the segments.  Compositing is associative: a segment with local sums
@@ -393,6 +202,12 @@ bool renderer_mfma_supported(const LpRendererArgs& a, const char** why) {
   if (a.grid.n_rows * C * 4 >= (int64_t)1 << 32) { *why = "grid-list of 4 GB or more"; return false; }
   if (tg && a.color_grid.n_rows * C * 4 >= (int64_t)1 << 32) { *why = "colour grid-list of 4 GB or more"; return false; }
   if (a.march.num_samples_inf > MAX_INF) { *why = "more than 256 beyond-far samples"; return false; }
+  // the tuned kernels are written for ONE decoder shape; the flex / two-grid subsets this family used to take (fp32-MFMA
+  // kernels with run-time layer flags) belong to the layer-looped family since round 4
+  if (!(H == HID && a.trunk.n_layers == 2 && a.opacity.n_layers == 2 && a.color.n_layers == 2 && !tg)) {
+    *why = "not the tuned default shape (2/2/2 layers x 32 hidden): layer-looped family";
+    return false;
+  }
   return true;
 }
 
@@ -430,7 +245,6 @@ static MfmaParams make_params(const LpRendererArgs& a) {
   return p;
 }
 
-static bool is_flex(const MfmaParams& p) { return !(p.hid == HID && p.t1 && p.t2 && p.oh && p.ch && !p.tg); }
 
 // Segment-parallel backward (LpRendererArgs.seg_prefix): available where renderer_fwd_bf3 / renderer_bwd_bf3 run (default
 // decoder shape), without beyond-far samples and early termination; worth it while the batch leaves wave slots
@@ -439,12 +253,8 @@ static bool is_flex(const MfmaParams& p) { return !(p.hid == HID && p.t1 && p.t2
 // 32 768 rays 1.75 -> 1.53 ms, 49 152 rays 2.12 -> 2.22 ms: on up to 32 768 rays.
 // LP_SEGMENTS=0 / 1 switches it off / on regardless of the batch size (A/B, tests).
 int renderer_mfma_segments(const LpRendererArgs& a) {
-  static const bool bf3 = getenv("LP_MFMA_F32") == nullptr && getenv("LP_MFMA_F32_BWD") == nullptr;
   static const int forced = getenv("LP_SEGMENTS") ? atoi(getenv("LP_SEGMENTS")) : -1;
-  static const bool bf3_c32 = getenv("LP_BF3_C32") == nullptr || atoi(getenv("LP_BF3_C32")) != 0;
-  // (default shape: the bf16x3 kernels; flex / two-grid shapes: the FLEX instantiations of the fp32-MFMA kernels)
-  const bool flex = is_flex(make_params(a));
-  if (forced == 0 || (!flex && (!bf3 || (a.grid.channels != 16 && !bf3_c32)))) return 1;
+  if (forced == 0) return 1;
   if (a.march.num_samples_inf != 0 || a.stop_neg_log_t > 0.0f) return 1;
   const int n_seg = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
   if (n_seg < 2) return 1;
@@ -474,19 +284,10 @@ static unsigned n_blocks(const LpRendererArgs& a) {
 
 template <int C, int GM>
 static int launch_fwd(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
-  const size_t lds = Lds::FWD_END * sizeof(float);
   int rc;
-  if ((rc = set_lds(renderer_fwd_mfma<C, GM>, lds))) return rc;
-  if ((rc = set_lds(renderer_fwd_mfma<C, GM, 3>, lds))) return rc;
   static const bool no_nc3 = getenv("LP_MFMA_NO_NC3") != nullptr;  // A/B knob
-  // measured on MI355X (scripts/fwd_variants.py): 1080p C=32 S=256: 110 ms pipelined vs 48 ms at 3 waves/SIMD;
-  // C=16: 256x256 rays 0.82 vs 0.86 ms, 512x512 rays 3.02 vs 2.85 ms at 4 waves/SIMD
-  static const int forced = getenv("LP_MFMA_FWD_VARIANT") ? atoi(getenv("LP_MFMA_FWD_VARIANT")) : -1;
-  const int variant = forced >= 0 ? forced : (C == 32 ? 3 : (a.rays.n_rays > 3 * 32768 ? 4 : 0));
-  // default shape: matrix products as bf16x3 on the bf16 matrix cores (lp_bf3.h); LP_MFMA_F32 keeps the fp32 MFMA kernels
-  static const bool f32_mfma = getenv("LP_MFMA_F32") != nullptr;
   static const int bf3_occ = getenv("LP_BF3_OCC") ? atoi(getenv("LP_BF3_OCC")) : 0;
-  if (!mp.tg && !is_flex(mp) && !f32_mfma) {
+  {
     const size_t lds3 = (size_t)LdsBf3<C>::FWD_END;
     const int occ = bf3_occ ? bf3_occ : (a.rays.n_rays > 2 * 32768 ? 3 : 2);
     // small batch with state records (seg_prefix survives lp_api.hip only where renderer_mfma_segments() > 1): one
@@ -524,51 +325,6 @@ static int launch_fwd(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t
 #undef LP_BF3_LAUNCH
     return LP_OK;
   }
-  if (mp.tg || is_flex(mp)) {
-    // small batch with state records: segment march + combine pass, as for the default shape above
-    static const bool seg_fwd = getenv("LP_SEG_FWD") == nullptr || atoi(getenv("LP_SEG_FWD")) != 0;
-    MfmaParams ms = mp;
-    unsigned nb = n_blocks(a);
-    const bool segf = a.seg_prefix && seg_fwd && !a.seg_forward_off;
-    if (segf) {
-      const int n_rec = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
-      static const int forced = getenv("LP_SEG_BLOCKS") ? atoi(getenv("LP_SEG_BLOCKS")) : 0;
-      int m = 1;
-      while (m < n_rec && (uint64_t)nb * ((n_rec + m - 1) / m) > 512u) ++m;
-      if (forced > 0) m = forced < n_rec ? forced : n_rec;
-      ms.seg_blocks = m;
-      ms.seg_fwd = 1;
-      nb *= (unsigned)((n_rec + m - 1) / m);
-    }
-    if (mp.tg) {
-      // two gathers per sample: two waves/SIMD and the run-time-loop grid-list variant (the triplane / voxel
-      // specialisations at three waves/SIMD spill 160-230 registers with C = 32)
-      if ((rc = set_lds(renderer_fwd_mfma_np<C, GM_GENERIC, 2, true, true>, lds))) return rc;
-      hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM_GENERIC, 2, true, true>), dim3(nb), dim3(256), lds, stream, a, ms);
-    } else {
-      if ((rc = set_lds(renderer_fwd_mfma_np<C, GM, 3, true>, lds))) return rc;
-      hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM, 3, true>), dim3(nb), dim3(256), lds, stream, a, ms);
-    }
-    if (segf)
-      hipLaunchKernelGGL(renderer_fwd_combine, dim3((unsigned)((a.rays.n_rays + 255) / 256)), dim3(256), 0, stream, a, ms.seg_blocks);
-  } else if (variant == 3 && a.color_chn <= 3 && !no_nc3) {
-    if ((rc = set_lds(renderer_fwd_mfma_np<C, GM, 3, false, false, 3>, lds))) return rc;
-    hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM, 3, false, false, 3>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
-  } else if (variant == 3) {
-    if ((rc = set_lds(renderer_fwd_mfma_np<C, GM, 3>, lds))) return rc;
-    hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM, 3>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
-  } else if (variant == 4 && a.color_chn <= 3 && !no_nc3) {
-    if ((rc = set_lds(renderer_fwd_mfma_np<C, GM, 4, false, false, 3>, lds))) return rc;
-    hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM, 4, false, false, 3>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
-  } else if (variant == 4) {
-    if ((rc = set_lds(renderer_fwd_mfma_np<C, GM, 4>, lds))) return rc;
-    hipLaunchKernelGGL((renderer_fwd_mfma_np<C, GM, 4>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
-  } else if (a.color_chn <= 3 && !no_nc3) {
-    hipLaunchKernelGGL((renderer_fwd_mfma<C, GM, 3>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
-  } else {
-    hipLaunchKernelGGL((renderer_fwd_mfma<C, GM>), dim3(n_blocks(a)), dim3(256), lds, stream, a, mp);
-  }
-  return LP_OK;
 }
 
 #define LP_DISPATCH_GM(CALL, CV)                                   \

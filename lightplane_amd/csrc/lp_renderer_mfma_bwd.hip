@@ -1,22 +1,19 @@
-// lp_renderer_mfma_bwd.hip -- Renderer backward on the CDNA4 matrix cores, second generation.
+// lp_renderer_mfma_bwd.hip -- Renderer backward of the tuned default shape on the CDNA4 matrix cores.
 //
-// Same maths and the same lane <-> (ray, feature) mapping as the forward kernel
-// (lp_renderer_mfma.hip): far -> near sweep that recomputes the decoder of every sample, then
-// back-propagates through it.  What is different from the first-generation backward is where the
-// WEIGHT gradients live.  dW = X^T dY contracts over rays; a wave that keeps the four 32x32 tiles
-// of its own 32 rays needs 64 accumulator registers for the whole kernel, which (with the
-// activations of the recompute) does not fit the 256-register budget of two waves per SIMD: the
-// compiler spilled ~200 registers and the kernel ran at a quarter of the MFMA rate.  Here the four
-// waves of a workgroup SHARE the contraction: every wave publishes its X / dY tiles of the current
-// layer in LDS (feature-major, [feature][ray]), the workgroup synchronises, and wave w accumulates
-// ONE 16x16 quadrant of the layer's dW over all 128 rays with v_mfma_f32_16x16x4_f32 (4
-// accumulator registers per layer, 16 in total).  Operands arrive as ds_read_b128 (8 rays per
-// lane), the bias gradient is a by-product of the B operand, nothing is summed across waves at
-// the end.  The ray encoding lives in LDS as well; the kernel has no scratch.
-//
-// LDS tiles are feature-major with a row stride of 36 floats: the transposing writes are 32
-// consecutive lanes per row (conflict-free), the quadrant reads are conflict-free once the 16
-// features of a quadrant are dealt to the MFMA lanes as even | odd | even (pi() below).
+// Same maths and the same lane <-> (ray, feature) mapping as the forward kernel (lp_renderer_mfma.hip): far -> near
+// sweep that recomputes the decoder of every sample (bf16x3, lp_bf3.h), then back-propagates through it.
+// WEIGHT gradients.  dW = X^T dY contracts over rays; a wave that keeps the four 32x32 tiles of its own 32 rays needs 64
+// accumulator registers for the whole kernel, which (with the activations of the recompute) does not fit the
+// 256-register budget of two waves per SIMD.  So the four waves of a workgroup SHARE the contraction: every wave
+// publishes its X / dY tiles of the current layer in LDS (feature-major, [feature][ray]), the workgroup synchronises, and
+// wave w accumulates ONE 16x16 quadrant of the layer's dW over all 128 rays with v_mfma_f32_16x16x4_f32 (4 accumulator
+// registers per layer, 16 in total).  Operands arrive as ds_read_b128 (8 rays per lane), the bias gradient is a
+// by-product of the B operand, nothing is summed across waves at the end.
+// LDS tiles are feature-major with a row stride of 36 floats: the transposing writes are 32 consecutive lanes per row
+// (conflict-free), the quadrant reads are conflict-free once the 16 features of a quadrant are dealt to the MFMA lanes as
+// even | odd | even (pi16() below).
+// (The fp32-MFMA generation of this kernel -- renderer_bwd_mfma2, rounds 1-3, with FLEX / two-grid instantiations -- was
+// retired in round 4: see lp_renderer_mfma.hip.)
 #include "lp_mfma_common.h"
 #include <type_traits>
 
@@ -51,18 +48,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int T_LD = 36;  // row stride of the feature-major tiles [32 features][32 rays + 4]
 
-// per-wave LDS area behind the weights (floats)
-struct LdsB {
-  static constexpr int WAVE0 = Lds::FWD_END;
-  static constexpr int XT = 0;                  // X  tile [32][36] (also: dx0 tile of the scatter)
-  static constexpr int YT = 32 * T_LD;          // dY tile [32][36]
-  static constexpr int ENC = 2 * 32 * T_LD;     // ray encoding [32 rays][36]
-  static constexpr int TS = 3 * 32 * T_LD;      // [5][32]: d raw_o, d raw_c[0..3] by ray
-  static constexpr int PER_WAVE = TS + 5 * 32;    // (the scatter's weight table lives in the dY tile)
-  static constexpr int END = WAVE0 + WAVES * PER_WAVE;
-};
-static_assert(2 * LdsB::END * 4 <= 160 * 1024, "two workgroups per CU must fit the 160 KB LDS");
-
 // feature of a 16-wide quadrant handled by MFMA lane index m (bank-conflict-free b128 reads)
 LP_DEV constexpr int pi16(int m) { return m < 4 ? 2 * m : (m < 12 ? 2 * (m - 4) + 1 : 2 * (m - 8)); }
 
@@ -78,21 +63,9 @@ LP_DEV void tile_store_fm(float* tile, int r, int h, const float (&v)[16]) {
   for (int q = 0; q < 16; ++q) tile[featq(q, h) * T_LD + r] = v[q];
 }
 
-// ein = e + ray encoding (this lane's 16 features; `enc` points at the lane's first chunk)
-LP_DEV void add_encoding(const float* enc, const float (&e)[16], float (&ein)[16]) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float4 v = *reinterpret_cast<const float4*>(enc + 8 * j);
-    ein[4 * j + 0] = e[4 * j + 0] + v.x;
-    ein[4 * j + 1] = e[4 * j + 1] + v.y;
-    ein[4 * j + 2] = e[4 * j + 2] + v.z;
-    ein[4 * j + 3] = e[4 * j + 3] + v.w;
-  }
-}
-
 // dW quadrant of one layer over the rays of the source waves [v0, v1): acc += X^T dY.
 // a_off / b_off: float offsets of this lane's rows inside a wave area (tile + feature*T_LD + 8*(lane>>4)).
-template <int STRIDE = LdsB::PER_WAVE>
+template <int STRIDE>
 LP_DEV f32x4 dw_quadrant(const float* wave0, int a_off, int b_off, int v0, int v1, f32x4 acc, float& db) {
   float s = 0.0f;
   for (int v = v0; v < v1; ++v) {
@@ -113,534 +86,6 @@ LP_DEV f32x4 dw_quadrant(const float* wave0, int a_off, int b_off, int v0, int v
   }
   db += s;
   return acc;
-}
-
-// FLEX: trunk of 1-2 layers, heads with or without hidden layer, hidden width 16 (zero-padded) or 32, chosen at
-// run time through mp.{t2,oh,ch,hid}; FLEX = false is the default shape with everything folded at compile time.
-// NC = colour channels evaluated (3: RGB, the padding column of the colour path is compiled out)
-template <int C, int GM, bool PLAIN, bool FLEX = false, bool TG = false, int NC = 4>
-__global__ void __launch_bounds__(256, 2) renderer_bwd_mfma2(const LpRendererArgs a, const MfmaParams mp) {
-  using M = Lds;
-  using B = LdsB;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_weights<C, FLEX>(a, mp, lds);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int h = lane >> 5, r = lane & 31;
-  float* const wave0 = lds + B::WAVE0;
-  float* const wv = wave0 + wave * B::PER_WAVE;
-  float* const xt = wv + B::XT;
-  float* const yt = wv + B::YT;
-  float* const enct = wv + B::ENC;
-  float* const ts = wv + B::TS;
-
-  // segment-parallel sweep of a small batch (LpRendererArgs.seg_prefix; flex / two-grid shapes: a run-time switch of the
-  // FLEX instantiations -- the default shape has its own kernel below): workgroup = (128 rays, mp.seg_blocks blocks of
-  // LP_SEG_LEN samples)
-  const bool seg_on = FLEX && a.seg_prefix != nullptr;
-  const int n_rec = seg_on ? segment_count(a.march) : 1;
-  const int seg_len = LP_SEG_LEN * mp.seg_blocks;
-  const int n_seg = seg_on ? (a.march.num_samples + seg_len - 1) / seg_len : 1;
-  const int blk = seg_on ? (int)blockIdx.x / n_seg : (int)blockIdx.x;
-  const int seg = seg_on ? (int)blockIdx.x - blk * n_seg : 0;
-  const int64_t ray_id = ((int64_t)blk * WAVES + wave) * RAYS_PER_WAVE + r;
-  const bool valid = ray_id < a.rays.n_rays;
-  const int64_t rid = valid ? ray_id : 0;
-  const Ray ray = load_ray(a.rays, rid);
-  const bool t2 = FLEX ? (mp.t2 != 0) : true, oh = FLEX ? (mp.oh != 0) : true, ch = FLEX ? (mp.ch != 0) : true;
-  constexpr bool tg = FLEX && TG;               // separate colour grid-list (its own instantiation)
-  constexpr bool t1 = !tg;                      // false: two-grid decoder (no trunk)
-  const int hid = FLEX ? mp.hid : HID;
-  const int hin = FLEX ? mp.hin : HID;          // input width of the heads = width of the ray encoding
-  {  // ray encoding -> LDS, [ray][36] (features >= hin are zero)
-    const float4* src = reinterpret_cast<const float4*>(a.rays.encoding + rid * hin + 4 * h);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<float4*>(enct + r * T_LD + 8 * j + 4 * h) =
-          (!FLEX || 8 * j + 4 * h < hin) ? src[2 * j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  }
-  // closing pair of the checkpoint list: last sample the forward marched for this wave (early termination)
-  // and the low word of the final -log T.  The sample loop is workgroup-uniform (barriers): it starts at
-  // the largest index of the four waves, a wave is `on` only up to its own.
-  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
-  const int n_ckpt = ckpt_count(a.march);
-  int s_last_w = s_tot - 1;
-  float nlt_lo = 0.0f;
-  if (a.neg_log_t_ckpt) {
-    const float2 e2 = *reinterpret_cast<const float2*>(a.neg_log_t_ckpt + (rid * n_ckpt + n_ckpt - 1) * 2);
-    s_last_w = __builtin_amdgcn_readfirstlane((int)e2.x);
-    s_last_w = s_last_w < 0 ? 0 : (s_last_w > s_tot - 1 ? s_tot - 1 : s_last_w);
-    nlt_lo = e2.y;
-  }
-  int s_begin = s_tot - 1;
-  if (PLAIN) {  // the PLAIN instantiation is only launched without early termination
-    __syncthreads();
-  } else {
-    if (lane == 0) ts[0] = (float)s_last_w;
-    __syncthreads();
-    s_begin = 0;
-#pragma unroll
-    for (int v = 0; v < WAVES; ++v) {
-      const int sv = (int)wave0[v * B::PER_WAVE + B::TS];
-      s_begin = sv > s_begin ? sv : s_begin;
-    }
-    __syncthreads();  // ts[] is reused by the sample loop
-  }
-  const int s_lo = seg_on ? seg * seg_len : 0;
-  if (seg_on) s_begin = (s_lo + seg_len - 1 < s_tot - 1) ? s_lo + seg_len - 1 : s_tot - 1;
-
-  float denc[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) denc[q] = 0.0f;
-  float gfeat[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-    gfeat[c] = (valid && a.grad_feature && c < a.color_chn) ? a.grad_feature[rid * a.color_chn + c] : 0.0f;
-  const float g_len = (valid && a.grad_ray_length) ? a.grad_ray_length[rid] : 0.0f;
-  const float g_nlt = epilogue_grad_nlt(a, rid, valid, a.neg_log_t[rid],
-                                        (valid && a.grad_neg_log_t) ? a.grad_neg_log_t[rid] : 0.0f, gfeat, 4);
-
-  const bool want_params = a.grad_mlp_params != nullptr;
-  const float delta0 = (a.march.num_samples > 1) ? (ray.far_t - ray.near_t) / (float)(a.march.num_samples - 1) : 1.0f;
-
-  // dW quadrant of this wave: rows 16*mi.., columns 16*ni..; MFMA lane (m16, ka)
-  const int mi = wave >> 1, ni = wave & 1;
-  const int m16 = lane & 15, ka = lane >> 4;
-  const int a_off = B::XT + (16 * mi + pi16(m16)) * T_LD + 8 * ka;
-  const int b_off = B::YT + (16 * ni + pi16(m16)) * T_LD + 8 * ka;
-  // trunk layer 1 has only C input rows: with C == 16 its two quadrants are split over the rays instead
-  const int a_off_t1 = (C == 16) ? B::XT + pi16(m16) * T_LD + 8 * ka : a_off;
-  const int t1_v0 = (C == 16) ? 2 * mi : 0, t1_v1 = (C == 16) ? 2 * mi + 2 : WAVES;
-  f32x4 dq_t1 = {0, 0, 0, 0}, dq_t2 = {0, 0, 0, 0}, dq_o1 = {0, 0, 0, 0}, dq_c1 = {0, 0, 0, 0};
-  float db_t1 = 0.0f, db_t2 = 0.0f, db_o1 = 0.0f, db_c1 = 0.0f;
-  // output layers of the heads: lane (f = l&31, half h) owns feature f, partial over 16 rays
-  float dwo2 = 0.0f, dwc2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  float dbo2 = 0.0f, dbc2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-
-  const bool gg = a.grad_grid_list[0] != nullptr;  // the host fills every entry or none
-  const bool ggc = tg && a.grad_color_grid_list[0] != nullptr;
-
-#ifdef LP_PHASE_TIMING
-  unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long t_last = __builtin_readcyclecounter();
-  int ph_cur = 9;
-#endif
-  float nlt = a.neg_log_t[rid];
-  float suffix = 0.0f, p_next = 0.0f;
-  if (seg_on) {  // start of a segment: -log T and the sums behind its last sample, from the forward's state records
-    const float4* pj = reinterpret_cast<const float4*>(a.seg_prefix + (rid * n_rec + s_begin / LP_SEG_LEN) * 8);
-    const float4* pt = reinterpret_cast<const float4*>(a.seg_prefix + (rid * n_rec + n_rec - 1) * 8);
-    const float4 j0 = pj[0], j1 = pj[1], t0 = pt[0];
-    nlt = j1.y;
-    nlt_lo = j1.z;
-    if (seg < n_seg - 1) {
-      float rest = g_len * (t0.x - j0.x);
-      rest = fmaf(gfeat[0], t0.y - j0.y, rest);
-      rest = fmaf(gfeat[1], t0.z - j0.z, rest);
-      rest = fmaf(gfeat[2], t0.w - j0.w, rest);
-      rest = fmaf(gfeat[3], pt[1].x - j1.x, rest);
-      suffix = -rest;
-    }
-  }
-  Sample<C> nx;
-  fetch_sample<C, GM, false, PLAIN>(a, lds, ray, s_begin, h, nx);
-  for (int s = s_begin; s >= s_lo; --s) {
-    const bool on = PLAIN || s <= s_last_w;  // wave-uniform; false only for samples a sibling wave still marches
-    const float depth = nx.depth, occ = nx.occ, x = nx.x, y = nx.y, z = nx.z;
-    float x0[C / 2];
-#pragma unroll
-    for (int q = 0; q < C / 2; ++q) x0[q] = nx.x0[q];
-    const int zo = opaque_zero();
-    const float* ldz = lds + zo;
-    const float* wl = lds + (4 * h) * W_LD + r + zo;   // forward operand base of this lane
-    const float* wt = lds + r * W_LD + 4 * h + zo;     // dX operand base of this lane
-
-    // ---------------- forward recompute ----------------
-    LP_MARK("fwd");
-    float h1[16], e[16], ho[16], hc[16];
-    float xc[C / 2];  // two-grid decoder: sampled colour-grid feature of this sample
-    if (tg) gather_list<C, true>(a.color_grid, a.march.mask_out_of_bounds != 0, ray, x, y, z, h, xc);
-    f32x16 acc;
-    if (t1) {
-      acc = layer<C / 2>(wl + M::WT1, x0, load_bias(lds, 0, h, zo));
-#pragma unroll
-      for (int q = 0; q < 16; ++q) h1[q] = relu_f(acc[q]);
-    } else {  // the opacity head reads relu(sampled feature)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) h1[q] = (q < C / 2) ? relu_f(x0[q < C / 2 ? q : 0]) : 0.0f;
-    }
-    if (t2) {
-      acc = layer<16>(wl + M::WT2, h1, load_bias(lds, 1, h, zo));
-#pragma unroll
-      for (int q = 0; q < 16; ++q) e[q] = relu_f(acc[q]);
-    } else {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) e[q] = h1[q];
-    }
-    if (oh) {
-      acc = layer<16>(wl + M::WO1, e, load_bias(lds, 2, h, zo));
-#pragma unroll
-      for (int q = 0; q < 16; ++q) ho[q] = relu_f(acc[q]);
-    } else {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) ho[q] = e[q];
-    }
-    {
-      float ein[16];
-      if (tg) {  // the colour head reads relu(sampled colour feature) + encoding
-        float ec[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) ec[q] = (q < C / 2) ? relu_f(xc[q < C / 2 ? q : 0]) : 0.0f;
-        add_encoding(enct + zo + r * T_LD + 4 * h, ec, ein);
-      } else {
-        add_encoding(enct + zo + r * T_LD + 4 * h, e, ein);
-      }
-      if (ch) {
-        acc = layer<16>(wl + M::WC1, ein, load_bias(lds, 3, h, zo));
-#pragma unroll
-        for (int q = 0; q < 16; ++q) hc[q] = relu_f(acc[q]);
-      } else {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) hc[q] = ein[q];
-      }
-    }
-    const Heads hd = heads_forward<NC>(lds, h, ho, hc, zo);
-    LP_SCHED_FENCE();
-    // ho / hc go to the (wave-private) tiles now: their registers turn into d ho / d hc below
-    if (want_params) {
-      tile_store_fm(xt, r, h, ho);
-      tile_store_fm(yt, r, h, hc);
-    }
-    LP_SCHED_FENCE();
-
-    // ---------------- compositing, backward ----------------
-    LP_MARK("compositing");
-    const float depth_prev =
-        PLAIN ? ray.near_t + lin01((s > 0) ? s - 1 : 0, a.march.num_samples) * (ray.far_t - ray.near_t)
-              : sample_depth_tab((s > 0) ? s - 1 : 0, a.march, ray.near_t, ray.far_t, lds + M::INF);
-    const float delta = (s == 0) ? delta0 : depth - depth_prev;
-    float raw = hd.raw_o;
-    if (!PLAIN && a.noise_sigma > 0.0f)
-      raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
-    const float opacity = a.gain * softplus_f(raw) * occ;
-    if (on && a.neg_log_t_ckpt) {
-      const int ck = PLAIN ? ((((s + 1) % LP_NLT_CKPT) == 0 || s == s_tot - 1) ? s / LP_NLT_CKPT : -1)
-                           : ckpt_index(s, a.march);
-      if (ck >= 0) {
-        const float2 c2 = *reinterpret_cast<const float2*>(a.neg_log_t_ckpt + (rid * n_ckpt + ck) * 2);
-        nlt = c2.x;
-        nlt_lo = c2.y;
-      }
-    }
-    const float t_i = __expf(-nlt);
-    nlt_add(nlt, nlt_lo, on ? -(opacity * delta) : 0.0f);
-    if (!(nlt > 0.0f)) { nlt = 0.0f; nlt_lo = 0.0f; }
-    const float t_im1 = __expf(-nlt);
-    const float w = t_im1 - t_i;
-    float sg[4];
-    float p_i = g_len * depth;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      sg[c] = (c < NC) ? sigmoid_f(hd.raw_c[c]) : 0.0f;
-      if (c < NC) p_i = fmaf(gfeat[c], sg[c] * occ, p_i);
-    }
-    suffix = on ? fmaf(t_i, p_i - p_next, suffix) : suffix;
-    p_next = on ? p_i : p_next;
-    const float d_a = suffix + g_nlt;
-    const bool contrib = valid && on;
-    const float dro = contrib ? d_a * delta * a.gain * occ * d_softplus_f(raw) : 0.0f;
-    float drc[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) drc[c] = (c < NC && contrib) ? w * gfeat[c] * occ * sg[c] * (1.0f - sg[c]) : 0.0f;
-
-    // ---------------- output layers of the heads (VALU) ----------------
-    LP_MARK("heads_bwd");
-    // d ho is formed where it is needed (opacity hidden layer): keep only the ReLU mask of ho
-    unsigned ho_mask = 0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) ho_mask |= (ho[q] > 0.0f) ? (1u << q) : 0u;
-    if (!oh) ho_mask = 0xFFFFu;  // no hidden layer: ho is the trunk output, its ReLU mask is applied with d e
-    float dhc[16];
-    {
-      // a fresh opaque offset: the colour output weights are re-read here instead of being kept in
-      // 64 registers since the forward heads
-      const float* wc2 = lds + M::WC2 + 16 * h + opaque_zero();
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int q = 4 * j + i;
-          const float4 wc = *reinterpret_cast<const float4*>(wc2 + (8 * j + i) * 4);
-          float v = drc[0] * wc.x;
-          v = fmaf(drc[1], wc.y, v);
-          v = fmaf(drc[2], wc.z, v);
-          if (NC > 3) v = fmaf(drc[3], wc.w, v);
-          dhc[q] = (!ch || hc[q] > 0.0f) ? v : 0.0f;
-        }
-        LP_SCHED_FENCE();
-      }
-    }
-    LP_SCHED_FENCE();
-    if (h == 0) {  // per-ray scalars: count each ray once
-      dbo2 += dro;
-#pragma unroll
-      for (int c = 0; c < NC; ++c) dbc2[c] += drc[c];
-    }
-#ifndef X_NOHEADDW
-    if (want_params) {
-      // dW of the two output layers: dW[f] += sum_ray h[ray][f] * d_raw[ray] (wave-private tiles)
-      if (h == 0) {
-        ts[r] = dro;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) ts[(1 + c) * 32 + r] = drc[c];
-      }
-      const float* xf = xt + r * T_LD + 16 * h;  // lane (f = r, half h): rays 16h .. 16h+15 of feature f
-      const float* yf = yt + r * T_LD + 16 * h;
-      const float* tf = ts + 16 * h;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float4 hov = *reinterpret_cast<const float4*>(xf + 4 * i);
-        const float4 hcv = *reinterpret_cast<const float4*>(yf + 4 * i);
-        const float4 d0 = *reinterpret_cast<const float4*>(tf + 4 * i);
-        dwo2 = fmaf(hov.x, d0.x, dwo2); dwo2 = fmaf(hov.y, d0.y, dwo2);
-        dwo2 = fmaf(hov.z, d0.z, dwo2); dwo2 = fmaf(hov.w, d0.w, dwo2);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          const float4 dc = *reinterpret_cast<const float4*>(tf + (1 + c) * 32 + 4 * i);
-          dwc2[c] = fmaf(hcv.x, dc.x, dwc2[c]); dwc2[c] = fmaf(hcv.y, dc.y, dwc2[c]);
-          dwc2[c] = fmaf(hcv.z, dc.z, dwc2[c]); dwc2[c] = fmaf(hcv.w, dc.w, dwc2[c]);
-        }
-        LP_SCHED_FENCE();  // keeps the 28 b128 reads from being hoisted together (112 registers)
-      }
-    }
-#endif
-    LP_SCHED_FENCE();
-
-    // Every layer below: publish the X / dY tiles, run the dX chain (MFMA) while the LDS writes land
-    // and the other waves arrive, barrier, dW quadrant (LDS reads + MFMA), barrier.
-    // ---------------- colour hidden layer ----------------
-    LP_MARK("c1");
-    // the four layer phases are coupled to the sibling waves by two barriers each: run them at raised priority
-    // so that the co-resident wave of the other workgroup (gathering / scattering) does not stretch them for
-    // all four waves (-2.4% kernel time)
-#ifndef LP_NO_PRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
-    if (ch) {
-      if (want_params) {
-        float ein[16];
-        if (tg) {
-          float ec[16];
-#pragma unroll
-          for (int q = 0; q < 16; ++q) ec[q] = (q < C / 2) ? relu_f(xc[q < C / 2 ? q : 0]) : 0.0f;
-          add_encoding(enct + zo + r * T_LD + 4 * h, ec, ein);
-        } else {
-          add_encoding(enct + zo + r * T_LD + 4 * h, e, ein);
-        }
-        tile_store_fm(xt, r, h, ein);
-        tile_store_fm(yt, r, h, dhc);
-      }
-      acc = (f32x16){0};
-      acc = layer_t(wt + M::WC1, dhc, acc);
-      if (want_params) {
-        lds_barrier();
-        dq_c1 = dw_quadrant(wave0, a_off, b_off, 0, WAVES, dq_c1, db_c1);
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[q] = dhc[q];  // the colour head is its output layer only
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) denc[q] += acc[q];
-    // d ho from the ReLU mask of ho
-    float dho[16];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float4 wo = *reinterpret_cast<const float4*>(ldz + M::WO2 + 8 * j + 4 * h);
-      dho[4 * j + 0] = (ho_mask & (1u << (4 * j + 0))) ? dro * wo.x : 0.0f;
-      dho[4 * j + 1] = (ho_mask & (1u << (4 * j + 1))) ? dro * wo.y : 0.0f;
-      dho[4 * j + 2] = (ho_mask & (1u << (4 * j + 2))) ? dro * wo.z : 0.0f;
-      dho[4 * j + 3] = (ho_mask & (1u << (4 * j + 3))) ? dro * wo.w : 0.0f;
-    }
-    if (want_params && ch) lds_barrier();
-    LP_SCHED_FENCE();
-    if (tg) {
-      // two-grid decoder: acc is d(relu(colour feature) + encoding); its scatter into the colour grid-list
-      // happens here, while the wave's tiles are idle between two layer phases; the opacity branch then
-      // starts from zero
-      if (ggc && !(mp.dbg & 2)) {
-#pragma unroll
-        for (int q = 0; q < C / 2; ++q) xt[featq(q, h) * DX_LD + r] = (xc[q] > 0.0f) ? acc[q] : 0.0f;
-        const bool live_c = valid && on && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
-#pragma unroll 1
-        for (int g = 0; g < a.color_grid.n_grids; ++g)
-          scatter_grid<C>(a.grad_color_grid_list[g], a.color_grid.grids[g], ray.b, x, y, z, live_c, lane, xt, yt, mp.dbg);
-      }
-      acc = (f32x16){0};
-    }
-    // ---------------- opacity hidden layer ----------------
-    LP_MARK("o1");
-    if (oh) {
-      if (want_params) {
-        tile_store_fm(xt, r, h, e);
-        tile_store_fm(yt, r, h, dho);
-      }
-      acc = layer_t(wt + M::WO1, dho, acc);
-      if (want_params) {
-        lds_barrier();
-        dq_o1 = dw_quadrant(wave0, a_off, b_off, 0, WAVES, dq_o1, db_o1);
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[q] += dho[q];  // the opacity head is its output layer only
-    }
-    float de[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) de[q] = (e[q] > 0.0f) ? acc[q] : 0.0f;
-    if (want_params && oh) lds_barrier();
-    LP_SCHED_FENCE();
-    // ---------------- trunk layer 2 ----------------
-    LP_MARK("t2");
-    float dh1[16];
-    if (t2) {
-      if (want_params) {
-        tile_store_fm(xt, r, h, h1);
-        tile_store_fm(yt, r, h, de);
-      }
-      acc = (f32x16){0};
-      acc = layer_t(wt + M::WT2, de, acc);
-      if (want_params) {
-        lds_barrier();
-        dq_t2 = dw_quadrant(wave0, a_off, b_off, 0, WAVES, dq_t2, db_t2);
-      }
-#pragma unroll
-      for (int q = 0; q < 16; ++q) dh1[q] = (h1[q] > 0.0f) ? acc[q] : 0.0f;
-      if (want_params) lds_barrier();
-    } else {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) dh1[q] = de[q];  // e is h1: its ReLU mask is already in d e
-    }
-    LP_SCHED_FENCE();
-    // ---------------- trunk layer 1 ----------------
-    LP_MARK("t1");
-    if (t1) {
-      if (want_params) {
-#pragma unroll
-        for (int q = 0; q < C / 2; ++q) xt[featq(q, h) * T_LD + r] = x0[q];
-        tile_store_fm(yt, r, h, dh1);
-      }
-      if (gg) {
-        acc = (f32x16){0};
-        acc = layer_t(wt + M::WT1, dh1, acc);  // rows >= C are zero weights
-      }
-      if (want_params) {
-        lds_barrier();
-        dq_t1 = dw_quadrant(wave0, a_off_t1, b_off, t1_v0, t1_v1, dq_t1, db_t1);
-        lds_barrier();
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[q] = dh1[q];  // no trunk: d e is the gradient of the sampled feature
-    }
-    // dx0 -> LDS right away ([channel][ray]; the X tile is free after the barrier): frees the accumulator
-    if (gg) {
-#pragma unroll
-      for (int q = 0; q < C / 2; ++q) xt[featq(q, h) * DX_LD + r] = acc[q];
-    }
-    LP_SCHED_FENCE();
-    // ---------------- next (nearer) sample + grid gradient ----------------
-    LP_MARK("fetch");
-    __builtin_amdgcn_s_setprio(0);
-    const bool live = valid && on && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));
-    // gather with one plane's loads in flight at a time (registers), consumed before the atomics
-    // below are issued: no wait ever has to drain the atomics
-    if (s > s_lo) fetch_sample<C, GM, true, PLAIN>(a, lds, ray, s - 1, h, nx);
-    LP_SCHED_FENCE();
-    LP_MARK("scatter");
-    if (gg && !(mp.dbg & 2)) {
-      const int ng = (GM == GM_TRIPLANE) ? 3 : (GM == GM_VOXEL) ? 1 : a.grid.n_grids;
-#pragma unroll 1
-      for (int g = 0; g < ng; ++g) scatter_grid<C, GM>(a.grad_grid_list[g], a.grid.grids[g], ray.b, x, y, z, live, lane, xt, yt, mp.dbg);
-    }
-  }
-
-  // ---------------- epilogue ----------------
-  LP_MARK("epilogue");
-#ifdef LP_PHASE_TIMING
-  if (lane == 0) {
-    for (int i = 0; i < 10; ++i) atomicAdd(&g_phase[i], ph[i]);
-  }
-#endif
-  if (valid && a.grad_encoding && !seg_on) {
-    float4* dst = reinterpret_cast<float4*>(a.grad_encoding + ray_id * hin + 4 * h);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (!FLEX || 8 * j + 4 * h < hin)
-        dst[2 * j] = make_float4(denc[4 * j], denc[4 * j + 1], denc[4 * j + 2], denc[4 * j + 3]);
-    }
-  } else if (valid && a.grad_encoding) {  // the segments of a ray add up
-    float* dst = a.grad_encoding + ray_id * hin + 4 * h;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (8 * j + 4 * h < hin) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) atomic_add_f32(dst + 8 * j + i, denc[4 * j + i]);
-      }
-    }
-  }
-  if (want_params) {
-    float* G = a.grad_mlp_params;
-    const int j = lane & 31;
-    // head output layers: lane (f, h) holds the partial over the 16 rays of its half
-    if (!FLEX || j < (oh ? hid : hin)) atomic_add_f32(G + mp.w_o2 + j, dwo2);
-    if (!FLEX || j < (ch ? hid : hin)) {
-      for (int c = 0; c < a.color_chn; ++c) atomic_add_f32(G + mp.w_c2 + (int64_t)j * mp.ldc2 + c, dwc2[c]);
-    }
-    float v = dbo2, c0 = dbc2[0], c1 = dbc2[1], c2 = dbc2[2], c3 = dbc2[3];
-#pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) {
-      v += __shfl_xor(v, m);
-      c0 += __shfl_xor(c0, m);
-      c1 += __shfl_xor(c1, m);
-      c2 += __shfl_xor(c2, m);
-      c3 += __shfl_xor(c3, m);
-    }
-    if (lane == 0) {
-      atomic_add_f32(G + mp.b_o2, v);
-      const float cv[4] = {c0, c1, c2, c3};
-      for (int c = 0; c < a.color_chn; ++c) atomic_add_f32(G + mp.b_c2 + c, cv[c]);
-    }
-    // dW quadrants: register i of lane (n16 = l&15, ka = l>>4) is dW[m0 + pi(4ka+i)][n0 + pi(n16)]
-    // (matrices are [in, hid] row-major; with hid == 16 the padded rows / columns are dropped)
-    const int col = 16 * ni + pi16(m16);
-    const bool col_ok = !FLEX || col < hid;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int prow = pi16(4 * ka + i);
-      const int row = 16 * mi + prow;
-      if (col_ok && (!FLEX || row < hid)) {
-        if (t2) atomic_add_f32(G + mp.w_t2 + row * hid + col, dq_t2[i]);
-      }
-      if (col_ok && (!FLEX || row < hin)) {  // first layers of the heads: [hin, hid]
-        if (oh) atomic_add_f32(G + mp.w_o1 + row * hid + col, dq_o1[i]);
-        if (ch) atomic_add_f32(G + mp.w_c1 + row * hid + col, dq_c1[i]);
-      }
-      const int row1 = (C == 16) ? prow : row;
-      if (t1 && col_ok && row1 < C) atomic_add_f32(G + mp.w_t1 + row1 * hid + col, dq_t1[i]);
-    }
-    // bias gradients: partial over the rays 8ka.. of every source wave -> sum over ka
-    db_t1 += __shfl_xor(db_t1, 16); db_t1 += __shfl_xor(db_t1, 32);
-    db_t2 += __shfl_xor(db_t2, 16); db_t2 += __shfl_xor(db_t2, 32);
-    db_o1 += __shfl_xor(db_o1, 16); db_o1 += __shfl_xor(db_o1, 32);
-    db_c1 += __shfl_xor(db_c1, 16); db_c1 += __shfl_xor(db_c1, 32);
-    if (ka == 0 && col_ok) {
-      if (mi == 0) {  // both quadrant rows see the same dY columns: count them once
-        if (t2) atomic_add_f32(G + mp.b_t2 + col, db_t2);
-        if (oh) atomic_add_f32(G + mp.b_o1 + col, db_o1);
-        if (ch) atomic_add_f32(G + mp.b_c1 + col, db_c1);
-      }
-      if (t1 && (C == 16 || mi == 0)) atomic_add_f32(G + mp.b_t1 + col, db_t1);
-    }
-  }
 }
 
 // =======================================================================================
@@ -1168,37 +613,6 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
 // host side
 // ---------------------------------------------------------------------------------------
 
-// LP_SEG_LEN-sample blocks per segment of a segment-parallel launch: as many segments as keep it within one round of
-// resident workgroups (every workgroup stages the weights and flushes its dW once)
-static int seg_blocks_for(const LpRendererArgs& a, unsigned ray_blocks) {
-  static const int forced = getenv("LP_SEG_BLOCKS") ? atoi(getenv("LP_SEG_BLOCKS")) : 0;
-  const int n_rec = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
-  int m = 1;
-  while (m < n_rec && (uint64_t)ray_blocks * ((n_rec + m - 1) / m) > 512u) ++m;
-  if (forced > 0) m = forced < n_rec ? forced : n_rec;
-  return m;
-}
-
-template <int C, int GM, bool PLAIN, bool FLEX, bool TG = false, int NC = 4>
-static int launch_bwd2p(const LpRendererArgs& a_, const MfmaParams& mp_, hipStream_t stream) {
-  LpRendererArgs a = a_;
-  MfmaParams mp = mp_;
-  const size_t lds = (mp.dbg & 16) ? 100 * 1024 : LdsB::END * sizeof(float);  // dbg 16: one workgroup per CU
-  const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_mfma2<C, GM, PLAIN, FLEX, TG, NC>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-  unsigned nb = (unsigned)((a.rays.n_rays + WAVES * RAYS_PER_WAVE - 1) / (WAVES * RAYS_PER_WAVE));
-  if (FLEX && a.seg_prefix) {  // small batch of a flex / two-grid shape: one workgroup per (128 rays, segment)
-    const int n_rec = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
-    mp.seg_blocks = seg_blocks_for(a, nb);
-    nb *= (unsigned)((n_rec + mp.seg_blocks - 1) / mp.seg_blocks);
-  } else {
-    a.seg_prefix = nullptr;  // (the default shape reaches this kernel only through LP_MFMA_F32*, without segments)
-  }
-  hipLaunchKernelGGL((renderer_bwd_mfma2<C, GM, PLAIN, FLEX, TG, NC>), dim3(nb), dim3(256), lds, stream, a, mp);
-  return LP_OK;
-}
-
 template <int C, int GM, bool PLAIN, int NC, int NW, bool SEG = false>
 static int launch_bwd3w(const LpRendererArgs& a, const MfmaParams& mp_, hipStream_t stream) {
   MfmaParams mp = mp_;
@@ -1243,34 +657,18 @@ template <int C, int GM>
 static int launch_bwd2(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
   const bool plain = !(a.noise_sigma > 0.0f) && !a.march.contract_coords && !a.scaffold && a.march.num_samples_inf == 0 &&
                      !(a.stop_neg_log_t > 0.0f);
-  const bool flex = !(mp.hid == HID && mp.t1 && mp.t2 && mp.oh && mp.ch && !mp.tg);
-  // default shape: recompute + dX chains as bf16x3 on the bf16 matrix cores (renderer_bwd_bf3).  Measured on MI355X
-  // (C = 16): cfg 2 backward 2.57 -> 2.31 ms, 1080p x S=128 73.6 -> 65.2 ms.  LP_MFMA_F32 / LP_MFMA_F32_BWD select the
-  // fp32-MFMA kernel.  C = 32: the 3.4 KB larger image leaves no room for the cb records, so cb stays in registers; with
-  // the build's default flags that kernel spilled 77 registers and measured 165 ms against the fp32-MFMA kernel's 164 ms at
-  // cfg 4; compiled spill-free (build.py, FILE_FLAGS) it measures 133 ms against 160 ms.  LP_BF3_C32=0: fp32-MFMA kernel.
+  // recompute + dX chains as bf16x3 on the bf16 matrix cores (renderer_bwd_bf3).  Measured on MI355X against the fp32-MFMA
+  // kernel this file held until round 4 (C = 16): cfg 2 backward 2.57 -> 2.31 ms, 1080p x S=128 73.6 -> 65.2 ms; C = 32 (the 3.4 KB
+  // larger image leaves no room for the cb records, so cb stays in registers; compiled spill-free: build.py FILE_FLAGS): cfg 4
+  // 160 -> 133 ms.
 #ifdef LP_DEV_ONE  // development aid: compile ONE instantiation (seconds instead of minutes) for register / ISA studies,
                    // e.g. scripts/kernel_resources.py lp_renderer_mfma_bwd.hip -DLP_DEV_ONE
   return launch_bwd3w<C, GM, true, 3, 4>(a, mp, stream);
 #else
-  static const bool bf3_bwd = getenv("LP_MFMA_F32") == nullptr && getenv("LP_MFMA_F32_BWD") == nullptr;
-  static const bool bf3_c32 = getenv("LP_BF3_C32") == nullptr || atoi(getenv("LP_BF3_C32")) != 0;
-  if ((C == 16 || bf3_c32) && !flex && !mp.tg && bf3_bwd) {
-    if (a.color_chn <= 3)
-      return plain ? launch_bwd3<C, GM, true, 3>(a, mp, stream) : launch_bwd3<C, GM, false, 3>(a, mp, stream);
-    return plain ? launch_bwd3<C, GM, true, 4>(a, mp, stream) : launch_bwd3<C, GM, false, 4>(a, mp, stream);
-  }
-  if (mp.tg)  // two-grid decoder
-    return plain ? launch_bwd2p<C, GM_GENERIC, true, true, true>(a, mp, stream)
-                 : launch_bwd2p<C, GM_GENERIC, false, true, true>(a, mp, stream);
-  if (flex)  // the non-default shapes share the run-time-loop grid-list variant (fewer instantiations)
-    return plain ? launch_bwd2p<C, GM_GENERIC, true, true>(a, mp, stream)
-                 : launch_bwd2p<C, GM_GENERIC, false, true>(a, mp, stream);
   static const bool no_nc3 = getenv("LP_MFMA_NO_NC3") != nullptr;  // A/B knob
   if (a.color_chn <= 3 && !no_nc3)  // RGB: the padding column of the colour path is compiled out
-    return plain ? launch_bwd2p<C, GM, true, false, false, 3>(a, mp, stream)
-                 : launch_bwd2p<C, GM, false, false, false, 3>(a, mp, stream);
-  return plain ? launch_bwd2p<C, GM, true, false>(a, mp, stream) : launch_bwd2p<C, GM, false, false>(a, mp, stream);
+    return plain ? launch_bwd3<C, GM, true, 3>(a, mp, stream) : launch_bwd3<C, GM, false, 3>(a, mp, stream);
+  return plain ? launch_bwd3<C, GM, true, 4>(a, mp, stream) : launch_bwd3<C, GM, false, 4>(a, mp, stream);
 #endif
 }
 

@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(256, 1) renderer_bwd_mfma_w(const LpRendererAr
   load_encoding_w<NB>(a, rid, h, enc);
 #pragma unroll
   for (int q = 0; q < 16 * NB; ++q) denc[q] = 0.0f;
-  // closing pair of the checkpoint list (see renderer_bwd_mfma2): workgroup-uniform first sample of the loop
+  // closing pair of the checkpoint list (see renderer_bwd_bf3, lp_renderer_mfma_bwd.hip): workgroup-uniform first sample of the loop
   const int s_tot = a.march.num_samples + a.march.num_samples_inf;
   const int n_ckpt = ckpt_count(a.march);
   int s_last_w = s_tot - 1;

@@ -15,8 +15,9 @@ n = int(os.environ.get("NPIX", "256")); S = int(os.environ.get("S", "128"))
 what = sys.argv[1] if len(sys.argv) > 1 else "renderer"
 
 
-def t(f, k=3):
-    f(); torch.cuda.synchronize()
+def t(f, k=10):
+    for _ in range(3): f()  # (round 3 timed 3 reps after ONE warm-up call: the first shape of a process read 15-30 % long)
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(k): f()
@@ -63,6 +64,10 @@ elif what == "renderer":
     shapes = [(2, 2, 2, 32, 16, 64, False), (4, 4, 4, 32, 16, 64, False), (4, 2, 4, 32, 16, 64, False), (2, 4, 2, 32, 16, 64, False),
               (3, 3, 3, 16, 16, 64, False), (0, 4, 4, 32, 16, 64, True), (0, 2, 2, 32, 16, 64, True), (4, 4, 4, 32, 32, 128, False),
               (2, 2, 2, 64, 32, 128, False), (1, 1, 1, 16, 16, 64, False)]
+    if os.environ.get("SHAPESET") == "shallow":  # the shapes the shallow two-waves-per-SIMD looped backward covers (round 4)
+        shapes = [(2, 2, 2, 32, 16, 64, False), (2, 2, 2, 32, 32, 128, False), (1, 1, 1, 16, 16, 64, False), (2, 1, 1, 32, 16, 64, False),
+                  (1, 1, 2, 32, 32, 128, False), (1, 2, 1, 16, 32, 128, False), (2, 1, 2, 32, 32, 128, False), (0, 2, 2, 32, 16, 64, True),
+                  (0, 2, 2, 32, 32, 128, True), (0, 1, 1, 16, 16, 64, True), (0, 2, 1, 32, 32, 128, True)]
     only = os.environ.get("SHAPES")  # e.g. SHAPES="4/2/4,4/4/4": only these layer triples
     for (nt, no, nc, H, C, G, sep) in shapes:
         if only and f"{nt}/{no}/{nc}" not in only.split(","):

@@ -546,15 +546,16 @@ np.savez({path!r}, ray_length=out[0].detach().cpu().numpy(), neg_log_t=out[1].de
 
 
 @pytest.mark.parametrize("grid", ["triplane24_c16", "voxel18_c16_b2", "voxel20_c32"])
-@pytest.mark.parametrize("variant", ["bf3_occ2", "bf3_occ3", "bf3_occ4", "f32_0", "f32_3", "f32_4"])
+@pytest.mark.parametrize("variant", ["bf3_occ2", "bf3_occ3", "bf3_occ4"])
 def test_forward_variants_agree(grid, variant, tmp_path):
     """Every forward instantiation the launcher can pick for the default decoder shape gives the oracle's outputs: the
     bf16x3 kernel at 2 / 3 / 4 waves per SIMD (LP_BF3_OCC; 3 is what batches above 65 536 rays select, i.e. every 1080p
-    batch) and the fp32-MFMA kernels behind LP_MFMA_F32 (LP_MFMA_FWD_VARIANT: 0 = software-pipelined, 3 / 4 = plain kernel
-    at 3 / 4 waves per SIMD).  The knobs are read once per process: child processes."""
+    batch).  (The fp32-MFMA forward variants this test also covered were retired in round 4.)  The knob is read once per
+    process: child processes."""
     path = str(tmp_path / f"v{variant}.npz")
     kind, num = variant.rsplit("_", 1)
-    extra = {"LP_BF3_OCC": num[-1]} if kind == "bf3" else {"LP_MFMA_F32": "1", "LP_MFMA_FWD_VARIANT": num}
+    assert kind == "bf3"
+    extra = {"LP_BF3_OCC": num[-1]}
     env = dict(os.environ, **extra)
     code = _VARIANT_CHILD.format(root=ROOT, grid=grid, mask=True, path=path)
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
@@ -597,11 +598,14 @@ sys.exit(pytest.main([{root!r} + "/tests/test_gpu_parity.py", "-m", "gpu", "-q",
 """
 
 
-@pytest.mark.parametrize("env", [{"LP_MFMA_F32": "1"}, {"LP_MFMA_F32_BWD": "1"}], ids=["fp32_mfma_kernels", "fp32_mfma_backward_only"])
+@pytest.mark.parametrize("env", [{"LP_BF3_NW": "8"}, {"LP_LOOP_NO_SHALLOW": "1"}], ids=["bf3_backward_eight_wave_workgroups", "looped_deep_instantiations"])
 def test_golden_suite_on_the_other_kernel_families(env):
-    """The default decoder shape runs the bf16x3 forward and (C = 16) the bf16x3 backward; this runs the golden /
-    cfg-2-sized / early-termination Renderer tests once more on the fp32-MFMA kernels they replace (still what the flex / two-grid shapes, LP_BF3_C32=0
-    and LP_MFMA_F32 select), so that every kernel that can be launched is held to the oracle."""
+    """Kernels the default selection does not launch on these cases but a user can reach: the eight-wave-workgroup form of the
+    tuned bf16x3 backward (what more than 64 beyond-far samples select; LP_BF3_NW=8 forces it) and the deep one-wave-per-SIMD
+    instantiations of the layer-looped backward on the shallow decoders (LP_LOOP_NO_SHALLOW=1; by default those run the
+    two-waves-per-SIMD instantiations of lp_renderer_loop_shallow.hip).  The golden / cfg-2-sized / early-termination Renderer
+    tests once more, so that every kernel that can be launched is held to the oracle.  (Until round 3 this test ran the
+    fp32-MFMA generation of the Renderer kernels, retired in round 4.)"""
     r = subprocess.run([sys.executable, "-c", _GOLDEN_CHILD.format(root=ROOT)], cwd=ROOT, env=dict(os.environ, **env),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
