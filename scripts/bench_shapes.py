@@ -104,6 +104,8 @@ elif what == "renderer":
 else:
     #        layers, feat, hidden, out
     shapes = [(2, 32, 32, 32), (3, 32, 64, 32), (4, 64, 64, 32), (4, 32, 64, 32), (3, 64, 64, 32), (3, 32, 32, 32), (4, 16, 16, 16)]
+    if os.environ.get("SHAPESET") == "shallow":  # two-layer MLPs: the fp32-MFMA family 2 vs the looped family's two-waves-per-SIMD backward
+        shapes = [(2, 32, 32, 32), (2, 16, 16, 16), (2, 32, 16, 16), (2, 16, 32, 32)]
     Sx = int(os.environ.get("S", "256"))
     for (nl, E, H, CO) in shapes:
         gen = torch.Generator().manual_seed(0)
