@@ -261,15 +261,10 @@ int lp_renderer_backward_segments(const LpRendererArgs* args) {
   return fam == 1 ? renderer_mfma_segments(*args) : fam == 2 ? renderer_mfma_wide_segments(*args) : fam == 3 ? renderer_loop_segments(*args) : 1;
 }
 
-// MLP-Splatter: 2 = [E,32,Cout] fp32-MFMA family, 3 = layer-looped bf16x3 family (2-4 layers, widths 16 / 32 / 64), 0 = generic.
-// LP_LOOP=1 (developer knob): the layer-looped family wherever it applies.
-static int splatter_mlp_family(const LpSplatterArgs& a) {
-  static const bool force_loop = getenv("LP_LOOP") != nullptr && atoi(getenv("LP_LOOP")) != 0;
-  const bool loop_ok = splatter_mlp_loop_supported(a);
-  if (force_loop && loop_ok) return 3;
-  if (splatter_mlp_mfma_supported(a)) return 2;
-  return loop_ok ? 3 : 0;
-}
+// MLP-Splatter: 3 = layer-looped bf16x3 family (2-4 layers, widths 16 / 32 / 64), 0 = generic.  (2 was the two-layer fp32-MFMA
+// family [E,32,Cout] of rounds 1-3, retired in round 4: the looped family's two-waves-per-SIMD backward measures within 1 % of
+// it or faster on every shape it covered -- profiles/r04_loop_shallow_ab.txt.)
+static int splatter_mlp_family(const LpSplatterArgs& a) { return splatter_mlp_loop_supported(a) ? 3 : 0; }
 
 int lp_splatter_kernel_family(const LpSplatterArgs* args) {
   if (!args) return set_error(LP_ENULL, "args is NULL");
@@ -362,7 +357,6 @@ int lp_splatter_forward(const LpSplatterArgs* args_, void* stream) {
     const int fam = splatter_mlp_family(*args);
     if (args->kernel == LP_KERNEL_MFMA && fam == 0)
       return set_error(LP_EUNSUPPORTED, "MFMA MLP-splatter kernel unavailable for this shape");
-    if (fam == 2 && args->kernel != LP_KERNEL_GENERIC) return splatter_mlp_forward_mfma(*args, (hipStream_t)stream);
     if (fam == 3 && args->kernel != LP_KERNEL_GENERIC) return splatter_mlp_forward_loop(*args, (hipStream_t)stream);
     return splatter_mlp_forward_launch(*args, (hipStream_t)stream);
   }
@@ -385,7 +379,6 @@ int lp_splatter_backward(const LpSplatterArgs* args_, void* stream) {
     const int fam = splatter_mlp_family(*args);
     if (args->kernel == LP_KERNEL_MFMA && fam == 0)
       return set_error(LP_EUNSUPPORTED, "MFMA MLP-splatter kernel unavailable for this shape");
-    if (fam == 2 && args->kernel != LP_KERNEL_GENERIC) return splatter_mlp_backward_mfma(*args, (hipStream_t)stream);
     if (fam == 3 && args->kernel != LP_KERNEL_GENERIC) return splatter_mlp_backward_loop(*args, (hipStream_t)stream);
     return splatter_mlp_backward_launch(*args, (hipStream_t)stream);
   }

@@ -41,10 +41,6 @@ int splatter_backward_launch(const LpSplatterArgs& a, hipStream_t stream);
 // MLP-Splatter: lp_splatter_mlp.hip
 int splatter_mlp_forward_launch(const LpSplatterArgs& a, hipStream_t stream);
 int splatter_mlp_backward_launch(const LpSplatterArgs& a, hipStream_t stream);
-// MLP-Splatter on the matrix cores ([E,32,Cout] family): lp_splatter_mlp_mfma.hip
-bool splatter_mlp_mfma_supported(const LpSplatterArgs& a);
-int splatter_mlp_forward_mfma(const LpSplatterArgs& a, hipStream_t stream);
-int splatter_mlp_backward_mfma(const LpSplatterArgs& a, hipStream_t stream);
 // MLP-Splatter, layer-looped bf16x3 family (2-4 layers, widths 16 / 32 / 64): lp_splatter_mlp_loop.hip
 bool splatter_mlp_loop_supported(const LpSplatterArgs& a);
 int splatter_mlp_forward_loop(const LpSplatterArgs& a, hipStream_t stream);

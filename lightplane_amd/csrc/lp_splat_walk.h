@@ -1,5 +1,5 @@
 // lp_splat_walk.h -- the Splatter's run-merged scatter walk on voxel grids, shared by the plain Splatter
-// (lp_splatter.hip: the splatted vector sits in registers) and the MFMA MLP-Splatter (lp_splatter_mlp_mfma.hip:
+// (lp_splatter.hip: the splatted vector sits in registers) and the MFMA MLP-Splatter (lp_splatter_mlp_loop.h:
 // in an LDS tile).
 #pragma once
 #include "lp_device.h"

@@ -1,12 +1,12 @@
 // lp_splatter_mlp_loop.h -- device code of the LAYER-LOOPED bf16x3 MFMA family of the MLP-Splatter.
 //
-// lp_splatter_mlp_mfma.hip covers LightplaneMLPSplatter's default shape ([E, 32, Cout], two layers, fp32 MFMA).  The module
-// is free-form (splatter_module.py:164-331: mlp_n_layers, mlp_hidden_chn) and the reference's own sweep uses hidden width
-// 64, 3-4 layers and 32 / 64 input features (tests/test_splatter_with_autograd.py:49-51).  This family covers
+// LightplaneMLPSplatter is free-form (splatter_module.py:164-331: mlp_n_layers, mlp_hidden_chn; default: two layers) and
+// the reference's own sweep uses hidden width 64, 3-4 layers and 32 / 64 input features
+// (tests/test_splatter_with_autograd.py:49-51).  This family -- the only MFMA family of the MLP-Splatter since round 4 -- covers
 //   2..4 layers [E, H, .., H, Cout], E (input-grid channels = encoding width) and H in {16, 32, 64}, Cout in {16, 32}
 // with the building blocks of lp_loop.h (32 x 32 blocks of row-major bf16 limb images, six limb products per chunk on
 // v_mfma_f32_32x32x16_bf16, workgroup-shared fp32 dW quadrants), the gather / scatter of the Renderer for the input
-// grid-list and the run-merged walks of the Splatter for the output grid-list -- the data flow of lp_splatter_mlp_mfma.hip.
+// grid-list and the run-merged walks of the Splatter for the output grid-list.
 // The backward keeps the hidden activations of the recompute in registers; NB = 2 (any width above 32) runs at one wave
 // per SIMD.
 #pragma once
@@ -67,7 +67,7 @@ LP_DEV void sloop_load_encoding(const LpSplatterArgs& a, int64_t rid, int h, flo
 }
 
 // Splatter-side walk of one plane output grid: the vector to splat sits in LDS as [channel][ray] (tile `vT`); features per
-// run and slot, then the unit weights eight slots at a time (lp_splatter_mlp_mfma.hip splat_walk_lds, same code)
+// run and slot, then the unit weights eight slots at a time 
 template <int C>
 LP_DEV void sloop_walk_lds(float* feat, float* wgt, const LpGrid& g, int b, float x, float y, float z, bool live, int lane,
                            const float* vT, float* wT) {
