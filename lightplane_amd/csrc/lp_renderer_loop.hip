@@ -132,22 +132,29 @@ static LoopParams loop_params(const LpRendererArgs& a) {
 // Segment-parallel march of a small batch (same rules as renderer_mfma_segments, lp_renderer_mfma.hip): the looped kernels
 // run one four-wave workgroup per CU, so 256 workgroups = 32 768 rays fill the chip once; below that a workgroup per
 // (128 rays, segment) fills it.  Not with 5..32 colour channels (the state records hold four colour sums).
+// (A shallow decoder's backward -- lp_renderer_loop_shallow.hip -- runs two workgroups per CU like the tuned family's: 512
+// workgroups = 65 536 rays fill the chip, and the tuned family's threshold of 32 768 rays applies.)
+static bool loop_is_shallow(const LpRendererArgs& a) {
+  static const bool no_shallow = getenv("LP_LOOP_NO_SHALLOW") != nullptr;
+  const LoopParams p = loop_params(a);
+  return loop_nb(p.hid, a.grid.channels) == 1 && a.color_chn <= 4 && p.n_t <= 2 && p.n_o <= 1 && p.n_c <= 1 && !no_shallow;
+}
 int renderer_loop_segments(const LpRendererArgs& a) {
   static const int forced = getenv("LP_SEGMENTS") ? atoi(getenv("LP_SEGMENTS")) : -1;
   if (forced == 0 || a.march.num_samples_inf != 0 || a.stop_neg_log_t > 0.0f || a.color_chn > 4) return 1;
   const int n_seg = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
   if (n_seg < 2) return 1;
-  if (forced < 0 && a.rays.n_rays > 24576) return 1;
+  if (forced < 0 && a.rays.n_rays > (loop_is_shallow(a) ? 32768 : 24576)) return 1;
   return n_seg;
 }
 
 // LP_SEG_LEN-sample blocks per segment: as many segments as keep the launch within one round of resident workgroups (every
 // workgroup stages up to 69 KB of limb images and flushes its dW once)
-static int loop_seg_blocks(const LpRendererArgs& a, unsigned ray_blocks) {
+static int loop_seg_blocks(const LpRendererArgs& a, unsigned ray_blocks, unsigned resident = 256u) {
   static const int forced = getenv("LP_SEG_BLOCKS") ? atoi(getenv("LP_SEG_BLOCKS")) : 0;
   const int n_rec = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
   int m = 1;
-  while (m < n_rec && (uint64_t)ray_blocks * ((n_rec + m - 1) / m) > 256u) ++m;
+  while (m < n_rec && (uint64_t)ray_blocks * ((n_rec + m - 1) / m) > resident) ++m;
   if (forced > 0) m = forced < n_rec ? forced : n_rec;
   return m;
 }
@@ -173,7 +180,7 @@ int renderer_forward_loop(const LpRendererArgs& a, hipStream_t stream) {
   const bool segf = a.seg_prefix && seg_fwd && !a.seg_forward_off && a.color_chn <= 4;
   if (segf) {
     const int n_rec = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
-    p.seg_blocks = loop_seg_blocks(a, nb);
+    p.seg_blocks = loop_seg_blocks(a, nb, loop_nb(p.hid, a.grid.channels) == 1 ? 512u : 256u);  // (NB = 1 forward: two workgroups per CU)
     p.seg_fwd = 1;
     nb *= (unsigned)((n_rec + p.seg_blocks - 1) / p.seg_blocks);
   }
@@ -209,7 +216,7 @@ int renderer_backward_loop(const LpRendererArgs& a, hipStream_t stream) {
   LoopParams p = loop_params(a);
   if (a.seg_prefix && a.color_chn <= 4) {  // small batch: one workgroup per (128 rays, segment)
     const int n_rec = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
-    p.seg_blocks = loop_seg_blocks(a, nb);
+    p.seg_blocks = loop_seg_blocks(a, nb, loop_is_shallow(a) ? 512u : 256u);
     nb *= (unsigned)((n_rec + p.seg_blocks - 1) / p.seg_blocks);
   }
   const size_t lds = loop_lds_bytes(p, true);

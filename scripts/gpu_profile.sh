@@ -8,6 +8,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp
 WL=${@:-cfg2 cfg3 cfg4}   # workloads to (re-)profile
 for w in $WL; do rm -rf $R/gpurun_out/prof_$w $R/gpurun_out/prof_$w.txt $R/gpurun_out/pmc[1-4]_$w; done
+unset LP_LOOP
 run() {  # workload, steps (trace), steps (pmc)
   w=$1
   B="python $R/bench.py --workload $w --no-cpu-baseline --no-extras"
@@ -25,6 +26,21 @@ for w in $WL; do
     cfg3) run cfg3 50 3 ;;
     cfg4) run cfg4 5 1 ;;
     small) run small 200 3 ;;
+    cfg5)  # BASELINE configs[4] at its per-GPU size: kernel trace only (a step takes ~0.27 s)
+      rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg5 -o bench -- python $R/bench.py --workload cfg5 --no-cpu-baseline --no-extras --steps 3 --warmup 1 > $R/gpurun_out/prof_cfg5.txt 2>&1
+      tail -1 $R/gpurun_out/prof_cfg5.txt | cut -c1-300 ;;
+    loop)  # the headline workload through the layer-looped family (LP_LOOP=1: shallow two-waves-per-SIMD backward)
+      export LP_LOOP=1
+      rm -rf $R/gpurun_out/prof_loop $R/gpurun_out/pmc[1-4]_loop
+      B="python $R/bench.py --workload cfg2 --no-cpu-baseline --no-extras"
+      rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_loop -o bench -- $B --steps 200 --warmup 3 > $R/gpurun_out/prof_loop.txt 2>&1
+      tail -1 $R/gpurun_out/prof_loop.txt | cut -c1-300
+      P="$B --steps 3 --warmup 1"
+      rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_ANY --output-format csv -d $R/gpurun_out/pmc1_loop -o pmc -- $P > /dev/null 2>&1
+      rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_INSTS_SALU --output-format csv -d $R/gpurun_out/pmc2_loop -o pmc -- $P > /dev/null 2>&1
+      rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc3_loop -o pmc -- $P > /dev/null 2>&1
+      rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/pmc4_loop -o pmc -- $P > /dev/null 2>&1
+      unset LP_LOOP ;;
   esac
 done
 find $R/gpurun_out/prof_* $R/gpurun_out/pmc[1-4]_* -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" -size +512k -delete

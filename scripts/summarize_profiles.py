@@ -18,9 +18,11 @@ os.makedirs(P, exist_ok=True)
 CMD = {"cfg2": "python bench.py --workload cfg2 --no-cpu-baseline --no-extras --steps 200 --warmup 3",
        "cfg3": "python bench.py --workload cfg3 --no-cpu-baseline --no-extras --steps 50 --warmup 3",
        "cfg4": "python bench.py --workload cfg4 --no-cpu-baseline --no-extras --steps 5 --warmup 3",
-       "small": "python bench.py --workload small --no-cpu-baseline --no-extras --steps 200 --warmup 3"}
+       "small": "python bench.py --workload small --no-cpu-baseline --no-extras --steps 200 --warmup 3",
+       "cfg5": "python bench.py --workload cfg5 --no-cpu-baseline --no-extras --steps 3 --warmup 1",
+       "loop": "LP_LOOP=1 python bench.py --workload cfg2 --no-cpu-baseline --no-extras --steps 200 --warmup 3"}
 out = {}
-for w in ("cfg2", "cfg3", "cfg4", "small"):
+for w in ("cfg2", "cfg3", "cfg4", "small", "cfg5", "loop"):
     if ONLY and w not in ONLY:
         continue
     stats = glob.glob(os.path.join(G, f"prof_{w}", "**", "*kernel_stats.csv"), recursive=True)
@@ -78,7 +80,7 @@ for w in ("cfg2", "cfg3", "cfg4", "small"):
         if e.get("SQ_BUSY_CYCLES") and (e.get("pmc_duration_ns") or e.get("trace_duration_ns")):
             e["clock_ghz"] = round(e["SQ_BUSY_CYCLES"] / 32.0 / (e.get("pmc_duration_ns") or e["trace_duration_ns"]), 4)
         e["workload"] = w
-        out[f"{w}: {k}"] = e
+        out[f"{w}: {k}"] = e  # ("loop" = the cfg-2 command with LP_LOOP=1: its entries never match bench.py's lookup for cfg2)
 json.dump(out, open(os.path.join(P, f"{ROUND}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps({k: {c: v[c] for c in v if c in ("hbm_bytes_per_launch", "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "_scratch", "SQ_WAVES")}
                   for k, v in out.items()}, indent=1))
