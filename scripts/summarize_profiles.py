@@ -19,10 +19,11 @@ CMD = {"cfg2": "python bench.py --workload cfg2 --no-cpu-baseline --no-extras --
        "cfg3": "python bench.py --workload cfg3 --no-cpu-baseline --no-extras --steps 50 --warmup 3",
        "cfg4": "python bench.py --workload cfg4 --no-cpu-baseline --no-extras --steps 5 --warmup 3",
        "small": "python bench.py --workload small --no-cpu-baseline --no-extras --steps 200 --warmup 3",
+       "1080p_s128": "python bench.py --workload 1080p_s128 --no-cpu-baseline --no-extras --steps 5 --warmup 3",
        "cfg5": "python bench.py --workload cfg5 --no-cpu-baseline --no-extras --steps 3 --warmup 1",
        "loop": "LP_LOOP=1 python bench.py --workload cfg2 --no-cpu-baseline --no-extras --steps 200 --warmup 3"}
 out = {}
-for w in ("cfg2", "cfg3", "cfg4", "small", "cfg5", "loop"):
+for w in ("cfg2", "cfg3", "cfg4", "small", "1080p_s128", "cfg5", "loop"):
     if ONLY and w not in ONLY:
         continue
     stats = glob.glob(os.path.join(G, f"prof_{w}", "**", "*kernel_stats.csv"), recursive=True)

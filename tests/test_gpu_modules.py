@@ -310,6 +310,29 @@ def test_bench_cfg5_two_ranks_on_one_gpu():
     assert res["config"]["rays_per_gpu"] == 2 * 48 * 48 + 8 * 1920
 
 
+def test_bench_default_command_two_ranks_on_one_gpu():
+    """The driver's multi-GPU command -- `torch.distributed.run ... bench.py --gpus N --steps K --warmup W`, default workload -- with
+    two gloo ranks on this GPU: the headline line with the sharded 1080p legs in `extras` (barrier + max over ranks), the
+    roofline / binding blocks looked up by rank 0 without a collective (the other rank must not wait for it forever)."""
+    import json
+    port = 29800 + (os.getpid() % 90)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LP_BENCH_EXTRAS_TIMEOUT="400")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "5",
+                        "--warmup", "2"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode()
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, out[-4000:]
+    res = json.loads(lines[-1])
+    assert res["n_gpus"] == 2 and res["value"] > 0 and res["scaling"] == "weak" and res["steps"] == 5
+    assert res["roofline"]["dominant_kernel"].startswith("lp::renderer_bwd_bf3<16")
+    assert "extras_error" not in res and set(res["extras"]) == {"renderer_1080p_s128", "renderer_cfg4_shard"}
+    for leg in res["extras"].values():
+        assert leg["n_gpus"] == 2 and leg["Mrays_per_s_fwd_bwd"] > 0, leg
+    assert "cpu_baseline" not in res  # reported at N = 1 only
+
+
 def test_backward_with_offloaded_saved_tensors():
     """Saved-tensor hooks (CPU offloading, checkpointing) hand the backward NEW tensors: the argument block the backward
     re-uses from the forward must take its pointers from them, not from the forward's addresses."""
