@@ -126,3 +126,52 @@ def test_oracle_fp64_close_to_fp32():
     out64 = O.lightplane_renderer_naive(r64, [g.double() for g in d["grids"]], dec64, **d["cfg"])
     for a, b in zip(out32, out64):
         _close("fp32-vs-fp64", a, b, tol=1e-5)
+
+
+def test_near_tie_masks_contain_every_fp32_vs_fp64_relu_flip():
+    """The theory behind the GPU suite's tie masks (tests/test_gpu_parity.py TieMasks), checked on flips that are certainly
+    flips: the oracle in fp32 against the same oracle in fp64 on a whole pinhole image.  Every `grad_grid` / `grad_encoding`
+    entry on which the two disagree by more than the 1e-4 bar must lie where a sample with a near-zero ReLU pre-activation
+    reaches (its tap rows, its ray) -- and the masks must be informative (cover well under all of the tensor)."""
+    from tests.test_gpu_coherent import coherent_renderer_inputs, oracle_renderer64
+    from tests.test_gpu_parity import TieMasks, run_oracle_renderer
+
+    d = coherent_renderer_inputs("triplane_plus_voxel_c16", "64x64_axis")
+    o32 = run_oracle_renderer(d)
+    o64 = oracle_renderer64(d)
+    ties = TieMasks(d)
+    n_flipped = 0
+    for i, (a, b) in enumerate(zip(o32[3], o64[3])):
+        scale = float(b.abs().max())
+        off = ((a.double() - b).abs() / scale) > 1e-4
+        mask = ties.grid_mask(i)().expand_as(off)
+        assert not bool((off & ~mask).any()), f"grid {i}: {int((off & ~mask).sum())} flipped entries outside the near-tie mask"
+        assert float(mask.float().mean()) < 0.6, f"grid {i}: the mask covers {float(mask.float().mean()):.2f} of the rows -- it says nothing"
+        n_flipped += int(off.sum())
+    off = ((o32[2].double() - o64[2]).abs() / float(o64[2].abs().max())) > 1e-4
+    mask = ties.encoding_mask()().expand_as(off)
+    assert not bool((off & ~mask).any()) and float(mask.float().mean()) < 0.1
+    assert n_flipped > 100, "this case is known to carry a few hundred flipped entries: the test would be vacuous without them"
+
+
+def test_chunked_splatter_oracle_equals_oracle():
+    """tests/test_gpu_config_scale.py evaluates the Splatter oracle in ray chunks for BASELINE configs[2] at full size (65 536
+    rays x 256 samples do not fit `lightplane_splatter_naive`'s [N, S, C] tensors); the chunked form is the oracle's own corner
+    arithmetic and must equal the oracle + autograd on a case small enough for both."""
+    from tests.synth import pinhole_rays
+    from tests.test_gpu_config_scale import splatter_oracle_chunked
+
+    gen = torch.Generator().manual_seed(5)
+    for mask in (True, False):
+        rays = pinhole_rays(24, 40, cam_dist=2.3, azimuth_deg=20.0, elevation_deg=35.0)
+        rays.encoding = torch.rand(rays.n_rays, 32, generator=gen).requires_grad_(True)
+        shape = [1, 12, 14, 10, 32]
+        cfg = dict(num_samples=20, num_samples_inf=0, mask_out_of_bounds_samples=mask, contract_coords=False)
+        up = torch.randn(*shape, generator=gen)
+        (want,) = O.lightplane_splatter_naive(rays, [shape], **cfg)
+        (want * up).sum().backward()
+        with torch.no_grad():
+            got, g_enc, wgrid = splatter_oracle_chunked(rays, shape, cfg, up, chunk=100)
+        _close("chunked oracle: out", got, want.detach().numpy(), tol=2e-6)
+        _close("chunked oracle: grad_encoding", g_enc, rays.encoding.grad.numpy(), tol=2e-6)
+        assert torch.equal(wgrid > 0, (want.detach() != 0).any(dim=-1))
