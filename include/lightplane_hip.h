@@ -51,12 +51,15 @@
 extern "C" {
 #endif
 
-#define LP_VERSION 202 /* 0.2.0: per-grid base pointers (zero-copy grid-lists), fused bg-colour / alpha epilogue,
+#define LP_VERSION 203 /* 0.2.0: per-grid base pointers (zero-copy grid-lists), fused bg-colour / alpha epilogue,
                            ray-embedding entry points; grad replicas removed
                            0.2.1: segment-parallel backward for small batches (LpRendererArgs.seg_prefix)
                            0.2.2: no struct change; lp_*_kernel_family() report family 3 (layer-looped MFMA kernels: Renderer
                                   decoders of 1-4 layers per MLP / up to 32 colour channels, MLP-Splatter of 2-4 layers and
-                                  widths 16 / 32 / 64), 64-channel Splatter walks */
+                                  widths 16 / 32 / 64), 64-channel Splatter walks
+                           0.2.3: no struct change; 64-channel Renderer grid-lists on family 3; the Renderer's family 1 is the tuned
+                                  default decoder shape only (every other shallow shape reports 3), lp_splatter_kernel_family() no
+                                  longer returns 2; lp_version() is NEGATIVE for a library built with -DLP_EXPERIMENTS */
 
 #define LP_MAX_GRIDS 8   /* grids per grid-list                         */
 #define LP_MAX_LAYERS 8  /* layers per MLP                              */
