@@ -476,7 +476,10 @@ int splatter_forward_launch(const LpSplatterArgs& a, hipStream_t stream) {
   const int Cw = a.out.channels;
   static const bool no_walk = getenv("LP_SPLAT_NO_WALK") != nullptr;  // A/B timing knob
   if ((Cw == 16 || Cw == 32 || Cw == 64) && a.out.n_rows < ((int64_t)1 << 31) && !no_walk) {
-    static const int rpw = getenv("LP_SPLAT_RPW") ? atoi(getenv("LP_SPLAT_RPW")) : 16;
+    // 32 rays per wave since round 4 (C = 16 / 32): the per-sample geometry is amortised over twice the rays and a run is cut at every
+    // 32nd ray instead of every 16th -- cfg 3 forward 2.26 -> 2.15 ms, cfg 5's splat forward 155.6 -> 149.4 ms
+    // (profiles/r04_splat_fwd_rpw32_ab.txt); LP_SPLAT_RPW=16 selects the 16-ray waves (A/B, tests)
+    static const int rpw = getenv("LP_SPLAT_RPW") ? atoi(getenv("LP_SPLAT_RPW")) : 32;
     static const int dbg = getenv("LP_SPLAT_DEBUG") ? atoi(getenv("LP_SPLAT_DEBUG")) : 0;  // timing experiments
     const int rpw_eff = Cw == 64 ? 16 : rpw;
     const unsigned ray_blocks = (unsigned)((a.rays.n_rays + 4 * rpw_eff - 1) / (4 * rpw_eff));

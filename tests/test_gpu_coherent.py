@@ -432,9 +432,10 @@ def test_mlp_splatter_segmented_march(name, mlp):
     check_mlp_splatter(d, _dev(), _lib.LP_KERNEL_AUTO, f"segmented {name}/mlp")
 
 
-def test_splatter_coherent_32_rays_per_wave():
-    """The same coherent Splatter cases with 32 rays per wave (LP_SPLAT_RPW is read once per process)."""
-    env = dict(os.environ, LP_SPLAT_RPW="32")
+def test_splatter_coherent_16_rays_per_wave():
+    """The same coherent Splatter cases with 16 rays per wave (the forward walk's default is 32 since round 4; LP_SPLAT_RPW is read
+    once per process)."""
+    env = dict(os.environ, LP_SPLAT_RPW="16")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_coherent.py"), "-m", "gpu",
                         "-q", "-x", "-k", "test_splatter_coherent_image or test_mlp_splatter_coherent_image",
                         "-p", "no:cacheprovider"],
