@@ -511,7 +511,33 @@ int splatter_backward_launch(const LpSplatterArgs& a, hipStream_t stream) {
     const int rpw_eff = (rpw == 8 && Cw != 64) ? 8 : 16;
     const unsigned ray_blocks = (unsigned)((a.rays.n_rays + 4 * rpw_eff - 1) / (4 * rpw_eff));
     if (ray_blocks == 0) return LP_OK;
-    const int n_seg = splat_segments(a, rpw_eff == 8 ? (ray_blocks + 1) / 2 : ray_blocks);
+    int n_seg = splat_segments(a, rpw_eff == 8 ? (ray_blocks + 1) / 2 : ray_blocks);
+    // Mid-sized batches: fill whole rounds of resident waves.  cfg 3 = 8 192 waves of 8 rays on 3 072 wave slots (C = 32: three waves
+    // per SIMD) = 2.67 rounds, the last one a third empty; three segments make it exactly 8 rounds: backward 2.04 -> 1.94 ms (2 or 4
+    // segments, 5.33 / 10.67 rounds: 2.18 / 2.21 ms -- profiles/r04_knob_sweep.txt).  Among 1, 2, 3, 4, 6 segments the fewest that bring
+    // the last round to >= 90 % full, for launches of up to 16 rounds (beyond that the tail does not matter).
+    static const int forced_seg = getenv("LP_SPLAT_SEGMENTS") ? atoi(getenv("LP_SPLAT_SEGMENTS")) : 0;
+    if (n_seg == 1 && forced_seg <= 0) {
+      static int n_simd = 0;
+      if (n_simd == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+          n_simd = 4 * cus;
+        else n_simd = 1024;
+      }
+      const int occ = Cw == 16 ? (rpw_eff == 8 ? 4 : 3) : (Cw == 32 ? (rpw_eff == 8 ? 3 : 2) : 2);
+      const uint64_t cap = (uint64_t)n_simd * occ, waves = (uint64_t)ray_blocks * 4;
+      const int s_tot = a.march.num_samples + a.march.num_samples_inf;
+      if (waves >= cap && waves <= 16 * cap) {
+        const int cand[5] = {1, 2, 3, 4, 6};
+        for (int i = 0; i < 5; ++i) {
+          const int n = cand[i];
+          if (n > 1 && s_tot / n < 16) break;
+          const uint64_t tot = waves * n, rounds = (tot + cap - 1) / cap;
+          if ((double)tot / (double)(rounds * cap) >= 0.9) { n_seg = n; break; }
+        }
+      }
+    }
     if (n_seg > 1) {  // the segments accumulate into grad_encoding
       const hipError_t e = hipMemsetAsync(a.grad_encoding, 0, (size_t)a.rays.n_rays * Cw * sizeof(float), stream);
       if (e != hipSuccess) return set_error((int)e, "hipMemsetAsync(grad_encoding): %s", hipGetErrorString(e));
