@@ -59,29 +59,6 @@ LP_DEV void split3_scalar(float x, unsigned short& l1, unsigned short& l2, unsig
   l3 = (unsigned short)(p3 & 0xffffu);
 }
 
-// B operand: N values of this lane (N = 8 or 16 -> 1 or 2 chunks) -> three limbs, 4 packed dwords per chunk and limb
-template <int N>
-struct Limbs {
-  u32x4_t l1[N / 8], l2[N / 8], l3[N / 8];
-};
-template <int N>
-LP_DEV void split3(const float (&v)[N], Limbs<N>& o) {
-#pragma unroll
-  for (int c = 0; c < N / 8; ++c) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float a = v[8 * c + 2 * i], b = v[8 * c + 2 * i + 1];
-      const unsigned p1 = pk_bf16(a, b);
-      const float ra = a - bf16_lo(p1), rb = b - bf16_hi(p1);
-      const unsigned p2 = pk_bf16(ra, rb);
-      const float sa = ra - bf16_lo(p2), sb = rb - bf16_hi(p2);
-      o.l1[c][i] = p1;
-      o.l2[c][i] = p2;
-      o.l3[c][i] = pk_bf16(sa, sb);
-    }
-  }
-}
-
 constexpr int BF3_SLOT = 16;                        // bytes per (lane) slot
 constexpr int BF3_CHUNK = 3 * 2 * 32 * BF3_SLOT;    // bytes per chunk: 3 limbs x 2 halves x 32 lanes = 3 KB
 
@@ -89,22 +66,6 @@ constexpr int BF3_CHUNK = 3 * 2 * 32 * BF3_SLOT;    // bytes per chunk: 3 limbs 
 // reads inside the sample loop)
 LP_DEV u32x4_t bf3_a(const char* img, int chunk, int limb, int lane) {
   return *reinterpret_cast<const u32x4_t*>(img + chunk * BF3_CHUNK + (limb * 2 + (lane >> 5)) * (32 * BF3_SLOT) + (lane & 31) * BF3_SLOT);
-}
-
-// acc += W-image chunks [chunk0, chunk0 + NCH) x B limbs; the six products of weight >= 2^-24, small ones first
-template <int NCH>
-LP_DEV f32x16 layer_bf3(const char* img, int chunk0, int lane, const Limbs<8 * NCH>& b, f32x16 acc) {
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const u32x4_t w1 = bf3_a(img, chunk0 + c, 0, lane), w2 = bf3_a(img, chunk0 + c, 1, lane), w3 = bf3_a(img, chunk0 + c, 2, lane);
-    acc = LP_MFMA_BF16(w3, b.l1[c], acc);
-    acc = LP_MFMA_BF16(w2, b.l2[c], acc);
-    acc = LP_MFMA_BF16(w1, b.l3[c], acc);
-    acc = LP_MFMA_BF16(w2, b.l1[c], acc);
-    acc = LP_MFMA_BF16(w1, b.l2[c], acc);
-    acc = LP_MFMA_BF16(w1, b.l1[c], acc);
-  }
-  return acc;
 }
 
 // One chunk (8 values) -> its three limbs, 4 packed dwords each (22 VALU instructions per pair of values x 4)

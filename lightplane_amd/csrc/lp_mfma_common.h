@@ -217,21 +217,6 @@ LP_DEV void gather_features(const LpRendererArgs& a, const Ray& ray, float x, fl
 // decoder
 // ---------------------------------------------------------------------------------------
 
-// One layer, forward form: acc (pre-loaded with the bias) += sum_kk A(kk) * in[kk] with
-// A(kk) = W[feat(kk,h)][l&31].  `w` already points at W + (4h)*W_LD + (l&31) (+ opaque zero).
-template <int K>
-LP_DEV f32x16 layer(const float* w, const float* in, f32x16 acc) {
-#pragma unroll
-  for (int kk = 0; kk < K; ++kk) acc = LP_MFMA(w[featq(kk, 0) * W_LD], in[kk], acc);
-  return acc;
-}
-// Backward (dX) form: A(kk) = W[l&31][feat(kk,h)].  `w` points at W + (l&31)*W_LD + 4h.
-LP_DEV f32x16 layer_t(const float* w, const float* in, f32x16 acc) {
-#pragma unroll
-  for (int kk = 0; kk < 16; ++kk) acc = LP_MFMA(w[featq(kk, 0)], in[kk], acc);
-  return acc;
-}
-
 struct Heads {
   float raw_o;
   float raw_c[4];
@@ -282,20 +267,6 @@ struct Act {
 #else
 #define LP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
-
-// Ask the scheduler for the issue order "1 MFMA, a few VALU, (1 global load), (1 LDS read)" N times:
-// a dependent v_mfma_f32_32x32x2_f32 chain stalls its wave 64 cycles per link (in-order issue), so
-// every instruction placed between two links is free.
-template <int N, int VALU_PER, int VMEM_EVERY>
-LP_DEV void interleave_hint() {
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // MFMA
-    if (VMEM_EVERY > 0 && (i % VMEM_EVERY) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // DS read (next operand)
-    __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER, 0);                // VALU
-  }
-}
 
 // this lane's 16 encoding features feat(q,h); `hid` = actual width (features >= hid read as 0)
 LP_DEV void load_encoding(const LpRendererArgs& a, int64_t rid, int h, float (&enc)[16], int hid = HID) {
