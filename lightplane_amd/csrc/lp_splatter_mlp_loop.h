@@ -229,10 +229,13 @@ __global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) splat_mlp_fwd_loop(const
 // ---------------------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------------------
-// ML = layers the instantiation is unrolled for: SLOOP_MAX, or 2 -- a two-layer MLP keeps ONE hidden activation, fits 256
-// registers and runs at two waves per SIMD (lp_splatter_mlp_loop_shallow.hip)
+// ML = layers the instantiation is unrolled for: SLOOP_MAX, or 2 -- a two-layer MLP keeps ONE hidden activation and fits 256
+// registers without spills (lp_splatter_mlp_loop_shallow.hip).  Every width-<= 32 instantiation is compiled for two waves per SIMD
+// (its images + tiles are <= 63 KB: two workgroups per CU): the four-layer ones were at 244 + 32 ... 256 + 82 registers, i.e. one
+// wave per SIMD for a handful of registers; under the bound <32,16> fits 254 without a spill and <32,32> spills 70 and is STILL 17 %
+// faster ([32,32,32,32]: 10.03 -> 8.30 ms fwd+bwd, profiles/r04_loop_shallow_ab.txt)
 template <int E, int CO, int NB, int ML = SLOOP_MAX>
-__global__ void __launch_bounds__(256, (NB == 1 && ML <= 2) ? 2 : 1) splat_mlp_bwd_loop(const LpSplatterArgs a, const LpRendererArgs rv, const SplatLoopParams sp) {
+__global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) splat_mlp_bwd_loop(const LpSplatterArgs a, const LpRendererArgs rv, const SplatLoopParams sp) {
   using T = SplatLoopTile;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   sloop_stage<NB>(a, sp, lds);
