@@ -160,10 +160,11 @@ LP_DEV void loop_pad_input(const float (&x0)[C / 2], float (&out)[NB][16]) {
 // (h, r) composites the 16 channels feat(q, h) of its ray
 // GM: GM_TRIPLANE (canonical triplane: shared axis computations, border re-expression in the scatter) or GM_GENERIC
 template <int C, int NB, bool TG, bool WC = false, int GM = GM_GENERIC>
-// (two-block instantiations with <= 32 grid channels are compiled for two waves per SIMD as well: the triplane form needed 215 + 48
-// registers -- seven too many -- and ran the reference example's 1/1/2 x 64 decoder, whose 41 KB of images allow two workgroups per
-// CU, at one wave per SIMD: forward 1.85 -> 1.14 ms with the bound; decoders whose images exclude a second workgroup are unaffected)
-__global__ void __launch_bounds__(256, (NB == 1 || C <= 32) ? 2 : 1) renderer_fwd_loop(const LpRendererArgs a, const LoopParams lp) {
+// (the two-block instantiations are compiled for two waves per SIMD as well: the triplane form needed 215 + 48 registers -- seven too
+// many -- and ran the reference example's 1/1/2 x 64 decoder, whose 41 KB of images allow two workgroups per CU, at one wave per
+// SIMD: forward 1.85 -> 0.98 ms with the bound (211 VGPRs, no scratch; 64 grid channels: 256 VGPRs, 10 spilled); decoders whose
+// images exclude a second workgroup keep one wave per SIMD whatever the bound says)
+__global__ void __launch_bounds__(256, 2) renderer_fwd_loop(const LpRendererArgs a, const LoopParams lp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   loop_stage<NB>(a, lp, lds);
   __syncthreads();
