@@ -166,7 +166,7 @@ LP_DEV void sloop_walk_lds(float* feat, float* wgt, const LpGrid& g, int b, floa
 // forward: `rv` is a Renderer-shaped view of the arguments (rv.grid = the INPUT grid-list) for the Renderer's gather
 // ---------------------------------------------------------------------------------------------------------------
 template <int E, int CO, int NB>
-__global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) splat_mlp_fwd_loop(const LpSplatterArgs a, const LpRendererArgs rv,
+__global__ void __launch_bounds__(256, 2) splat_mlp_fwd_loop(const LpSplatterArgs a, const LpRendererArgs rv,
                                                                             const SplatLoopParams sp) {
   using T = SplatLoopTile;
   extern __shared__ __attribute__((aligned(16))) float lds[];
