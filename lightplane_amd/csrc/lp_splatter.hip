@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(256) splat_bwd_kernel(const LpSplatterArgs a) 
 // and twice the gathers are in flight, for the price of the per-sample geometry being amortised over 8 rays instead of 16
 // (LP_SPLAT_BWD_RPW, measured in DESIGN.md 4.4).
 template <int C, int B, int RPW = 16>
-__global__ void __launch_bounds__(256, RPW == 8 ? (C < 32 ? 4 : 3) : ((B == 4 && C < 64) ? 3 : 2))
+__global__ void __launch_bounds__(256, RPW == 8 ? (C < 32 ? 4 : (C < 64 ? 3 : 2)) : ((B == 4 && C < 64) ? 3 : 2))
 splat_bwd_walk_kernel(const LpSplatterArgs a, int n_seg) {
   static_assert(RPW == 16 || (RPW == 8 && B == 8), "rays per wave: 16, or 8 with one batch of 8");
   constexpr int CPL = C / 16, NQ = 64 / RPW, SPQ = 8 / NQ;
@@ -508,7 +508,7 @@ int splatter_backward_launch(const LpSplatterArgs& a, hipStream_t stream) {
     // 8 rays per wave (round 4): cfg 3 backward 2.32 -> 2.01 ms -- 146 instead of 210 registers (C = 32), three waves per SIMD
     // instead of two, i.e. 1.5x the gathers in flight of a latency-bound walk; LP_SPLAT_BWD_RPW=16 selects the 16-ray waves
     static const int rpw = getenv("LP_SPLAT_BWD_RPW") ? atoi(getenv("LP_SPLAT_BWD_RPW")) : 8;
-    const int rpw_eff = (rpw == 8 && Cw != 64) ? 8 : 16;
+    const int rpw_eff = rpw == 8 ? 8 : 16;
     const unsigned ray_blocks = (unsigned)((a.rays.n_rays + 4 * rpw_eff - 1) / (4 * rpw_eff));
     if (ray_blocks == 0) return LP_OK;
     int n_seg = splat_segments(a, rpw_eff == 8 ? (ray_blocks + 1) / 2 : ray_blocks);
@@ -525,7 +525,7 @@ int splatter_backward_launch(const LpSplatterArgs& a, hipStream_t stream) {
           n_simd = 4 * cus;
         else n_simd = 1024;
       }
-      const int occ = Cw == 16 ? (rpw_eff == 8 ? 4 : 3) : (Cw == 32 ? (rpw_eff == 8 ? 3 : 2) : 2);
+      const int occ = Cw == 16 ? (rpw_eff == 8 ? 4 : 3) : (Cw == 32 ? (rpw_eff == 8 ? 3 : 2) : 2);  // (C = 64: two either way)
       const uint64_t cap = (uint64_t)n_simd * occ, waves = (uint64_t)ray_blocks * 4;
       const int s_tot = a.march.num_samples + a.march.num_samples_inf;
       if (waves >= cap && waves <= 16 * cap) {
@@ -546,6 +546,7 @@ int splatter_backward_launch(const LpSplatterArgs& a, hipStream_t stream) {
     // batches of 8 rays; batches of 4 at three waves/SIMD measured the same (cfg 3)
     if (Cw == 16 && rpw_eff == 8) hipLaunchKernelGGL((splat_bwd_walk_kernel<16, 8, 8>), dim3(blocks), dim3(256), 0, stream, a, n_seg);
     else if (Cw == 32 && rpw_eff == 8) hipLaunchKernelGGL((splat_bwd_walk_kernel<32, 8, 8>), dim3(blocks), dim3(256), 0, stream, a, n_seg);
+    else if (Cw == 64 && rpw_eff == 8) hipLaunchKernelGGL((splat_bwd_walk_kernel<64, 8, 8>), dim3(blocks), dim3(256), 0, stream, a, n_seg);
     else if (Cw == 16) hipLaunchKernelGGL((splat_bwd_walk_kernel<16, 8>), dim3(blocks), dim3(256), 0, stream, a, n_seg);
     else if (Cw == 32) hipLaunchKernelGGL((splat_bwd_walk_kernel<32, 8>), dim3(blocks), dim3(256), 0, stream, a, n_seg);
     else hipLaunchKernelGGL((splat_bwd_walk_kernel<64, 4>), dim3(blocks), dim3(256), 0, stream, a, n_seg);  // (batches of 8: 300 B of scratch)
