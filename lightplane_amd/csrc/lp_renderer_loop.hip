@@ -230,15 +230,20 @@ int renderer_backward_loop(const LpRendererArgs& a, hipStream_t stream) {
   }
 #define LP_LOOP_BWD(CV, NBV, TGV, MTV, MHV, WCV) rc = launch_bwd_loop<CV, NBV, TGV, MTV, MHV, WCV>(a, p, nb, lds, tri, stream)
   if (a.grid.channels == 64) {
-    LP_LOOP_BWD(64, 2, false, 2, 1, false);
+    if (p.n_t <= 1) LP_LOOP_BWD(64, 2, false, 1, 1, false);
+    else LP_LOOP_BWD(64, 2, false, 2, 1, false);
   } else if (a.grid.channels == 16) {
-    if (NB == 2) LP_LOOP_BWD(16, 2, false, 2, 1, false);
+    if (NB == 2 && p.n_t <= 1) LP_LOOP_BWD(16, 2, false, 1, 1, false);
+    else if (NB == 2) LP_LOOP_BWD(16, 2, false, 2, 1, false);
     else if (tg && wc) LP_LOOP_BWD(16, 1, true, 1, LOOP_MAX_H, true);
     else if (tg) LP_LOOP_BWD(16, 1, true, 1, LOOP_MAX_H, false);
     else if (wc) LP_LOOP_BWD(16, 1, false, LOOP_MAX_T, LOOP_MAX_H, true);
     else LP_LOOP_BWD(16, 1, false, LOOP_MAX_T, LOOP_MAX_H, false);
   } else {
-    if (NB == 2) LP_LOOP_BWD(32, 2, false, 2, 1, false);
+    // (one trunk layer -- the reference example's 1/1/2 x 64 --: an instantiation of its own keeps 32 activation + 18 dW registers
+    // fewer and fits the 512-register budget without scratch; the two-trunk-layer one spills 44-46)
+    if (NB == 2 && p.n_t <= 1) LP_LOOP_BWD(32, 2, false, 1, 1, false);
+    else if (NB == 2) LP_LOOP_BWD(32, 2, false, 2, 1, false);
     else if (tg && wc) LP_LOOP_BWD(32, 1, true, 1, LOOP_MAX_H, true);
     else if (tg) LP_LOOP_BWD(32, 1, true, 1, LOOP_MAX_H, false);
     else if (wc) LP_LOOP_BWD(32, 1, false, LOOP_MAX_T, LOOP_MAX_H, true);

@@ -81,6 +81,10 @@ GRIDS = {
     # 64 grid channels: the looped family's two-block instantiation, four channels per lane in the run-merged scatter
     "triplane24_c64": ((1, 24, 24, 24, 64), True, False, False, (2, 2, 2), 1),
     "voxel16_c64": ((1, 16, 16, 16, 64), False, False, False, (2, 1, 2), 1),
+    # the reference example's decoder depth (1 trunk layer, opacity head without hidden layer, colour head with one): with
+    # hidden=64 the two-block looped kernels' one-trunk-layer instantiations
+    "triplane24_c32_t1o1c2": ((1, 24, 24, 24, 32), True, False, False, (1, 1, 2), 1),
+    "voxel20_c16_t1o1c2": ((1, 20, 20, 20, 16), False, False, False, (1, 1, 2), 1),
 }
 # deep decoders (layer-looped MFMA family, lp_renderer_loop.hip): test_renderer_coherent_deep
 DEEP_GRIDS = {
@@ -162,7 +166,9 @@ def test_renderer_coherent_image(grid, image, kernel):
     ("triplane24_c16", dict(scaffold=True)),                        # non-PLAIN instantiation, occupancy zeros inside runs
     ("voxel20_c32", dict(hidden=16, mask_oob=True)),                 # flex family (hidden 16 padded to 32)
     ("triplane_plus_voxel_c16", dict(hidden=64, mask_oob=True)),     # width-64 family
-], ids=["triplane_nomask", "voxel_nomask_rgba", "triplane_scaffold", "voxel_flex_h16", "mixed_h64"])
+    ("triplane24_c32_t1o1c2", dict(hidden=64)),                      # the reference example's 1/1/2 x 64: two-block looped, one trunk layer
+    ("voxel20_c16_t1o1c2", dict(hidden=64, scaffold=True)),          # the same on 16 channels, non-PLAIN
+], ids=["triplane_nomask", "voxel_nomask_rgba", "triplane_scaffold", "voxel_flex_h16", "mixed_h64", "example_112_h64_c32", "example_112_h64_c16"])
 def test_renderer_coherent_variants(grid, kw):
     d = coherent_renderer_inputs(grid, "48x80_az30_el45", seed=3, **kw)
     check_renderer(d, _dev(), _lib.LP_KERNEL_AUTO, f"{grid}/{kw}")
