@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define LP_VERSION 203 /* 0.2.0: per-grid base pointers (zero-copy grid-lists), fused bg-colour / alpha epilogue,
+#define LP_VERSION 204 /* 0.2.0: per-grid base pointers (zero-copy grid-lists), fused bg-colour / alpha epilogue,
                            ray-embedding entry points; grad replicas removed
                            0.2.1: segment-parallel backward for small batches (LpRendererArgs.seg_prefix)
                            0.2.2: no struct change; lp_*_kernel_family() report family 3 (layer-looped MFMA kernels: Renderer
@@ -59,7 +59,9 @@ extern "C" {
                                   widths 16 / 32 / 64), 64-channel Splatter walks
                            0.2.3: no struct change; 64-channel Renderer grid-lists on family 3; the Renderer's family 1 is the tuned
                                   default decoder shape only (every other shallow shape reports 3), lp_splatter_kernel_family() no
-                                  longer returns 2; lp_version() is NEGATIVE for a library built with -DLP_EXPERIMENTS */
+                                  longer returns 2; lp_version() is NEGATIVE for a library built with -DLP_EXPERIMENTS
+                           0.2.4: no struct change; lp_renderer_kernel_family() no longer returns 2 (2/2/2 x 64 decoders run the
+                                  layer-looped family's two-block kernels and report 3); family 3 takes up to 256 beyond-far samples */
 
 #define LP_MAX_GRIDS 8   /* grids per grid-list                         */
 #define LP_MAX_LAYERS 8  /* layers per MLP                              */
@@ -261,12 +263,13 @@ int lp_abi_sizeof(int which);
 int lp_renderer_backward_segments(const LpRendererArgs* args);
 
 /* Which kernel family LP_KERNEL_AUTO selects for these arguments (no launch; shapes only):
- *   lp_renderer_kernel_family: 0 shape-generic VALU kernels, 1 MFMA hidden-32 family (tuned default shape and its subsets),
- *                              2 MFMA hidden-64 family (2/2/2 layers), 3 layer-looped bf16x3 MFMA family (1-4 layers per
- *                              MLP, one hidden width of 16 / 32 and <= 32 colour channels -- or 64 with at most 2 layers per MLP and <= 4 colour channels)
+ *   lp_renderer_kernel_family: 0 shape-generic VALU kernels, 1 tuned bf16x3 MFMA kernels of the default decoder (2/2/2 x 32),
+ *                              3 layer-looped bf16x3 MFMA family (1-4 layers per MLP, one hidden width of 16 / 32 and <= 32
+ *                              colour channels -- or width 64 / 64 grid channels with at most 2 layers per MLP and <= 4 colour
+ *                              channels); 2 (the fp32-MFMA hidden-64 family of 0.1 - 0.2.3) is no longer returned
  *   lp_splatter_kernel_family: 0 shape-generic kernels, 1 run-merged walk (plain Splatter, C in {16,32,64}),
- *                              2 MFMA MLP-Splatter ([E,32,Cout] family), 3 layer-looped bf16x3 MFMA MLP-Splatter (2-4
- *                              layers, widths 16 / 32 / 64, Cout 16 / 32)
+ *                              3 layer-looped bf16x3 MFMA MLP-Splatter (2-4 layers, widths 16 / 32 / 64, Cout 16 / 32);
+ *                              2 (the two-layer fp32-MFMA family of 0.1 - 0.2.2) is no longer returned
  * The generic kernels are correctness anchors, one to two orders of magnitude slower. */
 int lp_renderer_kernel_family(const LpRendererArgs* args);
 int lp_splatter_kernel_family(const LpSplatterArgs* args);

@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "liblightplane_hip.so")
-SOURCES = ["lp_api.hip", "lp_renderer_generic.hip", "lp_renderer_mfma.hip", "lp_renderer_mfma_bwd.hip", "lp_renderer_mfma_wide.hip", "lp_renderer_loop.hip", "lp_renderer_loop_shallow.hip", "lp_splatter.hip", "lp_splatter_mlp.hip", "lp_splatter_mlp_loop.hip", "lp_splatter_mlp_loop_shallow.hip", "lp_ray_embedding.hip"]
+SOURCES = ["lp_api.hip", "lp_renderer_generic.hip", "lp_renderer_mfma.hip", "lp_renderer_mfma_bwd.hip", "lp_renderer_loop.hip", "lp_renderer_loop_shallow.hip", "lp_splatter.hip", "lp_splatter_mlp.hip", "lp_splatter_mlp_loop.hip", "lp_splatter_mlp_loop_shallow.hip", "lp_ray_embedding.hip"]
 HEADERS = ["lp_device.h", "lp_host.h", "lp_mfma_common.h", "lp_generic_mlp.h", "lp_splat_walk.h", "lp_bf3.h", "lp_loop.h", "lp_renderer_loop.h", "lp_splatter_mlp_loop.h", os.path.join("..", "..", "include", "lightplane_hip.h")]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",

@@ -230,18 +230,18 @@ int lp_abi_sizeof(int which) {
   }
 }
 
-// kernel selection: 1 = width-32 MFMA family (tuned default shape + its flex subsets), 2 = width-64 MFMA family (2/2/2 layers),
-// 3 = layer-looped bf16x3 MFMA family (1-4 layers per MLP), 0 = the shape-generic kernel.  LP_LOOP=1 (developer knob, read
-// once): the layer-looped family wherever it applies, also for the shapes families 1 / 2 cover (A/B, test coverage).
+// kernel selection: 1 = the tuned bf16x3 kernels of the default shape (2/2/2 x 32), 3 = layer-looped bf16x3 MFMA family (1-4 layers
+// per MLP, widths 16 / 32 / 64), 0 = the shape-generic kernel.  (2 was the fp32-MFMA family of 2/2/2 x 64, retired in 0.2.4: the
+// two-block looped kernels with the eight-wave forward measure 1-2 % faster forward + backward and 25-29 % faster forward on it --
+// profiles/r04_h64_looped_vs_wide.txt.)  LP_LOOP=1 (developer knob, read once): the layer-looped family also for the shape family 1
+// covers (A/B, test coverage).
 static int select_renderer(const LpRendererArgs& a, const char** why) {
   const char* w32 = "";
-  const char* w64 = "";
   const char* wl = "";
   static const bool force_loop = getenv("LP_LOOP") != nullptr && atoi(getenv("LP_LOOP")) != 0;
   const bool loop_ok = renderer_loop_supported(a, &wl) && renderer_loop_fits(a);
   if (force_loop && loop_ok) return 3;
   if (renderer_mfma_supported(a, &w32)) return 1;
-  if (renderer_mfma_wide_supported(a, &w64)) return 2;
   if (loop_ok) return 3;
   *why = wl[0] ? wl : "weight images of this decoder exceed the 160 KB LDS";
   return 0;
@@ -258,7 +258,7 @@ int lp_renderer_backward_segments(const LpRendererArgs* args) {
   const char* why = "";
   if (args->kernel == LP_KERNEL_GENERIC) return 1;
   const int fam = select_renderer(*args, &why);
-  return fam == 1 ? renderer_mfma_segments(*args) : fam == 2 ? renderer_mfma_wide_segments(*args) : fam == 3 ? renderer_loop_segments(*args) : 1;
+  return fam == 1 ? renderer_mfma_segments(*args) : fam == 3 ? renderer_loop_segments(*args) : 1;
 }
 
 // MLP-Splatter: 3 = layer-looped bf16x3 family (2-4 layers, widths 16 / 32 / 64), 0 = generic.  (2 was the two-layer fp32-MFMA
@@ -304,7 +304,6 @@ int lp_renderer_forward(const LpRendererArgs* args, void* stream) {
   if (a.kernel == LP_KERNEL_MFMA && fam == 0)
     return set_error(LP_EUNSUPPORTED, "MFMA renderer kernel unavailable for this shape: %s", why);
   if (fam == 1 && a.kernel != LP_KERNEL_GENERIC) return renderer_forward_mfma(a, (hipStream_t)stream);
-  if (fam == 2 && a.kernel != LP_KERNEL_GENERIC) return renderer_forward_mfma_wide(a, (hipStream_t)stream);
   if (fam == 3 && a.kernel != LP_KERNEL_GENERIC) return renderer_forward_loop(a, (hipStream_t)stream);
   return renderer_forward_generic(a, (hipStream_t)stream);
 }
@@ -319,7 +318,6 @@ int lp_renderer_backward(const LpRendererArgs* args, void* stream) {
   if (a.kernel == LP_KERNEL_MFMA && fam == 0)
     return set_error(LP_EUNSUPPORTED, "MFMA renderer kernel unavailable for this shape: %s", why);
   if (fam == 1 && a.kernel != LP_KERNEL_GENERIC) return renderer_backward_mfma(a, (hipStream_t)stream);
-  if (fam == 2 && a.kernel != LP_KERNEL_GENERIC) return renderer_backward_mfma_wide(a, (hipStream_t)stream);
   if (fam == 3 && a.kernel != LP_KERNEL_GENERIC) return renderer_backward_loop(a, (hipStream_t)stream);
   return renderer_backward_generic(a, (hipStream_t)stream);
 }

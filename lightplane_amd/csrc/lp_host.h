@@ -21,12 +21,7 @@ bool renderer_mfma_supported(const LpRendererArgs& a, const char** why);
 int renderer_forward_mfma(const LpRendererArgs& a, hipStream_t stream);
 int renderer_backward_mfma(const LpRendererArgs& a, hipStream_t stream);
 int renderer_mfma_segments(const LpRendererArgs& a);  // segments of the segment-parallel backward (1 = none)
-int renderer_mfma_wide_segments(const LpRendererArgs& a);
 int renderer_forward_combine_launch(const LpRendererArgs& a, int seg_blocks, hipStream_t stream);  // chains the segments of a segmented forward
-// MFMA kernels, hidden width 64: lp_renderer_mfma_wide.hip
-bool renderer_mfma_wide_supported(const LpRendererArgs& a, const char** why);
-int renderer_forward_mfma_wide(const LpRendererArgs& a, hipStream_t stream);
-int renderer_backward_mfma_wide(const LpRendererArgs& a, hipStream_t stream);
 
 // layer-looped bf16x3 MFMA family (1-4 layers per MLP, hidden 16 / 32 / 64): lp_renderer_loop.hip
 bool renderer_loop_supported(const LpRendererArgs& a, const char** why);

@@ -11,7 +11,7 @@ namespace lp {
 typedef float f32x4l __attribute__((ext_vector_type(4)));
 #define LP_MFMA16L(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-constexpr int LOOP_N_INF = 64;      // beyond-far samples tabulated
+constexpr int LOOP_N_INF = 256;     // beyond-far samples tabulated (as many as the tuned family, lp_mfma_common.h MAX_INF)
 constexpr int LOOP_ST = 32 * RM_LD * 2;   // bytes of one limb of a 32 x 32 block (72-byte rows)
 constexpr int LOOP_BLK = 3 * LOOP_ST;     // bytes of a block image (three limbs)
 constexpr int LT_LD = 36;           // row stride of the feature-major fp32 tiles [32 features][32 rays + 4]

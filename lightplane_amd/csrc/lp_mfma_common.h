@@ -72,7 +72,7 @@ struct Lds {
 
 // (stage_weights, the fp32 [32][33] images of the first-generation Renderer kernels, went with them in round 4; the layout
 // constants above stay: the bf16x3 kernels address their small fp32 block -- biases, output layers, beyond-far table --
-// through them, and the width-64 family / the MLP-Splatter's two-layer family keep fp32 images of their own.)
+// through them.)
 // bias of layer `which` (0 t1, 1 t2, 2 o1, 3 c1) in accumulator-register order for half h
 LP_DEV f32x16 load_bias(const float* lds, int which, int h, int zo) {
   const float4* b = reinterpret_cast<const float4*>(lds + Lds::BIAS + which * 32 + 4 * h + zo);

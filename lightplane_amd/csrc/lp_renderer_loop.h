@@ -159,12 +159,15 @@ LP_DEV void loop_pad_input(const float (&x0)[C / 2], float (&out)[NB][16]) {
 // WC: 5..32 colour channels -- the colour output layer runs on the matrix cores like a hidden layer (without ReLU), lane
 // (h, r) composites the 16 channels feat(q, h) of its ray
 // GM: GM_TRIPLANE (canonical triplane: shared axis computations, border re-expression in the scatter) or GM_GENERIC
-template <int C, int NB, bool TG, bool WC = false, int GM = GM_GENERIC>
+// NW: waves per workgroup.  4, or 8 for decoders whose weight images exclude a second four-wave workgroup per CU (2/2/2 x 64: 97 KB):
+// the forward needs no per-wave LDS, so EIGHT waves can share one copy of the images and the SIMDs still host two waves each
+// (the staging loops stride by 256 threads: the upper four waves re-write what the lower four write, same values)
+template <int C, int NB, bool TG, bool WC = false, int GM = GM_GENERIC, int NW = WAVES>
 // (the two-block instantiations are compiled for two waves per SIMD as well: the triplane form needed 215 + 48 registers -- seven too
 // many -- and ran the reference example's 1/1/2 x 64 decoder, whose 41 KB of images allow two workgroups per CU, at one wave per
 // SIMD: forward 1.85 -> 0.98 ms with the bound (211 VGPRs, no scratch; 64 grid channels: 256 VGPRs, 10 spilled); decoders whose
 // images exclude a second workgroup keep one wave per SIMD whatever the bound says)
-__global__ void __launch_bounds__(256, 2) renderer_fwd_loop(const LpRendererArgs a, const LoopParams lp) {
+__global__ void __launch_bounds__(64 * NW, 2) renderer_fwd_loop(const LpRendererArgs a, const LoopParams lp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   loop_stage<NB>(a, lp, lds);
   __syncthreads();
@@ -178,7 +181,7 @@ __global__ void __launch_bounds__(256, 2) renderer_fwd_loop(const LpRendererArgs
   const int n_seg = segf ? (a.march.num_samples + seg_len - 1) / seg_len : 1;
   const int blk = segf ? (int)blockIdx.x / n_seg : (int)blockIdx.x;
   const int seg = segf ? (int)blockIdx.x - blk * n_seg : 0;
-  const int64_t ray_id = ((int64_t)blk * WAVES + wave) * RAYS_PER_WAVE + r;
+  const int64_t ray_id = ((int64_t)blk * NW + wave) * RAYS_PER_WAVE + r;
   const bool valid = ray_id < a.rays.n_rays;
   const int64_t rid = valid ? ray_id : 0;
   const Ray ray = load_ray(a.rays, rid);
@@ -876,6 +879,23 @@ static unsigned loop_blocks(const LpRendererArgs& a) {
 template <int C, int NB, bool TG, bool WC>
 static int launch_fwd_loop(const LpRendererArgs& a, const LoopParams& p, unsigned nb, size_t lds, bool tri, hipStream_t stream) {
   int rc;
+  if constexpr (NB == 2 && !TG && !WC) {
+    // images that exclude a second four-wave workgroup per CU (> 80 KB): eight-wave workgroups, one per CU, two waves per SIMD
+    static const bool no_nw8 = getenv("LP_LOOP_FWD_NW4") != nullptr;  // A/B
+    if (lds > 80 * 1024 && !no_nw8 && !p.seg_fwd) {
+      const unsigned nb8 = (unsigned)((a.rays.n_rays + 8 * RAYS_PER_WAVE - 1) / (8 * RAYS_PER_WAVE));
+      if constexpr (C <= 32) {
+        if (tri) {
+          if ((rc = loop_set_lds(renderer_fwd_loop<C, NB, TG, WC, GM_TRIPLANE, 8>, lds))) return rc;
+          hipLaunchKernelGGL((renderer_fwd_loop<C, NB, TG, WC, GM_TRIPLANE, 8>), dim3(nb8), dim3(512), lds, stream, a, p);
+          return LP_OK;
+        }
+      }
+      if ((rc = loop_set_lds(renderer_fwd_loop<C, NB, TG, WC, GM_GENERIC, 8>, lds))) return rc;
+      hipLaunchKernelGGL((renderer_fwd_loop<C, NB, TG, WC, GM_GENERIC, 8>), dim3(nb8), dim3(512), lds, stream, a, p);
+      return LP_OK;
+    }
+  }
   if constexpr (!TG && C <= 32) {  // (64 channels: the run-time grid-list form only)
     if (tri) {
       if ((rc = loop_set_lds(renderer_fwd_loop<C, NB, TG, WC, GM_TRIPLANE>, lds))) return rc;

@@ -3,7 +3,7 @@
 //
 // Shape family = the TUNED default shape: single grid-list with C in {16, 32} channels, trunk [C,32,32],
 // opacity [32,32,1], colour [32,32,>=Cc] with Cc <= 4 -- every BASELINE.json configuration.  Everything else runs the
-// layer-looped family (lp_renderer_loop*.hip), the width-64 family or lp_renderer_generic.hip.
+// layer-looped family (lp_renderer_loop*.hip) or lp_renderer_generic.hip.
 //
 // Mapping.  One wave = 32 rays.  Lane l = (h = l>>5, r = l&31) works on ray r and on the
 // feature subset F_h = { feat(q,h) = (q&3) + 8*(q>>2) + 4*h : q = 0..15 } of every 32-wide
@@ -196,7 +196,7 @@ bool renderer_mfma_supported(const LpRendererArgs& a, const char** why) {
   if (a.opacity.n_layers == 2) hidden(a.opacity.dims[1]);
   if (a.color.n_layers == 2) hidden(a.color.dims[1]);
   if (H == 0) H = C;  // two-grid decoder with single-layer heads: no hidden layer at all
-  if (H != 16 && H != 32) { *why = "hidden width other than 16 / 32 (64: wide family)"; return false; }
+  if (H != 16 && H != 32) { *why = "hidden width other than 16 / 32"; return false; }
   if (!same) { *why = "hidden widths differ between layers"; return false; }
   if (a.color_chn > 4) { *why = "more than 4 colour channels"; return false; }
   if (a.grid.n_rows * C * 4 >= (int64_t)1 << 32) { *why = "grid-list of 4 GB or more"; return false; }

@@ -117,7 +117,8 @@ def _warn_if_generic(a, cfg: _RendererCfg) -> None:
             "lightplane_amd: this decoder shape runs on the shape-generic Renderer kernels (10-100x slower). The "
             "MFMA families cover grid channels 16/32, grid-lists below 4 GB, trunk 1-4 (0 with a separate colour grid) / "
             "opacity 1-4 / colour 1-4 layers with ONE hidden width of 16 or 32 and <= 32 colour channels, or up to 2/2/2 "
-            "layers with hidden width 64 and / or 64 grid channels, <= 4 colour channels and no separate colour grid. "
+            "layers with hidden width 64 and / or 64 grid channels, <= 4 colour channels and no separate colour grid; at most 256 "
+            "beyond-far samples. "
             f"Got channels={cfg.channels}, trunk={cfg.dims_trunk}, opacity={cfg.dims_opacity}, "
             f"color={cfg.dims_color}, color_chn={cfg.color_chn}, separate colour grid={cfg.color_descs is not None}.")
 
@@ -143,10 +144,13 @@ def _shape_args(grid, decoder_params: DecoderParams, grid_sizes=None, color_grid
 
 
 def kernel_family(rays: Rays, grid, decoder_params: DecoderParams, grid_sizes=None, color_grid=None,
-                  color_grid_sizes=None) -> int:
-    """Kernel family ``LP_KERNEL_AUTO`` selects for these shapes: 0 generic, 1 MFMA hidden-32 (tuned), 2 MFMA hidden-64,
-    3 layer-looped MFMA (1-4 layers per MLP) (``lp_renderer_kernel_family``; needs no GPU)."""
+                  color_grid_sizes=None, num_samples_inf: int = 0, **_unused) -> int:
+    """Kernel family ``LP_KERNEL_AUTO`` selects for these shapes: 0 generic, 1 the tuned MFMA kernels of the default decoder
+    (2/2/2 x 32), 3 layer-looped MFMA (1-4 layers per MLP, widths 16 / 32 / 64) (``lp_renderer_kernel_family``; needs no GPU;
+    2, the fp32-MFMA hidden-64 family, was retired in 0.2.4).  ``num_samples_inf``: more than 256 beyond-far samples run the
+    generic kernels (keyword arguments of the render call other than that are accepted and ignored)."""
     a = _shape_args(grid, decoder_params, grid_sizes, color_grid, color_grid_sizes)
+    a.march.num_samples_inf = int(num_samples_inf)
     return int(_lib.lib().lp_renderer_kernel_family(ctypes.byref(a)))
 
 

@@ -68,6 +68,8 @@ elif what == "renderer":
         shapes = [(2, 2, 2, 32, 16, 64, False), (2, 2, 2, 32, 32, 128, False), (1, 1, 1, 16, 16, 64, False), (2, 1, 1, 32, 16, 64, False),
                   (1, 1, 2, 32, 32, 128, False), (1, 2, 1, 16, 32, 128, False), (2, 1, 2, 32, 32, 128, False), (0, 2, 2, 32, 16, 64, True),
                   (0, 2, 2, 32, 32, 128, True), (0, 1, 1, 16, 16, 64, True), (0, 2, 1, 32, 32, 128, True)]
+    if os.environ.get("SHAPESET") == "h64":  # the 2/2/2 x 64 decoder on both BASELINE grid shapes (two-block looped kernels)
+        shapes = [(2, 2, 2, 64, 16, 64, False), (2, 2, 2, 64, 32, 128, False)]
     only = os.environ.get("SHAPES")  # e.g. SHAPES="4/2/4,4/4/4": only these layer triples
     for (nt, no, nc, H, C, G, sep) in shapes:
         if only and f"{nt}/{no}/{nc}" not in only.split(","):
@@ -104,7 +106,7 @@ elif what == "renderer":
 else:
     #        layers, feat, hidden, out
     shapes = [(2, 32, 32, 32), (3, 32, 64, 32), (4, 64, 64, 32), (4, 32, 64, 32), (3, 64, 64, 32), (3, 32, 32, 32), (4, 16, 16, 16)]
-    if os.environ.get("SHAPESET") == "shallow":  # two-layer MLPs: the fp32-MFMA family 2 vs the looped family's two-waves-per-SIMD backward
+    if os.environ.get("SHAPESET") == "shallow":  # two-layer MLPs (looped family, two-waves-per-SIMD backward)
         shapes = [(2, 32, 32, 32), (2, 16, 16, 16), (2, 32, 16, 16), (2, 16, 32, 32)]
     Sx = int(os.environ.get("S", "256"))
     for (nl, E, H, CO) in shapes:

@@ -238,7 +238,7 @@ RENDERER_CASES = [
     RendererCase("color16", seed=12, color_chn=16, n_rays=8),
     RendererCase("triplane_c32", seed=13, is_triplane=True, grid_base=(2, 6, 5, 4, 32), n_rays=40, num_samples_inf=2),
     RendererCase("voxel_c32_color1", seed=14, grid_base=(1, 4, 5, 6, 32), color_chn=1, n_rays=70, num_samples=37),
-    # hidden width 64 (the reference's own example configuration): width-64 MFMA family
+    # hidden width 64 (the reference's own example configuration): two-block kernels of the layer-looped family (until 0.2.3: a width-64 fp32-MFMA family)
     RendererCase("triplane_h64_c32", seed=15, is_triplane=True, grid_base=(1, 6, 5, 4, 32), hidden=64, n_rays=40,
                  num_samples_inf=2, param_std=0.15),
     RendererCase("voxel_h64_c16_scaffold", seed=16, grid_base=(2, 6, 5, 7, 16), hidden=64, scaffold_size=(6, 4, 5),

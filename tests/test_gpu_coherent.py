@@ -165,7 +165,7 @@ def test_renderer_coherent_image(grid, image, kernel):
     ("voxel20_c32", dict(mask_oob=False, color_chn=4)),              # 4 colour channels: NC = 4 instantiations
     ("triplane24_c16", dict(scaffold=True)),                        # non-PLAIN instantiation, occupancy zeros inside runs
     ("voxel20_c32", dict(hidden=16, mask_oob=True)),                 # flex family (hidden 16 padded to 32)
-    ("triplane_plus_voxel_c16", dict(hidden=64, mask_oob=True)),     # width-64 family
+    ("triplane_plus_voxel_c16", dict(hidden=64, mask_oob=True)),     # hidden 64 (two-block looped kernels)
     ("triplane24_c32_t1o1c2", dict(hidden=64)),                      # the reference example's 1/1/2 x 64: two-block looped, one trunk layer
     ("voxel20_c16_t1o1c2", dict(hidden=64, scaffold=True)),          # the same on 16 channels, non-PLAIN
 ], ids=["triplane_nomask", "voxel_nomask_rgba", "triplane_scaffold", "voxel_flex_h16", "mixed_h64", "example_112_h64_c32", "example_112_h64_c16"])
@@ -221,8 +221,8 @@ def test_renderer_coherent_early_termination_exact_when_off():
     ("voxel20_c32", 72, dict()),                                   # C = 32 instantiations
     ("voxel20_c32", 50, dict(hidden=16)),                          # flex family (fp32-MFMA kernels, run-time segment switch)
     ("two_grid_triplane_c16", 66, dict()),                         # two-grid decoder: second scatter per sample
-    ("triplane_plus_voxel_c16", 50, dict(hidden=64)),              # width-64 family
-    ("voxel20_c32", 40, dict(hidden=64, scaffold=True)),           # width-64 family, C = 32, non-PLAIN
+    ("triplane_plus_voxel_c16", 50, dict(hidden=64)),              # hidden 64 (two-block looped kernels)
+    ("voxel20_c32", 40, dict(hidden=64, scaffold=True)),           # hidden 64 (two-block looped kernels), C = 32, non-PLAIN
     ("triplane24_c16_deep444", 72, dict()),                        # layer-looped family: ragged last segment
     ("voxel20_c32_deep342", 50, dict(scaffold=True, noise=True, color_chn=4)),  # layer-looped family, C = 32, fourth colour sum
     ("two_grid_mixed_c16_deep044", 66, dict()),                    # layer-looped two-grid decoder
@@ -326,7 +326,7 @@ def test_segmented_backward_is_not_used_where_it_cannot_be():
     assert lp.backward_segments(d32["rays"], d32["grids"], d32["decoder"], **d32["cfg"]) == 4
     dflex = coherent_renderer_inputs("triplane24_c16", "64x64_axis", num_samples=64, hidden=16)  # flex family: the same
     assert lp.backward_segments(dflex["rays"], dflex["grids"], dflex["decoder"], **dflex["cfg"]) == 4
-    dwide = coherent_renderer_inputs("triplane24_c16", "64x64_axis", num_samples=64, hidden=64)  # width-64 family: the same
+    dwide = coherent_renderer_inputs("triplane24_c16", "64x64_axis", num_samples=64, hidden=64)  # hidden 64: the same
     assert lp.backward_segments(dwide["rays"], dwide["grids"], dwide["decoder"], **dwide["cfg"]) == 4
     assert lp.backward_segments(dwide["rays"], dwide["grids"], dwide["decoder"], **dict(dwide["cfg"], num_samples_inf=1)) == 1
     big = pinhole_rays(256, 256, enc_dim=32, gen=torch.Generator().manual_seed(0))      # 65 536 rays fill the chip
@@ -605,12 +605,14 @@ sys.exit(pytest.main([{root!r} + "/tests/test_gpu_parity.py", "-m", "gpu", "-q",
 """
 
 
-@pytest.mark.parametrize("env", [{"LP_BF3_NW": "8"}, {"LP_LOOP_NO_SHALLOW": "1"}], ids=["bf3_backward_eight_wave_workgroups", "looped_deep_instantiations"])
+@pytest.mark.parametrize("env", [{"LP_BF3_NW": "8"}, {"LP_LOOP_NO_SHALLOW": "1"}, {"LP_LOOP": "1", "LP_SEG_FWD": "0"}],
+                         ids=["bf3_backward_eight_wave_workgroups", "looped_deep_instantiations", "looped_eight_wave_forward"])
 def test_golden_suite_on_the_other_kernel_families(env):
     """Kernels the default selection does not launch on these cases but a user can reach: the eight-wave-workgroup form of the
     tuned bf16x3 backward (what more than 64 beyond-far samples select; LP_BF3_NW=8 forces it) and the deep one-wave-per-SIMD
     instantiations of the layer-looped backward on the shallow decoders (LP_LOOP_NO_SHALLOW=1; by default those run the
-    two-waves-per-SIMD instantiations of lp_renderer_loop_shallow.hip).  The golden / cfg-2-sized / early-termination Renderer
+    two-waves-per-SIMD instantiations of lp_renderer_loop_shallow.hip) and the eight-wave-workgroup forward of the two-block looped
+    kernels (2/2/2 x 64 through LP_LOOP=1, with the small-batch segment-parallel forward off so that the march kernel runs).  The golden / cfg-2-sized / early-termination Renderer
     tests once more, so that every kernel that can be launched is held to the oracle.  (Until round 3 this test ran the
     fp32-MFMA generation of the Renderer kernels, retired in round 4.)"""
     r = subprocess.run([sys.executable, "-c", _GOLDEN_CHILD.format(root=ROOT)], cwd=ROOT, env=dict(os.environ, **env),

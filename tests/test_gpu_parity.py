@@ -641,6 +641,29 @@ def test_hip_graph_capture_of_forward_backward():
         lp.config.check_inputs = old
 
 
+@pytest.mark.parametrize("layers,hidden,C,n_inf,family", [((2, 2, 2), 32, 16, 70, 1), ((2, 2, 2), 64, 32, 70, 3), ((3, 2, 2), 32, 16, 130, 3),
+                                                          ((1, 1, 2), 64, 64, 256, 3), ((2, 2, 2), 64, 16, 257, 0)],
+                         ids=["tuned_inf70", "h64_inf70", "deep322_inf130", "example112_c64_inf256", "h64_inf257_generic"])
+def test_many_beyond_far_samples(layers, hidden, C, n_inf, family):
+    """More than 64 beyond-far samples (contracted coordinates): the tuned family switches to its eight-wave backward workgroups,
+    the layer-looped family tabulates up to 256 depth scales since 0.2.4 (64 before; the retired fp32-MFMA hidden-64 family took
+    256, so the 2/2/2 x 64 decoder keeps its range), 257 and more run the shape-generic kernels.  Outputs and every gradient
+    against the oracle."""
+    from tests.synth import RendererCase
+    dev = _dev()
+    case = RendererCase(f"inf{n_inf}", seed=500 + n_inf + hidden, n_rays=70, grid_base=(2, 5, 6, 7, C), is_triplane=hidden == 64,
+                        n_layers=layers, hidden=hidden, num_samples=11, num_samples_inf=n_inf, gain=0.25, contract=True, param_std=0.2)
+    d = case.build()
+    assert lp.kernel_family(d["rays"], d["grids"], d["decoder"], **d["cfg"]) == family
+    out, gp, ge, gg, _ = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO)
+    o_out, o_gp, o_ge, o_gg, _ = run_oracle_renderer(d)
+    for nm, a, b in (("ray_length", out[0], o_out[0]), ("neg_log_t", out[1], o_out[1]), ("feature", out[2], o_out[2]),
+                     ("grad_mlp_params", gp, o_gp), ("grad_encoding", ge, o_ge)):
+        _assert_close(f"{case.name}: {nm}", a, b.detach().numpy())
+    for i, (a, b) in enumerate(zip(gg, o_gg)):
+        _assert_close(f"{case.name}: grad_grid{i}", a, b.numpy())
+
+
 @pytest.mark.parametrize("color_chn,layers,sep,C,hidden", [(5, (2, 2, 2), False, 16, 32), (16, (4, 2, 3), False, 32, 32), (32, (1, 1, 1), False, 16, 16),
                                                       (12, (0, 3, 2), True, 16, 32), (8, (2, 1, 1), False, 32, 32)],
                          ids=["c5_222", "c16_423_C32", "c32_111_h16", "c12_two_grid_032", "c8_211_C32"])

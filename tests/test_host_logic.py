@@ -13,7 +13,7 @@ from lightplane_amd import _lib, grids, params
 
 def test_library_loads_and_exports_every_declared_symbol():
     L = _lib.lib()
-    assert L.lp_version() == 203
+    assert L.lp_version() == 204
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "lightplane_hip.h")).read()
     declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(lp_[a-z_0-9]+)\s*\(", hdr, flags=re.M))
     assert declared == set(_lib.EXPORTS), f"header vs binding mismatch: {declared ^ set(_lib.EXPORTS)}"
@@ -211,7 +211,7 @@ def test_backward_segments_query_without_gpu():
 
 def test_backward_segments_python_query_covers_every_mfma_family():
     """``lp.backward_segments`` (shapes only, no GPU): the default shape with 16 / 32 channels, the flex and two-grid
-    shapes and the width-64 family march small batches in segments; the shape-generic kernels do not."""
+    shapes and hidden width 64 (layer-looped family) march small batches in segments; the shape-generic kernels do not."""
     from tests.synth import grid_sizes_for, pinhole_rays, random_decoder, random_grids
     gen = torch.Generator().manual_seed(0)
     rays = pinhole_rays(32, 32, enc_dim=32, gen=gen)
@@ -226,7 +226,7 @@ def test_backward_segments_python_query_covers_every_mfma_family():
     assert q() == 4 and q(C=32) == 4
     assert q(layers=(1, 1, 1), hidden=16) == 4          # flex
     assert q(layers=(0, 2, 2), sep=True) == 4           # two-grid decoder
-    assert q(C=32, hidden=64) == 4                      # width-64 family
+    assert q(C=32, hidden=64) == 4                      # hidden 64: two-block looped kernels
     assert q(layers=(3, 2, 2)) == 4                     # layer-looped family
     assert q(num_samples=16) == 1 and q(num_samples_inf=2) == 1 and q(stop_transmittance=0.01) == 1
     assert lp.kernel_family(rays, random_grids(gen, grid_sizes_for((1, 8, 8, 8, 16), True)),
@@ -393,10 +393,11 @@ def test_kernel_family_selection():
     configuration must never fall back to the shape-generic kernels silently."""
     from lightplane_amd.renderer import kernel_family
     from tests.synth import RENDERER_CASES, grid_sizes_for, random_decoder
-    want = {"voxel_basic": 1, "triplane_basic": 1, "triplane_c32": 1, "voxel_c32_color1": 1, "triplane_h64_c32": 2,
-            "voxel_h64_c16_scaffold": 2, "triplane_colorgrid": 3, "colorgrid_c32_h16_voxel": 3, "colorgrid_heads1_inf": 3, "colorgrid_c32_mixed": 3,
+    want = {"voxel_basic": 1, "triplane_basic": 1, "triplane_c32": 1, "voxel_c32_color1": 1, "triplane_h64_c32": 3,
+            "voxel_h64_c16_scaffold": 3, "triplane_colorgrid": 3, "colorgrid_c32_h16_voxel": 3, "colorgrid_heads1_inf": 3, "colorgrid_c32_mixed": 3,
             "voxel_deep": 3, "triplane_h16_c32": 3, "color16": 3, "triplane_deep444": 3, "colorgrid_deep044": 3,
             "triplane_242_c32_color4": 3, "voxel_deep342_h64_c32": 0, "color16_deep323_h16": 3,
+            # (2/2/2 x 64: the two-block looped kernels since 0.2.4 -- the fp32-MFMA family 2 was retired)
             # shallow decoders other than the tuned 2/2/2 x 32 shape: the layer-looped family's two-waves-per-SIMD backward
             # (family 1's fp32-MFMA flex / two-grid kernels were retired in round 4)
             "nb2_like_t2_o1_c1": 3, "nb1_like_h16_111": 3, "flex_121_h16_c32_noise": 3, "flex_212_c32_scaffold": 3,
