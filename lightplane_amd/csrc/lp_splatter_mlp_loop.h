@@ -36,6 +36,14 @@ struct SplatLoopTile {
   static constexpr int PER_WAVE = WT + 8 * 32;
 };
 
+// the forward keeps one tile (the vector to splat, [channel][ray]) and the weight table per wave: 5.6 KB instead of 10.2 KB, so
+// that EIGHT waves fit beside 96 KB of limb images
+struct SplatLoopTileFwd {
+  static constexpr int XT = 0;
+  static constexpr int WT = 32 * LT_LD;
+  static constexpr int PER_WAVE = WT + 8 * 32;
+};
+
 template <int NB>
 LP_DEV void sloop_stage(const LpSplatterArgs& a, const SplatLoopParams& sp, float* lds) {
   const int tid = threadIdx.x;
@@ -165,10 +173,13 @@ LP_DEV void sloop_walk_lds(float* feat, float* wgt, const LpGrid& g, int b, floa
 // ---------------------------------------------------------------------------------------------------------------
 // forward: `rv` is a Renderer-shaped view of the arguments (rv.grid = the INPUT grid-list) for the Renderer's gather
 // ---------------------------------------------------------------------------------------------------------------
-template <int E, int CO, int NB>
-__global__ void __launch_bounds__(256, 2) splat_mlp_fwd_loop(const LpSplatterArgs a, const LpRendererArgs rv,
+// NW: waves per workgroup -- 4, or 8 where the limb images exclude a second four-wave workgroup per CU (three or four 64-wide
+// layers: 72 / 96 KB): eight waves share one copy of the images, two waves per SIMD (sloop_launch_fwd; the staging loops stride
+// by 256 threads, the upper four waves re-write what the lower four write)
+template <int E, int CO, int NB, int NW = WAVES>
+__global__ void __launch_bounds__(64 * NW, 2) splat_mlp_fwd_loop(const LpSplatterArgs a, const LpRendererArgs rv,
                                                                             const SplatLoopParams sp) {
-  using T = SplatLoopTile;
+  using T = SplatLoopTileFwd;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   sloop_stage<NB>(a, sp, lds);
   __syncthreads();
@@ -179,7 +190,7 @@ __global__ void __launch_bounds__(256, 2) splat_mlp_fwd_loop(const LpSplatterArg
   float* const vt = wv + T::XT;
   float* const wT = wv + T::WT;
   const int blk = (int)blockIdx.x / sp.n_seg, seg = (int)blockIdx.x - blk * sp.n_seg;
-  const int64_t ray_id = ((int64_t)blk * WAVES + wave) * RAYS_PER_WAVE + r;
+  const int64_t ray_id = ((int64_t)blk * NW + wave) * RAYS_PER_WAVE + r;
   const bool valid = ray_id < a.rays.n_rays;
   const int64_t rid = valid ? ray_id : 0;
   const Ray ray = load_ray(a.rays, rid);
@@ -427,16 +438,37 @@ static int sloop_nb(const LpSplatterArgs& a) {
 }
 
 template <typename K>
-static int sloop_launch(K kernel, const LpSplatterArgs& a, hipStream_t stream, bool backward) {
+static int sloop_launch(K kernel, const LpSplatterArgs& a, hipStream_t stream, bool backward, int nw = WAVES,
+                        int per_wave = SplatLoopTile::PER_WAVE);
+
+// forward: four-wave workgroups, two per CU, where images + tiles fit twice in the 160 KB; otherwise ONE eight-wave workgroup
+// per CU over one copy of the images (two-block MLPs of three / four layers) -- two waves per SIMD either way
+template <int E, int CO, int NB>
+static int sloop_launch_fwd(const LpSplatterArgs& a, hipStream_t stream) {
+  if constexpr (NB == 2) {
+    static const bool no_nw8 = getenv("LP_LOOP_FWD_NW4") != nullptr;  // A/B
+    static const bool force8 = getenv("LP_LOOP_FWD_NW8") != nullptr;  // tests: also for batches below one round of workgroups
+    const SplatLoopParams p0 = sloop_params(a, NB);
+    const size_t lds4 = (size_t)p0.img_end + (size_t)WAVES * SplatLoopTileFwd::PER_WAVE * 4;
+    const size_t lds8 = (size_t)p0.img_end + (size_t)8 * SplatLoopTileFwd::PER_WAVE * 4;
+    const unsigned nb8 = (unsigned)((a.rays.n_rays + 8 * RAYS_PER_WAVE - 1) / (8 * RAYS_PER_WAVE));
+    if (2 * lds4 > 160 * 1024 && lds8 <= 160 * 1024 && (nb8 >= 256u || force8) && !no_nw8)
+      return sloop_launch(splat_mlp_fwd_loop<E, CO, NB, 8>, a, stream, false, 8, SplatLoopTileFwd::PER_WAVE);
+  }
+  return sloop_launch(splat_mlp_fwd_loop<E, CO, NB, WAVES>, a, stream, false, WAVES, SplatLoopTileFwd::PER_WAVE);
+}
+
+template <typename K>
+static int sloop_launch(K kernel, const LpSplatterArgs& a, hipStream_t stream, bool backward, int nw, int per_wave) {
   SplatLoopParams p = sloop_params(a, sloop_nb(a));
-  const size_t lds = (size_t)p.img_end + (size_t)WAVES * SplatLoopTile::PER_WAVE * 4;
+  const size_t lds = (size_t)p.img_end + (size_t)nw * per_wave * 4;
   const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   LpRendererArgs rv = {};
   rv.grid = a.input_grid;
   rv.march = a.march;
   rv.rays = a.rays;
-  const unsigned nb = (unsigned)((a.rays.n_rays + WAVES * RAYS_PER_WAVE - 1) / (WAVES * RAYS_PER_WAVE));
+  const unsigned nb = (unsigned)((a.rays.n_rays + nw * RAYS_PER_WAVE - 1) / (nw * RAYS_PER_WAVE));
   // small batches (see splat_segments in lp_splatter.hip): segments of >= 16 samples, within one round of workgroups
   static const int forced = getenv("LP_SPLAT_SEGMENTS") ? atoi(getenv("LP_SPLAT_SEGMENTS")) : 0;
   const int s_tot = a.march.num_samples + a.march.num_samples_inf;
@@ -448,7 +480,7 @@ static int sloop_launch(K kernel, const LpSplatterArgs& a, hipStream_t stream, b
     const hipError_t e2 = hipMemsetAsync(a.grad_encoding, 0, (size_t)a.rays.n_rays * a.mlp.dims[0] * sizeof(float), stream);
     if (e2 != hipSuccess) return set_error((int)e2, "hipMemsetAsync(grad_encoding): %s", hipGetErrorString(e2));
   }
-  hipLaunchKernelGGL(kernel, dim3(nb * (unsigned)n_seg), dim3(256), lds, stream, a, rv, p);
+  hipLaunchKernelGGL(kernel, dim3(nb * (unsigned)n_seg), dim3(64 * nw), lds, stream, a, rv, p);
   return LP_OK;
 }
 

@@ -41,7 +41,16 @@ bool splatter_mlp_loop_supported(const LpSplatterArgs& a) {
 int splatter_mlp_forward_loop(const LpSplatterArgs& a, hipStream_t stream) {
   if (a.rays.n_rays == 0) return LP_OK;
   int rc;
-  LP_DISPATCH_SL(splat_mlp_fwd_loop, false);
+  const int E = a.mlp.dims[0], CO = a.mlp.dims[a.mlp.n_layers], NB = sloop_nb(a);
+#define LP_SL_FWD(EV, COV) rc = (NB == 1 && EV < 64) ? sloop_launch_fwd<EV, COV, (EV < 64 ? 1 : 2)>(a, stream) : sloop_launch_fwd<EV, COV, 2>(a, stream)
+  if (E == 16) {
+    if (CO == 16) LP_SL_FWD(16, 16); else LP_SL_FWD(16, 32);
+  } else if (E == 32) {
+    if (CO == 16) LP_SL_FWD(32, 16); else LP_SL_FWD(32, 32);
+  } else {
+    if (CO == 16) LP_SL_FWD(64, 16); else LP_SL_FWD(64, 32);
+  }
+#undef LP_SL_FWD
   if (rc) return rc;
   return check_launch("splat_mlp_fwd_loop");
 }

@@ -449,6 +449,19 @@ def test_splatter_coherent_16_rays_per_wave():
     assert r.returncode == 0, r.stdout.decode()[-3000:]
 
 
+def test_mlp_splatter_eight_wave_forward():
+    """MLP-Splatters whose limb images exclude a second four-wave workgroup per CU (three / four 64-wide layers) run their forward
+    on eight-wave workgroups when the batch fills the chip (65 536 rays and more); LP_LOOP_FWD_NW8=1 selects them for the small
+    golden / sweep cases too, so that the instantiations are held to the oracle (hidden 64, 3 and 4 layers, feature widths
+    32 / 64: the reference's own sweep shapes, tests/test_splatter_with_autograd.py:38-53)."""
+    env = dict(os.environ, LP_LOOP_FWD_NW8="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_sweep.py"), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "test_mlp_splatter_matches_oracle_and_golden or test_reference_splatter_sweep_axes"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+
+
 # --------------------------------------------------------------------------------------------------------------
 # BASELINE-config scale
 # --------------------------------------------------------------------------------------------------------------
