@@ -1,13 +1,13 @@
 #!/usr/bin/env python
 """Print a table of per-kernel register / scratch / occupancy figures of one .hip source
-(hipcc -Rpass-analysis=kernel-resource-usage), with the build's own flags."""
+(hipcc -Rpass-analysis=kernel-resource-usage), with the build's own flags (the per-file ones of build.py FILE_FLAGS included)."""
 import os, re, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 from lightplane_amd.csrc import build as B
 
 src = sys.argv[1]
-cmd = ["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(B.HERE, src), "-o", "/dev/null"] + sys.argv[2:]
+cmd = ["/opt/rocm/bin/hipcc"] + B.FLAGS + B.FILE_FLAGS.get(src, []) + ["-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(B.HERE, src), "-o", "/dev/null"] + sys.argv[2:]
 out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
 rows, cur = [], None
 for line in out.splitlines():
