@@ -620,7 +620,7 @@ def cpu_baseline(wl):
     cores = torch.get_num_threads()
     res = {"unit": "Mrays/s", "cores": cores, "kind": "port",
            "kind_note": "the reference itself (/root/reference, pure PyTorch) does not exist on the GPU box and cannot travel; the "
-                        "oracle is its restatement, pinned to 51 fixtures the reference's own naive functions produced (tests/golden)"}
+                        "oracle is its restatement, pinned to 53 fixtures the reference's own naive functions produced (tests/golden)"}
 
     # BASELINE configs[0] ("cfg 1"): 1k random rays, 32^3 x 16 voxel grid, 64 samples, 2/2/2 x 32 decoder
     from tests.synth import baseline_cfg1

@@ -61,7 +61,8 @@ extern "C" {
                                   default decoder shape only (every other shallow shape reports 3), lp_splatter_kernel_family() no
                                   longer returns 2; lp_version() is NEGATIVE for a library built with -DLP_EXPERIMENTS
                            0.2.4: no struct change; lp_renderer_kernel_family() no longer returns 2 (2/2/2 x 64 decoders run the
-                                  layer-looped family's two-block kernels and report 3); family 3 takes up to 256 beyond-far samples */
+                                  layer-looped family's two-block kernels and report 3); family 3 takes up to 256 beyond-far samples
+                                  and two-grid decoders of hidden width 64 (heads of at most 2 layers, 16 / 32 grid channels) */
 
 #define LP_MAX_GRIDS 8   /* grids per grid-list                         */
 #define LP_MAX_LAYERS 8  /* layers per MLP                              */

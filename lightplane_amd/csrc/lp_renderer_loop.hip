@@ -12,8 +12,8 @@ static int loop_nb(int H, int C = 16) { return (H <= 32 && C <= 32) ? 1 : 2; }
 
 // Shape family: grid-list(s) with C in {16, 32} channels below 4 GB; trunk of 1..4 layers, or none with a separate colour
 // grid-list; heads of 1..4 layers; every hidden width equal to H in {16, 32} -- or, on the two-block instantiation (H = 64, or
-// C = 64 grid channels with any of the three widths): at most 2 trunk layers, heads of at most 2 layers, no colour grid,
-// <= 4 colour channels; <= 256 beyond-far samples.
+// C = 64 grid channels with any of the three widths): at most 2 trunk layers, heads of at most 2 layers, <= 4 colour channels, a
+// colour grid only with C <= 32; <= 256 beyond-far samples.
 bool renderer_loop_supported(const LpRendererArgs& a, const char** why) {
   *why = "";
   const int C = a.grid.channels;
@@ -33,10 +33,11 @@ bool renderer_loop_supported(const LpRendererArgs& a, const char** why) {
   if (H == 0) H = C;  // two-grid decoder with single-layer heads: no hidden layer at all
   if (!same) { *why = "hidden widths differ between layers"; return false; }
   if (H != 16 && H != 32 && H != 64) { *why = "hidden width other than 16 / 32 / 64"; return false; }
-  if ((H == 64 || C == 64) && (a.trunk.n_layers > 2 || a.opacity.n_layers > 2 || a.color.n_layers > 2 || tg)) {
-    *why = "hidden width 64 / 64 grid channels with more than 2 layers per MLP (or a colour grid)";
+  if ((H == 64 || C == 64) && (a.trunk.n_layers > 2 || a.opacity.n_layers > 2 || a.color.n_layers > 2)) {
+    *why = "hidden width 64 / 64 grid channels with more than 2 layers per MLP";
     return false;
   }
+  if (C == 64 && tg) { *why = "64 grid channels with a separate colour grid"; return false; }
   if (a.color_chn > 32) { *why = "more than 32 colour channels"; return false; }
   if (a.color_chn > 4 && (H == 64 || C == 64)) { *why = "more than 4 colour channels with hidden width 64 / 64 grid channels"; return false; }
   if (a.grid.n_rows * C * 4 >= (int64_t)1 << 32) { *why = "grid-list of 4 GB or more"; return false; }
@@ -192,13 +193,15 @@ int renderer_forward_loop(const LpRendererArgs& a, hipStream_t stream) {
   if (a.grid.channels == 64) {
     LP_LOOP_FWD(64, 2, false, false);
   } else if (a.grid.channels == 16) {
-    if (NB == 2) LP_LOOP_FWD(16, 2, false, false);
+    if (NB == 2 && tg) LP_LOOP_FWD(16, 2, true, false);
+    else if (NB == 2) LP_LOOP_FWD(16, 2, false, false);
     else if (tg && wc) LP_LOOP_FWD(16, 1, true, true);
     else if (tg) LP_LOOP_FWD(16, 1, true, false);
     else if (wc) LP_LOOP_FWD(16, 1, false, true);
     else LP_LOOP_FWD(16, 1, false, false);
   } else {
-    if (NB == 2) LP_LOOP_FWD(32, 2, false, false);
+    if (NB == 2 && tg) LP_LOOP_FWD(32, 2, true, false);
+    else if (NB == 2) LP_LOOP_FWD(32, 2, false, false);
     else if (tg && wc) LP_LOOP_FWD(32, 1, true, true);
     else if (tg) LP_LOOP_FWD(32, 1, true, false);
     else if (wc) LP_LOOP_FWD(32, 1, false, true);
@@ -233,7 +236,8 @@ int renderer_backward_loop(const LpRendererArgs& a, hipStream_t stream) {
     if (p.n_t <= 1) LP_LOOP_BWD(64, 2, false, 1, 1, false);
     else LP_LOOP_BWD(64, 2, false, 2, 1, false);
   } else if (a.grid.channels == 16) {
-    if (NB == 2 && p.n_t <= 1) LP_LOOP_BWD(16, 2, false, 1, 1, false);
+    if (NB == 2 && tg) LP_LOOP_BWD(16, 2, true, 1, 1, false);  // two-grid decoder x 64: heads of at most two layers, no trunk
+    else if (NB == 2 && p.n_t <= 1) LP_LOOP_BWD(16, 2, false, 1, 1, false);
     else if (NB == 2) LP_LOOP_BWD(16, 2, false, 2, 1, false);
     else if (tg && wc) LP_LOOP_BWD(16, 1, true, 1, LOOP_MAX_H, true);
     else if (tg) LP_LOOP_BWD(16, 1, true, 1, LOOP_MAX_H, false);
@@ -242,7 +246,8 @@ int renderer_backward_loop(const LpRendererArgs& a, hipStream_t stream) {
   } else {
     // (one trunk layer -- the reference example's 1/1/2 x 64 --: an instantiation of its own keeps 32 activation + 18 dW registers
     // fewer and fits the 512-register budget without scratch; the two-trunk-layer one spills 44-46)
-    if (NB == 2 && p.n_t <= 1) LP_LOOP_BWD(32, 2, false, 1, 1, false);
+    if (NB == 2 && tg) LP_LOOP_BWD(32, 2, true, 1, 1, false);
+    else if (NB == 2 && p.n_t <= 1) LP_LOOP_BWD(32, 2, false, 1, 1, false);
     else if (NB == 2) LP_LOOP_BWD(32, 2, false, 2, 1, false);
     else if (tg && wc) LP_LOOP_BWD(32, 1, true, 1, LOOP_MAX_H, true);
     else if (tg) LP_LOOP_BWD(32, 1, true, 1, LOOP_MAX_H, false);

@@ -117,7 +117,8 @@ def _warn_if_generic(a, cfg: _RendererCfg) -> None:
             "lightplane_amd: this decoder shape runs on the shape-generic Renderer kernels (10-100x slower). The "
             "MFMA families cover grid channels 16/32, grid-lists below 4 GB, trunk 1-4 (0 with a separate colour grid) / "
             "opacity 1-4 / colour 1-4 layers with ONE hidden width of 16 or 32 and <= 32 colour channels, or up to 2/2/2 "
-            "layers with hidden width 64 and / or 64 grid channels, <= 4 colour channels and no separate colour grid; at most 256 "
+            "layers with hidden width 64 and / or 64 grid channels and <= 4 colour channels (a separate colour grid only with 16 / 32 "
+            "grid channels); at most 256 "
             "beyond-far samples. "
             f"Got channels={cfg.channels}, trunk={cfg.dims_trunk}, opacity={cfg.dims_opacity}, "
             f"color={cfg.dims_color}, color_chn={cfg.color_chn}, separate colour grid={cfg.color_descs is not None}.")

@@ -277,6 +277,12 @@ RENDERER_CASES = [
                  mask_oob=True, param_std=0.15),
     RendererCase("voxel_c64_h64_112_scaffold", seed=33, grid_base=(2, 5, 6, 7, 64), hidden=64, n_layers=(1, 1, 2), n_rays=40,
                  scaffold_size=(6, 4, 5), gain=3.0, mask_oob=True, param_std=0.1),
+    # two-grid decoder with hidden width 64 (use_separate_color_grid + mlp_hidden_chn 64): two-block looped kernels since 0.2.4
+    RendererCase("colorgrid_h64_c32_triplane", seed=34, is_triplane=True, grid_base=(2, 6, 5, 4, 32), separate_color_grid=True,
+                 n_layers=(0, 2, 2), hidden=64, n_rays=70, num_samples=21, mask_oob=True, param_std=0.15),
+    RendererCase("colorgrid_h64_c16_o1c2_inf", seed=35, grid_base=(2, 5, 6, 7, 16), separate_color_grid=True,
+                 color_grid_base=(2, 4, 3, 9, 16), n_layers=(0, 1, 2), hidden=64, n_rays=40, num_samples_inf=3, contract=True,
+                 scaffold_size=(6, 4, 5), gain=3.0, param_std=0.15),
 ]
 
 SPLATTER_CASES = [

@@ -168,7 +168,9 @@ def test_renderer_coherent_image(grid, image, kernel):
     ("triplane_plus_voxel_c16", dict(hidden=64, mask_oob=True)),     # hidden 64 (two-block looped kernels)
     ("triplane24_c32_t1o1c2", dict(hidden=64)),                      # the reference example's 1/1/2 x 64: two-block looped, one trunk layer
     ("voxel20_c16_t1o1c2", dict(hidden=64, scaffold=True)),          # the same on 16 channels, non-PLAIN
-], ids=["triplane_nomask", "voxel_nomask_rgba", "triplane_scaffold", "voxel_flex_h16", "mixed_h64", "example_112_h64_c32", "example_112_h64_c16"])
+    ("two_grid_triplane_c16", dict(hidden=64)),                      # two-grid decoder x 64 (two-block looped kernels since 0.2.4)
+], ids=["triplane_nomask", "voxel_nomask_rgba", "triplane_scaffold", "voxel_flex_h16", "mixed_h64", "example_112_h64_c32", "example_112_h64_c16",
+        "two_grid_h64"])
 def test_renderer_coherent_variants(grid, kw):
     d = coherent_renderer_inputs(grid, "48x80_az30_el45", seed=3, **kw)
     check_renderer(d, _dev(), _lib.LP_KERNEL_AUTO, f"{grid}/{kw}")
@@ -223,11 +225,12 @@ def test_renderer_coherent_early_termination_exact_when_off():
     ("two_grid_triplane_c16", 66, dict()),                         # two-grid decoder: second scatter per sample
     ("triplane_plus_voxel_c16", 50, dict(hidden=64)),              # hidden 64 (two-block looped kernels)
     ("voxel20_c32", 40, dict(hidden=64, scaffold=True)),           # hidden 64 (two-block looped kernels), C = 32, non-PLAIN
+    ("two_grid_triplane_c16", 66, dict(hidden=64)),                # two-grid decoder x 64
     ("triplane24_c16_deep444", 72, dict()),                        # layer-looped family: ragged last segment
     ("voxel20_c32_deep342", 50, dict(scaffold=True, noise=True, color_chn=4)),  # layer-looped family, C = 32, fourth colour sum
     ("two_grid_mixed_c16_deep044", 66, dict()),                    # layer-looped two-grid decoder
 ], ids=["triplane_s88", "triplane_s64_nomask", "triplane_s33", "mixed_s72", "voxel_b2_rgba_s96", "triplane_scaffold_noise_s70",
-        "triplane_16k_rays_s80", "voxel_c32_s72", "voxel_flex_h16_s50", "two_grid_s66", "mixed_h64_s50", "voxel_c32_h64_scaffold_s40",
+        "triplane_16k_rays_s80", "voxel_c32_s72", "voxel_flex_h16_s50", "two_grid_s66", "mixed_h64_s50", "voxel_c32_h64_scaffold_s40", "two_grid_h64_s66",
         "deep444_s72", "deep342_c32_scaffold_noise_s50", "deep_two_grid_s66"])
 def test_segmented_backward(grid, num_samples, kw):
     """4 096-ray image, S > 16: the backward runs one workgroup per (128 rays, block of 16 samples) and has to agree with

@@ -401,7 +401,8 @@ def test_kernel_family_selection():
             # shallow decoders other than the tuned 2/2/2 x 32 shape: the layer-looped family's two-waves-per-SIMD backward
             # (family 1's fp32-MFMA flex / two-grid kernels were retired in round 4)
             "nb2_like_t2_o1_c1": 3, "nb1_like_h16_111": 3, "flex_121_h16_c32_noise": 3, "flex_212_c32_scaffold": 3,
-            "triplane_c64_h32": 3, "voxel_c64_h64_112_scaffold": 3}
+            "triplane_c64_h32": 3, "voxel_c64_h64_112_scaffold": 3,
+            "colorgrid_h64_c32_triplane": 3, "colorgrid_h64_c16_o1c2_inf": 3}  # two-grid x 64: since 0.2.4
     for c in RENDERER_CASES:
         if c.name in want:
             d = c.build()
