@@ -27,6 +27,8 @@ for w in $WL; do
     cfg4) run cfg4 5 1 ;;
     small) run small 200 3 ;;
     1080p_s128) run 1080p_s128 5 1 ;;
+    h64_222) run h64_222 20 1 ;;             # 2/2/2 x 64 on the two-block looped kernels (eight-wave forward)
+    h64_example_112) run h64_example_112 20 1 ;;
     cfg5)  # BASELINE configs[4] at its per-GPU size: kernel trace only (a step takes ~0.27 s)
       rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg5 -o bench -- python $R/bench.py --workload cfg5 --no-cpu-baseline --no-extras --steps 3 --warmup 1 > $R/gpurun_out/prof_cfg5.txt 2>&1
       tail -1 $R/gpurun_out/prof_cfg5.txt | cut -c1-300 ;;

@@ -21,9 +21,14 @@ CMD = {"cfg2": "python bench.py --workload cfg2 --no-cpu-baseline --no-extras --
        "small": "python bench.py --workload small --no-cpu-baseline --no-extras --steps 200 --warmup 3",
        "1080p_s128": "python bench.py --workload 1080p_s128 --no-cpu-baseline --no-extras --steps 5 --warmup 3",
        "cfg5": "python bench.py --workload cfg5 --no-cpu-baseline --no-extras --steps 3 --warmup 1",
-       "loop": "LP_LOOP=1 python bench.py --workload cfg2 --no-cpu-baseline --no-extras --steps 200 --warmup 3"}
+       "loop": "LP_LOOP=1 python bench.py --workload cfg2 --no-cpu-baseline --no-extras --steps 200 --warmup 3",
+       "h64_222": "python bench.py --workload h64_222 --no-cpu-baseline --no-extras --steps 20 --warmup 3",
+       "h64_example_112": "python bench.py --workload h64_example_112 --no-cpu-baseline --no-extras --steps 20 --warmup 3"}
 out = {}
-for w in ("cfg2", "cfg3", "cfg4", "small", "1080p_s128", "cfg5", "loop"):
+summary_path = os.path.join(P, f"{ROUND}_pmc_summary.json")
+if ONLY and os.path.exists(summary_path):  # a partial re-profile keeps the other workloads' entries of this round
+    out = {k: v for k, v in json.load(open(summary_path)).items() if v.get("workload") not in ONLY}
+for w in CMD:
     if ONLY and w not in ONLY:
         continue
     stats = glob.glob(os.path.join(G, f"prof_{w}", "**", "*kernel_stats.csv"), recursive=True)
@@ -82,6 +87,6 @@ for w in ("cfg2", "cfg3", "cfg4", "small", "1080p_s128", "cfg5", "loop"):
             e["clock_ghz"] = round(e["SQ_BUSY_CYCLES"] / 32.0 / (e.get("pmc_duration_ns") or e["trace_duration_ns"]), 4)
         e["workload"] = w
         out[f"{w}: {k}"] = e  # ("loop" = the cfg-2 command with LP_LOOP=1: its entries never match bench.py's lookup for cfg2)
-json.dump(out, open(os.path.join(P, f"{ROUND}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+json.dump(out, open(summary_path, "w"), indent=1, sort_keys=True)
 print(json.dumps({k: {c: v[c] for c in v if c in ("hbm_bytes_per_launch", "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "_scratch", "SQ_WAVES")}
                   for k, v in out.items()}, indent=1))
