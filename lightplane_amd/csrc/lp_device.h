@@ -413,7 +413,7 @@ LP_DEV float scaffold_lookup(const float* scaffold, const LpGrid& s, int b, floa
 
 // softplus (torch: beta 1, linear above 20).  log1p(e) through the hardware log for e >= 2^-6 and
 // through its series below (|error| < 3e-8 there): a handful of VALU ops instead of libm's log1pf.
-#if defined(LP_X_RELU_F) || defined(LP_X_MASK_BIT_INT) || defined(LP_X_MASK_APPLY) || defined(LP_X_LOOP_NO_BARRIER)
+#if defined(LP_X_RELU_F) || defined(LP_X_MASK_BIT_INT) || defined(LP_X_MASK_APPLY)
 #ifndef LP_EXPERIMENTS
 #error "LP_X_* are A/B timing switches: build them with -DLP_EXPERIMENTS (LP_BUILD_FLAGS), which makes lp_version() negative so that the binding refuses the library unless LIGHTPLANE_AMD_ALLOW_EXPERIMENTAL=1"
 #endif

@@ -29,11 +29,7 @@ struct LoopLayer {
 inline int loop_layer_bytes(int rows_in, int cols) { return ((rows_in + 31) / 32) * ((cols + 31) / 32) * LOOP_BLK; }
 
 LP_DEV constexpr int pi16l(int m) { return m < 4 ? 2 * m : (m < 12 ? 2 * (m - 4) + 1 : 2 * (m - 8)); }
-#ifdef LP_X_LOOP_NO_BARRIER  // timing experiment (WRONG weight gradients): what the barrier coupling of a workgroup's waves costs
-LP_DEV void lds_barrier_l() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-#else
 LP_DEV void lds_barrier_l() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // staging
