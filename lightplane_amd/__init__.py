@@ -26,6 +26,16 @@ from .renderer import LightplaneFunction, backward_segments, kernel_family, ligh
 from .splatter import (LightplaneMLPSplatterFunction, LightplaneSplatterFunction, lightplane_mlp_splatter,  # noqa: E402
                        lightplane_splatter)
 from .modules import LightplaneMLPSplatter, LightplaneRenderer, LightplaneSplatter  # noqa: E402
+# The reference's sub-module import paths (`from lightplane.mlp_utils import DecoderParams`, tests/renderer_speed_benchmark.py:30)
+# exist as alias modules (re-exports only).  Two of them are named like the functions they hold, exactly as in the reference
+# (lightplane/__init__.py:8-9): load them first, then bind the FUNCTIONS to the package attributes, so that a later
+# `import lightplane_amd.lightplane_renderer` does not turn `lightplane_amd.lightplane_renderer(...)` into a module.
+import importlib as _importlib  # noqa: E402
+for _m in ("lightplane_renderer", "lightplane_splatter", "misc_utils", "mlp_utils", "ray_utils", "renderer_module", "splatter_module"):
+    _importlib.import_module(__name__ + "." + _m)  # (`from . import name` would skip a name the package already has)
+del _m
+from .renderer import lightplane_renderer  # noqa: E402,F811
+from .splatter import lightplane_splatter  # noqa: E402,F811
 
 __all__ = [
     "lightplane_renderer", "lightplane_splatter", "lightplane_mlp_splatter", "LightplaneRenderer",
