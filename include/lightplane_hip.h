@@ -298,6 +298,15 @@ int lp_hash_randn(const int32_t* x1, const int32_t* x2, float* out, int64_t n, i
  * list order.  Used by the tests to prove bit-exact integer indexing vs the oracle. */
 int lp_renderer_corner_rows(const LpRendererArgs* args, int64_t* rows, void* stream);
 
+/* Debug / parity hook: lp_renderer_backward() through the DUMP twin of the kernel it would launch (same template, same
+ * instruction sequence, stores added), which also writes the ReLU decisions of the backward's decoder recompute:
+ * dump[(ray * S_tot + sample) * 5 + {0: trunk layer 1, 1: trunk layer 2 (the trunk output), 2: opacity hidden, 3: colour
+ * hidden}] = bit f set when unit f is active, word 4 = 1 (sample contributed), 2 (visited, not contributing: beyond the ray's
+ * last marched sample), 0 (never visited).  dump_words must be n_rays * S_tot * 5.  Only the tuned bf16x3 family (kernel
+ * family 1, RGB, four-wave workgroups) has dump twins: LP_EUNSUPPORTED otherwise.  The tests force these decisions onto the
+ * fp64 oracle and require every gradient entry within 1e-4 (tests/test_gpu_config_scale.py::test_flips_are_flips). */
+int lp_renderer_backward_relu_dump(const LpRendererArgs* args, uint32_t* dump, int64_t dump_words, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

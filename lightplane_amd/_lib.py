@@ -107,7 +107,7 @@ EXPORTS = (
     "lp_version", "lp_last_error", "lp_abi_sizeof", "lp_renderer_forward", "lp_renderer_backward",
     "lp_splatter_forward", "lp_splatter_normalize", "lp_splatter_backward", "lp_hash_randn",
     "lp_renderer_corner_rows", "lp_renderer_kernel_family", "lp_splatter_kernel_family",
-    "lp_renderer_backward_segments",
+    "lp_renderer_backward_segments", "lp_renderer_backward_relu_dump",
     "lp_ray_embedding_forward", "lp_ray_embedding_backward",
 )
 
@@ -146,6 +146,8 @@ def lib() -> C.CDLL:
     L.lp_hash_randn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
     L.lp_renderer_corner_rows.restype = C.c_int
     L.lp_renderer_corner_rows.argtypes = [C.POINTER(LpRendererArgs), C.c_void_p, C.c_void_p]
+    L.lp_renderer_backward_relu_dump.restype = C.c_int
+    L.lp_renderer_backward_relu_dump.argtypes = [C.POINTER(LpRendererArgs), C.c_void_p, C.c_int64, C.c_void_p]
     L.lp_renderer_kernel_family.restype = C.c_int
     L.lp_renderer_kernel_family.argtypes = [C.POINTER(LpRendererArgs)]
     L.lp_renderer_backward_segments.restype = C.c_int

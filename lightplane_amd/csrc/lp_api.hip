@@ -10,6 +10,7 @@
 namespace lp {
 
 static thread_local char g_err[512] = "";
+thread_local uint32_t* g_relu_dump = nullptr;  // test hook, see lp_host.h
 
 int set_error(int code, const char* fmt, ...) {
   va_list ap;
@@ -329,6 +330,22 @@ int lp_renderer_corner_rows(const LpRendererArgs* args, int64_t* rows, void* str
   if ((rc = check_march(args->march))) return rc;
   if ((rc = check_grid_list("grid", args->grid, true))) return rc;
   return renderer_corner_rows_launch(*args, rows, (hipStream_t)stream);
+}
+
+int lp_renderer_backward_relu_dump(const LpRendererArgs* args, uint32_t* dump, int64_t dump_words, void* stream) {
+  if (!args || !dump) return set_error(LP_ENULL, "args / dump is NULL");
+  const int64_t want = args->rays.n_rays * (int64_t)(args->march.num_samples + args->march.num_samples_inf) * 5;
+  if (dump_words != want) return set_error(LP_EINVAL, "relu dump: %lld words given, [n_rays][S_tot][5] = %lld needed", (long long)dump_words, (long long)want);
+  LpRendererArgs a;
+  int rc = normalized_renderer_args(args, true, a);
+  if (rc) return rc;
+  const char* why = "";
+  if (a.kernel == LP_KERNEL_GENERIC || select_renderer(a, &why) != 1)
+    return set_error(LP_EUNSUPPORTED, "relu dump: only the tuned bf16x3 family (kernel family 1) has dump twins");
+  g_relu_dump = dump;
+  rc = lp_renderer_backward(args, stream);
+  g_relu_dump = nullptr;
+  return rc;
 }
 
 static int normalized_splatter_args(const LpSplatterArgs* args, bool backward, LpSplatterArgs& a) {

@@ -11,6 +11,10 @@ int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3
 // hipGetLastError() -> LP_OK or the positive hipError_t (message recorded).
 int check_launch(const char* what);
 
+// test hook (lp_renderer_backward_relu_dump, lp_api.hip): while non-NULL, the MFMA backwards launch their DUMP twins, which also
+// write the ReLU decisions of the recompute here.  Thread-local; NULL in every product call.
+extern thread_local uint32_t* g_relu_dump;
+
 // generic (shape-agnostic) kernels: lp_renderer_generic.hip
 int renderer_forward_generic(const LpRendererArgs& a, hipStream_t stream);
 int renderer_backward_generic(const LpRendererArgs& a, hipStream_t stream);

@@ -52,6 +52,9 @@ struct MfmaParams {
   // segment-parallel backward: LP_SEG_LEN-sample blocks per workgroup (chosen at launch, see launch_bwd3)
   int seg_blocks;
   int seg_fwd;  // forward of the flex / two-grid shapes: 1 = this launch marches segments (segment-local state records)
+  // test hook (lp_renderer_backward_relu_dump): the ReLU decisions of the backward's recompute, [ray][sample][5] words -- t1, t2, o1,
+  // c1 (bit f = unit f active) and 1 = "this sample was visited".  Only the DUMP instantiations read it.
+  uint32_t* relu_dump;
 };
 
 // LDS map (floats).  Weight matrices are kept ONCE, row-major [in][W_LD] with a padded row

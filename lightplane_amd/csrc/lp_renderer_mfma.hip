@@ -242,6 +242,7 @@ static MfmaParams make_params(const LpRendererArgs& a) {
   p.dbg = dbg;
   p.seg_blocks = 1;
   p.seg_fwd = 0;
+  p.relu_dump = g_relu_dump;
   return p;
 }
 

@@ -125,7 +125,9 @@ struct Bf3Lds {
   static constexpr int TOTAL = CB + (CB_LDS ? NW * 64 * 16 * 4 : 0);
 };
 
-template <int C, int GM, bool PLAIN, int NC, int NW, bool SEG = false>
+// DUMP (test hook, its own instantiations: the production kernels are unchanged): the ReLU decisions this backward takes are
+// written to mp.relu_dump -- the same instruction sequence computes them, only the stores are added.
+template <int C, int GM, bool PLAIN, int NC, int NW, bool SEG = false, bool DUMP = false>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(const LpRendererArgs a, const MfmaParams mp) {
   using M = Lds;
   using L = LdsBf3<C>;
@@ -324,6 +326,22 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
       for (int q = 0; q < 16; ++q) {
         ho_mask = mask_bit(ho_mask, ho[q], q);
         hc_mask = mask_bit(hc_mask, hc[q], q);
+      }
+      if constexpr (DUMP) {
+        unsigned m1 = 0, m2 = 0, mo = 0, mc = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const unsigned bit = 1u << featq(q, h);
+          m1 |= (h1[q] > 0.0f) ? bit : 0u;   // the conditions the backward below applies
+          m2 |= (e[q] > 0.0f) ? bit : 0u;
+          mo |= ((ho_mask >> q) & 1u) ? bit : 0u;
+          mc |= ((hc_mask >> q) & 1u) ? bit : 0u;
+        }
+        m1 |= __shfl_xor(m1, 32); m2 |= __shfl_xor(m2, 32); mo |= __shfl_xor(mo, 32); mc |= __shfl_xor(mc, 32);
+        if (valid && h == 0) {
+          uint32_t* d = mp.relu_dump + (rid * s_tot + s) * 5;
+          d[0] = m1; d[1] = m2; d[2] = mo; d[3] = mc; d[4] = on ? 1u : 2u;
+        }
       }
       LP_SCHED_FENCE();
       // ho / hc go to the (wave-private) tiles: the output layers' dW reads them from there
@@ -613,7 +631,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
 // host side
 // ---------------------------------------------------------------------------------------
 
-template <int C, int GM, bool PLAIN, int NC, int NW, bool SEG = false>
+template <int C, int GM, bool PLAIN, int NC, int NW, bool SEG = false, bool DUMP = false>
 static int launch_bwd3w(const LpRendererArgs& a, const MfmaParams& mp_, hipStream_t stream) {
   MfmaParams mp = mp_;
   const unsigned ray_blocks = (unsigned)((a.rays.n_rays + NW * RAYS_PER_WAVE - 1) / (NW * RAYS_PER_WAVE));
@@ -634,15 +652,23 @@ static int launch_bwd3w(const LpRendererArgs& a, const MfmaParams& mp_, hipStrea
   constexpr size_t lds = (size_t)Bf3Lds<C, NW>::TOTAL;
   static_assert(lds * (NW == 8 ? 1 : 2) <= 160 * 1024, "the workgroups of one CU must fit the 160 KB LDS");
   static_assert(NW == 8 || 2 * lds <= 160 * 1024, "two 4-wave workgroups per CU");
-  const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_bf3<C, GM, PLAIN, NC, NW, SEG>,
+  const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_bf3<C, GM, PLAIN, NC, NW, SEG, DUMP>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   const unsigned nb = ray_blocks * segs;
-  hipLaunchKernelGGL((renderer_bwd_bf3<C, GM, PLAIN, NC, NW, SEG>), dim3(nb), dim3(64 * NW), lds, stream, a, mp);
+  hipLaunchKernelGGL((renderer_bwd_bf3<C, GM, PLAIN, NC, NW, SEG, DUMP>), dim3(nb), dim3(64 * NW), lds, stream, a, mp);
   return LP_OK;
 }
 template <int C, int GM, bool PLAIN, int NC>
 static int launch_bwd3(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
+  if (mp.relu_dump) {  // test hook: the DUMP twins exist for RGB, four-wave workgroups (what the parity tests at config scale run)
+    if (NC != 3 || a.march.num_samples_inf > LdsBf3Rm<C>::N_INF)
+      return set_error(LP_EUNSUPPORTED, "relu dump: only the NC = 3, four-wave instantiations have a dump twin");
+    if constexpr (NC == 3) {
+      if (a.seg_prefix) return launch_bwd3w<C, GM, PLAIN, NC, 4, true, true>(a, mp, stream);
+      return launch_bwd3w<C, GM, PLAIN, NC, 4, false, true>(a, mp, stream);
+    }
+  }
   // segment-parallel sweep of a small batch (seg_prefix survives lp_api.hip only where renderer_mfma_segments() > 1)
   if (a.seg_prefix) return launch_bwd3w<C, GM, PLAIN, NC, 4, true>(a, mp, stream);
   // four-wave workgroups (two per CU) unless the beyond-far table does not fit their small block; LP_BF3_NW=8 for A/B

@@ -167,6 +167,32 @@ def backward_segments(rays: Rays, grid, decoder_params: DecoderParams, num_sampl
     return int(_lib.lib().lp_renderer_backward_segments(ctypes.byref(a)))
 
 
+_RELU_DUMP = None
+
+
+class relu_dump_recorder:
+    """Test hook (``lp_renderer_backward_relu_dump``, include/lightplane_hip.h): inside the context every Renderer backward runs
+    the DUMP twin of its kernel and leaves the ReLU decisions it took in ``.dump`` -- int32 ``[n_rays, S_tot, 5]``: words 0..3 = trunk
+    layer 1, trunk layer 2, opacity hidden, colour hidden (bit f = unit f active), word 4 = 1 where the sample contributed.  Raises
+    for shapes without a dump twin (anything but the tuned bf16x3 family)."""
+
+    def __init__(self):
+        self.dump = None
+
+    def reset(self, n_rays, s_tot, dev):
+        self.dump = torch.zeros(n_rays, s_tot, 5, dtype=torch.int32, device=dev)
+        return self.dump
+
+    def __enter__(self):
+        global _RELU_DUMP
+        self._prev, _RELU_DUMP = _RELU_DUMP, self
+        return self
+
+    def __exit__(self, *exc):
+        global _RELU_DUMP
+        _RELU_DUMP = self._prev
+
+
 class LightplaneFunction(torch.autograd.Function):
     """Autograd boundary of the Renderer (name kept from the reference, :296).
 
@@ -285,7 +311,12 @@ class LightplaneFunction(torch.autograd.Function):
                 a.grad_color_grid = _lib.ptr(grad_cgrids[0])
         a.grad_mlp_params, a.grad_encoding = _lib.ptr(grad_params), _lib.ptr(grad_enc)
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().lp_renderer_backward(ctypes.byref(a), stream), "lp_renderer_backward")
+            if _RELU_DUMP is not None:  # test hook (relu_dump_recorder): the DUMP twin of the same kernel
+                d = _RELU_DUMP.reset(directions.shape[0], cfg.num_samples + cfg.num_samples_inf, dev)
+                _lib.check(_lib.lib().lp_renderer_backward_relu_dump(ctypes.byref(a), d.data_ptr(), d.numel(), stream),
+                           "lp_renderer_backward_relu_dump")
+            else:
+                _lib.check(_lib.lib().lp_renderer_backward(ctypes.byref(a), stream), "lp_renderer_backward")
         if config.check_finite_grads:
             for name, g in [("mlp_params", grad_params), ("encoding", grad_enc)] + \
                     [("grid", g) for g in (grad_grids or [])] + [("color_grid", g) for g in (grad_cgrids or [])]:

@@ -164,9 +164,47 @@ class relu_margin_recorder:
             self.margin = m if self.margin is None else torch.minimum(self.margin, m)
 
 
+_RELU_FORCER = None
+
+
+class relu_mask_forcer:
+    """Test diagnostics: while active, the k-th ReLU site the decoder evaluates (call order: every hidden ReLU of the trunk, the
+    trunk output, the opacity head's hidden ReLUs, the colour head's -- naive_renderer.py:328-501 as restated in ``eval_decoder``)
+    takes its branch from ``masks[k]`` (bool, same shape as the pre-activation; entries of ``keep[k]`` that are False fall back to
+    the sign of the pre-activation): ``y = x * mask``.  With the decisions a GPU backward really took (the DUMP twins of the HIP
+    kernels, include/lightplane_hip.h ``lp_renderer_backward_relu_dump``) forced onto it, the oracle differentiates the SAME
+    piecewise-linear branch: a near-tie unit the kernel resolved the other way stops being a difference of O(1) in the
+    gradient and becomes one of O(|pre-activation|) in the output (tests: ``test_flips_are_flips``)."""
+
+    def __init__(self, masks, keep=None):
+        self.masks, self.keep, self.k, self.n_forced = masks, keep, 0, 0
+
+    def __enter__(self):
+        global _RELU_FORCER
+        self._prev, _RELU_FORCER = _RELU_FORCER, self
+        self.k = 0
+        return self
+
+    def __exit__(self, *exc):
+        global _RELU_FORCER
+        _RELU_FORCER = self._prev
+
+    def apply(self, x):
+        m = self.masks[self.k]
+        assert m.shape == x.shape, (self.k, tuple(m.shape), tuple(x.shape))
+        own = x.detach() > 0
+        if self.keep is not None:
+            m = torch.where(self.keep[self.k], m, own)
+        self.n_forced += int((m != own).sum())
+        self.k += 1
+        return x * m.to(x.dtype)
+
+
 def _relu(x):
     if _RELU_RECORDER is not None:
         _RELU_RECORDER.update(x)
+    if _RELU_FORCER is not None:
+        return _RELU_FORCER.apply(x)
     return torch.relu(x)
 
 

@@ -25,7 +25,7 @@ import lightplane_amd as lp
 from lightplane_amd import _lib
 from oracle import lightplane_oracle as O
 from tests.synth import baseline_cfg1, cfg2_inputs, grid_sizes_for, pinhole_rays, random_decoder, random_grids
-from tests.test_gpu_parity import TieMasks, _assert_close, _dev, assert_grad_close, run_hip_renderer
+from tests.test_gpu_parity import TieMasks, _assert_close, _dev, assert_grad_close, forced_oracle_check, run_hip_renderer
 
 pytestmark = pytest.mark.gpu
 F64 = torch.float64
@@ -143,6 +143,65 @@ def test_1080p_backward_block(C, G, S):
     assert_grad_close("1080p block: grad_mlp_params", gp, o_gp.numpy(), 4 * 32, want64=q_gp.numpy(), tie_mask=ties.params_mask())
     for i, (a, b, c) in enumerate(zip(gg, o_gg, q_gg)):
         assert_grad_close(f"1080p block: grad_grid{i}", a, b.numpy(), 8 * C, want64=c.numpy(), tie_mask=ties.grid_mask(i))
+
+
+def _block_case(C, G, S, H=1080, W=1920, y0=517, x0=1003, bh=24, bw=40, seed=7):
+    """test_1080p_backward_block's inputs: a pinhole image whose upstream gradient lives on one pixel block."""
+    gen = torch.Generator().manual_seed(seed)
+    sizes = grid_sizes_for((1, G, G, G, C), True)
+    grids = random_grids(gen, sizes)
+    dec = random_decoder(gen, 2, 2, 2, C, 32, 3, std=0.15)
+    rays = pinhole_rays(H, W, enc_dim=32, gen=gen, azimuth_deg=35.0, elevation_deg=25.0)
+    idx = (torch.arange(y0, y0 + bh)[:, None] * W + torch.arange(x0, x0 + bw)[None, :]).reshape(-1)
+    n = H * W
+    up = [torch.zeros(n), torch.zeros(n), torch.zeros(n, 3)]
+    up[0][idx] = torch.randn(idx.numel(), generator=gen)
+    up[1][idx] = torch.randn(idx.numel(), generator=gen)
+    up[2][idx] = torch.randn(idx.numel(), 3, generator=gen)
+    cfg = dict(num_samples=S, gain=1.0, num_samples_inf=0, mask_out_of_bounds_samples=False, contract_coords=False,
+               inject_noise_sigma=0.0, inject_noise_seed=0)
+    return dict(rays=rays, grids=grids, color_grids=None, decoder=dec, scaffold=None, cfg=cfg, sizes=sizes, upstream=tuple(up)), idx
+
+
+FLIP_PROOF_CASES = ["cfg2_full", "cfg4_block_c32_s256", "1080p_block_c16_s128", "cfg2_segmented_64x64", "cfg2_segmented_inf8_noise", "cfg1_voxel"]
+
+
+@pytest.mark.parametrize("case", FLIP_PROOF_CASES)
+def test_flips_are_flips(case):
+    """The ReLU-flip allowance of assert_grad_close, replaced by a proof on the launches bench.py times (round-4 review, next 2).
+    The production backward's ReLU decisions are read back (lp_renderer_backward_relu_dump: the DUMP twin of the kernel that
+    ran) and forced onto the fp64 oracle; EVERY entry of grad_grid / grad_encoding / grad_mlp_params and every output then
+    meets 1e-4 outright.  cfg 2 full = the headline launch; the cfg-4 block = BASELINE configs[3]'s per-GPU launch; the
+    segmented cases run the SEG instantiation (small batches), one of them the non-PLAIN kernel (beyond-far samples + noise)."""
+    dev = _dev()
+    idx, extra = None, {}
+    if case == "cfg2_full":
+        d = cfg2_inputs()
+    elif case == "cfg4_block_c32_s256":
+        d, idx = _block_case(32, 128, 256)
+    elif case == "1080p_block_c16_s128":
+        d, idx = _block_case(16, 64, 128)
+    elif case.startswith("cfg2_segmented"):
+        d = cfg2_inputs(height=64, width=64)
+        if case.endswith("inf8_noise"):
+            d["cfg"] = dict(d["cfg"], num_samples_inf=8, inject_noise_sigma=0.3, inject_noise_seed=11)
+        assert lp.backward_segments(d["rays"], d["grids"], d["decoder"], num_samples=d["cfg"]["num_samples"],
+                                    num_samples_inf=d["cfg"].get("num_samples_inf", 0)) > 1, "this case must run the segmented kernels"
+    else:
+        d = baseline_cfg1()
+    assert lp.kernel_family(d["rays"], d["grids"], d["decoder"]) == 1
+    forced_oracle_check(case, d, dev, idx)
+
+
+def test_relu_dump_refuses_other_families():
+    """Only the tuned family has dump twins: every other shape must refuse loudly (never a silent production launch)."""
+    from lightplane_amd.renderer import relu_dump_recorder
+    from tests.synth import RENDERER_CASES
+    dev = _dev()
+    d = next(c for c in RENDERER_CASES if c.name == "triplane_deep444").build()
+    with relu_dump_recorder():
+        with pytest.raises(_lib.LightplaneHipError, match="relu dump"):
+            run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO)
 
 
 INDEX_CASES = {

@@ -113,17 +113,31 @@ class TieMasks:
         self.color_grid = None if d.get("color_grids") is None else row_masks(d["color_grids"])
         self._done = True
 
+    class _Mask:
+        """Lazy mask + the measured number of near-tie SAMPLES behind it (assert_grad_close bounds the allowance by it)."""
+
+        def __init__(self, owner, get):
+            self.owner, self.get = owner, get
+
+        def __call__(self):
+            self.owner._compute()
+            return self.get()
+
+        def n_near(self):
+            self.owner._compute()
+            return self.owner.n_near
+
     def grid_mask(self, i):
-        return lambda: (self._compute(), self.grid[i])[1]
+        return TieMasks._Mask(self, lambda: self.grid[i])
 
     def color_grid_mask(self, i):
-        return lambda: (self._compute(), self.color_grid[i])[1]
+        return TieMasks._Mask(self, lambda: self.color_grid[i])
 
     def encoding_mask(self):
-        return lambda: (self._compute(), self.ray[:, None])[1]
+        return TieMasks._Mask(self, lambda: self.ray[:, None])
 
     def params_mask(self):  # a flipped unit moves a row / a column of weight matrices and bias entries: any entry may move
-        return lambda: (self._compute(), torch.tensor(self.n_near > 0))[1]
+        return TieMasks._Mask(self, lambda: torch.tensor(self.n_near > 0))
 
 
 def assert_grad_close(name, got, want, entries_per_sample, tol=1e-4, want64=None, flip_samples=FLIP_SAMPLES, tie_mask=None):
@@ -165,23 +179,29 @@ def assert_grad_close(name, got, want, entries_per_sample, tol=1e-4, want64=None
     n_un = int(unexplained.sum())
     both = torch.minimum(err, err64)
     worst_un = float(both[unexplained].max()) if n_un else 0.0
-    n_outside, worst_outside, dense = None, 0.0, False
+    n_outside, worst_outside, dense, cover, n_near = None, 0.0, False, None, None
     if tie_mask is not None and n_un:
         tm = torch.as_tensor(tie_mask()).expand_as(unexplained)
         outside = unexplained & ~tm
         n_outside = int(outside.sum())
         worst_outside = float(both[outside].max()) if n_outside else 0.0
-        dense = float(tm.float().mean()) > 0.5  # (config-scale batches: near ties reach most rows, the mask says little)
-    allowed = flip_samples * entries_per_sample
+        cover = float(tm.float().mean())
+        dense = cover > 0.5  # (config-scale batches: near ties reach most rows, the mask says little)
+        n_near = tie_mask.n_near() if hasattr(tie_mask, "n_near") else None
+    # the allowance is the number of near-tie samples the fp64 oracle MEASURED (never more than flip_samples), not a constant
+    allowed = (flip_samples if n_near is None else min(flip_samples, n_near)) * entries_per_sample
     FLIP_EVENTS.append(dict(name=name, tol=tol, n_off=n_off, explained=n_off - n_un, unexplained=n_un, allowed=allowed, worst=worst,
-                            worst_unexplained=worst_un, outside_tie_mask=n_outside, l2=l2))
+                            worst_unexplained=worst_un, outside_tie_mask=n_outside, l2=l2, near_tie_samples=n_near, mask_cover=cover))
     print(f"flip-allowance {name}: {n_off} entries above {tol:g}, {n_off - n_un} explained by the second oracle, "
-          f"worst {worst:.3e}, worst unexplained {worst_un:.3e}, outside the near-tie mask: {n_outside}, rel L2 {l2:.3e}")
+          f"worst {worst:.3e}, worst unexplained {worst_un:.3e}, outside the near-tie mask: {n_outside}, rel L2 {l2:.3e}, "
+          f"near-tie samples measured: {n_near}, mask covers {cover if cover is None else round(cover, 4)} of the tensor, allowed {allowed}")
     if tie_mask is not None and not dense:
         # every entry that misses both oracles is PROVEN to sit on a near-tie ReLU (none outside the mask): its size is then the
         # full contribution of the flipped unit, which nothing bounds relative to the tensor's largest entry (grad_encoding of
-        # one ray can be dominated by one sample) -- the count stays bounded, the magnitude bars are loose
-        ok = n_un <= allowed and not n_outside and worst <= 0.5 and l2 <= 5e-2
+        # one ray can be dominated by one sample) -- the count stays bounded by the MEASURED near-tie count and the relative
+        # L2 bar of the other branch stays; only the per-entry magnitude bar is loose.  (The tuned family does not need this
+        # branch at all: forced_oracle_check below replaces it by a proof.)
+        ok = n_un <= allowed and not n_outside and worst <= 0.5 and l2 <= 1e-3
     else:
         ok = n_un <= allowed and worst <= 5e-2 and l2 <= 1e-3 and worst_un <= UNEXPLAINED_MAX and not n_outside
     assert ok, (f"{name}: max err / scale = {worst:.3e} > {tol} and not a ReLU-flip pattern: {n_un} entries above the bar against "
@@ -189,6 +209,96 @@ def assert_grad_close(name, got, want, entries_per_sample, tol=1e-4, want64=None
                 + (f"; {n_outside} of them where no near-tie ReLU reaches (worst {worst_outside:.3e})" if tie_mask is not None
                    else f" (allowed {UNEXPLAINED_MAX:g} without a tie mask)")
                 + f"; {n_off - n_un} more explained by the fp64 oracle; allowed count {allowed}; relative L2 {l2:.3e} (allowed 1e-3)")
+
+
+def unpack_relu_dump(dump):
+    """int32 [R, S, 5] (lp_renderer_backward_relu_dump) -> (list of four bool [R, S, 32] masks in the oracle's ReLU call order,
+    bool [R, S] "the kernel visited this sample")."""
+    d = dump.cpu().to(torch.int64) & 0xFFFFFFFF
+    bits = torch.arange(32, dtype=torch.int64)
+    masks = [((d[..., k, None] >> bits) & 1).bool() for k in range(4)]
+    return masks, d[..., 4] != 0
+
+
+def run_hip_renderer_with_dump(d, dev, **extra):
+    """The production backward AND the same backward through the DUMP twin of its kernel (ReLU decisions recorded)."""
+    from lightplane_amd.renderer import relu_dump_recorder
+    prod = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO, **extra)
+    with relu_dump_recorder() as rec:
+        twin = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO, **extra)
+    assert rec.dump is not None, "the backward did not go through the dump hook"
+    # the twin is the same template with stores added: same arithmetic, so its gradients equal the production launch's up to
+    # the order of the fp32 atomics
+    for nm, a, b in [("grad_mlp_params", prod[1], twin[1]), ("grad_encoding", prod[2], twin[2])] + \
+            [(f"grad_grid{i}", a, b) for i, (a, b) in enumerate(zip(prod[3], twin[3]))]:
+        sc = float(a.abs().max()) + 1e-30
+        e = float((a - b).abs().max()) / sc
+        assert e <= 2e-5, f"dump twin vs production launch: {nm} differs by {e:.3e}"
+    return prod, rec.dump
+
+
+def oracle_forced(d, dump, idx=None, chunk=2048, dtype=torch.float64):
+    """fp64 oracle forward + backward over the rays ``idx`` (default all), in chunks, with the kernel's own ReLU decisions
+    (``dump`` [n_rays_total, S, 5] from the DUMP twin) forced onto every unit of every sample the kernel visited.
+    Returns (outs, grad_params, grad_encoding, grad_grids, n_forced = units whose forced branch differs from the oracle's own)."""
+    import copy
+    rays = d["rays"] if idx is None else d["rays"][idx]
+    up = d["upstream"] if idx is None else tuple(u[idx] for u in d["upstream"])
+    dump = dump if idx is None else dump[idx.to(dump.device)]
+    masks, visited = unpack_relu_dump(dump)
+    dec = d["decoder"]
+    params = dec.mlp_params.to(dtype).clone().requires_grad_(True)
+    grids = [g.to(dtype).clone().requires_grad_(True) for g in d["grids"]]
+    outs, g_enc, n_forced = [[], [], []], [], 0
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    try:
+        for lo in range(0, rays.n_rays, chunk):
+            r = rays[lo:lo + chunk]
+            for f in ("directions", "origins", "near", "far", "encoding"):
+                setattr(r, f, getattr(r, f).to(dtype))
+            r.encoding = r.encoding.clone().requires_grad_(True)
+            dd = copy.copy(dec)
+            dd.mlp_params = params
+            keep = [visited[lo:lo + chunk, :, None].expand(-1, -1, 32)] * 4
+            with O.relu_mask_forcer([m[lo:lo + chunk] for m in masks], keep) as forcer:
+                out = O.lightplane_renderer_naive(r, grids, dd, **d["cfg"])
+            assert forcer.k == 4, f"the oracle evaluated {forcer.k} ReLU sites, the dump holds 4 (2/2/2 decoder)"
+            n_forced += forcer.n_forced
+            u = [x[lo:lo + chunk].to(dtype) for x in up]
+            ((out[0] * u[0]).sum() + (out[1] * u[1]).sum() + (out[2] * u[2]).sum()).backward()
+            for k in range(3):
+                outs[k].append(out[k].detach())
+            g_enc.append(r.encoding.grad)
+    finally:
+        torch.set_num_threads(old_threads)
+    return [torch.cat(o) for o in outs], params.grad, torch.cat(g_enc), [g.grad for g in grids], n_forced
+
+
+FORCED_EVENTS = []  # one record per forced-oracle check; printed by conftest.pytest_terminal_summary
+
+
+def forced_oracle_check(name, d, dev, idx=None, tol=1e-4, **extra):
+    """THE PROOF behind the ReLU-flip allowance (round-4 review, next 2): the production backward's own ReLU decisions, read
+    back from the DUMP twin of its kernel, are forced onto the fp64 oracle; then EVERY entry of every gradient family and every
+    output has to meet the north_star bar outright -- no allowance, no second oracle, no mask.  Whatever separated the kernel
+    from the unforced oracles was a ReLU branch taken the other way at a near tie, or this fails."""
+    prod, dump = run_hip_renderer_with_dump(d, dev, **extra)
+    out, gp, ge, gg, _ = prod
+    f_out, f_gp, f_ge, f_gg, n_forced = oracle_forced(d, dump, idx)
+    sel = (lambda t: t) if idx is None else (lambda t: t[idx.to(t.device)])
+    worst = {}
+    for nm, a, b in [("ray_length", sel(out[0]), f_out[0]), ("neg_log_t", sel(out[1]), f_out[1]), ("feature", sel(out[2]), f_out[2]),
+                     ("grad_mlp_params", gp, f_gp), ("grad_encoding", sel(ge), f_ge)] + \
+            [(f"grad_grid{i}", a, b) for i, (a, b) in enumerate(zip(gg, f_gg))]:
+        worst[nm] = _rel_err(a, b.numpy())
+    visited = int((dump[..., 4] != 0).sum()) if idx is None else int((dump[idx.to(dump.device)][..., 4] != 0).sum())
+    FORCED_EVENTS.append(dict(name=name, forced_units=n_forced, visited_samples=visited, worst={k: float(f"{v:.3e}") for k, v in worst.items()}))
+    print(f"forced-oracle {name}: {n_forced} ReLU units forced against the fp64 oracle's own sign over {visited} visited samples; "
+          f"max err / scale: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+    bad = {k: v for k, v in worst.items() if not v <= tol}
+    assert not bad, f"{name}: with the kernel's own ReLU decisions forced onto the fp64 oracle these still miss {tol:g}: {bad}"
+    return n_forced
 
 
 def _rays_to(rays, dev, requires_grad=False):
