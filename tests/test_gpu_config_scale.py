@@ -163,7 +163,7 @@ def _block_case(C, G, S, H=1080, W=1920, y0=517, x0=1003, bh=24, bw=40, seed=7):
     return dict(rays=rays, grids=grids, color_grids=None, decoder=dec, scaffold=None, cfg=cfg, sizes=sizes, upstream=tuple(up)), idx
 
 
-FLIP_PROOF_CASES = ["cfg2_full", "cfg4_block_c32_s256", "1080p_block_c16_s128", "cfg2_segmented_64x64", "cfg2_segmented_inf8_noise", "cfg1_voxel"]
+FLIP_PROOF_CASES = ["cfg2_full", "cfg4_block_c32_s256", "1080p_block_c16_s128", "cfg2_segmented_64x64", "cfg2_segmented_noise_mask", "cfg2_64x64_inf8_contract", "cfg1_voxel"]
 
 
 @pytest.mark.parametrize("case", FLIP_PROOF_CASES)
@@ -172,7 +172,8 @@ def test_flips_are_flips(case):
     The production backward's ReLU decisions are read back (lp_renderer_backward_relu_dump: the DUMP twin of the kernel that
     ran) and forced onto the fp64 oracle; EVERY entry of grad_grid / grad_encoding / grad_mlp_params and every output then
     meets 1e-4 outright.  cfg 2 full = the headline launch; the cfg-4 block = BASELINE configs[3]'s per-GPU launch; the
-    segmented cases run the SEG instantiation (small batches), one of them the non-PLAIN kernel (beyond-far samples + noise)."""
+    segmented cases run the SEG instantiations (small batches; PLAIN and non-PLAIN), one case the non-PLAIN one-sweep kernel
+    (beyond-far samples, contraction, opacity noise)."""
     dev = _dev()
     idx, extra = None, {}
     if case == "cfg2_full":
@@ -181,10 +182,13 @@ def test_flips_are_flips(case):
         d, idx = _block_case(32, 128, 256)
     elif case == "1080p_block_c16_s128":
         d, idx = _block_case(16, 64, 128)
+    elif case == "cfg2_64x64_inf8_contract":  # the non-PLAIN kernel, one sweep per ray (beyond-far samples are never segmented)
+        d = cfg2_inputs(height=64, width=64)
+        d["cfg"] = dict(d["cfg"], num_samples_inf=8, contract_coords=True, inject_noise_sigma=0.3, inject_noise_seed=5)
     elif case.startswith("cfg2_segmented"):
         d = cfg2_inputs(height=64, width=64)
-        if case.endswith("inf8_noise"):
-            d["cfg"] = dict(d["cfg"], num_samples_inf=8, inject_noise_sigma=0.3, inject_noise_seed=11)
+        if case.endswith("noise_mask"):  # the non-PLAIN SEG instantiation
+            d["cfg"] = dict(d["cfg"], inject_noise_sigma=0.3, inject_noise_seed=11, mask_out_of_bounds_samples=True)
         assert lp.backward_segments(d["rays"], d["grids"], d["decoder"], num_samples=d["cfg"]["num_samples"],
                                     num_samples_inf=d["cfg"].get("num_samples_inf", 0)) > 1, "this case must run the segmented kernels"
     else:
