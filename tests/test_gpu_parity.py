@@ -278,14 +278,14 @@ def oracle_forced(d, dump, idx=None, chunk=2048, dtype=torch.float64):
 FORCED_EVENTS = []  # one record per forced-oracle check; printed by conftest.pytest_terminal_summary
 
 
-def forced_oracle_check(name, d, dev, idx=None, tol=1e-4, **extra):
+def forced_oracle_check(name, d, dev, idx=None, tol=1e-4, chunk=2048, **extra):
     """THE PROOF behind the ReLU-flip allowance (round-4 review, next 2): the production backward's own ReLU decisions, read
     back from the DUMP twin of its kernel, are forced onto the fp64 oracle; then EVERY entry of every gradient family and every
     output has to meet the north_star bar outright -- no allowance, no second oracle, no mask.  Whatever separated the kernel
     from the unforced oracles was a ReLU branch taken the other way at a near tie, or this fails."""
     prod, dump = run_hip_renderer_with_dump(d, dev, **extra)
     out, gp, ge, gg, _ = prod
-    f_out, f_gp, f_ge, f_gg, n_forced = oracle_forced(d, dump, idx)
+    f_out, f_gp, f_ge, f_gg, n_forced = oracle_forced(d, dump, idx, chunk=chunk)
     sel = (lambda t: t) if idx is None else (lambda t: t[idx.to(t.device)])
     worst = {}
     for nm, a, b in [("ray_length", sel(out[0]), f_out[0]), ("neg_log_t", sel(out[1]), f_out[1]), ("feature", sel(out[2]), f_out[2]),

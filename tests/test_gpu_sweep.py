@@ -21,32 +21,39 @@ from tests.test_gpu_parity import (_dev, _rel_err, assert_grad_close, run_hip_ml
 pytestmark = pytest.mark.gpu
 
 F64 = torch.float64
-TOL = 2e-4
+TOL = 1e-4  # north_star's bar (2e-4 until round 4)
+ILL_CONDITIONED = 2.0
 
 
 def _check(name, got, want64, ref32=None, inf=False, grad_entries=None):
-    """Error against the fp64 oracle within TOL, or against the fp32 oracle -- the reference's own arithmetic: the cell a
-    sample falls into, the scaffold cell it looks up and the out-of-bounds mask are DEFINED by fp32 coordinate arithmetic,
-    and the fp64 run decides differently for a sample on a boundary -- within north_star's 1e-4.  Two documented escapes,
-    both confined:
-    * ``inf`` (cases with beyond-far samples only: interval lengths ~1e5 make the reference's own fp32 gradients cancel
-      catastrophically, 1e-3 .. 6e-3 on some seeds): within 3x the fp32 oracle's own error;
-    * gradient tensors (``grad_entries`` = entries one sample touches): the ReLU-flip allowance of assert_grad_close --
-      entries that miss the fp64 oracle but meet the fp32 one are explained (the kernel took the fp32 oracle's branch),
-      the rest is counted, bounded and printed."""
-    e = _rel_err(got, want64.detach().numpy())
-    if e <= TOL:
+    """north_star's 1e-4 against the fp32 oracle (the reference's own arithmetic: the cell a sample falls into, the scaffold cell
+    it looks up and the out-of-bounds mask are DEFINED by fp32 coordinate arithmetic) or against the fp64 oracle (where the fp32
+    oracle's own summation order carries an error of that size).  Measured over all 104 sweep cases / 813 tensors
+    (scripts/sweep_errors_all.py, profiles/r05_sweep_errors.json): 806 tensors meet 1e-4 against one of the two outright; the 7
+    others are gradients of three cases with beyond-far samples, where interval lengths ~1e5 make the REFERENCE's fp32 gradients
+    cancel catastrophically -- the fp32 oracle itself is 5e-4 .. 5.7e-3 away from fp64 there, the kernel 1.2e-3 .. 9.5e-3
+    (at most 1.7x as far).  So:
+    * ``inf`` cases only, and only for a tensor on which the fp32 oracle itself misses 1e-4 against fp64 ("1e-4 of the naive
+      reference" is then not defined to better than that error): the kernel has to be within ILL_CONDITIONED (2x) of the fp32
+      oracle's own error against fp64 (round 4: 3x, and without the precondition);
+    * gradient tensors (``grad_entries`` = entries one sample touches): the counted ReLU-flip allowance of assert_grad_close
+      (not needed by any of the 813 tensors at the committed seeds; kept because atomics reorder sums from run to run)."""
+    e64 = _rel_err(got, want64.detach().numpy())
+    if e64 <= TOL:
         return
-    if ref32 is not None and _rel_err(got, ref32.detach().numpy()) <= 1e-4:
+    e32 = _rel_err(got, ref32.detach().numpy()) if ref32 is not None else float("inf")
+    if e32 <= TOL:
         return
     if inf and ref32 is not None:
-        bound = max(TOL, 3.0 * _rel_err(ref32, want64.detach().numpy()))
-        assert e <= bound, f"{name}: max err / scale = {e:.3e} > {bound:.3e}"
-        return
+        own = _rel_err(ref32, want64.detach().numpy())
+        if own > TOL:
+            assert e64 <= ILL_CONDITIONED * own, (f"{name}: max err / scale = {e64:.3e} against fp64 > {ILL_CONDITIONED:g} x the fp32 oracle's own "
+                                                  f"error {own:.3e} (beyond-far samples: fp32 ill-conditioned)")
+            return
     if grad_entries is not None and ref32 is not None:
-        assert_grad_close(name, got, want64.detach().numpy(), grad_entries, tol=TOL, want64=ref32.detach().numpy())
+        assert_grad_close(name, got, ref32.detach().numpy(), grad_entries, tol=TOL, want64=want64.detach().numpy())
         return
-    assert e <= TOL, f"{name}: max err / scale = {e:.3e} > {TOL:.3e}"
+    assert False, f"{name}: max err / scale = {e64:.3e} (fp64 oracle), {e32:.3e} (fp32 oracle) > {TOL:g}"
 
 
 def _rays64(rays):
