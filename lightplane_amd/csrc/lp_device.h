@@ -547,7 +547,9 @@ LP_DEV float epilogue_grad_nlt(const LpRendererArgs& a, int64_t rid, bool valid,
 // row with 0 instead of lane 0's row, so a run starting at row 0 right behind a dead first ray (row -1) was merged into
 // the dead run and never flushed (found by tests/test_gpu_coherent.py, reproduced by scripts/scatter_plane_test.hip).
 // These helpers read first, with all lanes enabled, and combine afterwards.
-LP_DEV int lane_prev(int v) { return __shfl_up(v, 1); }
+// (DPP wave_shr:1 -- one VALU instruction -- instead of __shfl_up's ds_bpermute round trip through the LDS crossbar; lane 0 and
+// any lane whose source is disabled get 0, which run_head() never looks at for r == 0.)
+LP_DEV int lane_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
 LP_DEV bool run_head(int r, int row, int prev_row) { return (r == 0) | (row != prev_row); }
 LP_DEV bool run_head(int r, int row, int prev_row, int ok, int prev_ok) {
   return (r == 0) | (row != prev_row) | (ok != prev_ok);

@@ -442,6 +442,126 @@ LP_DEV void scatter_plane(float* gg, const LpGrid& g, int b, float x, float y, f
   scatter_plane_ax<C>(gg, (int)g.row_offset + b * (U * V), U, u, v, live, lane, dxT, wT, dbg);
 }
 
+// Canonical triplane (GM_TRIPLANE), all three planes in one call.  What the per-plane walk above spent per plane BEFORE its ray
+// loop -- two axis computations with their border re-expression, the run-time choice of the plane's orientation, the
+// previous lane's row through ds_bpermute, the grid descriptor re-read from the kernel arguments (scalar loads + a
+// wait that also drains the LDS queue) -- was ~100 of its ~190 vector instructions (profiles/r05_scatter_*).  Here the three
+// axes are evaluated ONCE per sample (three computations instead of six) and normalised (cell index, two weights, dead
+// flag); a plane picks its (u, v) pair with eight v_cndmask on the scalar plane index; the previous lane's row comes from a
+// DPP wave shift (one VALU instruction, no LDS round trip).  The ray walk itself (scalar-branched run merge, one atomic per
+// run and row) is the one of scatter_plane_ax.
+struct AxisNorm {
+  int i;        // first cell of the pair, both cells in range unless dead
+  float w0, w1;
+  bool dead;
+};
+LP_DEV AxisNorm axis_norm(float c, int size) {
+  AxisTap t;
+  axis_taps<false>(c, size, t.i0, t.w, t.ok);
+  const bool only0 = t.ok[0] & !t.ok[1], only1 = !t.ok[0] & t.ok[1];  // a border cell: one tap in range (selects, no branches)
+  AxisNorm n;
+  n.i = t.i0 + (only1 ? 1 : 0) - (only0 ? 1 : 0);
+  n.w0 = only0 ? 0.0f : (only1 ? t.w[1] : t.w[0]);
+  n.w1 = only1 ? 0.0f : (only0 ? t.w[0] : t.w[1]);
+  n.dead = !(t.ok[0] | t.ok[1]);
+  return n;
+}
+template <int C>
+LP_DEV void scatter_triplane(float* const* gg_list, const LpGridList& gl, int b, float x, float y, float z, bool live, int lane,
+                             const float* dxT, float* wT, int dbg) {
+  constexpr int CPL = C / 16;
+  const int h = lane >> 5, r = lane & 31, sub = lane & 15, grp = lane >> 4;
+  const int W = gl.grids[0].W, H = gl.grids[0].H, D = gl.grids[1].D;
+  const AxisNorm ax = axis_norm(x, W), ay = axis_norm(y, H), az = axis_norm(z, D);
+  // ---- all three planes' rows, weights (wT[plane][slot][ray], slot = u-bit + 2 v-bit) and run masks, straight-line ----
+  const bool d0 = !live | ax.dead | ay.dead, d1 = !live | ax.dead | az.dead, d2 = !live | ay.dead | az.dead;
+  const int row_xy = d0 ? -1 : (int)gl.grids[0].row_offset + (b * H + ay.i) * W + ax.i;
+  const int row_xz = d1 ? -1 : (int)gl.grids[1].row_offset + (b * D + az.i) * W + ax.i;
+  const int row_yz = d2 ? -1 : (int)gl.grids[2].row_offset + (b * D + az.i) * H + ay.i;
+  const float wy = h ? ay.w1 : ay.w0, wz = h ? az.w1 : az.w0;  // the v-weight of this lane's two slots
+  float* const wl = wT + (2 * h) * 32 + r;
+  wl[0] = d0 ? 0.0f : ax.w0 * wy;
+  wl[32] = d0 ? 0.0f : ax.w1 * wy;
+  wl[128] = d1 ? 0.0f : ax.w0 * wz;
+  wl[160] = d1 ? 0.0f : ax.w1 * wz;
+  wl[256] = d2 ? 0.0f : ay.w0 * wz;
+  wl[288] = d2 ? 0.0f : ay.w1 * wz;
+  const bool first = r == 0;
+  const unsigned m_xy = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(first | (row_xy != lane_prev(row_xy))));
+  const unsigned m_xz = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(first | (row_xz != lane_prev(row_xz))));
+  const unsigned m_yz = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(first | (row_yz != lane_prev(row_yz))));
+  const float4* dsrc[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) dsrc[j] = reinterpret_cast<const float4*>(dxT + (sub + 16 * j) * DX_LD);
+  // ---- the walk, one plane at a time (the code of the walk exists once) ----
+#pragma unroll 1
+  for (int g = 0; g < 3; ++g) {
+    const int row0 = g == 0 ? row_xy : (g == 1 ? row_xz : row_yz);
+    const unsigned mask = g == 0 ? m_xy : (g == 1 ? m_xz : m_yz);
+    const int U = g == 2 ? H : W;
+    const float4* wsrc = reinterpret_cast<const float4*>(wT + g * 128 + grp * 32);
+    const int koff = (grp & 1) + (grp >> 1) * U;
+    const unsigned lane_off = (unsigned)koff * (unsigned)(C * 4) + (unsigned)(sub * 4);  // bytes inside a 2 x 2 cell
+    float* const gg = gg_list[g];
+    float run[CPL];
+    int s_row = __builtin_amdgcn_readlane(row0, 0);
+    auto flush = [&](int row) {
+      if (row >= 0 && !(dbg & 1)) {
+        char* rb = reinterpret_cast<char*>(gg) + (int64_t)row * (C * 4);  // scalar
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) atomic_add_f32(reinterpret_cast<float*>(rb + lane_off + 64 * j), run[j]);
+      }
+    };
+    if (mask == 1u) {  // all 32 rays in one cell: no run logic at all
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) run[j] = 0.0f;
+#pragma unroll
+      for (int c4 = 0; c4 < 8; ++c4) {
+        const float4 w = wsrc[c4];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          const float4 d = dsrc[j][c4];
+          run[j] = fmaf(w.x, d.x, run[j]);
+          run[j] = fmaf(w.y, d.y, run[j]);
+          run[j] = fmaf(w.z, d.z, run[j]);
+          run[j] = fmaf(w.w, d.w, run[j]);
+        }
+      }
+      flush(s_row);
+      continue;
+    }
+#pragma unroll
+    for (int c8 = 0; c8 < 4; ++c8) {  // 8 rays at a time
+      const float4 w0 = wsrc[2 * c8], w1 = wsrc[2 * c8 + 1];
+      const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+      float dx[CPL][8];
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const float4 d0v = dsrc[j][2 * c8], d1v = dsrc[j][2 * c8 + 1];
+        dx[j][0] = d0v.x; dx[j][1] = d0v.y; dx[j][2] = d0v.z; dx[j][3] = d0v.w;
+        dx[j][4] = d1v.x; dx[j][5] = d1v.y; dx[j][6] = d1v.z; dx[j][7] = d1v.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rr = 8 * c8 + i;
+        if (rr == 0) {
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) run[j] = 0.0f;
+        } else if ((mask >> rr) & 1u) {
+          flush(s_row);
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) run[j] = 0.0f;
+          s_row = __builtin_amdgcn_readlane(row0, rr);
+        }
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) run[j] = fmaf(w[i], dx[j][i], run[j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    flush(s_row);
+  }
+}
+
 // COLS = false: always the per-slot walk (the MLP-Splatter backward, with a coarse input grid and a large register
 // footprint of its own, is 7 % faster with it)
 template <int C, int GMS = GM_GENERIC, bool COLS = true>

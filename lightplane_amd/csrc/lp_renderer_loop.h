@@ -788,9 +788,13 @@ __global__ void __launch_bounds__(256, (NB == 1 && MT <= 2 && MH <= 1 && !WC) ? 
     if (gg && !(lp.dbg & 2)) {
       const int ng = (GM == GM_TRIPLANE) ? 3 : a.grid.n_grids;
       float* const wtab = (C == 64) ? wv + T::WT : yt;
+      if constexpr (GM == GM_TRIPLANE && C != 64) {  // all three planes in one call (its weight table needs 3 x 128 floats: the dY tile)
+        scatter_triplane<C>(a.grad_grid_list, a.grid, ray.b, x, y, z, live, lane, xt, wtab, lp.dbg);
+      } else {
 #pragma unroll 1
-      for (int gi = 0; gi < ng; ++gi)
-        scatter_grid<C, GM>(a.grad_grid_list[gi], a.grid.grids[gi], ray.b, x, y, z, live, lane, xt, wtab, lp.dbg);
+        for (int gi = 0; gi < ng; ++gi)
+          scatter_grid<C, GM>(a.grad_grid_list[gi], a.grid.grids[gi], ray.b, x, y, z, live, lane, xt, wtab, lp.dbg);
+      }
     }
   }
 

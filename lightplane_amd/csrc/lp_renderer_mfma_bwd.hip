@@ -537,10 +537,17 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
     LP_SCHED_FENCE();
     LP_MARK("scatter");
     if (gg && !(mp.dbg & 2)) {
-      const int ng = (GM == GM_TRIPLANE) ? 3 : (GM == GM_VOXEL) ? 1 : a.grid.n_grids;
+#ifndef LP_SCATTER_V1
+      if constexpr (GM == GM_TRIPLANE) {
+        scatter_triplane<C>(a.grad_grid_list, a.grid, ray.b, x, y, z, live, lane, xt, yt, mp.dbg);
+      } else
+#endif
+      {
+        const int ng = (GM == GM_TRIPLANE) ? 3 : (GM == GM_VOXEL) ? 1 : a.grid.n_grids;
 #pragma unroll 1
-      for (int g = 0; g < ng; ++g)
-        scatter_grid<C, GM>(a.grad_grid_list[g], a.grid.grids[g], ray.b, x, y, z, live, lane, xt, yt, mp.dbg);
+        for (int g = 0; g < ng; ++g)
+          scatter_grid<C, GM>(a.grad_grid_list[g], a.grid.grids[g], ray.b, x, y, z, live, lane, xt, yt, mp.dbg);
+      }
     }
   }
 

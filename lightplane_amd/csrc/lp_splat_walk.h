@@ -35,7 +35,11 @@ struct SplatSrcLds {  // tile [channel][ld] in LDS
 // instead of two.
 // SPLAT: interpolation convention (true = Splatter, false = Renderer: the gradient scatter of its backward);
 // wgt == nullptr: no unit-weight grid (Renderer).
-template <int C, int RPW, class Src, bool SPLAT = true>
+// WLD: row stride (floats) of the weight table wT[8][WLD].  With WLD = RPW = 32 the four corner pairs a ds_read_b128 lane group
+// serves read rows 64 floats apart -- the same banks (64 x 4 B) at different addresses: a 2-way conflict on every weight read
+// (47 % of the forward walk's LDS cycles, profiles/r04_pmc_summary.json).  WLD = RPW + 8 puts the rows of any corner-pair set
+// (k_lo in {0,2,4,6}, {0,1,4,5}, {0,1,2,3}) on distinct 16-byte bank slots; callers whose table has the room pass it.
+template <int C, int RPW, class Src, bool SPLAT = true, int WLD = RPW>
 LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, float x, float y, float z, bool live,
                            int lane, const Src& src, float* wT, int dbg) {
   constexpr int CPL = C / 16;
@@ -54,7 +58,7 @@ LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, floa
     float v = tp.w[i];
 #pragma unroll
     for (int qq = 1; qq < NQ; ++qq) v = (q == qq) ? tp.w[qq * SPQ + i] : v;
-    wT[(q * SPQ + i) * RPW + r] = v;
+    wT[(q * SPQ + i) * WLD + r] = v;
   }
   const int row0 = tp.row0, iu = tp.iu, cell = tp.cell;
   const int ok = (int)tp.ok;
@@ -78,8 +82,8 @@ LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, floa
     const int k_hi = k_lo + (1 << A);
     const int koff = b0 * s0 + b1 * s1;  // rows of this corner pair relative to row0
     const unsigned bit_lo = 1u << k_lo, bit_hi = 1u << k_hi;
-    const float4* wlo = reinterpret_cast<const float4*>(wT + k_lo * RPW);
-    const float4* whi = reinterpret_cast<const float4*>(wT + k_hi * RPW);
+    const float4* wlo = reinterpret_cast<const float4*>(wT + k_lo * WLD);
+    const float4* whi = reinterpret_cast<const float4*>(wT + k_hi * WLD);
     const int64_t hi_off = (int64_t)sA * C;
     // slots on the near / far side along A (all four corner pairs): a column is only carried over if the old
     // and the new cell agree on its validity (a masked or padding ray in the neighbouring cell has ok == 0)
@@ -165,8 +169,8 @@ LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, floa
   // per run (about eight runs per 16 rays).
   {
     const int koff = (grp & 1) * tp.sv + (grp >> 1) * tp.st;
-    const float4* wlo = reinterpret_cast<const float4*>(wT + (2 * grp) * RPW);
-    const float4* whi = reinterpret_cast<const float4*>(wT + (2 * grp + 1) * RPW);
+    const float4* wlo = reinterpret_cast<const float4*>(wT + (2 * grp) * WLD);
+    const float4* whi = reinterpret_cast<const float4*>(wT + (2 * grp + 1) * WLD);
     const int W = g.W;
     float acc = 0.0f;
     int s_row = __builtin_amdgcn_readlane(row0, 0);

@@ -170,7 +170,8 @@ __global__ void __launch_bounds__(256) splat_fwd_walk_kernel(const LpSplatterArg
   constexpr int LD = RPW + 4;  // row stride of the transposed encoding tile [channel][ray]
   constexpr int NQ = 64 / RPW;
   constexpr int CPL = C / 16;
-  __shared__ __attribute__((aligned(16))) float lds[4][C * LD > 8 * RPW ? C * LD : 8 * RPW];
+  constexpr int WLD = RPW + 8;  // padded stride of the weight table of the voxel walk (bank-conflict free, lp_splat_walk.h)
+  __shared__ __attribute__((aligned(16))) float lds[4][C * LD > 8 * WLD ? C * LD : 8 * WLD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane / RPW, r = lane % RPW;
   float* tile = lds[wave];
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(256) splat_fwd_walk_kernel(const LpSplatterArg
     for (int g = 0; g < a.out.n_grids; ++g) {
       const LpGrid& og = a.out.grids[g];
       if (og.D > 1 && og.H > 1 && og.W > 1 && !(dbg & 4))
-        splat_walk_vox<C, RPW>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, SplatSrcRegs<CPL, RPW>{enc}, wT, dbg);
+        splat_walk_vox<C, RPW, SplatSrcRegs<CPL, RPW>, true, WLD>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, SplatSrcRegs<CPL, RPW>{enc}, wT, dbg);
       else
         splat_walk<C, RPW>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, enc, wT, dbg);
     }
