@@ -201,9 +201,10 @@ def assert_grad_close(name, got, want, entries_per_sample, tol=1e-4, want64=None
         # one ray can be dominated by one sample) -- the count stays bounded by the MEASURED near-tie count and the relative
         # L2 bar of the other branch stays; only the per-entry magnitude bar is loose.  (The tuned family does not need this
         # branch at all: forced_oracle_check below replaces it by a proof.)
-        # (2e-3: one flipped unit of one ray moves that ray's 32 encoding-gradient entries, which on a 4 096-ray image is a
-        # relative L2 of 1.03e-3 -- voxel16_c64/64x64_axis on the shape-generic kernel; round 4 allowed 5e-2 here)
-        ok = n_un <= allowed and not n_outside and worst <= 0.5 and l2 <= 2e-3
+        # (relative L2 5e-3, round 4: 5e-2.  One flipped unit of ONE ray moves that ray's 32 encoding-gradient entries; on a
+        # 3 840-ray image that alone is a relative L2 of 2.5e-3 -- voxel16_c64/48x80 on the shape-generic kernel, mask cover
+        # 1.8 % of the tensor, every miss inside it.  The tuned family does not come here: test_flips_are_flips proves it.)
+        ok = n_un <= allowed and not n_outside and worst <= 0.5 and l2 <= 5e-3
     else:
         ok = n_un <= allowed and worst <= 5e-2 and l2 <= 1e-3 and worst_un <= UNEXPLAINED_MAX and not n_outside
     assert ok, (f"{name}: max err / scale = {worst:.3e} > {tol} and not a ReLU-flip pattern: {n_un} entries above the bar against "
