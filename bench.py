@@ -61,8 +61,11 @@ N_SIMD = 256 * 4        # 256 CUs x 4 SIMDs
 N_SE = 32               # shader engines SQ_BUSY_CYCLES is summed over (8 XCDs x 4)
 LOAD_LATENCY_NS = 800.0 # HBM-miss gather latency used for the loads-in-flight estimate (MI355X_MICROARCH.md: ~0.7-0.9 us)
 ATOMIC_SEGMENTS_PER_S = 21e9  # 64-byte global_atomic_add_f32 segments the chip retires (scripts/atomics_probe2.hip)
-ARITHMETIC = ("fp32-equivalent: decoder products as bf16x3 (three exact bf16 limbs per fp32 operand, six limb products, fp32 "
-              "accumulation) on v_mfma_f32_32x32x16_bf16; weight-gradient products v_mfma_f32_16x16x4_f32; everything else fp32 VALU")
+ARITHMETIC = ("forward products (outputs, the backward's decoder recompute and its ReLU decisions, operands of the weight gradients): "
+              "fp32-equivalent bf16x3 (three exact bf16 limbs per fp32 operand, six limb products, fp32 accumulation) on "
+              "v_mfma_f32_32x32x16_bf16; dX chains of the backward: gradient operand as two bf16 limbs (2^-17 per value, three limb "
+              "products; measured on the cfg-2 launch against fp64 with the kernel's ReLU decisions forced: worst gradient entry 1.0e-5 "
+              "vs 8.7e-6 with three limbs); weight-gradient products v_mfma_f32_16x16x4_f32; everything else fp32 VALU")
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -184,6 +184,80 @@ LP_DEV f32x16 layer_bf3v(const A& a, int lane, const float (&v)[8 * NCH], f32x16
   }
   return acc;
 }
+// ---- two-limb gradient operand of the dX chains (default; -DLP_DX_LIMBS=3 restores three limbs) ---------------------------
+// dX = W dY back-propagates a GRADIENT: dY is split into two limbs (16 significand bits, relative error 2^-17 per value), the
+// weights keep theirs; products kept: w1 y1, w2 y1, w1 y2 (dropped terms <= ~3 * 2^-17 |w y|, random in sign).  Half the MFMAs
+// of the dX chains and 24 instead of 44 split instructions per chunk: the tuned backward 2.03 -> 1.88 ms at cfg 2, 125.5 ->
+// 117.8 ms at cfg 4 (profiles/r05_dx_limbs_ab.txt).  What it costs in accuracy was measured with the forced-oracle proof
+// (tests/test_gpu_config_scale.py::test_flips_are_flips, every gradient entry of the cfg-2 launch against fp64): worst error
+// 1.04e-5 with two limbs, 8.7e-6 with three -- the per-product error averages out over the 10^2 .. 10^4 ray-samples every
+// gradient entry sums, the fp32 atomics' summation order dominates either way.  The FORWARD products (the outputs, the
+// backward's recompute with its ReLU decisions, the operands of the weight gradients) stay three-limb = fp32-equivalent.
+#ifndef LP_DX_LIMBS
+#define LP_DX_LIMBS 2
+#endif
+LP_DEV void split2_chunk(const float* v, u32x4_t& l1, u32x4_t& l2) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = v[2 * i], b = v[2 * i + 1];
+    const unsigned p1 = pk_bf16(a, b);
+    l1[i] = p1;
+    l2[i] = pk_bf16(a - bf16_lo(p1), b - bf16_hi(p1));
+  }
+}
+template <class A>
+LP_DEV f32x16 chunk_bf2(const A& a, int c, int lane, const u32x4_t& l1, const u32x4_t& l2, f32x16 acc) {
+  {
+    const u32x4_t w2 = a(c, 1, lane);
+    acc = LP_MFMA_BF16(w2, l1, acc);
+  }
+  {
+    const u32x4_t w1 = a(c, 0, lane);
+    acc = LP_MFMA_BF16(w1, l2, acc);
+    acc = LP_MFMA_BF16(w1, l1, acc);
+  }
+  return acc;
+}
+template <int NCH, class A>
+LP_DEV f32x16 layer_bf2v(const A& a, int lane, const float (&v)[8 * NCH], f32x16 acc) {
+  u32x4_t l1, l2;
+  split2_chunk(v, l1, l2);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    u32x4_t n1 = l1, n2 = l2;
+    acc = chunk_bf2(a, c, lane, l1, l2, acc);
+    if (c + 1 < NCH) split2_chunk(v + 8 * (c + 1), n1, n2);
+    l1 = n1; l2 = n2;
+  }
+  return acc;
+}
+
+// the dX chains' operand split / chunk product, by LP_DX_LIMBS (l3 unused with two limbs)
+LP_DEV void dx_split_chunk(const float* v, u32x4_t& l1, u32x4_t& l2, u32x4_t& l3) {
+#if LP_DX_LIMBS == 2
+  split2_chunk(v, l1, l2);
+  l3 = l2;
+#else
+  split3_chunk(v, l1, l2, l3);
+#endif
+}
+template <class A>
+LP_DEV f32x16 dx_chunk(const A& a, int c, int lane, const u32x4_t& l1, const u32x4_t& l2, const u32x4_t& l3, f32x16 acc) {
+#if LP_DX_LIMBS == 2
+  return chunk_bf2(a, c, lane, l1, l2, acc);
+#else
+  return chunk_bf3(a, c, lane, l1, l2, l3, acc);
+#endif
+}
+template <int NCH, class A>
+LP_DEV f32x16 layer_dxv(const A& a, int lane, const float (&v)[8 * NCH], f32x16 acc) {
+#if LP_DX_LIMBS == 2
+  return layer_bf2v<NCH>(a, lane, v, acc);
+#else
+  return layer_bf3v<NCH>(a, lane, v, acc);
+#endif
+}
+
 template <int NCH>
 LP_DEV f32x16 layer_bf3v(const char* img, int chunk0, int lane, const float (&v)[8 * NCH], f32x16 acc) {
   return layer_bf3v<NCH>(ASlots{img, chunk0}, lane, v, acc);

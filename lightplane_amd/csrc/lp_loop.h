@@ -61,10 +61,10 @@ LP_DEV void loop_stage_layer(char* lds, float* sm, const float* P, const LoopLay
 // ---------------------------------------------------------------------------------------------------------------
 // issue order "1 MFMA, 1 LDS operand read, a few VALU" for the 6 NB MFMAs of a chunk and the 44 VALU instructions of the next
 // chunk's limb split (see bf3_interleave_hint, lp_bf3.h)
-template <int NB>
+template <int NB, int NP = 6>  // NP = limb products per chunk and block
 LP_DEV void loop_interleave_hint() {
 #pragma unroll
-  for (int i = 0; i < 6 * NB; ++i) {
+  for (int i = 0; i < NP * NB; ++i) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // MFMA
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               // DS read (A operand)
     __builtin_amdgcn_sched_group_barrier(0x002, NB == 1 ? 8 : 4, 0);  // VALU
@@ -140,13 +140,13 @@ LP_DEV void loop_layer_dx(const char* lbase, const LoopLayer& L, int lane, const
     for (int c = 0; c < 2; ++c) {
       if (c < out_chunks) {
         u32x4_t l1, l2, l3;
-        split3_chunk(&dy[0][8 * c], l1, l2, l3);
-        dx[0] = chunk_bf3(ARowsBwd{lbase + L.img, LOOP_ST, 31}, c, lane, l1, l2, l3, dx[0]);
+        dx_split_chunk(&dy[0][8 * c], l1, l2, l3);
+        dx[0] = dx_chunk(ARowsBwd{lbase + L.img, LOOP_ST, 31}, c, lane, l1, l2, l3, dx[0]);
       }
     }
   } else {
     u32x4_t l1, l2, l3;
-    split3_chunk(&dy[0][0], l1, l2, l3);
+    dx_split_chunk(&dy[0][0], l1, l2, l3);
 #pragma unroll
     for (int c = 0; c < 2 * NB; ++c) {
       if (c < out_chunks) {  // wave-uniform; software-pipelined like loop_layer_fwd
@@ -154,11 +154,11 @@ LP_DEV void loop_layer_dx(const char* lbase, const LoopLayer& L, int lane, const
 #pragma unroll
         for (int ib = 0; ib < NB; ++ib) {
           if (ib == 0 || ib < in_blocks)
-            dx[ib] = chunk_bf3(ARowsBwd{lbase + L.img + (ib * L.ob + (c >> 1)) * LOOP_BLK, LOOP_ST, 31}, c & 1, lane, l1, l2, l3, dx[ib]);
+            dx[ib] = dx_chunk(ARowsBwd{lbase + L.img + (ib * L.ob + (c >> 1)) * LOOP_BLK, LOOP_ST, 31}, c & 1, lane, l1, l2, l3, dx[ib]);
         }
         if (c + 1 < 2 * NB) {
-          split3_chunk(&dy[(c + 1) >> 1][8 * ((c + 1) & 1)], n1, n2, n3);
-          loop_interleave_hint<NB>();
+          dx_split_chunk(&dy[(c + 1) >> 1][8 * ((c + 1) & 1)], n1, n2, n3);
+          loop_interleave_hint<NB, LP_DX_LIMBS == 2 ? 3 : 6>();
         }
         l1 = n1; l2 = n2; l3 = n3;
       }

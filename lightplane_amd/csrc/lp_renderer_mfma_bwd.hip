@@ -455,7 +455,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
         tile_store_fm(xt, r, h, e);
         tile_store_fm(yt, r, h, dhc);
       }
-      acc = layer_bf3v<2>(Ab(I3{}), lane, dhc, acc);
+      acc = layer_dxv<2>(Ab(I3{}), lane, dhc, acc);
 #pragma unroll
       for (int q = 0; q < 16; ++q) dsum[q] += dhc[q];
       if (want_params) {
@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
         dho[4 * j + 3] = mask_apply(ho_mask, 4 * j + 3, dro * wo.w);
       }
       if (want_params) tile_store_fm(yt, r, h, dho);  // the X tile still holds e
-      acc = layer_bf3v<2>(Ab(I2{}), lane, dho, acc);
+      acc = layer_dxv<2>(Ab(I2{}), lane, dho, acc);
       if (want_params) {
         lds_barrier();
         dq_o1 = dw_quadrant<B::PER_WAVE>(wave0, a_off, b_off, v0, v0 + 4, dq_o1, db_o1);
@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
         tile_store_fm(xt, r, h, h1);
         tile_store_fm(yt, r, h, de);
       }
-      acc = layer_bf3v<2>(Ab(I1{}), lane, de, (f32x16){0});
+      acc = layer_dxv<2>(Ab(I1{}), lane, de, (f32x16){0});
       if (want_params) {
         lds_barrier();
         dq_t2 = dw_quadrant<B::PER_WAVE>(wave0, a_off, b_off, v0, v0 + 4, dq_t2, db_t2);
@@ -516,7 +516,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
         tile_store_fm(yt, r, h, dh1);
       }
       if (gg) {
-        acc = layer_bf3v<2>(Ab(I0{}), lane, dh1, (f32x16){0});  // rows >= C of the result are unused
+        acc = layer_dxv<2>(Ab(I0{}), lane, dh1, (f32x16){0});  // rows >= C of the result are unused
       }
       if (want_params) {
         lds_barrier();
