@@ -232,30 +232,25 @@ LP_DEV f32x16 layer_bf2v(const A& a, int lane, const float (&v)[8 * NCH], f32x16
   return acc;
 }
 
-// the dX chains' operand split / chunk product, by LP_DX_LIMBS (l3 unused with two limbs)
+// the dX chains' operand split / chunk product with DXL = 2 or 3 limbs of the gradient operand (l3 unused with two)
+template <int DXL>
 LP_DEV void dx_split_chunk(const float* v, u32x4_t& l1, u32x4_t& l2, u32x4_t& l3) {
-#if LP_DX_LIMBS == 2
-  split2_chunk(v, l1, l2);
-  l3 = l2;
-#else
-  split3_chunk(v, l1, l2, l3);
-#endif
+  if constexpr (DXL == 2) {
+    split2_chunk(v, l1, l2);
+    l3 = l2;
+  } else {
+    split3_chunk(v, l1, l2, l3);
+  }
 }
-template <class A>
+template <int DXL, class A>
 LP_DEV f32x16 dx_chunk(const A& a, int c, int lane, const u32x4_t& l1, const u32x4_t& l2, const u32x4_t& l3, f32x16 acc) {
-#if LP_DX_LIMBS == 2
-  return chunk_bf2(a, c, lane, l1, l2, acc);
-#else
-  return chunk_bf3(a, c, lane, l1, l2, l3, acc);
-#endif
+  if constexpr (DXL == 2) return chunk_bf2(a, c, lane, l1, l2, acc);
+  else return chunk_bf3(a, c, lane, l1, l2, l3, acc);
 }
 template <int NCH, class A>
 LP_DEV f32x16 layer_dxv(const A& a, int lane, const float (&v)[8 * NCH], f32x16 acc) {
-#if LP_DX_LIMBS == 2
-  return layer_bf2v<NCH>(a, lane, v, acc);
-#else
-  return layer_bf3v<NCH>(a, lane, v, acc);
-#endif
+  if constexpr (LP_DX_LIMBS == 2) return layer_bf2v<NCH>(a, lane, v, acc);
+  else return layer_bf3v<NCH>(a, lane, v, acc);
 }
 
 template <int NCH>

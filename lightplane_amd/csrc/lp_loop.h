@@ -34,13 +34,14 @@ LP_DEV void lds_barrier_l() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" :
 // ---------------------------------------------------------------------------------------------------------------
 // staging
 // ---------------------------------------------------------------------------------------------------------------
+// (the staging loops stride by the launch's block size: the eight-wave forwards stage every element once, not twice)
 template <int NB>
 LP_DEV void loop_stage_layer(char* lds, float* sm, const float* P, const LoopLayer& L, int tid) {
   const int in_blocks = (L.rows_in + 31) >> 5;
   for (int ib = 0; ib < in_blocks; ++ib) {
     for (int ob = 0; ob < L.ob; ++ob) {
       char* blk = lds + L.img + (ib * L.ob + ob) * LOOP_BLK;
-      for (int i = tid; i < 32 * 32; i += 256) {
+      for (int i = tid; i < 32 * 32; i += (int)blockDim.x) {
         const int k = i >> 5, m = i & 31;
         const int row = 32 * ib + k, col = 32 * ob + m;
         const float w = (row < L.rows_in && col < L.cols) ? P[L.w + (int64_t)row * L.ld + col] : 0.0f;
@@ -53,7 +54,7 @@ LP_DEV void loop_stage_layer(char* lds, float* sm, const float* P, const LoopLay
       }
     }
   }
-  for (int i = tid; i < 32 * NB; i += 256) sm[L.bias + i] = (i < L.cols) ? P[L.b + i] : 0.0f;
+  for (int i = tid; i < 32 * NB; i += (int)blockDim.x) sm[L.bias + i] = (i < L.cols) ? P[L.b + i] : 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -131,7 +132,8 @@ LP_DEV void loop_layer_fwd(const char* lbase, const float* sm, const LoopLayer& 
 }
 
 // dX += W dY (blocks of the layer's INPUT): dy = NB blocks of this lane's 16 output features
-template <int NB>
+// DXL: limbs of the gradient operand (lp_bf3.h; 2 only where the caller's chain is short, see renderer_bwd_loop)
+template <int NB, int DXL = 3>
 LP_DEV void loop_layer_dx(const char* lbase, const LoopLayer& L, int lane, const float (&dy)[NB][16], f32x16 (&dx)[NB]) {
   const int out_chunks = (L.cols + 15) >> 4;
   const int in_blocks = (L.rows_in + 31) >> 5;
@@ -140,13 +142,13 @@ LP_DEV void loop_layer_dx(const char* lbase, const LoopLayer& L, int lane, const
     for (int c = 0; c < 2; ++c) {
       if (c < out_chunks) {
         u32x4_t l1, l2, l3;
-        dx_split_chunk(&dy[0][8 * c], l1, l2, l3);
-        dx[0] = dx_chunk(ARowsBwd{lbase + L.img, LOOP_ST, 31}, c, lane, l1, l2, l3, dx[0]);
+        dx_split_chunk<DXL>(&dy[0][8 * c], l1, l2, l3);
+        dx[0] = dx_chunk<DXL>(ARowsBwd{lbase + L.img, LOOP_ST, 31}, c, lane, l1, l2, l3, dx[0]);
       }
     }
   } else {
     u32x4_t l1, l2, l3;
-    dx_split_chunk(&dy[0][0], l1, l2, l3);
+    dx_split_chunk<DXL>(&dy[0][0], l1, l2, l3);
 #pragma unroll
     for (int c = 0; c < 2 * NB; ++c) {
       if (c < out_chunks) {  // wave-uniform; software-pipelined like loop_layer_fwd
@@ -154,11 +156,11 @@ LP_DEV void loop_layer_dx(const char* lbase, const LoopLayer& L, int lane, const
 #pragma unroll
         for (int ib = 0; ib < NB; ++ib) {
           if (ib == 0 || ib < in_blocks)
-            dx[ib] = dx_chunk(ARowsBwd{lbase + L.img + (ib * L.ob + (c >> 1)) * LOOP_BLK, LOOP_ST, 31}, c & 1, lane, l1, l2, l3, dx[ib]);
+            dx[ib] = dx_chunk<DXL>(ARowsBwd{lbase + L.img + (ib * L.ob + (c >> 1)) * LOOP_BLK, LOOP_ST, 31}, c & 1, lane, l1, l2, l3, dx[ib]);
         }
         if (c + 1 < 2 * NB) {
-          dx_split_chunk(&dy[(c + 1) >> 1][8 * ((c + 1) & 1)], n1, n2, n3);
-          loop_interleave_hint<NB, LP_DX_LIMBS == 2 ? 3 : 6>();
+          dx_split_chunk<DXL>(&dy[(c + 1) >> 1][8 * ((c + 1) & 1)], n1, n2, n3);
+          loop_interleave_hint<NB, DXL == 2 ? 3 : 6>();
         }
         l1 = n1; l2 = n2; l3 = n3;
       }
@@ -213,7 +215,7 @@ LP_DEV void loop_dw_zero(LoopDw<NB>& d) {
 // Backward of one layer: dW (workgroup-shared quadrants) and dX.  x = the layer's input activation, dy = upstream gradient
 // (already masked by the layer's own ReLU).  Publishes the X / dY tiles of one block pair, runs the dX chain while the LDS
 // writes land, then barrier -> quadrant -> barrier per block pair.
-template <int NB>
+template <int NB, int DXL = 3>
 LP_DEV void loop_layer_bwd(const char* lbase, const LoopLayer& L, int lane, float* xt, float* yt, const float* wave0, int stride,
                            int a_off, int b_off, bool want_params, bool want_dx, const float (&x)[NB][16], const float (&dy)[NB][16],
                            LoopDw<NB>& dw, f32x16 (&dx)[NB]) {
@@ -223,7 +225,7 @@ LP_DEV void loop_layer_bwd(const char* lbase, const LoopLayer& L, int lane, floa
     loop_tile_store(xt, r, h, x[0]);
     loop_tile_store(yt, r, h, dy[0]);
   }
-  if (want_dx) loop_layer_dx<NB>(lbase, L, lane, dy, dx);
+  if (want_dx) loop_layer_dx<NB, DXL>(lbase, L, lane, dy, dx);
   if (want_params) {
 #pragma unroll
     for (int ib = 0; ib < NB; ++ib) {

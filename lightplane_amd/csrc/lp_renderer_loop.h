@@ -61,12 +61,12 @@ LP_DEV void loop_stage(const LpRendererArgs& a, const LoopParams& lp, float* lds
   for (int l = 0; l < lp.n_o; ++l) loop_stage_layer<NB>(b, lds, P, lp.o[l], tid);
   for (int l = 0; l < lp.n_c; ++l) loop_stage_layer<NB>(b, lds, P, lp.c[l], tid);
   if (a.color_chn > 4) loop_stage_layer<NB>(b, lds, P, lp.co, tid);
-  for (int i = tid; i < 32 * NB; i += 256) {
+  for (int i = tid; i < 32 * NB; i += (int)blockDim.x) {
     lds[lp.wo2 + i] = (i < lp.ho_w) ? P[lp.w_o2 + i] : 0.0f;
 #pragma unroll
     for (int c = 0; c < 4; ++c) lds[lp.wc2 + i * 4 + c] = (i < lp.hc_w && c < a.color_chn) ? P[lp.w_c2 + (int64_t)i * lp.ldc2 + c] : 0.0f;
   }
-  for (int i = tid; i < LOOP_N_INF; i += 256) lds[lp.inf + i] = (i < a.march.num_samples_inf) ? inf_scale(i, a.march) : 0.0f;
+  for (int i = tid; i < LOOP_N_INF; i += (int)blockDim.x) lds[lp.inf + i] = (i < a.march.num_samples_inf) ? inf_scale(i, a.march) : 0.0f;
   if (tid == 0) {
     lds[lp.hb] = P[lp.b_o2];
 #pragma unroll
@@ -324,6 +324,10 @@ __global__ void __launch_bounds__(64 * NW, 2) renderer_fwd_loop(const LpRenderer
 template <int C, int NB, bool TG, int MT, int MH, bool WC = false, int GM = GM_GENERIC>
 __global__ void __launch_bounds__(256, (NB == 1 && MT <= 2 && MH <= 1 && !WC) ? 2 : 1) renderer_bwd_loop(const LpRendererArgs a, const LoopParams lp) {
   using T = LoopTile;
+  // gradient operand of the dX chains: two limbs (lp_bf3.h) where the chain is short -- at most two trunk layers and one hidden
+  // layer per head, i.e. the shallow and the two-block (hidden 64) instantiations; deep decoders keep three: the per-layer error
+  // compounds along a 7-layer chain (4/2/3 x 32 on 70 rays x 15 samples: grad_mlp_params 1.05e-4 with two limbs)
+  constexpr int DXL = (MT <= 2 && MH <= 1) ? LP_DX_LIMBS : 3;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   loop_stage<NB>(a, lp, lds);
   const float* const geo = lds + lp.inf - Lds::INF;
@@ -629,7 +633,7 @@ __global__ void __launch_bounds__(256, (NB == 1 && MT <= 2 && MH <= 1 && !WC) ? 
       f32x16 dxc[NB];
 #pragma unroll
       for (int b = 0; b < NB; ++b) dxc[b] = (f32x16){0};
-      loop_layer_bwd<NB>(lbase, lp.co, lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, true, hc, dyc, dw_co, dxc);
+      loop_layer_bwd<NB, DXL>(lbase, lp.co, lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, true, hc, dyc, dw_co, dxc);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
 #pragma unroll
@@ -664,14 +668,14 @@ __global__ void __launch_bounds__(256, (NB == 1 && MT <= 2 && MH <= 1 && !WC) ? 
 #pragma unroll
         for (int b = 0; b < NB; ++b) dx[b] = (f32x16){0};
         if (l > 0) {
-          loop_layer_bwd<NB>(lbase, lp.c[l], lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, true, cA[l > 0 ? l - 1 : 0], g, dw_c[l], dx);
+          loop_layer_bwd<NB, DXL>(lbase, lp.c[l], lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, true, cA[l > 0 ? l - 1 : 0], g, dw_c[l], dx);
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) g[b][q] = (cA[l > 0 ? l - 1 : 0][b][q] > 0.0f) ? dx[b][q] : 0.0f;
           }
         } else {
-          loop_layer_bwd<NB>(lbase, lp.c[0], lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, true, cin, g, dw_c[0], dx);
+          loop_layer_bwd<NB, DXL>(lbase, lp.c[0], lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, true, cin, g, dw_c[0], dx);
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
 #pragma unroll
@@ -728,14 +732,14 @@ __global__ void __launch_bounds__(256, (NB == 1 && MT <= 2 && MH <= 1 && !WC) ? 
 #pragma unroll
         for (int b = 0; b < NB; ++b) dx[b] = (f32x16){0};
         if (l > 0) {
-          loop_layer_bwd<NB>(lbase, lp.o[l], lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, true, oA[l > 0 ? l - 1 : 0], g, dw_o[l], dx);
+          loop_layer_bwd<NB, DXL>(lbase, lp.o[l], lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, true, oA[l > 0 ? l - 1 : 0], g, dw_o[l], dx);
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) g[b][q] = (oA[l > 0 ? l - 1 : 0][b][q] > 0.0f) ? dx[b][q] : 0.0f;
           }
         } else {
-          loop_layer_bwd<NB>(lbase, lp.o[0], lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, true, e, g, dw_o[0], dx);
+          loop_layer_bwd<NB, DXL>(lbase, lp.o[0], lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, true, e, g, dw_o[0], dx);
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
 #pragma unroll
@@ -758,14 +762,14 @@ __global__ void __launch_bounds__(256, (NB == 1 && MT <= 2 && MH <= 1 && !WC) ? 
 #pragma unroll
         for (int b = 0; b < NB; ++b) dx[b] = (f32x16){0};
         if (l > 0) {
-          loop_layer_bwd<NB>(lbase, lp.t[l], lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, true, tA[l > 0 ? l - 1 : 0], g, dw_t[l], dx);
+          loop_layer_bwd<NB, DXL>(lbase, lp.t[l], lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, true, tA[l > 0 ? l - 1 : 0], g, dw_t[l], dx);
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) g[b][q] = (tA[l > 0 ? l - 1 : 0][b][q] > 0.0f) ? dx[b][q] : 0.0f;
           }
         } else {
-          loop_layer_bwd<NB>(lbase, lp.t[0], lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, gg, xin, g, dw_t[0], dx);
+          loop_layer_bwd<NB, DXL>(lbase, lp.t[0], lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, gg, xin, g, dw_t[0], dx);
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
 #pragma unroll

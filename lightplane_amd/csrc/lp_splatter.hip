@@ -526,7 +526,20 @@ int splatter_backward_launch(const LpSplatterArgs& a, hipStream_t stream) {
           n_simd = 4 * cus;
         else n_simd = 1024;
       }
-      const int occ = Cw == 16 ? (rpw_eff == 8 ? 4 : 3) : (Cw == 32 ? (rpw_eff == 8 ? 3 : 2) : 2);  // (C = 64: two either way)
+      // resident workgroups per CU (= waves per SIMD: four-wave workgroups) of the instantiation that will run, asked from
+      // the runtime once per instantiation (C = 16 / 32 / 64 at 8 rays per wave: 4 / 3 / 2 with this compiler) -- not a table
+      // that has to track the register allocator
+      const int ki = (Cw == 16 ? 0 : Cw == 32 ? 1 : 2) + (rpw_eff == 8 ? 0 : 3);
+      static int occ_cache[6] = {0, 0, 0, 0, 0, 0};
+      if (occ_cache[ki] == 0) {
+        const void* kfn = ki == 0 ? (const void*)splat_bwd_walk_kernel<16, 8, 8> : ki == 1 ? (const void*)splat_bwd_walk_kernel<32, 8, 8>
+                        : ki == 2 ? (const void*)splat_bwd_walk_kernel<64, 8, 8> : ki == 3 ? (const void*)splat_bwd_walk_kernel<16, 8>
+                        : ki == 4 ? (const void*)splat_bwd_walk_kernel<32, 8> : (const void*)splat_bwd_walk_kernel<64, 4>;
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, 256, 0) != hipSuccess || nb < 1) nb = 2;
+        occ_cache[ki] = nb > 8 ? 8 : nb;
+      }
+      const int occ = occ_cache[ki];
       const uint64_t cap = (uint64_t)n_simd * occ, waves = (uint64_t)ray_blocks * 4;
       const int s_tot = a.march.num_samples + a.march.num_samples_inf;
       if (waves >= cap && waves <= 16 * cap) {
@@ -539,6 +552,9 @@ int splatter_backward_launch(const LpSplatterArgs& a, hipStream_t stream) {
         }
       }
     }
+    // (With n_seg > 1 the segments of a ray ADD their partial grad_encoding with fp32 atomics: the sum's order, hence its last
+    // bits, vary from run to run -- like every grid / parameter gradient of this library.  LP_SPLAT_SEGMENTS=1 restores the
+    // single-writer, bit-reproducible form.)
     if (n_seg > 1) {  // the segments accumulate into grad_encoding
       const hipError_t e = hipMemsetAsync(a.grad_encoding, 0, (size_t)a.rays.n_rays * Cw * sizeof(float), stream);
       if (e != hipSuccess) return set_error((int)e, "hipMemsetAsync(grad_encoding): %s", hipGetErrorString(e));

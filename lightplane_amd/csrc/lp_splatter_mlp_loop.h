@@ -48,7 +48,7 @@ template <int NB>
 LP_DEV void sloop_stage(const LpSplatterArgs& a, const SplatLoopParams& sp, float* lds) {
   const int tid = threadIdx.x;
   for (int l = 0; l < sp.n; ++l) loop_stage_layer<NB>(reinterpret_cast<char*>(lds), lds, a.mlp_params, sp.l[l], tid);
-  for (int i = tid; i < LOOP_N_INF; i += 256) lds[sp.inf + i] = (i < a.march.num_samples_inf) ? inf_scale(i, a.march) : 0.0f;
+  for (int i = tid; i < LOOP_N_INF; i += (int)blockDim.x) lds[sp.inf + i] = (i < a.march.num_samples_inf) ? inf_scale(i, a.march) : 0.0f;
 }
 
 // sampled feature + ray encoding -> NB blocks: x0 register q holds channel 8 (q >> 2) + 4 h + (q & 3), i.e. register

@@ -144,12 +144,28 @@ def _shape_args(grid, decoder_params: DecoderParams, grid_sizes=None, color_grid
     return a
 
 
+#: keyword arguments of ``lightplane_renderer`` that ``kernel_family`` / ``backward_segments`` accept and ignore (they do not
+#: influence the shape-only answer); anything else raises, so that a typo such as ``num_sample_inf=`` cannot pass silently
+_RENDER_KWARGS = frozenset((
+    "num_samples", "gain", "mask_out_of_bounds_samples", "contract_coords", "disparity_at_inf", "inject_noise_sigma",
+    "inject_noise_seed", "scaffold", "kernel", "stop_transmittance", "regenerate_code", "triton_block_size", "triton_num_warps",
+    "allow_unsupported", "checkpointing", "use_naive_impl"))
+
+
+def _check_render_kwargs(fn: str, kw) -> None:
+    unknown = sorted(set(kw) - _RENDER_KWARGS)
+    if unknown:
+        raise TypeError(f"{fn}() got unexpected keyword argument(s) {unknown}: not a keyword of lightplane_renderer")
+
+
 def kernel_family(rays: Rays, grid, decoder_params: DecoderParams, grid_sizes=None, color_grid=None,
                   color_grid_sizes=None, num_samples_inf: int = 0, **_unused) -> int:
     """Kernel family ``LP_KERNEL_AUTO`` selects for these shapes: 0 generic, 1 the tuned MFMA kernels of the default decoder
     (2/2/2 x 32), 3 layer-looped MFMA (1-4 layers per MLP, widths 16 / 32 / 64) (``lp_renderer_kernel_family``; needs no GPU;
     2, the fp32-MFMA hidden-64 family, was retired in 0.2.4).  ``num_samples_inf``: more than 256 beyond-far samples run the
-    generic kernels (keyword arguments of the render call other than that are accepted and ignored)."""
+    generic kernels.  Only the shapes and ``num_samples_inf`` influence the answer; the other keywords of the render call
+    (``_RENDER_KWARGS``) are accepted and ignored, an unknown keyword raises."""
+    _check_render_kwargs("kernel_family", _unused)
     a = _shape_args(grid, decoder_params, grid_sizes, color_grid, color_grid_sizes)
     a.march.num_samples_inf = int(num_samples_inf)
     return int(_lib.lib().lp_renderer_kernel_family(ctypes.byref(a)))
@@ -160,6 +176,7 @@ def backward_segments(rays: Rays, grid, decoder_params: DecoderParams, num_sampl
                       **_unused) -> int:
     """Number of ray segments the backward of this call is split into (``lp_renderer_backward_segments``; needs no
     GPU): 1 = one sweep per ray, > 1 = small batch, every block of 16 samples of a ray in its own workgroup."""
+    _check_render_kwargs("backward_segments", _unused)
     a = _shape_args(grid, decoder_params, grid_sizes, color_grid, color_grid_sizes)
     a.rays.n_rays = int(rays.directions.shape[0])
     a.march.num_samples, a.march.num_samples_inf = int(num_samples), int(num_samples_inf)

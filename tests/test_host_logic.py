@@ -669,3 +669,20 @@ def test_reference_submodule_import_paths():
     import lightplane_amd.lightplane_splatter  # noqa: F401
     assert callable(lp.lightplane_renderer) and callable(lp.lightplane_splatter)
     assert lp.mlp_utils.DecoderParams is lp.DecoderParams and lp.misc_utils.flatten_grid is lp.flatten_grid
+
+
+def test_kernel_family_rejects_unknown_keywords():
+    """``kernel_family`` / ``backward_segments`` take the render call's keywords (and ignore the ones that do not influence a
+    shape-only answer) -- but a typo must not pass silently."""
+    from tests.synth import grid_sizes_for, random_decoder, random_grids, random_rays
+
+    g = torch.Generator().manual_seed(0)
+    grids = random_grids(g, grid_sizes_for((1, 4, 4, 4, 16), True))
+    rays = random_rays(g, 32, 1, 32)
+    dec = random_decoder(g, 2, 2, 2, 16, 32, 3)
+    assert lp.kernel_family(rays, grids, dec, num_samples=8, gain=1.0, mask_out_of_bounds_samples=True, inject_noise_sigma=0.1) == 1
+    with pytest.raises(TypeError, match="num_sample_inf"):
+        lp.kernel_family(rays, grids, dec, num_sample_inf=3)
+    with pytest.raises(TypeError, match="num_sample"):
+        lp.backward_segments(rays, grids, dec, num_samples=64, num_sample_inf=3)
+    assert lp.backward_segments(rays, grids, dec, num_samples=64, gain=1.0) >= 1
