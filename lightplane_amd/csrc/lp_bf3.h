@@ -89,9 +89,17 @@ struct ASlots {
   LP_DEV u32x4_t operator()(int c, int limb, int lane) const { return bf3_a(img, chunk0 + c, limb, lane); }
 };
 // (b) ONE row-major image per layer serving both orientations: limb p of W[row k_in][col m_out] at
-//     layer + p * limb_stride + (k_in * RM_LD + m_out) * 2.  RM_LD = 36 elements (72 B rows): the backward's two
-//     ds_read_b64 per lane and the forward's transposed reads are bank-conflict free.
-constexpr int RM_LD = 36;
+//     layer + p * limb_stride + rm_off(k_in, m_out).  Rows are 64 bytes (32 bf16) and every group of four rows is skewed by a
+//     further 8 bytes: row k starts at byte 64 k + 8 (k >> 2), i.e. at bank 16 (k & 3) + 2 (k >> 2) of the 64 four-byte banks.
+//     * forward (two ds_read_b64_tr_b16 per lane): one instruction covers four consecutive rows k0 .. k0 + 3 (k0 a multiple of
+//       4) completely -- 4 x 64 B on four disjoint 16-bank ranges: conflict-free;
+//     * backward (two ds_read_b64 per lane, 32 lanes = 32 rows at one column offset): start banks 16 a + 2 b, a < 4, b < 8 --
+//       32 distinct even banks, 8 bytes each: conflict-free.
+//     (Rounds 2-4 used plain 72-byte rows, RM_LD = 36: conflict-free for the backward reads, but the four rows of a transposed
+//     read span 288 B and wrap onto their own first banks -- a 2-way conflict on every forward operand read, 84 extra LDS cycles
+//     per wave-sample of the tuned backward = ALL of its SQ_LDS_BANK_CONFLICT count, profiles/r04_pmc_summary.json.)
+LP_DEV constexpr int rm_off(int k, int m) { return k * 64 + (k >> 2) * 8 + m * 2; }
+LP_DEV constexpr int rm_bytes(int rows) { return rows * 64 + ((rows + 3) >> 2) * 8; }
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 //     backward (dX) form: lane (k = l & 31, h) needs W[k][feat(8c + j, h)], j = 0..7 = columns 16c + 4h .. +3 and 16c + 8 + 4h .. +3
@@ -99,7 +107,7 @@ struct ARowsBwd {
   const char* layer;
   int limb_stride, row_mask;  // row_mask = rows - 1: lanes beyond a 16-row matrix re-read valid rows (their output rows are unused)
   LP_DEV u32x4_t operator()(int c, int limb, int lane) const {
-    const char* p = layer + limb * limb_stride + (((lane & 31) & row_mask) * RM_LD + 16 * c + 4 * (lane >> 5)) * 2;
+    const char* p = layer + limb * limb_stride + rm_off((lane & 31) & row_mask, 16 * c + 4 * (lane >> 5));
     const u32x2_t a = *reinterpret_cast<const u32x2_t*>(p), b = *reinterpret_cast<const u32x2_t*>(p + 16);
     return (u32x4_t){a.x, a.y, b.x, b.y};
   }
@@ -114,10 +122,10 @@ struct AColsFwd {
   int limb_stride;
   LP_DEV u32x4_t operator()(int c, int limb, int lane) const {
     const int s = lane & 15, m0 = lane & 16, h = lane >> 5;
-    const char* p = layer + limb * limb_stride + ((16 * c + 4 * h + (s >> 2)) * RM_LD + m0 + 4 * (s & 3)) * 2;
+    const char* p = layer + limb * limb_stride + rm_off(16 * c + 4 * h + (s >> 2), m0 + 4 * (s & 3));
     typedef __attribute__((address_space(3))) s16x4_t* lds_ptr;
     const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
-    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 8 * RM_LD * 2));
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + (rm_off(8, 0) - rm_off(0, 0))));  // rows + 8
     const u32x2_t ua = __builtin_bit_cast(u32x2_t, a), ub = __builtin_bit_cast(u32x2_t, b);
     return (u32x4_t){ua.x, ua.y, ub.x, ub.y};
   }
@@ -128,7 +136,7 @@ LP_DEV void stage_matrix_rm(char* layer, int limb_stride, const float* P, int64_
     const int k = i >> 5, m = i & 31;
     unsigned short l1, l2, l3;
     split3_scalar(P[off + (int64_t)k * ld + m], l1, l2, l3);
-    char* base = layer + (k * RM_LD + m) * 2;
+    char* base = layer + rm_off(k, m);
     *reinterpret_cast<unsigned short*>(base) = l1;
     *reinterpret_cast<unsigned short*>(base + limb_stride) = l2;
     *reinterpret_cast<unsigned short*>(base + 2 * limb_stride) = l3;
@@ -370,7 +378,7 @@ template <int C>
 struct LdsBf3Rm {
   static constexpr int N_INF = 64;
   static constexpr int SMALL_BYTES = (Lds::INF - Lds::BIAS + N_INF) * 4;
-  static constexpr int ST_T1 = C * RM_LD * 2, ST_32 = 32 * RM_LD * 2;      // limb strides (bytes)
+  static constexpr int ST_T1 = rm_bytes(C), ST_32 = rm_bytes(32);          // limb strides (bytes)
   static constexpr int IMG = SMALL_BYTES;
   static constexpr int L_T1 = IMG, L_T2 = L_T1 + 3 * ST_T1, L_O1 = L_T2 + 3 * ST_32, L_C1 = L_O1 + 3 * ST_32;
   static constexpr int END = L_C1 + 3 * ST_32;

@@ -12,7 +12,7 @@ typedef float f32x4l __attribute__((ext_vector_type(4)));
 #define LP_MFMA16L(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 constexpr int LOOP_N_INF = 256;     // beyond-far samples tabulated (as many as the tuned family, lp_mfma_common.h MAX_INF)
-constexpr int LOOP_ST = 32 * RM_LD * 2;   // bytes of one limb of a 32 x 32 block (72-byte rows)
+constexpr int LOOP_ST = rm_bytes(32);     // bytes of one limb of a 32 x 32 block (skewed 64-byte rows, lp_bf3.h)
 constexpr int LOOP_BLK = 3 * LOOP_ST;     // bytes of a block image (three limbs)
 constexpr int LT_LD = 36;           // row stride of the feature-major fp32 tiles [32 features][32 rays + 4]
 
@@ -47,7 +47,7 @@ LP_DEV void loop_stage_layer(char* lds, float* sm, const float* P, const LoopLay
         const float w = (row < L.rows_in && col < L.cols) ? P[L.w + (int64_t)row * L.ld + col] : 0.0f;
         unsigned short l1, l2, l3;
         split3_scalar(w, l1, l2, l3);
-        char* base = blk + (k * RM_LD + m) * 2;
+        char* base = blk + rm_off(k, m);
         *reinterpret_cast<unsigned short*>(base) = l1;
         *reinterpret_cast<unsigned short*>(base + LOOP_ST) = l2;
         *reinterpret_cast<unsigned short*>(base + 2 * LOOP_ST) = l3;
