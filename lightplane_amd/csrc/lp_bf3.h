@@ -98,8 +98,8 @@ struct ASlots {
 //     (Rounds 2-4 used plain 72-byte rows, RM_LD = 36: conflict-free for the backward reads, but the four rows of a transposed
 //     read span 288 B and wrap onto their own first banks -- a 2-way conflict on every forward operand read, 84 extra LDS cycles
 //     per wave-sample of the tuned backward = ALL of its SQ_LDS_BANK_CONFLICT count, profiles/r04_pmc_summary.json.)
-LP_DEV constexpr int rm_off(int k, int m) { return k * 64 + (k >> 2) * 8 + m * 2; }
-LP_DEV constexpr int rm_bytes(int rows) { return rows * 64 + ((rows + 3) >> 2) * 8; }
+__host__ __device__ constexpr int rm_off(int k, int m) { return k * 64 + (k >> 2) * 8 + m * 2; }
+__host__ __device__ constexpr int rm_bytes(int rows) { return rows * 64 + ((rows + 3) >> 2) * 8; }
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 //     backward (dX) form: lane (k = l & 31, h) needs W[k][feat(8c + j, h)], j = 0..7 = columns 16c + 4h .. +3 and 16c + 8 + 4h .. +3
