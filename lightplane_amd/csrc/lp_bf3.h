@@ -89,17 +89,22 @@ struct ASlots {
   LP_DEV u32x4_t operator()(int c, int limb, int lane) const { return bf3_a(img, chunk0 + c, limb, lane); }
 };
 // (b) ONE row-major image per layer serving both orientations: limb p of W[row k_in][col m_out] at
-//     layer + p * limb_stride + rm_off(k_in, m_out).  Rows are 64 bytes (32 bf16) and every group of four rows is skewed by a
-//     further 8 bytes: row k starts at byte 64 k + 8 (k >> 2), i.e. at bank 16 (k & 3) + 2 (k >> 2) of the 64 four-byte banks.
-//     * forward (two ds_read_b64_tr_b16 per lane): one instruction covers four consecutive rows k0 .. k0 + 3 (k0 a multiple of
-//       4) completely -- 4 x 64 B on four disjoint 16-bank ranges: conflict-free;
-//     * backward (two ds_read_b64 per lane, 32 lanes = 32 rows at one column offset): start banks 16 a + 2 b, a < 4, b < 8 --
-//       32 distinct even banks, 8 bytes each: conflict-free.
-//     (Rounds 2-4 used plain 72-byte rows, RM_LD = 36: conflict-free for the backward reads, but the four rows of a transposed
-//     read span 288 B and wrap onto their own first banks -- a 2-way conflict on every forward operand read, 84 extra LDS cycles
-//     per wave-sample of the tuned backward = ALL of its SQ_LDS_BANK_CONFLICT count, profiles/r04_pmc_summary.json.)
-__host__ __device__ constexpr int rm_off(int k, int m) { return k * 64 + (k >> 2) * 8 + m * 2; }
-__host__ __device__ constexpr int rm_bytes(int rows) { return rows * 64 + ((rows + 3) >> 2) * 8; }
+//     layer + p * limb_stride + rm_off(k_in, m_out).  Layout (round 5; rounds 2-4: plain 72-byte rows):
+//     * rows are 64 bytes (32 bf16); every group of four rows is skewed by a further 16 bytes: row k starts at byte
+//       64 k + 16 (k >> 2);
+//     * inside every 16-column chunk the four 4-column blocks are stored in the order 0, 2, 1, 3, so that the eight columns
+//       a backward lane needs -- 16c + 4h .. +3 and 16c + 8 + 4h .. +3 -- are 16 CONTIGUOUS bytes.
+//     forward (two ds_read_b64_tr_b16 per lane): one instruction covers four consecutive rows k0 .. k0 + 3 (k0 a multiple of 4)
+//       completely -- 4 x 64 B on four disjoint 16-bank ranges of the 64 four-byte banks: conflict-free (72-byte rows: the four
+//       rows span 288 B and wrap onto their own first banks, a 2-way conflict on EVERY forward operand read: 84 LDS cycles per
+//       wave-sample of the tuned backward, 336 of the 2/2/2 x 64 forward -- scripts/tr_b16_pmc.sh);
+//     backward: ONE ds_read_b128 per lane (was: two ds_read_b64, which the compiler fuses into a ds_read2_b64 -- 32 banks, 16-lane
+//       groups: with 64-byte rows those conflict); the four non-contiguous 16-lane groups of a ds_read_b128 each see start banks
+//       16 (k & 3) + 4 (k >> 2) that do not overlap (all four groups, both loaders: scripts/lds_bank_model.py; measured: profiles/r05_lds_bank_conflicts.txt).
+__host__ __device__ constexpr int rm_off(int k, int m) {
+  return k * 64 + (k >> 2) * 16 + ((m >> 4) * 16 + ((((m >> 2) & 1) << 1) | ((m >> 3) & 1)) * 4 + (m & 3)) * 2;
+}
+__host__ __device__ constexpr int rm_bytes(int rows) { return rows * 64 + ((rows + 3) >> 2) * 16; }
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 //     backward (dX) form: lane (k = l & 31, h) needs W[k][feat(8c + j, h)], j = 0..7 = columns 16c + 4h .. +3 and 16c + 8 + 4h .. +3
@@ -107,9 +112,8 @@ struct ARowsBwd {
   const char* layer;
   int limb_stride, row_mask;  // row_mask = rows - 1: lanes beyond a 16-row matrix re-read valid rows (their output rows are unused)
   LP_DEV u32x4_t operator()(int c, int limb, int lane) const {
-    const char* p = layer + limb * limb_stride + rm_off((lane & 31) & row_mask, 16 * c + 4 * (lane >> 5));
-    const u32x2_t a = *reinterpret_cast<const u32x2_t*>(p), b = *reinterpret_cast<const u32x2_t*>(p + 16);
-    return (u32x4_t){a.x, a.y, b.x, b.y};
+    // columns 16c + 4h .. +3 and 16c + 8 + 4h .. +3 = blocks h and 2 + h of the chunk = physical blocks 2h, 2h + 1: 16 bytes
+    return *reinterpret_cast<const u32x4_t*>(layer + limb * limb_stride + rm_off((lane & 31) & row_mask, 16 * c + 4 * (lane >> 5)));
   }
 };
 //     forward form: lane (m = l & 31, h) needs W[feat(8c + j, h)][m] = column m of rows 16c + 4h .. +3 and 16c + 8 + 4h .. +3:

@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Bank-conflict model of the LDS accesses of the bf16x3 kernels (no GPU): the rules of MI355X_MICROARCH.md's LDS section (lane
+groups per instruction, 64 or 32 four-byte banks) applied to the address patterns of lp_bf3.h / lp_renderer_mfma_bwd.hip, and the
+algebra of the row-major limb image layout (rm_off).  Prints the extra LDS cycles per wave instruction (0 = conflict-free).
+The model was checked against SQ_LDS_BANK_CONFLICT on isolated reads (scripts/tr_b16_pmc.sh): it predicts the 2 extra cycles of
+every ds_read_b64_tr_b16 on 72-byte rows and the 0 of the skewed 64-byte rows."""
+G128 = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+G128 = G128 + [[l + 32 for l in g] for g in G128]      # ds_read_b128: four non-contiguous 16-lane groups
+G64 = [list(range(32)), list(range(32, 64))]           # ds_read_b64 / ds_read_b64_tr_b16 / ds_write_b32: two halves
+G16 = [list(range(16 * i, 16 * i + 16)) for i in range(4)]  # ds_read2_b64 (per access), ds_write_b64: contiguous 16-lane groups
+
+
+def extra(groups, addr, width, nbanks=64):
+    tot = 0
+    for g in groups:
+        banks = {}
+        for l in g:
+            a = addr(l)
+            for d in range(width // 4):
+                dw = a // 4 + d
+                banks.setdefault(dw % nbanks, set()).add(dw)
+        tot += max(len(v) for v in banks.values()) - 1
+    return tot
+
+
+def rm_off(k, m):  # lp_bf3.h
+    return k * 64 + (k >> 2) * 16 + ((m >> 4) * 16 + ((((m >> 2) & 1) << 1) | ((m >> 3) & 1)) * 4 + (m & 3)) * 2
+
+
+def rm_off_r4(k, m):  # rounds 2-4: 72-byte rows
+    return (k * 36 + m) * 2
+
+
+if __name__ == "__main__":
+    for rows in (16, 32):  # a bijection onto rm_bytes(rows)
+        offs = {rm_off(k, m) for k in range(rows) for m in range(32)}
+        assert len(offs) == rows * 32 and max(offs) + 2 <= rows * 64 + ((rows + 3) >> 2) * 16
+    for k in range(32):
+        for c in (0, 1):
+            for h in (0, 1):  # the backward lane's eight columns are 16 contiguous, 16-byte aligned bytes
+                base = rm_off(k, 16 * c + 4 * h)
+                want = [16 * c + 4 * h + j for j in range(4)] + [16 * c + 8 + 4 * h + j for j in range(4)]
+                assert base % 16 == 0 and [rm_off(k, m) for m in want] == [base + 2 * i for i in range(8)]
+    for c in (0, 1):
+        for h in (0, 1):
+            for s in range(16):
+                for m0 in (0, 16):  # the forward supplier lane's four columns are 8 contiguous, 8-byte aligned bytes
+                    row, col = 16 * c + 4 * h + (s >> 2), m0 + 4 * (s & 3)
+                    base = rm_off(row, col)
+                    assert base % 8 == 0 and [rm_off(row, col + j) for j in range(4)] == [base + 2 * j for j in range(4)]
+                    assert rm_off(row + 8, col) - base == rm_off(8, 0)
+    print("layout algebra ok")
+    base = 1440
+    for c in (0, 1):
+        tr = lambda off: extra(G64, lambda l: base + off(16 * c + 4 * (l >> 5) + ((l & 15) >> 2), (l & 16) + 4 * (l & 3)), 8)
+        print(f"chunk {c}: forward ds_read_b64_tr_b16: round-5 layout {tr(rm_off)}, 72-byte rows {tr(rm_off_r4)}")
+        print(f"chunk {c}: backward ds_read_b128 (round 5) {extra(G128, lambda l: base + rm_off(l & 31, 16 * c + 4 * (l >> 5)), 16)}, "
+              f"16-row matrix {extra(G128, lambda l: base + rm_off((l & 31) & 15, 16 * c + 4 * (l >> 5)), 16)}; "
+              f"72-byte rows: two ds_read_b64 {extra(G64, lambda l: base + rm_off_r4(l & 31, 16 * c + 4 * (l >> 5)), 8)}, "
+              f"fused ds_read2_b64 {extra(G16, lambda l: base + rm_off_r4(l & 31, 16 * c + 4 * (l >> 5)), 8, 32)}")

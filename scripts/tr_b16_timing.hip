@@ -4,6 +4,7 @@
 //   pattern 1: rounds 2-4 layout, 72-byte rows: lane (s = l & 15, m0 = l & 16, h = l >> 5) -> row 4h + (s >> 2), column m0 + 4 (s & 3)
 //   pattern 2: round 5 layout, 64-byte rows + 8 bytes of skew per group of four rows
 //   pattern 3: lane l -> 8 l bytes (a dense 512-byte block)
+//   patterns 4-7: the BACKWARD loader's row reads (ARowsBwd: lane k reads 8 bytes of row k at one column offset) under four row layouts
 // standalone: hipcc --offload-arch=gfx950 -O3 scripts/tr_b16_timing.hip -o /tmp/trt
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -21,7 +22,11 @@ __global__ void k(unsigned long long* out, int pattern) {
   if (pattern == 0) off = 0;
   else if (pattern == 1) off = (row * 36 + col) * 2;
   else if (pattern == 2) off = row * 64 + (row >> 2) * 8 + col * 2;
-  else off = l * 8;
+  else if (pattern == 3) off = l * 8;
+  else if (pattern == 4) off = (l & 31) * 72 + 8 * (l >> 5);                          // backward row reads, 72-byte rows
+  else if (pattern == 5) off = (l & 31) * 64 + ((l & 31) >> 2) * 8 + 8 * (l >> 5);   // backward row reads, skewed 64-byte rows
+  else if (pattern == 6) off = (l & 31) * 80 + 8 * (l >> 5);                          // 80-byte rows
+  else off = (l & 31) * 64 + ((l & 31) >> 2) * 16 + 8 * (l >> 5);                     // 64-byte rows + 16 bytes of skew per four rows
   unsigned addr = (unsigned)(size_t)lds + off;
   unsigned long long acc = 0, v;
   unsigned long long t0, t1;
@@ -45,7 +50,7 @@ int main() {
   unsigned long long* d;
   CK(hipMalloc(&d, 65 * 8));
   for (int tr = 0; tr < 2; ++tr)
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < 8; ++p) {
       unsigned long long best = ~0ull;
       for (int rep = 0; rep < 5; ++rep) {
         if (tr) hipLaunchKernelGGL(k<true>, dim3(1), dim3(64), 0, 0, d, p);
