@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define LP_VERSION 204 /* 0.2.0: per-grid base pointers (zero-copy grid-lists), fused bg-colour / alpha epilogue,
+#define LP_VERSION 205 /* 0.2.0: per-grid base pointers (zero-copy grid-lists), fused bg-colour / alpha epilogue,
                            ray-embedding entry points; grad replicas removed
                            0.2.1: segment-parallel backward for small batches (LpRendererArgs.seg_prefix)
                            0.2.2: no struct change; lp_*_kernel_family() report family 3 (layer-looped MFMA kernels: Renderer
@@ -62,7 +62,10 @@ extern "C" {
                                   longer returns 2; lp_version() is NEGATIVE for a library built with -DLP_EXPERIMENTS
                            0.2.4: no struct change; lp_renderer_kernel_family() no longer returns 2 (2/2/2 x 64 decoders run the
                                   layer-looped family's two-block kernels and report 3); family 3 takes up to 256 beyond-far samples
-                                  and two-grid decoders of hidden width 64 (heads of at most 2 layers, 16 / 32 grid channels) */
+                                  and two-grid decoders of hidden width 64 (heads of at most 2 layers, 16 / 32 grid channels)
+                           0.2.5: no struct change; new test hook lp_renderer_backward_relu_dump(); the dX chains of the MFMA
+                                  backwards take the gradient operand as two bf16 limbs (-DLP_DX_LIMBS=3 restores
+                                  three) */
 
 #define LP_MAX_GRIDS 8   /* grids per grid-list                         */
 #define LP_MAX_LAYERS 8  /* layers per MLP                              */

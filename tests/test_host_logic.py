@@ -13,7 +13,7 @@ from lightplane_amd import _lib, grids, params
 
 def test_library_loads_and_exports_every_declared_symbol():
     L = _lib.lib()
-    assert L.lp_version() == 204
+    assert L.lp_version() == 205
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "lightplane_hip.h")).read()
     declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(lp_[a-z_0-9]+)\s*\(", hdr, flags=re.M))
     assert declared == set(_lib.EXPORTS), f"header vs binding mismatch: {declared ^ set(_lib.EXPORTS)}"
