@@ -230,18 +230,37 @@ LP_DEV f32x16 chunk_bf2(const A& a, int c, int lane, const u32x4_t& l1, const u3
   }
   return acc;
 }
+// `trow` (optional): this lane's row of a two-limb bf16 tile [ray][feature] in the rm_off layout (limb 2 at + rm_bytes(32)): the
+// limbs the chain forms anyway are published there for the weight-gradient products (limb_tile_store below) -- no extra VALU.
 template <int NCH, class A>
-LP_DEV f32x16 layer_bf2v(const A& a, int lane, const float (&v)[8 * NCH], f32x16 acc) {
+LP_DEV f32x16 layer_bf2v(const A& a, int lane, const float (&v)[8 * NCH], f32x16 acc, char* trow = nullptr) {
   u32x4_t l1, l2;
   split2_chunk(v, l1, l2);
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     u32x4_t n1 = l1, n2 = l2;
+    if (trow) {
+      *reinterpret_cast<u32x4_t*>(trow + 32 * c) = l1;
+      *reinterpret_cast<u32x4_t*>(trow + 32 * c + rm_bytes(32)) = l2;
+    }
     acc = chunk_bf2(a, c, lane, l1, l2, acc);
     if (c + 1 < NCH) split2_chunk(v + 8 * (c + 1), n1, n2);
     l1 = n1; l2 = n2;
   }
   return acc;
+}
+// Two-limb bf16 tile [ray][feature] of one wave (rm_off layout, limb 2 at + rm_bytes(32)): lane (h, r) owns ray r and, per chunk
+// c, the features 16c + 4h .. +3 and 16c + 8 + 4h .. +3 -- which the layout stores as 16 contiguous bytes (ONE ds_write_b128 per
+// limb and chunk).  trow = tile + rm_off(r, 4 h).
+template <int NCH>
+LP_DEV void limb_tile_store(char* trow, const float (&v)[8 * NCH]) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    u32x4_t l1, l2;
+    split2_chunk(v + 8 * c, l1, l2);
+    *reinterpret_cast<u32x4_t*>(trow + 32 * c) = l1;
+    *reinterpret_cast<u32x4_t*>(trow + 32 * c + rm_bytes(32)) = l2;
+  }
 }
 
 // the dX chains' operand split / chunk product with DXL = 2 or 3 limbs of the gradient operand (l3 unused with two)
@@ -260,8 +279,8 @@ LP_DEV f32x16 dx_chunk(const A& a, int c, int lane, const u32x4_t& l1, const u32
   else return chunk_bf3(a, c, lane, l1, l2, l3, acc);
 }
 template <int NCH, class A>
-LP_DEV f32x16 layer_dxv(const A& a, int lane, const float (&v)[8 * NCH], f32x16 acc) {
-  if constexpr (LP_DX_LIMBS == 2) return layer_bf2v<NCH>(a, lane, v, acc);
+LP_DEV f32x16 layer_dxv(const A& a, int lane, const float (&v)[8 * NCH], f32x16 acc, char* trow = nullptr) {
+  if constexpr (LP_DX_LIMBS == 2) return layer_bf2v<NCH>(a, lane, v, acc, trow);
   else return layer_bf3v<NCH>(a, lane, v, acc);
 }
 

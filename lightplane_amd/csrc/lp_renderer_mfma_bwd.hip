@@ -88,6 +88,65 @@ LP_DEV f32x4 dw_quadrant(const float* wave0, int a_off, int b_off, int v0, int v
   return acc;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradients on the bf16 pipe (round 5; default with LP_DX_LIMBS == 2, -DLP_DW_FP32 keeps the fp32 quadrants above).
+// The fp32 16x16x4 products are 32 cycles each that no VALU instruction overlaps (112 per wave-sample = 22 % of the SIMD's
+// time).  Here the dY operand comes from two-limb bf16 tiles [ray][feature] that the dX chain publishes for free (the limbs
+// it forms anyway: layer_bf2v's `trow`), the X operand from the fp32 feature-major tile of the fp32 scheme, split into two limbs
+// by the CONSUMING lane (24 VALU per source wave), and wave w accumulates its 16 x 16 quadrant with
+// v_mfma_f32_16x16x32_bf16: K = the 32 rays of one source wave, three limb products x1 y1, x2 y1, x1 y2 (dropped terms
+// ~2^-16 |x y|, random in sign, summed over 10^6..10^7 ray-samples per entry).  Operand layout: lane (m = l & 15, kq = l >> 4)
+// supplies the rays 8 kq .. 8 kq + 7 of one feature -- A: row pi16(m) of its quadrant of the fp32 tile (two ds_read_b128),
+// B: column 16 ni + m of the limb tiles (two ds_read_b64_tr_b16 of four consecutive tile rows each, conflict-free in the rm_off
+// layout); A and B use the same ray order.  Result: lane holds dW[16 mi + pi16(4 kq + i)][16 ni + m], i = 0..3.
+// The bias gradient (column sums of dY) used to be a by-product of the fp32 B operand.  Now: one more product per limb with a
+// ONE-HOT A operand (row `li` all ones, li = layer index 0..3): D[li][n] += sum_k dY[k][n], every other row += 0 -- the four
+// layers share ONE f32x4 accumulator (lanes 0..15 hold rows 0..3 = the four layers' bias gradients of column 16 ni + m).
+// Measured (profiles/r05_dw_bf16_ab.txt): cfg 2 backward 1.90 -> 1.85 ms, cfg 4 120.4 -> 113.2 ms.  The version with
+// PRODUCER-side X limbs (kept from the recompute's splits, no split instruction at all, statically 15 % fewer cycles) is
+// correct but needs ~40 more registers than the kernel has: 49 spilled, 2.07 / 158 ms (scripts/experiments/r05_dw_keep_limbs.patch).
+typedef __bf16 bf16x8_dw __attribute__((ext_vector_type(8)));
+#define LP_MFMA16B(a, b, c) \
+  __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_dw, (a)), __builtin_bit_cast(bf16x8_dw, (b)), (c), 0, 0, 0)
+constexpr int LT_LIMB = rm_bytes(32);  // bytes of one limb tile [32 rays][32 features]
+
+// eight rays (tile rows 8 kq .. 8 kq + 7) of one feature column: p = the supplier address of the first four rows
+LP_DEV u32x4_t limb_tile_operand(const char* p) {
+  typedef __attribute__((address_space(3))) s16x4_t* lds_ptr;
+  const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+  const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + (rm_off(4, 0) - rm_off(0, 0))));  // rows + 4
+  const u32x2_t ua = __builtin_bit_cast(u32x2_t, a), ub = __builtin_bit_cast(u32x2_t, b);
+  return (u32x4_t){ua.x, ua.y, ub.x, ub.y};
+}
+// a_off_bytes: byte offset of this lane's row of the fp32 X tile inside a wave area; y_off: its supplier address in the dY limb tile;
+// onehot: the A operand of the bias product
+template <int STRIDE_BYTES>
+LP_DEV f32x4 dw_quadrant_xf(const char* wave0b, int a_off_bytes, int y_off, int v0, int v1, f32x4 acc, f32x4& acc_db, unsigned onehot, bool do_db = true) {
+  const u32x4_t oh = {onehot, onehot, onehot, onehot};
+#pragma unroll 1
+  for (int v = v0; v < v1; ++v) {
+    const char* base = wave0b + v * STRIDE_BYTES;
+    const float4 x0v = *reinterpret_cast<const float4*>(base + a_off_bytes);
+    const float4 x1v = *reinterpret_cast<const float4*>(base + a_off_bytes + 16);
+    const u32x4_t b2 = limb_tile_operand(base + y_off + LT_LIMB);
+    const float xv[8] = {x0v.x, x0v.y, x0v.z, x0v.w, x1v.x, x1v.y, x1v.z, x1v.w};
+    u32x4_t a1, a2;
+    split2_chunk(xv, a1, a2);
+    if (do_db) acc_db = LP_MFMA16B(oh, b2, acc_db);
+    acc = LP_MFMA16B(a1, b2, acc);
+    const u32x4_t b1 = limb_tile_operand(base + y_off);
+    if (do_db) acc_db = LP_MFMA16B(oh, b1, acc_db);
+    acc = LP_MFMA16B(a1, b1, acc);
+    acc = LP_MFMA16B(a2, b1, acc);
+  }
+  return acc;
+}
+#if LP_DX_LIMBS == 2 && !defined(LP_DW_FP32)
+#define LP_DW_BF16 1
+#else
+#define LP_DW_BF16 0
+#endif
+
 // =======================================================================================
 // Backward of the default shape with the recompute and the dX chains as bf16x3 on the bf16 matrix cores (lp_bf3.h).
 //
@@ -225,6 +284,12 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
   const int m16 = lane & 15, ka = lane >> 4;
   const int a_off = B::XT + (16 * mi + pi16(m16)) * T_LD + 8 * ka;
   const int b_off = B::YT + (16 * ni + pi16(m16)) * T_LD + 8 * ka;
+  // bf16 dW (LP_DW_BF16): the dY limb tile [ray][feature] aliases the dY tile area; this lane publishes row r of its wave's
+  // tile, and as MFMA lane (m16, ka) it supplies rows 8 ka + (m16 >> 2), columns 16 ni + 4 (m16 & 3) .. +3 of a source wave's
+  char* const yrow = reinterpret_cast<char*>(wv) + B::YT * 4 + rm_off(r, 4 * h);
+  const int yq_off = B::YT * 4 + rm_off(8 * ka + (m16 >> 2), 4 * (m16 & 3)) + 32 * ni;   // (16 ni columns = 32 ni bytes)
+  f32x4 dq_b = {0, 0, 0, 0};  // bias gradients of the four hidden layers (rows 0 c1, 1 o1, 2 t2, 3 t1; lanes 0..15)
+  auto onehot = [&](int li) -> unsigned { return (lane & 15) == li ? 0x3F803F80u : 0u; };  // bf16 (1, 1) in the row of layer li
   // trunk layer 1 has only C input rows: with C == 16 its two quadrants (ni) are split over four ray groups instead
   const int a_off_t1 = (C == 16) ? B::XT + pi16(m16) * T_LD + 8 * ka : a_off;
   // (NW = 8: four ray groups of two source waves; NW = 4: two groups -- wave >> 1 -- of two source waves)
@@ -286,7 +351,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
 
     // ---------------- forward recompute (bf16x3) ----------------
     LP_MARK("fwd");
-    float h1[16], e[16];
+    float h1[16];
+    float e[16];
     unsigned ho_mask = 0, hc_mask = 0;
     Heads hd;
     {
@@ -296,10 +362,10 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
 #pragma unroll
         for (int q = 0; q < 16; ++q) h1[q] = relu_f(acc[q]);
       }
-      {
-        acc = layer_bf3v<2>(Af(I1{}), lane, h1, load_bias(sm, 1, h, zo));
+      acc = layer_bf3v<2>(Af(I1{}), lane, h1, load_bias(sm, 1, h, zo));
 #pragma unroll
-        for (int q = 0; q < 16; ++q) e[q] = relu_f(acc[q]);
+      for (int q = 0; q < 16; ++q) {
+        e[q] = relu_f(acc[q]);
       }
       float ho[16], hc[16];
       {
@@ -332,7 +398,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const unsigned bit = 1u << featq(q, h);
-          m1 |= (h1[q] > 0.0f) ? bit : 0u;   // the conditions the backward below applies
+          m1 |= (h1[q] > 0.0f) ? bit : 0u;
           m2 |= (e[q] > 0.0f) ? bit : 0u;
           mo |= ((ho_mask >> q) & 1u) ? bit : 0u;
           mc |= ((hc_mask >> q) & 1u) ? bit : 0u;
@@ -451,16 +517,25 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
 #endif
     f32x16 acc = (f32x16){0};
     {
+#if LP_DW_BF16
+      if (want_params) tile_store_fm(xt, r, h, e);
+      acc = layer_dxv<2>(Ab(I3{}), lane, dhc, acc, want_params ? yrow : nullptr);
+#else
       if (want_params) {
         tile_store_fm(xt, r, h, e);
         tile_store_fm(yt, r, h, dhc);
       }
       acc = layer_dxv<2>(Ab(I3{}), lane, dhc, acc);
+#endif
 #pragma unroll
       for (int q = 0; q < 16; ++q) dsum[q] += dhc[q];
       if (want_params) {
         lds_barrier();
+#if LP_DW_BF16
+        dq_c1 = dw_quadrant_xf<B::PER_WAVE * 4>(reinterpret_cast<const char*>(wave0), a_off * 4, yq_off, v0, v0 + 4, dq_c1, dq_b, onehot(0));
+#else
         dq_c1 = dw_quadrant<B::PER_WAVE>(wave0, a_off, b_off, v0, v0 + 4, dq_c1, db_c1);
+#endif
         lds_barrier();
       }
     }
@@ -477,11 +552,19 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
         dho[4 * j + 2] = mask_apply(ho_mask, 4 * j + 2, dro * wo.z);
         dho[4 * j + 3] = mask_apply(ho_mask, 4 * j + 3, dro * wo.w);
       }
+#if LP_DW_BF16
+      acc = layer_dxv<2>(Ab(I2{}), lane, dho, acc, want_params ? yrow : nullptr);  // the X tile still holds e
+#else
       if (want_params) tile_store_fm(yt, r, h, dho);  // the X tile still holds e
       acc = layer_dxv<2>(Ab(I2{}), lane, dho, acc);
+#endif
       if (want_params) {
         lds_barrier();
+#if LP_DW_BF16
+        dq_o1 = dw_quadrant_xf<B::PER_WAVE * 4>(reinterpret_cast<const char*>(wave0), a_off * 4, yq_off, v0, v0 + 4, dq_o1, dq_b, onehot(1));
+#else
         dq_o1 = dw_quadrant<B::PER_WAVE>(wave0, a_off, b_off, v0, v0 + 4, dq_o1, db_o1);
+#endif
         lds_barrier();
       }
     }
@@ -493,14 +576,23 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
     LP_MARK("t2");
     float dh1[16];
     {
+#if LP_DW_BF16
+      if (want_params) tile_store_fm(xt, r, h, h1);
+      acc = layer_dxv<2>(Ab(I1{}), lane, de, (f32x16){0}, want_params ? yrow : nullptr);
+#else
       if (want_params) {
         tile_store_fm(xt, r, h, h1);
         tile_store_fm(yt, r, h, de);
       }
       acc = layer_dxv<2>(Ab(I1{}), lane, de, (f32x16){0});
+#endif
       if (want_params) {
         lds_barrier();
+#if LP_DW_BF16
+        dq_t2 = dw_quadrant_xf<B::PER_WAVE * 4>(reinterpret_cast<const char*>(wave0), a_off * 4, yq_off, v0, v0 + 4, dq_t2, dq_b, onehot(2));
+#else
         dq_t2 = dw_quadrant<B::PER_WAVE>(wave0, a_off, b_off, v0, v0 + 4, dq_t2, db_t2);
+#endif
       }
 #pragma unroll
       for (int q = 0; q < 16; ++q) dh1[q] = (h1[q] > 0.0f) ? acc[q] : 0.0f;
@@ -510,6 +602,17 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
     // ---------------- trunk layer 1 ----------------
     LP_MARK("t1");
     {
+#if LP_DW_BF16
+      if (want_params) {
+#pragma unroll
+        for (int q = 0; q < C / 2; ++q) xt[featq(q, h) * T_LD + r] = x0[q];
+      }
+      if (gg) {
+        acc = layer_dxv<2>(Ab(I0{}), lane, dh1, (f32x16){0}, want_params ? yrow : nullptr);  // rows >= C of the result are unused
+      } else if (want_params) {
+        limb_tile_store<2>(yrow, dh1);
+      }
+#else
       if (want_params) {
 #pragma unroll
         for (int q = 0; q < C / 2; ++q) xt[featq(q, h) * T_LD + r] = x0[q];
@@ -518,9 +621,14 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
       if (gg) {
         acc = layer_dxv<2>(Ab(I0{}), lane, dh1, (f32x16){0});  // rows >= C of the result are unused
       }
+#endif
       if (want_params) {
         lds_barrier();
+#if LP_DW_BF16
+        dq_t1 = dw_quadrant_xf<B::PER_WAVE * 4>(reinterpret_cast<const char*>(wave0), a_off_t1 * 4, yq_off, t1_v0, t1_v1, dq_t1, dq_b, onehot(3));
+#else
         dq_t1 = dw_quadrant<B::PER_WAVE>(wave0, a_off_t1, b_off, t1_v0, t1_v1, dq_t1, db_t1);
+#endif
         lds_barrier();
       }
     }
@@ -584,11 +692,18 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
         for (int q = 0; q < 16; ++q) enc[q] = 0.0f;
       }
       __syncthreads();  // every wave is done with its tiles (the scatter of the last sample reads them)
+#if LP_DW_BF16
+      tile_store_fm(xt, r, h, enc);
+      limb_tile_store<2>(yrow, dsum);
+      lds_barrier();
+      dq_c1 = dw_quadrant_xf<B::PER_WAVE * 4>(reinterpret_cast<const char*>(wave0), a_off * 4, yq_off, v0, v0 + 4, dq_c1, dq_b, 0u, false);
+#else
       tile_store_fm(xt, r, h, enc);
       tile_store_fm(yt, r, h, dsum);
       float db_unused = 0.0f;
       lds_barrier();
       dq_c1 = dw_quadrant<B::PER_WAVE>(wave0, a_off, b_off, v0, v0 + 4, dq_c1, db_unused);  // the bias saw d hc already
+#endif
     }
     float* G = a.grad_mlp_params;
     const int j = lane & 31;
@@ -608,21 +723,28 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
       const float cv[4] = {c0, c1, c2, c3};
       for (int c = 0; c < a.color_chn; ++c) atomic_add_f32(G + mp.b_c2 + c, cv[c]);
     }
+#if LP_DW_BF16
+    const int col = 16 * ni + m16;   // 16x16x32 accumulator: column = lane & 15, rows 4 (lane >> 4) + i
+#else
     const int col = 16 * ni + pi16(m16);
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int prow = pi16(4 * ka + i);
-      const int row = 16 * mi + prow;
-      atomic_add_f32(G + mp.w_t2 + row * HID + col, dq_t2[i]);
-      atomic_add_f32(G + mp.w_o1 + row * HID + col, dq_o1[i]);
-      atomic_add_f32(G + mp.w_c1 + row * HID + col, dq_c1[i]);
-      const int row1 = (C == 16) ? prow : row;
+      const int prow = pi16(4 * ka + i);  // (the X rows are read from the fp32 tile through pi16, by the fp32 and the bf16 products alike)
+      atomic_add_f32(G + mp.w_t2 + (16 * mi + prow) * HID + col, dq_t2[i]);
+      atomic_add_f32(G + mp.w_o1 + (16 * mi + prow) * HID + col, dq_o1[i]);
+      atomic_add_f32(G + mp.w_c1 + (16 * mi + prow) * HID + col, dq_c1[i]);
+      const int row1 = (C == 16) ? prow : 16 * mi + prow;
       if (row1 < C) atomic_add_f32(G + mp.w_t1 + row1 * HID + col, dq_t1[i]);
     }
+#if LP_DW_BF16
+    db_c1 = dq_b[0]; db_o1 = dq_b[1]; db_t2 = dq_b[2]; db_t1 = dq_b[3];  // lanes 0..15 (ka == 0): rows 0..3 of the one-hot products
+#else
     db_t1 += __shfl_xor(db_t1, 16); db_t1 += __shfl_xor(db_t1, 32);
     db_t2 += __shfl_xor(db_t2, 16); db_t2 += __shfl_xor(db_t2, 32);
     db_o1 += __shfl_xor(db_o1, 16); db_o1 += __shfl_xor(db_o1, 32);
     db_c1 += __shfl_xor(db_c1, 16); db_c1 += __shfl_xor(db_c1, 32);
+#endif
     if (ka == 0) {
       if (mi == 0) {  // both quadrant rows of a ray group see the same dY columns: count them once per group
         atomic_add_f32(G + mp.b_t2 + col, db_t2);
