@@ -531,6 +531,10 @@ def counter_clock_ghz(v):
 def issue_bound(v, kname, dw_f32_mfma=None):
     """Issue cycles per SIMD of one launch from its instruction counts (see binding_ceiling)."""
     valu, mfma = v["SQ_INSTS_VALU"], v["SQ_INSTS_MFMA"]
+    if "renderer_bwd_bf3" in kname and kname.count(",") >= 6:
+        # the tuned backward since round 5 (seven template arguments: the instantiations with a DUMP twin): its weight-gradient
+        # products run on the bf16 pipe too (v_mfma_f32_16x16x32_bf16) -- no MFMA serialises with the VALU any more
+        return valu * 4.0 / N_SIMD
     if "bf3" in kname or "_loop" in kname:  # bf16x3 families: only the fp32 16x16x4 dW MFMAs serialise with the VALU
         f32 = min(dw_f32_mfma, mfma) if dw_f32_mfma else mfma * 112.0 / 202.0
         return (valu * 4.0 + f32 * 32.0) / N_SIMD
@@ -542,10 +546,10 @@ def binding_ceiling(workload, wl, fwd_ms, bwd_ms, observed=None):
     """The ceiling that actually binds the dominant kernel, next to the nominal HBM line (whose algorithmic bytes are served
     by the L2 and by run-merging in registers: fractions above 1 are possible there and say nothing about a hardware limit).
 
-    Renderer backward: INSTRUCTION ISSUE.  A SIMD issues one wave64 VALU instruction per 4 cycles, and the fp32
-    v_mfma_f32_16x16x4_f32 of the weight-gradient quadrants (32 cycles each) do not overlap with VALU work
-    (profiles/r02_mfma_valu_overlap.txt), while the bf16 32x32x16 MFMAs do.  bound = (VALU x 4 + fp32-MFMA x 32) cycles per
-    SIMD / clock; frac_issue = bound / measured time (1.0 = nothing but issue; the rest is waits: barriers, LDS, memory).
+    Renderer backward: INSTRUCTION ISSUE.  A SIMD issues one wave64 VALU instruction per 4 cycles, and fp32
+    v_mfma_f32_16x16x4_f32 (the weight-gradient quadrants of the looped family, and of the tuned family until round 4; 32 cycles
+    each) do not overlap with VALU work (profiles/r02_mfma_valu_overlap.txt), while the bf16 MFMAs do.  bound = (VALU x 4 +
+    fp32-MFMA x 32) cycles per SIMD / clock (tuned family since round 5: VALU x 4 -- every product is on the bf16 pipe); frac_issue = bound / measured time (1.0 = nothing but issue; the rest is waits: barriers, LDS, memory).
     The clock is the one the counters saw (SQ_BUSY_CYCLES / 32 SEs / duration), not the nominal 2.4 GHz.
     Splatter forward: ATOMIC SEGMENTS.  frac_segments = 64-byte atomic segments per launch (WRITE_SIZE / 64 B) / time / 21 G/s.
     Splatter backward walk: issue bound as above + the loads in flight its latency-bound gather sustains.

@@ -286,8 +286,12 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
   const int b_off = B::YT + (16 * ni + pi16(m16)) * T_LD + 8 * ka;
   // bf16 dW (LP_DW_BF16): the dY limb tile [ray][feature] aliases the dY tile area; this lane publishes row r of its wave's
   // tile, and as MFMA lane (m16, ka) it supplies rows 8 ka + (m16 >> 2), columns 16 ni + 4 (m16 & 3) .. +3 of a source wave's
-  char* const yrow = reinterpret_cast<char*>(wv) + B::YT * 4 + rm_off(r, 4 * h);
-  const int yq_off = B::YT * 4 + rm_off(8 * ka + (m16 >> 2), 4 * (m16 & 3)) + 32 * ni;   // (16 ni columns = 32 ni bytes)
+  // (ray k sits in tile row rho(k) = k with bits 1 and 3 swapped: the eight lanes of a ds_write_b128 group then write rows whose
+  // 16-byte pieces fall on eight different bank slots, and the transposed reads stay conflict-free -- scripts/lds_bank_model.py;
+  // with rows in ray order every limb-tile write was a 2-way conflict: 128 LDS cycles per wave-sample)
+  auto rho = [](int k) { return (k & 0x15) | ((k & 2) << 2) | ((k & 8) >> 2); };
+  char* const yrow = reinterpret_cast<char*>(wv) + B::YT * 4 + rm_off(rho(r), 4 * h);
+  const int yq_off = B::YT * 4 + rm_off(rho(8 * ka + (m16 >> 2)), 4 * (m16 & 3)) + 32 * ni;   // (16 ni columns = 32 ni bytes)
   f32x4 dq_b = {0, 0, 0, 0};  // bias gradients of the four hidden layers (rows 0 c1, 1 o1, 2 t2, 3 t1; lanes 0..15)
   auto onehot = [&](int li) -> unsigned { return (lane & 15) == li ? 0x3F803F80u : 0u; };  // bf16 (1, 1) in the row of layer li
   // trunk layer 1 has only C input rows: with C == 16 its two quadrants (ni) are split over four ray groups instead

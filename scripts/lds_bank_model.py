@@ -50,6 +50,15 @@ if __name__ == "__main__":
                     assert base % 8 == 0 and [rm_off(row, col + j) for j in range(4)] == [base + 2 * j for j in range(4)]
                     assert rm_off(row + 8, col) - base == rm_off(8, 0)
     print("layout algebra ok")
+    # dY limb tile of the bf16 weight-gradient products (lp_renderer_mfma_bwd.hip): lane (h, r) writes 16 bytes of row rho(r) per
+    # chunk (ds_write_b128: contiguous 8-lane groups, 32 banks); MFMA lane (m16, ka) supplies row rho(8 ka + (m16 >> 2)) [+ 4]
+    G8 = [list(range(8 * i, 8 * i + 8)) for i in range(8)]
+    rho = lambda k: (k & 0x15) | ((k & 2) << 2) | ((k & 8) >> 2)
+    ident = lambda k: k
+    for nm, f in (("rows in ray order", ident), ("rows rho(ray) (bits 1 <-> 3)", rho)):
+        w = [extra(G8, lambda l: rm_off(f(l & 31), 4 * (l >> 5)) + 32 * c, 16, 32) for c in (0, 1)]
+        t = [extra(G64, lambda l: rm_off(f(8 * (l >> 4) + ((l & 15) >> 2)), 4 * (l & 3)) + 32 * ni + 272 * add, 8, 64) for ni in (0, 1) for add in (0, 1)]
+        print(f"dY limb tile, {nm}: ds_write_b128 {w}, ds_read_b64_tr_b16 {t}")
     base = 1440
     for c in (0, 1):
         tr = lambda off: extra(G64, lambda l: base + off(16 * c + 4 * (l >> 5) + ((l & 15) >> 2), (l & 16) + 4 * (l & 3)), 8)
