@@ -252,12 +252,21 @@ LP_DEV f32x16 layer_bf2v(const A& a, int lane, const float (&v)[8 * NCH], f32x16
 // Two-limb bf16 tile [ray][feature] of one wave (rm_off layout, limb 2 at + rm_bytes(32)): lane (h, r) owns ray r and, per chunk
 // c, the features 16c + 4h .. +3 and 16c + 8 + 4h .. +3 -- which the layout stores as 16 contiguous bytes (ONE ds_write_b128 per
 // limb and chunk).  trow = tile + rm_off(r, 4 h).
+// (The values pass an empty asm: without it LLVM recognises that the forward products split the same activations a few hundred
+// instructions earlier, re-uses THOSE limbs and keeps ten 4-register tuples alive across the whole sample -- 49 spilled registers in
+// the tuned backward, 2.07 instead of 1.8 ms; splitting again costs 24 VALU instructions per chunk and no register.)
 template <int NCH>
 LP_DEV void limb_tile_store(char* trow, const float (&v)[8 * NCH]) {
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     u32x4_t l1, l2;
-    split2_chunk(v + 8 * c, l1, l2);
+    float w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      w[i] = v[8 * c + i];
+      asm volatile("" : "+v"(w[i]));
+    }
+    split2_chunk(w, l1, l2);
     *reinterpret_cast<u32x4_t*>(trow + 32 * c) = l1;
     *reinterpret_cast<u32x4_t*>(trow + 32 * c + rm_bytes(32)) = l2;
   }

@@ -91,20 +91,18 @@ LP_DEV f32x4 dw_quadrant(const float* wave0, int a_off, int b_off, int v0, int v
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradients on the bf16 pipe (round 5; default with LP_DX_LIMBS == 2, -DLP_DW_FP32 keeps the fp32 quadrants above).
 // The fp32 16x16x4 products are 32 cycles each that no VALU instruction overlaps (112 per wave-sample = 22 % of the SIMD's
-// time).  Here the dY operand comes from two-limb bf16 tiles [ray][feature] that the dX chain publishes for free (the limbs
-// it forms anyway: layer_bf2v's `trow`), the X operand from the fp32 feature-major tile of the fp32 scheme, split into two limbs
-// by the CONSUMING lane (24 VALU per source wave), and wave w accumulates its 16 x 16 quadrant with
-// v_mfma_f32_16x16x32_bf16: K = the 32 rays of one source wave, three limb products x1 y1, x2 y1, x1 y2 (dropped terms
-// ~2^-16 |x y|, random in sign, summed over 10^6..10^7 ray-samples per entry).  Operand layout: lane (m = l & 15, kq = l >> 4)
-// supplies the rays 8 kq .. 8 kq + 7 of one feature -- A: row pi16(m) of its quadrant of the fp32 tile (two ds_read_b128),
-// B: column 16 ni + m of the limb tiles (two ds_read_b64_tr_b16 of four consecutive tile rows each, conflict-free in the rm_off
-// layout); A and B use the same ray order.  Result: lane holds dW[16 mi + pi16(4 kq + i)][16 ni + m], i = 0..3.
+// time).  Here the PRODUCER lanes publish two-limb bf16 tiles [ray][feature] -- the dY limbs are the ones the dX chain forms
+// anyway (layer_bf2v's `trow`), the X limbs cost one two-limb split per activation (limb_tile_store, 24 VALU per chunk) -- and
+// wave w accumulates its 16 x 16 quadrant with v_mfma_f32_16x16x32_bf16: K = the 32 rays of one source wave, three limb
+// products x1 y1, x2 y1, x1 y2 (dropped terms ~2^-16 |x y|, random in sign, summed over 10^6..10^7 ray-samples per entry).
+// Operand layout: lane (m = l & 15, kq = l >> 4) supplies the rays 8 kq .. 8 kq + 7 of feature f0 + m: two
+// ds_read_b64_tr_b16 of four consecutive tile rows each; A and B use the same ray order by construction.  Tile rows: ray k sits
+// in row rho(k) (bits 1 and 3 of k swapped) of the rm_off layout: the ds_write_b128 of the producers and the transposed reads of
+// the consumers are both bank-conflict free (scripts/lds_bank_model.py).  Result: lane holds dW[16 mi + 4 kq + i][16 ni + m].
 // The bias gradient (column sums of dY) used to be a by-product of the fp32 B operand.  Now: one more product per limb with a
 // ONE-HOT A operand (row `li` all ones, li = layer index 0..3): D[li][n] += sum_k dY[k][n], every other row += 0 -- the four
 // layers share ONE f32x4 accumulator (lanes 0..15 hold rows 0..3 = the four layers' bias gradients of column 16 ni + m).
-// Measured (profiles/r05_dw_bf16_ab.txt): cfg 2 backward 1.90 -> 1.85 ms, cfg 4 120.4 -> 113.2 ms.  The version with
-// PRODUCER-side X limbs (kept from the recompute's splits, no split instruction at all, statically 15 % fewer cycles) is
-// correct but needs ~40 more registers than the kernel has: 49 spilled, 2.07 / 158 ms (scripts/experiments/r05_dw_keep_limbs.patch).
+// Measured: profiles/r05_dw_bf16_ab.txt.
 typedef __bf16 bf16x8_dw __attribute__((ext_vector_type(8)));
 #define LP_MFMA16B(a, b, c) \
   __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_dw, (a)), __builtin_bit_cast(bf16x8_dw, (b)), (c), 0, 0, 0)
@@ -118,25 +116,22 @@ LP_DEV u32x4_t limb_tile_operand(const char* p) {
   const u32x2_t ua = __builtin_bit_cast(u32x2_t, a), ub = __builtin_bit_cast(u32x2_t, b);
   return (u32x4_t){ua.x, ua.y, ub.x, ub.y};
 }
-// a_off_bytes: byte offset of this lane's row of the fp32 X tile inside a wave area; y_off: its supplier address in the dY limb tile;
-// onehot: the A operand of the bias product
+// x_off / y_off: byte offsets of this lane's supplier address inside a wave area (X / dY limb tile, limb 1); onehot: the A operand
+// of the bias product
 template <int STRIDE_BYTES>
-LP_DEV f32x4 dw_quadrant_xf(const char* wave0b, int a_off_bytes, int y_off, int v0, int v1, f32x4 acc, f32x4& acc_db, unsigned onehot, bool do_db = true) {
+LP_DEV f32x4 dw_quadrant_bf(const char* wave0b, int x_off, int y_off, int v0, int v1, f32x4 acc, f32x4& acc_db, unsigned onehot, bool do_db = true) {
   const u32x4_t oh = {onehot, onehot, onehot, onehot};
 #pragma unroll 1
   for (int v = v0; v < v1; ++v) {
     const char* base = wave0b + v * STRIDE_BYTES;
-    const float4 x0v = *reinterpret_cast<const float4*>(base + a_off_bytes);
-    const float4 x1v = *reinterpret_cast<const float4*>(base + a_off_bytes + 16);
     const u32x4_t b2 = limb_tile_operand(base + y_off + LT_LIMB);
-    const float xv[8] = {x0v.x, x0v.y, x0v.z, x0v.w, x1v.x, x1v.y, x1v.z, x1v.w};
-    u32x4_t a1, a2;
-    split2_chunk(xv, a1, a2);
-    if (do_db) acc_db = LP_MFMA16B(oh, b2, acc_db);
+    const u32x4_t a1 = limb_tile_operand(base + x_off);
+    if (do_db) acc_db = LP_MFMA16B(oh, b2, acc_db);  // (wave-uniform)
     acc = LP_MFMA16B(a1, b2, acc);
     const u32x4_t b1 = limb_tile_operand(base + y_off);
     if (do_db) acc_db = LP_MFMA16B(oh, b1, acc_db);
     acc = LP_MFMA16B(a1, b1, acc);
+    const u32x4_t a2 = limb_tile_operand(base + x_off + LT_LIMB);
     acc = LP_MFMA16B(a2, b1, acc);
   }
   return acc;
@@ -284,14 +279,14 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
   const int m16 = lane & 15, ka = lane >> 4;
   const int a_off = B::XT + (16 * mi + pi16(m16)) * T_LD + 8 * ka;
   const int b_off = B::YT + (16 * ni + pi16(m16)) * T_LD + 8 * ka;
-  // bf16 dW (LP_DW_BF16): the dY limb tile [ray][feature] aliases the dY tile area; this lane publishes row r of its wave's
-  // tile, and as MFMA lane (m16, ka) it supplies rows 8 ka + (m16 >> 2), columns 16 ni + 4 (m16 & 3) .. +3 of a source wave's
-  // (ray k sits in tile row rho(k) = k with bits 1 and 3 swapped: the eight lanes of a ds_write_b128 group then write rows whose
-  // 16-byte pieces fall on eight different bank slots, and the transposed reads stay conflict-free -- scripts/lds_bank_model.py;
-  // with rows in ray order every limb-tile write was a 2-way conflict: 128 LDS cycles per wave-sample)
+  // bf16 dW (LP_DW_BF16): the limb tiles [ray][feature] alias the X / dY tile areas; this lane publishes row rho(r) of its wave's
+  // tiles, and as MFMA lane (m16, ka) it supplies rows rho(8 ka + (m16 >> 2)) [+ 4], columns f0 + 4 (m16 & 3) .. +3 of a source wave's
+  // (rho: see dw_quadrant_bf -- with rows in ray order every limb-tile write was a 2-way bank conflict, 128 LDS cycles per sample)
   auto rho = [](int k) { return (k & 0x15) | ((k & 2) << 2) | ((k & 8) >> 2); };
-  char* const yrow = reinterpret_cast<char*>(wv) + B::YT * 4 + rm_off(rho(r), 4 * h);
-  const int yq_off = B::YT * 4 + rm_off(rho(8 * ka + (m16 >> 2)), 4 * (m16 & 3)) + 32 * ni;   // (16 ni columns = 32 ni bytes)
+  char* const xrow = reinterpret_cast<char*>(wv) + B::XT * 4 + rm_off(rho(r), 4 * h);
+  char* const yrow = xrow + (B::YT - B::XT) * 4;   // (a constant apart: folds into the store's offset field)
+  const int xq_off = B::XT * 4 + rm_off(rho(8 * ka + (m16 >> 2)), 4 * (m16 & 3)) + 32 * mi;   // (16 mi columns = 32 mi bytes)
+  const int yq_off = B::YT * 4 + rm_off(rho(8 * ka + (m16 >> 2)), 4 * (m16 & 3)) + 32 * ni;
   f32x4 dq_b = {0, 0, 0, 0};  // bias gradients of the four hidden layers (rows 0 c1, 1 o1, 2 t2, 3 t1; lanes 0..15)
   auto onehot = [&](int li) -> unsigned { return (lane & 15) == li ? 0x3F803F80u : 0u; };  // bf16 (1, 1) in the row of layer li
   // trunk layer 1 has only C input rows: with C == 16 its two quadrants (ni) are split over four ray groups instead
@@ -522,7 +517,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
     f32x16 acc = (f32x16){0};
     {
 #if LP_DW_BF16
-      if (want_params) tile_store_fm(xt, r, h, e);
+      if (want_params) limb_tile_store<2>(xrow, e);
       acc = layer_dxv<2>(Ab(I3{}), lane, dhc, acc, want_params ? yrow : nullptr);
 #else
       if (want_params) {
@@ -536,7 +531,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
       if (want_params) {
         lds_barrier();
 #if LP_DW_BF16
-        dq_c1 = dw_quadrant_xf<B::PER_WAVE * 4>(reinterpret_cast<const char*>(wave0), a_off * 4, yq_off, v0, v0 + 4, dq_c1, dq_b, onehot(0));
+        dq_c1 = dw_quadrant_bf<B::PER_WAVE * 4>(reinterpret_cast<const char*>(wave0), xq_off, yq_off, v0, v0 + 4, dq_c1, dq_b, onehot(0));
 #else
         dq_c1 = dw_quadrant<B::PER_WAVE>(wave0, a_off, b_off, v0, v0 + 4, dq_c1, db_c1);
 #endif
@@ -565,7 +560,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
       if (want_params) {
         lds_barrier();
 #if LP_DW_BF16
-        dq_o1 = dw_quadrant_xf<B::PER_WAVE * 4>(reinterpret_cast<const char*>(wave0), a_off * 4, yq_off, v0, v0 + 4, dq_o1, dq_b, onehot(1));
+        dq_o1 = dw_quadrant_bf<B::PER_WAVE * 4>(reinterpret_cast<const char*>(wave0), xq_off, yq_off, v0, v0 + 4, dq_o1, dq_b, onehot(1));
 #else
         dq_o1 = dw_quadrant<B::PER_WAVE>(wave0, a_off, b_off, v0, v0 + 4, dq_o1, db_o1);
 #endif
@@ -581,7 +576,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
     float dh1[16];
     {
 #if LP_DW_BF16
-      if (want_params) tile_store_fm(xt, r, h, h1);
+      if (want_params) limb_tile_store<2>(xrow, h1);
       acc = layer_dxv<2>(Ab(I1{}), lane, de, (f32x16){0}, want_params ? yrow : nullptr);
 #else
       if (want_params) {
@@ -593,7 +588,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
       if (want_params) {
         lds_barrier();
 #if LP_DW_BF16
-        dq_t2 = dw_quadrant_xf<B::PER_WAVE * 4>(reinterpret_cast<const char*>(wave0), a_off * 4, yq_off, v0, v0 + 4, dq_t2, dq_b, onehot(2));
+        dq_t2 = dw_quadrant_bf<B::PER_WAVE * 4>(reinterpret_cast<const char*>(wave0), xq_off, yq_off, v0, v0 + 4, dq_t2, dq_b, onehot(2));
 #else
         dq_t2 = dw_quadrant<B::PER_WAVE>(wave0, a_off, b_off, v0, v0 + 4, dq_t2, db_t2);
 #endif
@@ -607,10 +602,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
     LP_MARK("t1");
     {
 #if LP_DW_BF16
-      if (want_params) {
-#pragma unroll
-        for (int q = 0; q < C / 2; ++q) xt[featq(q, h) * T_LD + r] = x0[q];
-      }
+      if (want_params) limb_tile_store<C / 16>(xrow, x0);
       if (gg) {
         acc = layer_dxv<2>(Ab(I0{}), lane, dh1, (f32x16){0}, want_params ? yrow : nullptr);  // rows >= C of the result are unused
       } else if (want_params) {
@@ -629,7 +621,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
       if (want_params) {
         lds_barrier();
 #if LP_DW_BF16
-        dq_t1 = dw_quadrant_xf<B::PER_WAVE * 4>(reinterpret_cast<const char*>(wave0), a_off_t1 * 4, yq_off, t1_v0, t1_v1, dq_t1, dq_b, onehot(3));
+        dq_t1 = dw_quadrant_bf<B::PER_WAVE * 4>(reinterpret_cast<const char*>(wave0), (C == 16) ? xq_off - 32 * mi : xq_off, yq_off, t1_v0, t1_v1, dq_t1, dq_b, onehot(3));
 #else
         dq_t1 = dw_quadrant<B::PER_WAVE>(wave0, a_off_t1, b_off, t1_v0, t1_v1, dq_t1, db_t1);
 #endif
@@ -697,10 +689,10 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
       }
       __syncthreads();  // every wave is done with its tiles (the scatter of the last sample reads them)
 #if LP_DW_BF16
-      tile_store_fm(xt, r, h, enc);
+      limb_tile_store<2>(xrow, enc);
       limb_tile_store<2>(yrow, dsum);
       lds_barrier();
-      dq_c1 = dw_quadrant_xf<B::PER_WAVE * 4>(reinterpret_cast<const char*>(wave0), a_off * 4, yq_off, v0, v0 + 4, dq_c1, dq_b, 0u, false);
+      dq_c1 = dw_quadrant_bf<B::PER_WAVE * 4>(reinterpret_cast<const char*>(wave0), xq_off, yq_off, v0, v0 + 4, dq_c1, dq_b, 0u, false);
 #else
       tile_store_fm(xt, r, h, enc);
       tile_store_fm(yt, r, h, dsum);
@@ -734,7 +726,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
 #endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int prow = pi16(4 * ka + i);  // (the X rows are read from the fp32 tile through pi16, by the fp32 and the bf16 products alike)
+#if LP_DW_BF16
+      const int prow = 4 * ka + i;        // 16x16x32 accumulator: rows 4 (lane >> 4) + i
+#else
+      const int prow = pi16(4 * ka + i);  // fp32 quadrants: the X rows are read through pi16
+#endif
       atomic_add_f32(G + mp.w_t2 + (16 * mi + prow) * HID + col, dq_t2[i]);
       atomic_add_f32(G + mp.w_o1 + (16 * mi + prow) * HID + col, dq_o1[i]);
       atomic_add_f32(G + mp.w_c1 + (16 * mi + prow) * HID + col, dq_c1[i]);
