@@ -833,12 +833,12 @@ def relabel(roof):
 
 GRID_TILE_STAGING = {
     "built": False,
-    "why": ("north_star names LDS staging of grid tiles; measured instead of built.  cfg-2 backward: FETCH_SIZE 12 MB per launch against "
+    "why": ("north_star names LDS staging of grid tiles; measured instead of built.  cfg-2 backward: FETCH_SIZE ~10 MB per launch against "
             "12.9 GB of algorithmic gather bytes (the 786 KB grid is L1 / L2 resident; L2->fabric traffic is 0.06x the algorithmic bytes), "
-            "the gather phase is 3.5 k of 36.3 k cycles per wave-sample (profiles/r04_backward_phase_cycles.txt) while instruction issue "
-            "is 0.71-0.77 of the kernel time; a 128-ray workgroup's footprint on an edge-on plane spans 131 KB (more than the LDS left beside "
+            "the gather phase is 3.7 k of 31.9 k cycles per wave-sample (profiles/r05_backward_phase_cycles.txt) while VALU issue "
+            "is ~0.6 of the kernel time; a 128-ray workgroup's footprint on an edge-on plane spans 131 KB (more than the LDS left beside "
             "the weight images) and is camera dependent.  MLP weights ARE LDS staged (bf16x3 limb images)."),
-    "evidence": ["profiles/r04_pmc_summary.json", "profiles/r04_backward_phase_cycles.txt"],
+    "evidence": ["profiles/r05_pmc_summary.json", "profiles/r05_backward_phase_cycles.txt"],
 }
 
 
