@@ -34,8 +34,11 @@ FILE_FLAGS = {
     "lp_renderer_mfma_bwd.hip": os.environ.get("LP_BWD_FLAGS", "-mllvm -disable-machine-licm -mllvm -sink-insts-to-avoid-spills=1").split(),
     # the shallow two-waves-per-SIMD backward of the layer-looped family: the same two switches take it from 49 spilled
     # registers to none (they cost the deep one-wave instantiations of lp_renderer_loop.hip 1-2 %, so those keep the defaults)
-    "lp_renderer_loop_shallow.hip": os.environ.get("LP_LOOP_FLAGS", "-mllvm -disable-machine-licm -mllvm -sink-insts-to-avoid-spills=1").split(),
-    "lp_splatter_mlp_loop_shallow.hip": os.environ.get("LP_LOOP_FLAGS", "-mllvm -disable-machine-licm -mllvm -sink-insts-to-avoid-spills=1").split(),
+    # (-DLP_LOOP_DW_FP32: the two-waves-per-SIMD instantiations keep the fp32 weight-gradient quadrants -- with the bf16 ones of
+    # lp_loop.h the 32-channel shallow backwards spill 16-27 registers; the one-wave instantiations of lp_renderer_loop.hip /
+    # lp_splatter_mlp_loop.hip have the room)
+    "lp_renderer_loop_shallow.hip": os.environ.get("LP_LOOP_FLAGS", "-mllvm -disable-machine-licm -mllvm -sink-insts-to-avoid-spills=1").split() + ["-DLP_LOOP_DW_FP32"],
+    "lp_splatter_mlp_loop_shallow.hip": os.environ.get("LP_LOOP_FLAGS", "-mllvm -disable-machine-licm -mllvm -sink-insts-to-avoid-spills=1").split() + ["-DLP_LOOP_DW_FP32"],
 }
 
 

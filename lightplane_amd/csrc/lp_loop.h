@@ -196,6 +196,50 @@ LP_DEV f32x4l loop_dw_quadrant(const float* wave0, int stride, int a_off, int b_
   return acc;
 }
 
+// Weight gradients on the bf16 pipe (round 5, as in lp_renderer_mfma_bwd.hip: see the comment above dw_quadrant_bf there):
+// the producer lanes publish X and dY of a block pair as two-limb bf16 tiles [ray][feature] (rm_off layout, ray k in row
+// loop_rho(k), limb 2 at + rm_bytes(32)), the quadrant is three v_mfma_f32_16x16x32_bf16 per source wave; the bias gradient is
+// the row 0 of a one-hot product.  -DLP_LOOP_DW_FP32 keeps the fp32 quadrants.
+#ifndef LP_LOOP_DW_FP32
+#define LP_LOOP_DW_BF16 1
+#else
+#define LP_LOOP_DW_BF16 0
+#endif
+typedef __bf16 bf16x8_l __attribute__((ext_vector_type(8)));
+#define LP_MFMA16BL(a, b, c) \
+  __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_l, (a)), __builtin_bit_cast(bf16x8_l, (b)), (c), 0, 0, 0)
+LP_DEV constexpr int loop_rho(int k) { return (k & 0x15) | ((k & 2) << 2) | ((k & 8) >> 2); }
+// eight rays (tile rows loop_rho(8 kq + j), j = 0..7) of one feature column: p = the supplier address of the first four rows
+LP_DEV u32x4_t loop_limb_operand(const char* p) {
+  typedef __attribute__((address_space(3))) s16x4_t* lds_ptr;
+  const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+  const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + (rm_off(4, 0) - rm_off(0, 0))));  // rays + 4
+  const u32x2_t ua = __builtin_bit_cast(u32x2_t, a), ub = __builtin_bit_cast(u32x2_t, b);
+  return (u32x4_t){ua.x, ua.y, ub.x, ub.y};
+}
+// x_off / y_off: byte offsets of this lane's supplier address inside a wave area (X / dY limb tile, limb 1); db: += the column sum of
+// dY (valid in lanes 0..15: row 0 of the one-hot product; the other lanes add 0) when with_db
+LP_DEV f32x4l loop_dw_quadrant_bf(const char* wave0b, int stride_bytes, int x_off, int y_off, f32x4l acc, float& db, bool with_db, int lane) {
+  const unsigned one = (lane & 15) == 0 ? 0x3F803F80u : 0u;  // bf16 (1, 1) in row 0
+  const u32x4_t oh = {one, one, one, one};
+  f32x4l t = {0, 0, 0, 0};
+#pragma unroll 1
+  for (int v = 0; v < WAVES; ++v) {
+    const char* base = wave0b + v * stride_bytes;
+    const u32x4_t b2 = loop_limb_operand(base + y_off + rm_bytes(32));
+    const u32x4_t a1 = loop_limb_operand(base + x_off);
+    if (with_db) t = LP_MFMA16BL(oh, b2, t);  // (wave-uniform)
+    acc = LP_MFMA16BL(a1, b2, acc);
+    const u32x4_t b1 = loop_limb_operand(base + y_off);
+    if (with_db) t = LP_MFMA16BL(oh, b1, t);
+    acc = LP_MFMA16BL(a1, b1, acc);
+    const u32x4_t a2 = loop_limb_operand(base + x_off + rm_bytes(32));
+    acc = LP_MFMA16BL(a2, b1, acc);
+  }
+  db += t[0];
+  return acc;
+}
+
 // accumulators of one layer's weight gradient: this wave's quadrant of every block + its share of the bias gradient
 template <int NB>
 struct LoopDw {
@@ -221,10 +265,20 @@ LP_DEV void loop_layer_bwd(const char* lbase, const LoopLayer& L, int lane, floa
                            LoopDw<NB>& dw, f32x16 (&dx)[NB]) {
   const int h = lane >> 5, r = lane & 31;
   const int in_blocks = (L.rows_in + 31) >> 5;
+#if LP_LOOP_DW_BF16
+  // (a_off / b_off are BYTE offsets of the supplier addresses here, see the callers)
+  char* const xrow = reinterpret_cast<char*>(xt) + rm_off(loop_rho(r), 4 * h);
+  char* const yrow = reinterpret_cast<char*>(yt) + rm_off(loop_rho(r), 4 * h);
+  if (want_params) {
+    limb_tile_store<2>(xrow, x[0]);
+    limb_tile_store<2>(yrow, dy[0]);
+  }
+#else
   if (want_params) {
     loop_tile_store(xt, r, h, x[0]);
     loop_tile_store(yt, r, h, dy[0]);
   }
+#endif
   if (want_dx) loop_layer_dx<NB, DXL>(lbase, L, lane, dy, dx);
   if (want_params) {
 #pragma unroll
@@ -233,12 +287,22 @@ LP_DEV void loop_layer_bwd(const char* lbase, const LoopLayer& L, int lane, floa
       for (int ob = 0; ob < NB; ++ob) {
         if (ib < in_blocks && ob < L.ob) {  // workgroup-uniform
           if (ib + ob > 0) {
+#if LP_LOOP_DW_BF16
+            limb_tile_store<2>(xrow, x[ib]);
+            limb_tile_store<2>(yrow, dy[ob]);
+#else
             loop_tile_store(xt, r, h, x[ib]);
             loop_tile_store(yt, r, h, dy[ob]);
+#endif
           }
           lds_barrier_l();
           float db_unused = 0.0f;
+#if LP_LOOP_DW_BF16
+          dw.q[ib][ob] = loop_dw_quadrant_bf(reinterpret_cast<const char*>(wave0), stride * 4, a_off, b_off, dw.q[ib][ob],
+                                             ib == 0 ? dw.db[ob] : db_unused, ib == 0, lane);
+#else
           dw.q[ib][ob] = loop_dw_quadrant(wave0, stride, a_off, b_off, dw.q[ib][ob], ib == 0 ? dw.db[ob] : db_unused);
+#endif
           lds_barrier_l();
         }
       }
@@ -255,10 +319,18 @@ LP_DEV void loop_dw_flush(float* G, const LoopLayer& L, const LoopDw<NB>& dw, in
   for (int ib = 0; ib < NB; ++ib) {
 #pragma unroll
     for (int ob = 0; ob < NB; ++ob) {
+#if LP_LOOP_DW_BF16
+      const int col = 32 * ob + 16 * ni + m16;  // 16x16x32 accumulator: column = lane & 15, rows 4 (lane >> 4) + i
+#else
       const int col = 32 * ob + 16 * ni + pi16l(m16);
+#endif
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+#if LP_LOOP_DW_BF16
+        const int row = 32 * ib + 16 * mi + 4 * ka + i;
+#else
         const int row = 32 * ib + 16 * mi + pi16l(4 * ka + i);
+#endif
         if (row < L.rows_in && col < L.cols) atomic_add_f32(G + L.w + (int64_t)row * L.ld + col, dw.q[ib][ob][i]);
       }
     }
@@ -268,7 +340,11 @@ LP_DEV void loop_dw_flush(float* G, const LoopLayer& L, const LoopDw<NB>& dw, in
     float d = dw.db[ob];
     d += __shfl_xor(d, 16);
     d += __shfl_xor(d, 32);
+#if LP_LOOP_DW_BF16
+    const int col = 32 * ob + 16 * ni + m16;
+#else
     const int col = 32 * ob + 16 * ni + pi16l(m16);
+#endif
     if (ka == 0 && mi == 0 && col < L.cols) atomic_add_f32(G + L.b + col, d);
   }
 }

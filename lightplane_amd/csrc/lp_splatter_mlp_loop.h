@@ -274,8 +274,14 @@ __global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) splat_mlp_bwd_loop(const
   const bool mask = a.march.mask_out_of_bounds != 0;
   const int mi = wave >> 1, ni = wave & 1;
   const int m16 = lane & 15, ka = lane >> 4;
+#if LP_LOOP_DW_BF16
+  // byte offsets of this MFMA lane's supplier address in a source wave's X / dY limb tiles (lp_loop.h, loop_dw_quadrant_bf)
+  const int a_off = T::XT * 4 + rm_off(loop_rho(8 * ka + (m16 >> 2)), 4 * (m16 & 3)) + 32 * mi;
+  const int b_off = T::YT * 4 + rm_off(loop_rho(8 * ka + (m16 >> 2)), 4 * (m16 & 3)) + 32 * ni;
+#else
   const int a_off = T::XT + (16 * mi + pi16l(m16)) * LT_LD + 8 * ka;
   const int b_off = T::YT + (16 * ni + pi16l(m16)) * LT_LD + 8 * ka;
+#endif
   LoopDw<NB> dw[ML];
 #pragma unroll
   for (int l = 0; l < ML; ++l) loop_dw_zero<NB>(dw[l]);
