@@ -535,6 +535,13 @@ def issue_bound(v, kname, dw_f32_mfma=None):
         # the tuned backward since round 5 (seven template arguments: the instantiations with a DUMP twin): its weight-gradient
         # products run on the bf16 pipe too (v_mfma_f32_16x16x32_bf16) -- no MFMA serialises with the VALU any more
         return valu * 4.0 / N_SIMD
+    if "renderer_bwd_loop" in kname:
+        # layer-looped backward <C, NB, TG, MT, MH, WC, GM>: the two-waves-per-SIMD shallow instantiations (NB = 1, MT <= 2, MH <= 1, no
+        # wide colour) keep fp32 weight-gradient quadrants; every other (one-wave) instantiation has them on the bf16 pipe since round 5
+        m = re.search(r"<\s*(\d+),\s*(\d+),\s*(\w+),\s*(\d+),\s*(\d+),\s*(\w+)", kname)
+        shallow = bool(m) and int(m.group(2)) == 1 and int(m.group(4)) <= 2 and int(m.group(5)) <= 1 and m.group(6) == "false"
+        if m and not shallow:
+            return valu * 4.0 / N_SIMD
     if "bf3" in kname or "_loop" in kname:  # bf16x3 families: only the fp32 16x16x4 dW MFMAs serialise with the VALU
         f32 = min(dw_f32_mfma, mfma) if dw_f32_mfma else mfma * 112.0 / 202.0
         return (valu * 4.0 + f32 * 32.0) / N_SIMD
