@@ -686,3 +686,39 @@ def test_kernel_family_rejects_unknown_keywords():
     with pytest.raises(TypeError, match="num_sample"):
         lp.backward_segments(rays, grids, dec, num_samples=64, num_sample_inf=3)
     assert lp.backward_segments(rays, grids, dec, num_samples=64, gain=1.0) >= 1
+
+
+def test_limb_image_layout_matches_the_bank_model(tmp_path):
+    """scripts/lds_bank_model.py argues about LDS bank conflicts with a Python restatement of `rm_off` (lp_bf3.h: the layout of the
+    row-major limb images and of the limb tiles of the weight-gradient products).  The shipped header and the model must be the same
+    function: a host program compiled from the header prints rm_off for every (row, column); the model's algebra checks (bijection,
+    16 contiguous bytes per backward lane, 8 per forward supplier lane) then hold for the shipped layout."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "rm_off_dump.hip"
+    src.write_text('#include <cstdio>\n#include "lp_bf3.h"\nint main() {\n  for (int k = 0; k < 32; ++k)\n    for (int m = 0; m < 32; ++m) '
+                   'printf("%d %d %d\\n", k, m, lp::rm_off(k, m));\n  printf("bytes %d %d\\n", lp::rm_bytes(16), lp::rm_bytes(32));\n  return 0;\n}\n')
+    exe = tmp_path / "rm_off_dump"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-I", os.path.join(repo, "lightplane_amd", "csrc"), str(src), "-o", str(exe)],
+                   check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = subprocess.run([str(exe)], check=True, stdout=subprocess.PIPE, timeout=60).stdout.decode().split("\n")
+    sys.path.insert(0, os.path.join(repo, "scripts"))
+    import lds_bank_model as M
+    got = {}
+    for line in out:
+        p = line.split()
+        if len(p) == 3 and p[0] != "bytes":
+            got[(int(p[0]), int(p[1]))] = int(p[2])
+    assert len(got) == 32 * 32 and all(M.rm_off(k, m) == v for (k, m), v in got.items())
+    assert [l for l in out if l.startswith("bytes")] == [f"bytes {16 * 64 + 4 * 16} {32 * 64 + 8 * 16}"]
+    # and the model's verdicts for that layout: forward transposed reads and backward ds_read_b128 conflict-free
+    base = 1440
+    for c in (0, 1):
+        assert M.extra(M.G64, lambda l: base + M.rm_off(16 * c + 4 * (l >> 5) + ((l & 15) >> 2), (l & 16) + 4 * (l & 3)), 8) == 0
+        assert M.extra(M.G128, lambda l: base + M.rm_off(l & 31, 16 * c + 4 * (l >> 5)), 16) == 0
+        assert M.extra(M.G64, lambda l: base + M.rm_off_r4(16 * c + 4 * (l >> 5) + ((l & 15) >> 2), (l & 16) + 4 * (l & 3)), 8) == 2  # rounds 2-4
