@@ -61,11 +61,37 @@ N_SIMD = 256 * 4        # 256 CUs x 4 SIMDs
 N_SE = 32               # shader engines SQ_BUSY_CYCLES is summed over (8 XCDs x 4)
 LOAD_LATENCY_NS = 800.0 # HBM-miss gather latency used for the loads-in-flight estimate (MI355X_MICROARCH.md: ~0.7-0.9 us)
 ATOMIC_SEGMENTS_PER_S = 21e9  # 64-byte global_atomic_add_f32 segments the chip retires (scripts/atomics_probe2.hip)
-ARITHMETIC = ("forward products (outputs, the backward's decoder recompute and its ReLU decisions, operands of the weight gradients): "
-              "fp32-equivalent bf16x3 (three exact bf16 limbs per fp32 operand, six limb products, fp32 accumulation) on "
-              "v_mfma_f32_32x32x16_bf16; dX chains of the backward: gradient operand as two bf16 limbs (2^-17 per value, three limb "
-              "products; measured on the cfg-2 launch against fp64 with the kernel's ReLU decisions forced: worst gradient entry 1.0e-5 "
-              "vs 8.7e-6 with three limbs); weight-gradient products v_mfma_f32_16x16x4_f32; everything else fp32 VALU")
+def arithmetic_string(info=None):
+    """The record's `arithmetic` field, composed from lp_build_info() of the library that is LOADED (limb counts and matrix
+    instructions as compiled), never from a hand-written constant: the string cannot go stale against the kernels (round-5 review)."""
+    info = info or _lib.build_info()
+    t = info["tuned_bwd"]
+    dx = ("gradient operand of the dX chains as two bf16 limbs (2^-17 per value, three of nine limb products)" if t["dx_limbs"] == 2
+          else "dX chains three-limb (fp32-equivalent)")
+    if "bf16" in t["dw"]:
+        dw = ("weight gradients: two-limb bf16 operands on v_mfma_f32_16x16x32_bf16, three limb products (measured on the cfg-2 launch "
+              "against fp64 with the kernel's ReLU decisions forced: worst gradient entry 1.05e-5 vs 8.7e-6 with three limbs and fp32 "
+              "products, profiles/r05_dx_limbs_ab.txt, r05_dw_bf16_ab.txt)")
+    else:
+        dw = "weight gradients: fp32 operands on v_mfma_f32_16x16x4_f32"
+    return ("tuned family (the headline kernels): forward products -- outputs, the backward's decoder recompute and its ReLU decisions -- "
+            "fp32-equivalent bf16x3 (three exact bf16 limbs per fp32 operand, six limb products, fp32 accumulation) on "
+            f"v_mfma_f32_32x32x16_bf16; backward: {dx}; {dw}; everything else fp32 VALU.  LpRendererArgs.arithmetic = LP_ARITH_FP32 "
+            f"selects per call: {t['arith_fp32']} (the reference's arithmetic; `extras.renderer_cfg2_fp32_arithmetic`).  Other "
+            f"families: looped deep {info['loop_bwd_deep']['dw']} / shallow {info['loop_bwd_shallow']['dw']}")
+
+
+def build_record():
+    """What ran: the loaded library's own report (version, source hash, test hooks) and whether it was built from this tree."""
+    info = _lib.build_info()
+    return {"lib_version": info["version"], "src_hash": info["src_hash"], "built_from_this_tree": _lib.build_matches_tree(),
+            "test_hooks": info["test_hooks"], "tuned_bwd": info["tuned_bwd"], "per_file_flags": info["flags"]["per_file"]}
+
+
+ARITHMETIC = None  # filled by main() from the loaded library (arithmetic_string)
+STEP_PROTOCOL = ("forward + backward of the op with the upstream gradients handed to torch.autograd.backward (no loss kernels in the "
+                 "timed step; rounds 1-4 timed loss(...).backward(), i.e. + 6 elementwise / reduction kernels: `extras.headline_with_loss_"
+                 "kernels` times that protocol once)")
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -100,10 +126,10 @@ def camera_pose(name, rank):
 
 
 class RendererWorkload:
-    def __init__(self, name, rank, dev, pg, kernel):
+    def __init__(self, name, rank, dev, pg, kernel, arithmetic=_lib.LP_ARITH_DEFAULT, with_loss=False):
         from tests.synth import grid_sizes_for, pinhole_rays, random_decoder, random_grids
 
-        self.name, self.pg, self.kernel = name, pg, kernel
+        self.name, self.pg, self.kernel, self.arithmetic, self.with_loss = name, pg, kernel, arithmetic, with_loss
         H, W, S, C, G, self.desc = RENDER_CFGS[name]
         self.S, self.C = S, C
         gen = torch.Generator().manual_seed(0)
@@ -159,7 +185,8 @@ class RendererWorkload:
         if replicated:
             g, p = parallel.replicate_with_grad_allreduce([self.flat, self.params], self.pg)
         d = lp.DecoderParams(p, self.dec.n_hidden_trunk, self.dec.n_hidden_opacity, self.dec.n_hidden_color, COLOR)
-        return lp.lightplane_renderer(self.rays, g, d, num_samples=self.S, gain=1.0, grid_sizes=self.sizes, kernel=self.kernel)
+        return lp.lightplane_renderer(self.rays, g, d, num_samples=self.S, gain=1.0, grid_sizes=self.sizes, kernel=self.kernel,
+                                      arithmetic=self.arithmetic)
 
     def loss(self, out):
         return (out[0] * self.up[0]).sum() + (out[1] * self.up[1]).sum() + (out[2] * self.up[2]).sum()
@@ -169,7 +196,10 @@ class RendererWorkload:
         # the timed region: they are the harness's, not the hot path's)
         self.zero_grads()
         out = self.forward()
-        torch.autograd.backward(list(out[:3]), self.up)
+        if self.with_loss:  # the protocol of rounds 1-4 (and of the reference's benchmark): a scalar loss and its backward
+            self.loss(out).backward()
+        else:
+            torch.autograd.backward(list(out[:3]), self.up)
 
     roofline_kernel = "renderer backward"
 
@@ -428,12 +458,12 @@ class JointWorkload:
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": b, "frac_fwd_plus_bwd": round(ach / HBM_PEAK_GBS, 5)}
 
 
-def make_workload(name, rank, dev, pg, kernel):
+def make_workload(name, rank, dev, pg, kernel, **kw):
     if name == "cfg3":
         return SplatterWorkload(rank, dev, pg)
     if name == "cfg5":
         return JointWorkload(rank, int(os.environ.get("WORLD_SIZE", "1")), dev, pg, kernel)
-    return RendererWorkload(name, rank, dev, pg, kernel)
+    return RendererWorkload(name, rank, dev, pg, kernel, **kw)
 
 
 def event_times(wl, reps):
@@ -532,8 +562,13 @@ def issue_bound(v, kname, dw_f32_mfma=None):
     """Issue cycles per SIMD of one launch from its instruction counts (see binding_ceiling)."""
     valu, mfma = v["SQ_INSTS_VALU"], v["SQ_INSTS_MFMA"]
     if "renderer_bwd_bf3" in kname and kname.count(",") >= 6:
-        # the tuned backward since round 5 (seven template arguments: the instantiations with a DUMP twin): its weight-gradient
-        # products run on the bf16 pipe too (v_mfma_f32_16x16x32_bf16) -- no MFMA serialises with the VALU any more
+        # the tuned backward since round 5 (<C, GM, PLAIN, NC, NW, SEG, DUMP, F32>): its weight-gradient products run on the bf16 pipe
+        # too (v_mfma_f32_16x16x32_bf16) -- no MFMA serialises with the VALU any more -- unless it is an LP_ARITH_FP32 instantiation
+        # (last argument true: fp32 quadrants, v_mfma_f32_16x16x4_f32, 32 cycles each on top of the VALU)
+        args = [x.strip() for x in kname[kname.index("<") + 1: kname.rindex(">")].split(",")] if "<" in kname and ">" in kname else []
+        if len(args) >= 8 and args[7] == "true":
+            f32 = min(dw_f32_mfma, mfma) if dw_f32_mfma else mfma * 112.0 / 292.0
+            return (valu * 4.0 + f32 * 32.0) / N_SIMD
         return valu * 4.0 / N_SIMD
     if "renderer_bwd_loop" in kname:
         # layer-looped backward <C, NB, TG, MT, MH, WC, GM>: the two-waves-per-SIMD shallow instantiations (NB = 1, MT <= 2, MH <= 1, no
@@ -705,9 +740,10 @@ def cpu_baseline(wl):
 # ----------------------------------------------------------------------------------------------------------------
 
 
-def measure_extra(name, dev, kernel, reps):
-    """Short single-GPU measurement of another configuration (events only) for the `extras` block."""
-    wl = make_workload(name, 0, dev, None, kernel)
+def measure_extra(name, dev, kernel, reps, **kw):
+    """Short single-GPU measurement of another configuration (events only) for the `extras` block.  ``kw``: RendererWorkload
+    switches (arithmetic=LP_ARITH_FP32: the reference's arithmetic; with_loss=True: the step protocol of rounds 1-4)."""
+    wl = make_workload(name, 0, dev, None, kernel, **kw)
     for _ in range(2 if name in ("cfg4", "1080p_s128") else 10):
         wl.step()
     reps = max(reps, 5)
@@ -728,6 +764,21 @@ def measure_extra(name, dev, kernel, reps):
            "peak_bwd_mem_mb": round(peak_mb, 2), "roofline": roof}
     if isinstance(wl, RendererWorkload):
         out["mlp_fp32_frac_of_peak"] = round(wl.mlp_flops_fwdbwd() / ((fwd_ms + bwd_ms) * 1e-3) / FP32_PEAK, 5)
+    if kw.get("arithmetic"):
+        out["arithmetic"] = ("LP_ARITH_FP32 (LpRendererArgs.arithmetic, per call): " + _lib.build_info()["tuned_bwd"]["arith_fp32"] +
+                             " -- the reference's arithmetic (triton_src/shared/const.py:9 ALLOW_TF32 = False); same forward kernel")
+    if kw.get("with_loss"):  # wall time of whole steps: the loss kernels sit between the forward and the backward events
+        for _ in range(3):
+            wl.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = max(reps, 20)
+        for _ in range(n):
+            wl.step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        out.update(step_protocol="loss(out).backward() (rounds 1-4, reference tests/renderer_speed_benchmark.py:172-174)",
+                   ms_per_step=round(ms, 4), Mrays_per_s_fwd_bwd=round(wl.n_rays / ms / 1e3, 4))
     del wl
     torch.cuda.empty_cache()
     return out
@@ -864,6 +915,10 @@ def soft(fn, *a, **kw):
 
 
 EXTRAS = (  # key in `extras`, leg
+    # the headline workload in the reference's arithmetic (three-limb dX chains, fp32 dW products), selected per call
+    ("renderer_cfg2_fp32_arithmetic", lambda dev, k: measure_extra("cfg2", dev, k, 20, arithmetic=_lib.LP_ARITH_FP32)),
+    # ... and with the step protocol of rounds 1-4 (scalar loss + its backward inside the step), once, for comparison across rounds
+    ("headline_with_loss_kernels", lambda dev, k: measure_extra("cfg2", dev, k, 20, with_loss=True)),
     ("splatter_cfg3", lambda dev, k: measure_extra("cfg3", dev, k, 10)),
     ("renderer_1080p_s128", lambda dev, k: measure_extra("1080p_s128", dev, k, 5)),
     ("renderer_cfg4_shard", lambda dev, k: measure_extra("cfg4", dev, k, 5)),
@@ -933,6 +988,8 @@ def main():
     if world != args.gpus and rank == 0:  # the launcher's world size is what runs; say so instead of dying
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; running {world} rank(s)", file=sys.stderr, flush=True)
 
+    global ARITHMETIC
+    ARITHMETIC = arithmetic_string()
     lp.config.check_inputs = False  # the grid_idx range check is a host sync, not part of the op
     if args.workload.startswith("refbench"):  # the reference's own benchmark tables (single GPU, its protocol; no timed-step loop)
         assert world == 1, "refbench is a single-GPU table"
@@ -1023,7 +1080,7 @@ def main():
                        else f"Mrays/sec fwd+bwd ({args.workload}); peak bwd mem (MB)"),
             "value": round(value, 4), "unit": "Mrays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "arithmetic": ARITHMETIC, "data": "synthetic",
+            "dtype": "f32", "arithmetic": ARITHMETIC, "build": soft(build_record), "step_protocol": STEP_PROTOCOL, "data": "synthetic",
             "config": {"workload": wl.desc, "rays_per_gpu": wl.n_rays,
                        "parallelism": f"ray-shard dp{world}, grid replicated, "
                                       + ("un-normalised splat + weights all-reduced" if args.workload == "cfg3" else

@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define LP_VERSION 205 /* 0.2.0: per-grid base pointers (zero-copy grid-lists), fused bg-colour / alpha epilogue,
+#define LP_VERSION 206 /* 0.2.0: per-grid base pointers (zero-copy grid-lists), fused bg-colour / alpha epilogue,
                            ray-embedding entry points; grad replicas removed
                            0.2.1: segment-parallel backward for small batches (LpRendererArgs.seg_prefix)
                            0.2.2: no struct change; lp_*_kernel_family() report family 3 (layer-looped MFMA kernels: Renderer
@@ -65,7 +65,10 @@ extern "C" {
                                   and two-grid decoders of hidden width 64 (heads of at most 2 layers, 16 / 32 grid channels)
                            0.2.5: no struct change; new test hook lp_renderer_backward_relu_dump(); the dX chains of the MFMA
                                   backwards take the gradient operand as two bf16 limbs (-DLP_DX_LIMBS=3 restores
-                                  three) */
+                                  three)
+                           0.2.6: LpRendererArgs.arithmetic (LP_ARITH_FP32: every product of the backward fp32-equivalent, selectable
+                                  per call); lp_build_info(); lp_renderer_relu_dump_words() and dump twins for the layer-looped
+                                  family (the dump of family 1 keeps its five words per sample) */
 
 #define LP_MAX_GRIDS 8   /* grids per grid-list                         */
 #define LP_MAX_LAYERS 8  /* layers per MLP                              */
@@ -92,6 +95,18 @@ extern "C" {
 #define LP_KERNEL_AUTO 0    /* MFMA kernel when the shape allows it, else generic */
 #define LP_KERNEL_GENERIC 1 /* force the shape-generic VALU kernel               */
 #define LP_KERNEL_MFMA 2    /* force the MFMA kernel (LP_EUNSUPPORTED if n/a)    */
+
+/* arithmetic of the Renderer BACKWARD (LpRendererArgs.arithmetic).  The forward products -- the outputs, the backward's decoder
+ * recompute and its ReLU decisions -- are fp32-equivalent in every mode (bf16x3: three exact bf16 limbs per operand, six limb
+ * products, fp32 accumulation; the shape-generic kernels: plain fp32 FMAs).
+ *   LP_ARITH_DEFAULT  the gradient operand of the dX chains and both operands of the weight gradients as TWO bf16 limbs (16
+ *                     significand bits, three of nine limb products) where the kernel family does so -- lp_build_info() names the
+ *                     limb counts of the library at hand; results stay inside 1e-4 of the fp32 reference
+ *   LP_ARITH_FP32     the reference's arithmetic (triton_src/shared/const.py:9 ALLOW_TF32 = False): three limbs for every operand
+ *                     of the dX chains, weight gradients on v_mfma_f32_16x16x4_f32.  The tuned family (kernel family 1) has
+ *                     instantiations for it; every other shape runs the shape-generic fp32 kernels (family 0: slow, exact). */
+#define LP_ARITH_DEFAULT 0
+#define LP_ARITH_FP32 1
 
 typedef struct LpGrid {
   int32_t B, D, H, W;  /* batch and spatial extent                         */
@@ -208,6 +223,8 @@ typedef struct LpRendererArgs {
    * then differ from the single sweep by rounding (~1e-7 relative).
    * Pass the same pointer to forward and backward, and only when lp_renderer_backward_segments() > 1. */
   float* seg_prefix;
+  int32_t arithmetic;     /* LP_ARITH_* (backward only; the forward is fp32-equivalent in every mode) */
+  int32_t _pad;
 } LpRendererArgs;
 
 typedef struct LpSplatterArgs {
@@ -255,6 +272,11 @@ typedef struct LpRayEmbedArgs {
 } LpRayEmbedArgs;
 
 int lp_version(void); /* LP_VERSION; negative = built with -DLP_EXPERIMENTS (A/B timing switches), not a product build */
+/* What this binary was built from, as one JSON object (static storage): "version", "src_hash" (sha256 over csrc/ *.hip, *.h,
+ * build.py and this header, as lightplane_amd/csrc/build.py source_hash() computes it -- compare with the tree), "flags" (global
+ * + per-file compiler flags), and per kernel family the limb counts / matrix instructions its backward was compiled with
+ * ("tuned_bwd", "loop_bwd_deep", "loop_bwd_shallow", "mlp_splatter_bwd"), "test_hooks" (1 = the DUMP twins are in). */
+const char* lp_build_info(void);
 const char* lp_last_error(void);
 /* sizeof() of the ABI structs as compiled into the library, for binding self-checks:
  * which = 0 LpGrid, 1 LpGridList, 2 LpRays, 3 LpMarch, 4 LpMlp, 5 LpRendererArgs,
@@ -305,10 +327,19 @@ int lp_renderer_corner_rows(const LpRendererArgs* args, int64_t* rows, void* str
  * instruction sequence, stores added), which also writes the ReLU decisions of the backward's decoder recompute:
  * dump[(ray * S_tot + sample) * 5 + {0: trunk layer 1, 1: trunk layer 2 (the trunk output), 2: opacity hidden, 3: colour
  * hidden}] = bit f set when unit f is active, word 4 = 1 (sample contributed), 2 (visited, not contributing: beyond the ray's
- * last marched sample), 0 (never visited).  dump_words must be n_rays * S_tot * 5.  Only the tuned bf16x3 family (kernel
- * family 1, RGB, four-wave workgroups) has dump twins: LP_EUNSUPPORTED otherwise.  The tests force these decisions onto the
+ * last marched sample), 0 (never visited).  dump_words must be n_rays * S_tot * lp_renderer_relu_dump_words(args).  The tuned
+ * bf16x3 family (kernel family 1, RGB, four-wave workgroups) and the layer-looped family (3) have dump twins: LP_EUNSUPPORTED
+ * otherwise, and in a library built without -DLP_TEST_HOOKS (lp_build_info() "test_hooks": 0).  The tests force these decisions onto the
  * fp64 oracle and require every gradient entry within 1e-4 (tests/test_gpu_config_scale.py::test_flips_are_flips). */
 int lp_renderer_backward_relu_dump(const LpRendererArgs* args, uint32_t* dump, int64_t dump_words, void* stream);
+/* Words per (ray, sample) of that dump for these arguments (shapes only, no launch), or LP_EUNSUPPORTED:
+ *   family 1: 5 (above);
+ *   family 3 (layer-looped): NB * n_sites + 1, NB = 32-bit words per ReLU site (1 up to 32 units, 2 for hidden width 64 / 64 grid
+ *     channels), sites in the reference's evaluation order (naive_renderer.py:328-501) -- single grid-list: trunk layers 1 .. n_t,
+ *     opacity hidden layers, colour hidden layers; two-grid decoder: relu(sampled feature), opacity hidden layers, relu(sampled
+ *     colour feature), colour hidden layers -- word k * NB + b holds units 32 b .. 32 b + 31 of site k, the last word the
+ *     visited flag (1 / 2 / 0 as above). */
+int lp_renderer_relu_dump_words(const LpRendererArgs* args);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,7 @@ def n_nlt_ckpt(num_samples: int, num_samples_inf: int) -> int:
     return 2 * ((num_samples + c - 1) // c + num_samples_inf + 1)
 
 LP_KERNEL_AUTO, LP_KERNEL_GENERIC, LP_KERNEL_MFMA = 0, 1, 2
+LP_ARITH_DEFAULT, LP_ARITH_FP32 = 0, 1  # LpRendererArgs.arithmetic (include/lightplane_hip.h)
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)
@@ -75,7 +76,7 @@ class LpRendererArgs(C.Structure):
         ("grad_encoding", C.c_void_p),
         ("grad_grid_list", C.c_void_p * LP_MAX_GRIDS), ("grad_color_grid_list", C.c_void_p * LP_MAX_GRIDS),
         ("bg_color", C.c_void_p), ("alpha", C.c_void_p), ("grad_alpha", C.c_void_p), ("alpha_mode", C.c_int32),
-        ("stop_neg_log_t", C.c_float), ("seg_prefix", C.c_void_p),
+        ("stop_neg_log_t", C.c_float), ("seg_prefix", C.c_void_p), ("arithmetic", C.c_int32), ("_pad", C.c_int32),
     ]
 
 
@@ -107,7 +108,7 @@ EXPORTS = (
     "lp_version", "lp_last_error", "lp_abi_sizeof", "lp_renderer_forward", "lp_renderer_backward",
     "lp_splatter_forward", "lp_splatter_normalize", "lp_splatter_backward", "lp_hash_randn",
     "lp_renderer_corner_rows", "lp_renderer_kernel_family", "lp_splatter_kernel_family",
-    "lp_renderer_backward_segments", "lp_renderer_backward_relu_dump",
+    "lp_renderer_backward_segments", "lp_renderer_backward_relu_dump", "lp_renderer_relu_dump_words", "lp_build_info",
     "lp_ray_embedding_forward", "lp_ray_embedding_backward",
 )
 
@@ -148,6 +149,9 @@ def lib() -> C.CDLL:
     L.lp_renderer_corner_rows.argtypes = [C.POINTER(LpRendererArgs), C.c_void_p, C.c_void_p]
     L.lp_renderer_backward_relu_dump.restype = C.c_int
     L.lp_renderer_backward_relu_dump.argtypes = [C.POINTER(LpRendererArgs), C.c_void_p, C.c_int64, C.c_void_p]
+    L.lp_renderer_relu_dump_words.restype = C.c_int
+    L.lp_renderer_relu_dump_words.argtypes = [C.POINTER(LpRendererArgs)]
+    L.lp_build_info.restype = C.c_char_p
     L.lp_renderer_kernel_family.restype = C.c_int
     L.lp_renderer_kernel_family.argtypes = [C.POINTER(LpRendererArgs)]
     L.lp_renderer_backward_segments.restype = C.c_int
@@ -169,6 +173,24 @@ def lib() -> C.CDLL:
             )
     _LIB = L
     return L
+
+
+def build_info() -> dict:
+    """``lp_build_info()`` of the loaded library, parsed: version, ``src_hash`` (lightplane_amd/csrc/build.py ``source_hash()`` of the
+    sources it was compiled from), compiler flags, and the arithmetic every backward family was compiled with."""
+    import json
+    return json.loads(lib().lp_build_info().decode())
+
+
+def build_matches_tree() -> Optional[bool]:
+    """True / False: the loaded library was built from the csrc/ + header of this tree (``src_hash``); None when the sources are
+    not there to compare with (an installed binary)."""
+    try:
+        from .csrc import build as _b
+        want = _b.source_hash()
+    except Exception:
+        return None
+    return build_info().get("src_hash") == want
 
 
 def check(rc: int, what: str) -> None:

@@ -17,6 +17,10 @@
                        are one to two orders of magnitude slower than the MFMA / walk families.  Default on.
 ``stop_transmittance`` early ray termination of the Renderer (extension, see ``lightplane_renderer``): a wavefront stops
                        marching once every ray's transmittance is below this value.  0 (default) = off, exact.
+``arithmetic``         arithmetic of the Renderer backward (``LpRendererArgs.arithmetic``, include/lightplane_hip.h): 0 (default) =
+                       two-limb bf16 operands in the dX chains / weight gradients where the kernel family uses them (inside
+                       1e-4 of the fp32 reference), 1 = ``LP_ARITH_FP32``, the reference's arithmetic (three limbs, fp32
+                       weight-gradient products; shapes outside the tuned family then run the shape-generic fp32 kernels).
 """
 import os
 
@@ -27,3 +31,4 @@ segment_backward: bool = os.environ.get("LIGHTPLANE_AMD_SEGMENT_BACKWARD", "1") 
 segment_forward: bool = os.environ.get("LIGHTPLANE_AMD_SEGMENT_FORWARD", "1") != "0"
 warn_generic_kernel: bool = os.environ.get("LIGHTPLANE_AMD_WARN_GENERIC", "1") != "0"
 stop_transmittance: float = float(os.environ.get("LIGHTPLANE_AMD_STOP_TRANSMITTANCE", "0"))
+arithmetic: int = int(os.environ.get("LIGHTPLANE_AMD_ARITHMETIC", "0"))

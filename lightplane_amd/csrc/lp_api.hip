@@ -6,6 +6,13 @@
 
 #include "lp_host.h"
 #include "lp_mfma_common.h"
+#if __has_include("build/lp_build_gen.h")
+#include "build/lp_build_gen.h"  // written by build.py: LP_BUILD_SRC_HASH, LP_BUILD_FLAGS_JSON
+#endif
+#ifndef LP_BUILD_SRC_HASH
+#define LP_BUILD_SRC_HASH "unknown (not built by lightplane_amd/csrc/build.py)"
+#define LP_BUILD_FLAGS_JSON "null"
+#endif
 
 namespace lp {
 
@@ -122,6 +129,8 @@ static int check_renderer(const LpRendererArgs& a, bool backward) {
       return set_error(LP_EINVAL, "mlp_n_layers_trunk has to be 0 when use_separate_color_grid");
   }
   if (!(a.stop_neg_log_t >= 0.0f)) return set_error(LP_EINVAL, "stop_neg_log_t must be >= 0 (0 = no early termination)");
+  if (a.arithmetic != LP_ARITH_DEFAULT && a.arithmetic != LP_ARITH_FP32)
+    return set_error(LP_EINVAL, "arithmetic %d is neither LP_ARITH_DEFAULT nor LP_ARITH_FP32", a.arithmetic);
   if (backward && a.stop_neg_log_t > 0.0f && !a.neg_log_t_ckpt)
     return set_error(LP_ENULL, "early termination needs neg_log_t_ckpt in the backward (it records where the forward stopped)");
   if ((rc = check_mlp("trunk", a.trunk, true))) return rc;
@@ -217,6 +226,21 @@ int lp_version(void) { return LP_VERSION; }
 
 const char* lp_last_error(void) { return g_err; }
 
+const char* lp_build_info(void) {
+  static char info[4096];
+  static const bool once = [] {
+    snprintf(info, sizeof(info),
+             "{\"version\": %d, \"src_hash\": \"%s\", \"test_hooks\": %s, \"tuned_bwd\": %s, \"loop_bwd_deep\": %s, "
+             "\"loop_bwd_shallow\": %s, \"mlp_splatter_bwd\": %s, \"forward\": \"bf16x3 (three exact bf16 limbs per fp32 operand, six limb "
+             "products, fp32 accumulation) on v_mfma_f32_32x32x16_bf16; generic kernels: fp32 FMA\", \"flags\": %s}",
+             lp_version(), LP_BUILD_SRC_HASH, build_info_tuned_bwd_aux(), build_info_tuned_bwd(), build_info_loop_deep(),
+             build_info_loop_shallow(), build_info_splatter_mlp(), LP_BUILD_FLAGS_JSON);
+    return true;
+  }();
+  (void)once;
+  return info;
+}
+
 int lp_abi_sizeof(int which) {
   switch (which) {
     case 0: return (int)sizeof(LpGrid);
@@ -236,9 +260,15 @@ int lp_abi_sizeof(int which) {
 // two-block looped kernels with the eight-wave forward measure 1-2 % faster forward + backward and 25-29 % faster forward on it --
 // profiles/r04_h64_looped_vs_wide.txt.)  LP_LOOP=1 (developer knob, read once): the layer-looped family also for the shape family 1
 // covers (A/B, test coverage).
+// LP_ARITH_FP32 (LpRendererArgs.arithmetic): the tuned family where it has such instantiations, the generic fp32 kernels otherwise.
 static int select_renderer(const LpRendererArgs& a, const char** why) {
   const char* w32 = "";
   const char* wl = "";
+  if (a.arithmetic == LP_ARITH_FP32) {
+    if (renderer_mfma_f32_supported(a)) return 1;
+    *why = "LP_ARITH_FP32 outside the tuned family's four-wave instantiations: shape-generic fp32 kernels";
+    return 0;
+  }
   static const bool force_loop = getenv("LP_LOOP") != nullptr && atoi(getenv("LP_LOOP")) != 0;
   const bool loop_ok = renderer_loop_supported(a, &wl) && renderer_loop_fits(a);
   if (force_loop && loop_ok) return 3;
@@ -332,16 +362,28 @@ int lp_renderer_corner_rows(const LpRendererArgs* args, int64_t* rows, void* str
   return renderer_corner_rows_launch(*args, rows, (hipStream_t)stream);
 }
 
+int lp_renderer_relu_dump_words(const LpRendererArgs* args) {
+  if (!args) return set_error(LP_ENULL, "args is NULL");
+  const char* why = "";
+  const int fam = args->kernel == LP_KERNEL_GENERIC ? 0 : select_renderer(*args, &why);
+  if (args->arithmetic != LP_ARITH_DEFAULT) return set_error(LP_EUNSUPPORTED, "relu dump: the LP_ARITH_FP32 instantiations have no dump twin");
+  if (fam == 1) {
+    if (args->march.num_samples_inf > 64) return set_error(LP_EUNSUPPORTED, "relu dump: the tuned family's eight-wave workgroups (> 64 beyond-far samples) have no dump twin");
+    return 5;
+  }
+  if (fam == 3) return renderer_loop_dump_words(*args);
+  return set_error(LP_EUNSUPPORTED, "relu dump: the shape-generic kernels have no dump twin");
+}
+
 int lp_renderer_backward_relu_dump(const LpRendererArgs* args, uint32_t* dump, int64_t dump_words, void* stream) {
   if (!args || !dump) return set_error(LP_ENULL, "args / dump is NULL");
-  const int64_t want = args->rays.n_rays * (int64_t)(args->march.num_samples + args->march.num_samples_inf) * 5;
-  if (dump_words != want) return set_error(LP_EINVAL, "relu dump: %lld words given, [n_rays][S_tot][5] = %lld needed", (long long)dump_words, (long long)want);
   LpRendererArgs a;
   int rc = normalized_renderer_args(args, true, a);
   if (rc) return rc;
-  const char* why = "";
-  if (a.kernel == LP_KERNEL_GENERIC || select_renderer(a, &why) != 1)
-    return set_error(LP_EUNSUPPORTED, "relu dump: only the tuned bf16x3 family (kernel family 1) has dump twins");
+  const int w = lp_renderer_relu_dump_words(&a);
+  if (w < 0) return w;
+  const int64_t want = args->rays.n_rays * (int64_t)(args->march.num_samples + args->march.num_samples_inf) * w;
+  if (dump_words != want) return set_error(LP_EINVAL, "relu dump: %lld words given, [n_rays][S_tot][%d] = %lld needed", (long long)dump_words, w, (long long)want);
   g_relu_dump = dump;
   rc = lp_renderer_backward(args, stream);
   g_relu_dump = nullptr;

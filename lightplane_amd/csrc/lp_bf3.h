@@ -204,7 +204,11 @@ LP_DEV f32x16 layer_bf3v(const A& a, int lane, const float (&v)[8 * NCH], f32x16
 // (tests/test_gpu_config_scale.py::test_flips_are_flips, every gradient entry of the cfg-2 launch against fp64): worst error
 // 1.04e-5 with two limbs, 8.7e-6 with three -- the per-product error averages out over the 10^2 .. 10^4 ray-samples every
 // gradient entry sums, the fp32 atomics' summation order dominates either way.  The FORWARD products (the outputs, the
-// backward's recompute with its ReLU decisions, the operands of the weight gradients) stay three-limb = fp32-equivalent.
+// backward's recompute with its ReLU decisions) stay three-limb = fp32-equivalent.  The WEIGHT gradients of the tuned family and of
+// the one-wave looped kernels take two limbs per operand as well (dw_quadrant_bf, lp_renderer_mfma_bwd.h: v_mfma_f32_16x16x32_bf16,
+// three limb products; measured on the same launch: 1.05e-5, profiles/r05_dw_bf16_ab.txt); the two-waves-per-SIMD shallow looped
+// kernels keep fp32 quadrants (v_mfma_f32_16x16x4_f32).  LpRendererArgs.arithmetic = LP_ARITH_FP32 selects, per call, instantiations
+// with three limbs in the dX chains and fp32 quadrants (the reference's arithmetic); lp_build_info() reports what was compiled.
 #ifndef LP_DX_LIMBS
 #define LP_DX_LIMBS 2
 #endif
@@ -287,9 +291,9 @@ LP_DEV f32x16 dx_chunk(const A& a, int c, int lane, const u32x4_t& l1, const u32
   if constexpr (DXL == 2) return chunk_bf2(a, c, lane, l1, l2, acc);
   else return chunk_bf3(a, c, lane, l1, l2, l3, acc);
 }
-template <int NCH, class A>
+template <int NCH, int DXL = LP_DX_LIMBS, class A>
 LP_DEV f32x16 layer_dxv(const A& a, int lane, const float (&v)[8 * NCH], f32x16 acc, char* trow = nullptr) {
-  if constexpr (LP_DX_LIMBS == 2) return layer_bf2v<NCH>(a, lane, v, acc, trow);
+  if constexpr (DXL == 2) return layer_bf2v<NCH>(a, lane, v, acc, trow);
   else return layer_bf3v<NCH>(a, lane, v, acc);
 }
 

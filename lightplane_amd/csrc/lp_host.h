@@ -25,6 +25,7 @@ bool renderer_mfma_supported(const LpRendererArgs& a, const char** why);
 int renderer_forward_mfma(const LpRendererArgs& a, hipStream_t stream);
 int renderer_backward_mfma(const LpRendererArgs& a, hipStream_t stream);
 int renderer_mfma_segments(const LpRendererArgs& a);  // segments of the segment-parallel backward (1 = none)
+bool renderer_mfma_f32_supported(const LpRendererArgs& a);  // the tuned family has an LP_ARITH_FP32 instantiation for these arguments
 int renderer_forward_combine_launch(const LpRendererArgs& a, int seg_blocks, hipStream_t stream);  // chains the segments of a segmented forward
 
 // layer-looped bf16x3 MFMA family (1-4 layers per MLP, hidden 16 / 32 / 64): lp_renderer_loop.hip
@@ -33,6 +34,13 @@ bool renderer_loop_fits(const LpRendererArgs& a);  // its weight images + tiles 
 int renderer_loop_segments(const LpRendererArgs& a);  // segments of the segment-parallel march (1 = none)
 int renderer_forward_loop(const LpRendererArgs& a, hipStream_t stream);
 int renderer_backward_loop(const LpRendererArgs& a, hipStream_t stream);
+int renderer_loop_dump_words(const LpRendererArgs& a);  // words per (ray, sample) of the ReLU dump
+// per-translation-unit arithmetic reports for lp_build_info() (JSON fragments, static storage)
+const char* build_info_tuned_bwd();
+const char* build_info_tuned_bwd_aux();
+const char* build_info_loop_deep();
+const char* build_info_loop_shallow();
+const char* build_info_splatter_mlp();
 
 // splatter: lp_splatter.hip
 int splatter_forward_launch(const LpSplatterArgs& a, hipStream_t stream);

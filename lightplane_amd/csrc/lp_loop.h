@@ -256,6 +256,14 @@ LP_DEV void loop_dw_zero(LoopDw<NB>& d) {
   }
 }
 
+// The two functions below have a body per dW mode (LP_LOOP_DW_FP32 is a per-translation-unit flag of build.py): an inline
+// namespace per mode gives them distinct symbols, so the shallow (fp32 quadrants) and the deep (bf16 quadrants) translation units
+// never hold two definitions of one name.  (The library is built with -fno-gpu-rdc: device code is per translation unit.)
+#if LP_LOOP_DW_BF16
+inline namespace dw_bf16 {
+#else
+inline namespace dw_fp32 {
+#endif
 // Backward of one layer: dW (workgroup-shared quadrants) and dX.  x = the layer's input activation, dy = upstream gradient
 // (already masked by the layer's own ReLU).  Publishes the X / dY tiles of one block pair, runs the dX chain while the LDS
 // writes land, then barrier -> quadrant -> barrier per block pair.
@@ -348,6 +356,8 @@ LP_DEV void loop_dw_flush(float* G, const LoopLayer& L, const LoopDw<NB>& dw, in
     if (ka == 0 && mi == 0 && col < L.cols) atomic_add_f32(G + L.b + col, d);
   }
 }
+
+}  // inline namespace dw_bf16 / dw_fp32
 
 template <int NB>
 LP_DEV void loop_copy(const float (&src)[NB][16], float (&dst)[NB][16]) {

@@ -40,6 +40,10 @@ struct LoopParams {
   // segment-parallel march of a small batch (LpRendererArgs.seg_prefix): LP_SEG_LEN-sample blocks per workgroup;
   // seg_fwd: this forward launch marches segments (segment-local state records, chained by renderer_fwd_combine)
   int seg_blocks, seg_fwd;
+  // test hook (lp_renderer_backward_relu_dump): ReLU decisions of the backward's recompute, [ray][sample][dump_words] words -- NB words
+  // per ReLU site in the reference's evaluation order, then the visited flag (include/lightplane_hip.h).  Only the DUMP twins read it.
+  uint32_t* relu_dump;
+  int dump_words;
 };
 
 // per-wave LDS area behind the images (floats)
@@ -321,7 +325,10 @@ __global__ void __launch_bounds__(64 * NW, 2) renderer_fwd_loop(const LpRenderer
 // ---------------------------------------------------------------------------------------------------------------
 // MT / MH: the trunk layers / hidden head layers this instantiation holds registers for (the kernel's loops are unrolled to
 // them; NB = 2 is instantiated for the 2 / 2 / 2 shape only: 64-wide activations are 32 registers each)
-template <int C, int NB, bool TG, int MT, int MH, bool WC = false, int GM = GM_GENERIC>
+// DUMP (test hook, its own instantiations in lp_renderer_loop_dump.hip / lp_renderer_loop_shallow_dump.hip, built with the flags of
+// their production twins): the ReLU decisions of the recompute are also written to lp.relu_dump -- same instruction sequence, stores
+// added.
+template <int C, int NB, bool TG, int MT, int MH, bool WC = false, int GM = GM_GENERIC, bool DUMP = false>
 __global__ void __launch_bounds__(256, (NB == 1 && MT <= 2 && MH <= 1 && !WC) ? 2 : 1) renderer_bwd_loop(const LpRendererArgs a, const LoopParams lp) {
   using T = LoopTile;
   // gradient operand of the dX chains: two limbs (lp_bf3.h) where the chain is short -- at most two trunk layers and one hidden
@@ -533,6 +540,43 @@ __global__ void __launch_bounds__(256, (NB == 1 && MT <= 2 && MH <= 1 && !WC) ? 
       raw = hd.raw_o;
 #pragma unroll
       for (int c = 0; c < 4; ++c) raw_c[c] = hd.raw_c[c];
+    }
+    if constexpr (DUMP) {
+      // sites in the reference's evaluation order (naive_renderer.py:328-501): single grid-list: trunk layers, opacity hidden
+      // layers, colour hidden layers; two-grid decoder: relu(feature), opacity hidden layers, relu(colour feature), colour hidden
+      // layers.  A post-ReLU activation is > 0 exactly where the unit is active -- the test every mask of this backward applies.
+      uint32_t* const dsite = lp.relu_dump + (rid * (int64_t)s_tot + s) * lp.dump_words;
+      int k = 0;
+      auto put = [&](const float (&v)[NB][16]) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          unsigned m = 0;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) m |= (v[b][q] > 0.0f) ? (1u << featq(q, h)) : 0u;
+          m |= __shfl_xor(m, 32);
+          if (valid && h == 0) dsite[k * NB + b] = m;
+        }
+        ++k;
+      };
+      if (TG) put(xin);
+#pragma unroll
+      for (int l = 0; l < MT; ++l) {
+        if (!TG && l < lp.n_t) put(tA[l]);
+      }
+#pragma unroll
+      for (int l = 0; l < MH; ++l) {
+        if (l < lp.n_o) put(oA[l]);
+      }
+      if (TG) {
+        float xcp[NB][16];
+        loop_pad_input<C, NB, true>(xc, xcp);
+        put(xcp);
+      }
+#pragma unroll
+      for (int l = 0; l < MH; ++l) {
+        if (l < lp.n_c) put(cA[l]);
+      }
+      if (valid && h == 0) dsite[k * NB] = on ? 1u : 2u;
     }
     LP_SCHED_FENCE();
 
@@ -922,23 +966,68 @@ static int launch_fwd_loop(const LpRendererArgs& a, const LoopParams& p, unsigne
   return LP_OK;
 }
 
-template <int C, int NB, bool TG, int MT, int MH, bool WC>
+template <int C, int NB, bool TG, int MT, int MH, bool WC, bool DUMP = false>
 static int launch_bwd_loop(const LpRendererArgs& a, const LoopParams& p, unsigned nb, size_t lds, bool tri, hipStream_t stream) {
   int rc;
   if constexpr (!TG && C <= 32) {
     if (tri) {
-      if ((rc = loop_set_lds(renderer_bwd_loop<C, NB, TG, MT, MH, WC, GM_TRIPLANE>, lds))) return rc;
-      hipLaunchKernelGGL((renderer_bwd_loop<C, NB, TG, MT, MH, WC, GM_TRIPLANE>), dim3(nb), dim3(256), lds, stream, a, p);
+      if ((rc = loop_set_lds(renderer_bwd_loop<C, NB, TG, MT, MH, WC, GM_TRIPLANE, DUMP>, lds))) return rc;
+      hipLaunchKernelGGL((renderer_bwd_loop<C, NB, TG, MT, MH, WC, GM_TRIPLANE, DUMP>), dim3(nb), dim3(256), lds, stream, a, p);
       return LP_OK;
     }
   }
-  if ((rc = loop_set_lds(renderer_bwd_loop<C, NB, TG, MT, MH, WC, GM_GENERIC>, lds))) return rc;
-  hipLaunchKernelGGL((renderer_bwd_loop<C, NB, TG, MT, MH, WC, GM_GENERIC>), dim3(nb), dim3(256), lds, stream, a, p);
+  if ((rc = loop_set_lds(renderer_bwd_loop<C, NB, TG, MT, MH, WC, GM_GENERIC, DUMP>, lds))) return rc;
+  hipLaunchKernelGGL((renderer_bwd_loop<C, NB, TG, MT, MH, WC, GM_GENERIC, DUMP>), dim3(nb), dim3(256), lds, stream, a, p);
   return LP_OK;
 }
 
-// backward of a SHALLOW decoder (<= 2 trunk layers -- none with a colour grid --, heads with at most one hidden layer, hidden
-// width 16 / 32, <= 4 colour channels): lp_renderer_loop_shallow.hip
+// The instantiation table of the family's backward, shared by the production translation units and their DUMP twins.
+// SHALLOW decoders (<= 2 trunk layers -- none with a colour grid --, heads with at most one hidden layer, hidden width 16 / 32,
+// <= 4 colour channels) at two waves per SIMD: lp_renderer_loop_shallow.hip (+ _dump)
+template <bool DUMP>
+static int loop_bwd_table_shallow(const LpRendererArgs& a, const LoopParams& p, unsigned nb, size_t lds, bool tri, hipStream_t stream) {
+  const bool tg = a.color_grid.n_grids > 0;
+  if (a.grid.channels == 16) {
+    if (tg) return launch_bwd_loop<16, 1, true, 1, 1, false, DUMP>(a, p, nb, lds, tri, stream);
+    return launch_bwd_loop<16, 1, false, 2, 1, false, DUMP>(a, p, nb, lds, tri, stream);
+  }
+  if (tg) return launch_bwd_loop<32, 1, true, 1, 1, false, DUMP>(a, p, nb, lds, tri, stream);
+  return launch_bwd_loop<32, 1, false, 2, 1, false, DUMP>(a, p, nb, lds, tri, stream);
+}
+// deep (up to 4 / 4 / 4 layers), wide-colour and two-block (hidden 64 / 64 grid channels) decoders at one wave per SIMD:
+// lp_renderer_loop.hip (+ lp_renderer_loop_dump.hip); NB = blocks of 32 features
+template <bool DUMP>
+static int loop_bwd_table_deep(const LpRendererArgs& a, const LoopParams& p, int NB, unsigned nb, size_t lds, bool tri, hipStream_t stream) {
+  const bool tg = a.color_grid.n_grids > 0, wc = a.color_chn > 4;
+#define LP_LOOP_BWD(CV, NBV, TGV, MTV, MHV, WCV) return launch_bwd_loop<CV, NBV, TGV, MTV, MHV, WCV, DUMP>(a, p, nb, lds, tri, stream)
+  if (a.grid.channels == 64) {
+    if (p.n_t <= 1) LP_LOOP_BWD(64, 2, false, 1, 1, false);
+    else LP_LOOP_BWD(64, 2, false, 2, 1, false);
+  } else if (a.grid.channels == 16) {
+    if (NB == 2 && tg) LP_LOOP_BWD(16, 2, true, 1, 1, false);  // two-grid decoder x 64: heads of at most two layers, no trunk
+    else if (NB == 2 && p.n_t <= 1) LP_LOOP_BWD(16, 2, false, 1, 1, false);
+    else if (NB == 2) LP_LOOP_BWD(16, 2, false, 2, 1, false);
+    else if (tg && wc) LP_LOOP_BWD(16, 1, true, 1, LOOP_MAX_H, true);
+    else if (tg) LP_LOOP_BWD(16, 1, true, 1, LOOP_MAX_H, false);
+    else if (wc) LP_LOOP_BWD(16, 1, false, LOOP_MAX_T, LOOP_MAX_H, true);
+    else LP_LOOP_BWD(16, 1, false, LOOP_MAX_T, LOOP_MAX_H, false);
+  } else {
+    // (one trunk layer -- the reference example's 1/1/2 x 64 --: an instantiation of its own keeps 32 activation + 18 dW registers
+    // fewer and fits the 512-register budget without scratch; the two-trunk-layer one spills 44-46)
+    if (NB == 2 && tg) LP_LOOP_BWD(32, 2, true, 1, 1, false);
+    else if (NB == 2 && p.n_t <= 1) LP_LOOP_BWD(32, 2, false, 1, 1, false);
+    else if (NB == 2) LP_LOOP_BWD(32, 2, false, 2, 1, false);
+    else if (tg && wc) LP_LOOP_BWD(32, 1, true, 1, LOOP_MAX_H, true);
+    else if (tg) LP_LOOP_BWD(32, 1, true, 1, LOOP_MAX_H, false);
+    else if (wc) LP_LOOP_BWD(32, 1, false, LOOP_MAX_T, LOOP_MAX_H, true);
+    else LP_LOOP_BWD(32, 1, false, LOOP_MAX_T, LOOP_MAX_H, false);
+  }
+#undef LP_LOOP_BWD
+}
+
 int renderer_backward_loop_shallow(const LpRendererArgs& a, const LoopParams& p, unsigned nb, size_t lds, bool tri, hipStream_t stream);
+// DUMP twins (with -DLP_TEST_HOOKS; LP_EUNSUPPORTED without)
+int renderer_backward_loop_shallow_dump(const LpRendererArgs& a, const LoopParams& p, unsigned nb, size_t lds, bool tri, hipStream_t stream);
+int renderer_backward_loop_deep_dump(const LpRendererArgs& a, const LoopParams& p, int NB, unsigned nb, size_t lds, bool tri, hipStream_t stream);
 
 }  // namespace lp

@@ -127,8 +127,13 @@ static LoopParams loop_params(const LpRendererArgs& a) {
   p.dbg = dbg;
   p.seg_blocks = 1;
   p.seg_fwd = 0;
+  p.relu_dump = g_relu_dump;  // test hook (NULL in every product call)
+  p.dump_words = NB * ((tg ? 2 : p.n_t) + p.n_o + p.n_c) + 1;
   return p;
 }
+
+// words per (ray, sample) of the ReLU dump (include/lightplane_hip.h, lp_renderer_relu_dump_words)
+int renderer_loop_dump_words(const LpRendererArgs& a) { return loop_params(a).dump_words; }
 
 // Segment-parallel march of a small batch (same rules as renderer_mfma_segments, lp_renderer_mfma.hip): the looped kernels
 // run one four-wave workgroup per CU, so 256 workgroups = 32 768 rays fill the chip once; below that a workgroup per
@@ -228,35 +233,26 @@ int renderer_backward_loop(const LpRendererArgs& a, hipStream_t stream) {
   int rc = LP_OK;
   static const bool no_shallow = getenv("LP_LOOP_NO_SHALLOW") != nullptr;  // A/B: the deep one-wave-per-SIMD instantiations for every shape
   if (NB == 1 && !wc && p.n_t <= 2 && p.n_o <= 1 && p.n_c <= 1 && !no_shallow) {
-    if ((rc = renderer_backward_loop_shallow(a, p, nb, lds, tri, stream))) return rc;
+    rc = p.relu_dump ? renderer_backward_loop_shallow_dump(a, p, nb, lds, tri, stream) : renderer_backward_loop_shallow(a, p, nb, lds, tri, stream);
+    if (rc) return rc;
     return check_launch("renderer_bwd_loop (shallow)");
   }
-#define LP_LOOP_BWD(CV, NBV, TGV, MTV, MHV, WCV) rc = launch_bwd_loop<CV, NBV, TGV, MTV, MHV, WCV>(a, p, nb, lds, tri, stream)
-  if (a.grid.channels == 64) {
-    if (p.n_t <= 1) LP_LOOP_BWD(64, 2, false, 1, 1, false);
-    else LP_LOOP_BWD(64, 2, false, 2, 1, false);
-  } else if (a.grid.channels == 16) {
-    if (NB == 2 && tg) LP_LOOP_BWD(16, 2, true, 1, 1, false);  // two-grid decoder x 64: heads of at most two layers, no trunk
-    else if (NB == 2 && p.n_t <= 1) LP_LOOP_BWD(16, 2, false, 1, 1, false);
-    else if (NB == 2) LP_LOOP_BWD(16, 2, false, 2, 1, false);
-    else if (tg && wc) LP_LOOP_BWD(16, 1, true, 1, LOOP_MAX_H, true);
-    else if (tg) LP_LOOP_BWD(16, 1, true, 1, LOOP_MAX_H, false);
-    else if (wc) LP_LOOP_BWD(16, 1, false, LOOP_MAX_T, LOOP_MAX_H, true);
-    else LP_LOOP_BWD(16, 1, false, LOOP_MAX_T, LOOP_MAX_H, false);
-  } else {
-    // (one trunk layer -- the reference example's 1/1/2 x 64 --: an instantiation of its own keeps 32 activation + 18 dW registers
-    // fewer and fits the 512-register budget without scratch; the two-trunk-layer one spills 44-46)
-    if (NB == 2 && tg) LP_LOOP_BWD(32, 2, true, 1, 1, false);
-    else if (NB == 2 && p.n_t <= 1) LP_LOOP_BWD(32, 2, false, 1, 1, false);
-    else if (NB == 2) LP_LOOP_BWD(32, 2, false, 2, 1, false);
-    else if (tg && wc) LP_LOOP_BWD(32, 1, true, 1, LOOP_MAX_H, true);
-    else if (tg) LP_LOOP_BWD(32, 1, true, 1, LOOP_MAX_H, false);
-    else if (wc) LP_LOOP_BWD(32, 1, false, LOOP_MAX_T, LOOP_MAX_H, true);
-    else LP_LOOP_BWD(32, 1, false, LOOP_MAX_T, LOOP_MAX_H, false);
-  }
-#undef LP_LOOP_BWD
+  (void)tg;
+  rc = p.relu_dump ? renderer_backward_loop_deep_dump(a, p, NB, nb, lds, tri, stream) : loop_bwd_table_deep<false>(a, p, NB, nb, lds, tri, stream);
   if (rc) return rc;
   return check_launch("renderer_bwd_loop");
+}
+
+// what this translation unit's backward computes in (lp_build_info)
+const char* build_info_loop_deep() {
+#define LP_STR2(x) #x
+#define LP_STR(x) LP_STR2(x)
+  return "{\"dx_limbs\": \"" LP_STR(LP_DX_LIMBS) " (two-block / <= 2 trunk + 1 hidden head layers), 3 (deeper chains)\", \"dw\": "
+#if LP_LOOP_DW_BF16
+         "\"two-limb bf16 operands, v_mfma_f32_16x16x32_bf16\"}";
+#else
+         "\"fp32 operands, v_mfma_f32_16x16x4_f32\"}";
+#endif
 }
 
 }  // namespace lp

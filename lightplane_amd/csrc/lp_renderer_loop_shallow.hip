@@ -16,13 +16,19 @@
 namespace lp {
 
 int renderer_backward_loop_shallow(const LpRendererArgs& a, const LoopParams& p, unsigned nb, size_t lds, bool tri, hipStream_t stream) {
-  const bool tg = a.color_grid.n_grids > 0;
-  if (a.grid.channels == 16) {
-    if (tg) return launch_bwd_loop<16, 1, true, 1, 1, false>(a, p, nb, lds, tri, stream);
-    return launch_bwd_loop<16, 1, false, 2, 1, false>(a, p, nb, lds, tri, stream);
-  }
-  if (tg) return launch_bwd_loop<32, 1, true, 1, 1, false>(a, p, nb, lds, tri, stream);
-  return launch_bwd_loop<32, 1, false, 2, 1, false>(a, p, nb, lds, tri, stream);
+  return loop_bwd_table_shallow<false>(a, p, nb, lds, tri, stream);
+}
+
+// what this translation unit's backward computes in (lp_build_info)
+const char* build_info_loop_shallow() {
+#define LP_STR2(x) #x
+#define LP_STR(x) LP_STR2(x)
+  return "{\"dx_limbs\": " LP_STR(LP_DX_LIMBS) ", \"dw\": "
+#if LP_LOOP_DW_BF16
+         "\"two-limb bf16 operands, v_mfma_f32_16x16x32_bf16\"}";
+#else
+         "\"fp32 operands, v_mfma_f32_16x16x4_f32\"}";
+#endif
 }
 
 }  // namespace lp

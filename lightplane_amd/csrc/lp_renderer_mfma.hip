@@ -253,9 +253,15 @@ static MfmaParams make_params(const LpRendererArgs& a) {
 // (scripts/bench_small_batch.py, S = 128, backward kernel): 4 096 rays 1.80 -> 0.51 ms, 16 384 rays 1.80 -> 0.88 ms,
 // 32 768 rays 1.75 -> 1.53 ms, 49 152 rays 2.12 -> 2.22 ms: on up to 32 768 rays.
 // LP_SEGMENTS=0 / 1 switches it off / on regardless of the batch size (A/B, tests).
+// LP_ARITH_FP32 instantiations exist for four-wave workgroups (<= 64 beyond-far samples), one sweep per ray
+bool renderer_mfma_f32_supported(const LpRendererArgs& a) {
+  const char* why = "";
+  return renderer_mfma_supported(a, &why) && a.march.num_samples_inf <= 64;
+}
+
 int renderer_mfma_segments(const LpRendererArgs& a) {
   static const int forced = getenv("LP_SEGMENTS") ? atoi(getenv("LP_SEGMENTS")) : -1;
-  if (forced == 0) return 1;
+  if (forced == 0 || a.arithmetic != LP_ARITH_DEFAULT) return 1;
   if (a.march.num_samples_inf != 0 || a.stop_neg_log_t > 0.0f) return 1;
   const int n_seg = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
   if (n_seg < 2) return 1;

@@ -68,4 +68,15 @@ int splatter_mlp_backward_loop(const LpSplatterArgs& a, hipStream_t stream) {
   return check_launch("splat_mlp_bwd_loop");
 }
 
+// what the MLP-Splatter's looped backward computes in (lp_build_info): the dX chains keep three limbs; dW per translation unit
+const char* build_info_splatter_mlp() {
+  return "{\"dx_limbs\": 3, \"dw\": "
+#if LP_LOOP_DW_BF16
+         "\"deeper than two layers / width 64: two-limb bf16 operands, v_mfma_f32_16x16x32_bf16; two-layer MLPs (two waves per SIMD): "
+         "fp32 operands, v_mfma_f32_16x16x4_f32\"}";
+#else
+         "\"fp32 operands, v_mfma_f32_16x16x4_f32\"}";
+#endif
+}
+
 }  // namespace lp

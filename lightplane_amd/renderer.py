@@ -65,6 +65,7 @@ class _RendererCfg:
     n_color_tensors: int = 0
     grid_is_list: bool = False
     alpha_mode: int = 0            # fused module epilogue: 0 none, 1 alpha = 1 - T, 2 log T
+    arithmetic: int = 0            # LP_ARITH_* of the backward (include/lightplane_hip.h)
 
 
 def _fill_args(cfg: _RendererCfg, grids, color_grids, mlp_params, directions, origins, grid_idx, near, far,
@@ -98,6 +99,7 @@ def _fill_args(cfg: _RendererCfg, grids, color_grids, mlp_params, directions, or
     a.kernel = cfg.kernel
     a.stop_neg_log_t = float(cfg.stop_neg_log_t)
     a.alpha_mode = int(cfg.alpha_mode)
+    a.arithmetic = int(cfg.arithmetic)
     return a
 
 
@@ -105,8 +107,8 @@ _warned_shapes = set()
 
 
 def _warn_if_generic(a, cfg: _RendererCfg) -> None:
-    if not config.warn_generic_kernel or cfg.kernel != _lib.LP_KERNEL_AUTO:
-        return
+    if not config.warn_generic_kernel or cfg.kernel != _lib.LP_KERNEL_AUTO or cfg.arithmetic != _lib.LP_ARITH_DEFAULT:
+        return  # (LP_ARITH_FP32 outside the tuned family asks for the generic fp32 kernels by definition)
     key = (cfg.channels, tuple(cfg.dims_trunk), tuple(cfg.dims_opacity), tuple(cfg.dims_color), cfg.color_chn,
            cfg.color_descs is not None)
     if key in _warned_shapes:
@@ -148,7 +150,7 @@ def _shape_args(grid, decoder_params: DecoderParams, grid_sizes=None, color_grid
 #: influence the shape-only answer); anything else raises, so that a typo such as ``num_sample_inf=`` cannot pass silently
 _RENDER_KWARGS = frozenset((
     "num_samples", "gain", "mask_out_of_bounds_samples", "contract_coords", "disparity_at_inf", "inject_noise_sigma",
-    "inject_noise_seed", "scaffold", "kernel", "stop_transmittance", "regenerate_code", "triton_block_size", "triton_num_warps",
+    "inject_noise_seed", "scaffold", "stop_transmittance", "regenerate_code", "triton_block_size", "triton_num_warps",
     "allow_unsupported", "checkpointing", "use_naive_impl"))
 
 
@@ -159,21 +161,42 @@ def _check_render_kwargs(fn: str, kw) -> None:
 
 
 def kernel_family(rays: Rays, grid, decoder_params: DecoderParams, grid_sizes=None, color_grid=None,
-                  color_grid_sizes=None, num_samples_inf: int = 0, **_unused) -> int:
-    """Kernel family ``LP_KERNEL_AUTO`` selects for these shapes: 0 generic, 1 the tuned MFMA kernels of the default decoder
-    (2/2/2 x 32), 3 layer-looped MFMA (1-4 layers per MLP, widths 16 / 32 / 64) (``lp_renderer_kernel_family``; needs no GPU;
-    2, the fp32-MFMA hidden-64 family, was retired in 0.2.4).  ``num_samples_inf``: more than 256 beyond-far samples run the
-    generic kernels.  Only the shapes and ``num_samples_inf`` influence the answer; the other keywords of the render call
-    (``_RENDER_KWARGS``) are accepted and ignored, an unknown keyword raises."""
+                  color_grid_sizes=None, num_samples_inf: int = 0, kernel: int = _lib.LP_KERNEL_AUTO,
+                  arithmetic: Optional[int] = None, **_unused) -> int:
+    """Kernel family that runs these shapes: 0 generic, 1 the tuned MFMA kernels of the default decoder (2/2/2 x 32), 3
+    layer-looped MFMA (1-4 layers per MLP, widths 16 / 32 / 64) (``lp_renderer_kernel_family``; needs no GPU; 2, the fp32-MFMA
+    hidden-64 family, was retired in 0.2.4).  ``num_samples_inf``: more than 256 beyond-far samples run the generic kernels;
+    ``kernel=LP_KERNEL_GENERIC`` forces family 0; ``arithmetic=LP_ARITH_FP32`` (default ``config.arithmetic``) leaves the tuned
+    family where it has such instantiations and family 0 elsewhere.  The other keywords of the render call (``_RENDER_KWARGS``) are
+    accepted and ignored, an unknown keyword raises."""
     _check_render_kwargs("kernel_family", _unused)
+    if int(kernel) == _lib.LP_KERNEL_GENERIC:
+        return 0
     a = _shape_args(grid, decoder_params, grid_sizes, color_grid, color_grid_sizes)
     a.march.num_samples_inf = int(num_samples_inf)
+    a.arithmetic = int(config.arithmetic if arithmetic is None else arithmetic)
     return int(_lib.lib().lp_renderer_kernel_family(ctypes.byref(a)))
+
+
+def relu_dump_words(rays: Rays, grid, decoder_params: DecoderParams, grid_sizes=None, color_grid=None, color_grid_sizes=None,
+                    num_samples_inf: int = 0, kernel: int = _lib.LP_KERNEL_AUTO, arithmetic: Optional[int] = None, **_unused) -> int:
+    """Words per (ray, sample) of the ReLU dump of these shapes (``lp_renderer_relu_dump_words``; test hook, needs no GPU), or 0
+    where the kernel that would run has no DUMP twin (shape-generic kernels, LP_ARITH_FP32, the tuned family's eight-wave
+    workgroups, a library built without -DLP_TEST_HOOKS)."""
+    _check_render_kwargs("relu_dump_words", _unused)
+    if not int(_lib.build_info().get("test_hooks", 0)):
+        return 0
+    a = _shape_args(grid, decoder_params, grid_sizes, color_grid, color_grid_sizes)
+    a.march.num_samples_inf = int(num_samples_inf)
+    a.kernel = int(kernel)
+    a.arithmetic = int(config.arithmetic if arithmetic is None else arithmetic)
+    w = int(_lib.lib().lp_renderer_relu_dump_words(ctypes.byref(a)))
+    return max(w, 0)
 
 
 def backward_segments(rays: Rays, grid, decoder_params: DecoderParams, num_samples: int, num_samples_inf: int = 0,
                       grid_sizes=None, color_grid=None, color_grid_sizes=None, stop_transmittance: float = 0.0,
-                      **_unused) -> int:
+                      kernel: int = _lib.LP_KERNEL_AUTO, arithmetic: Optional[int] = None, **_unused) -> int:
     """Number of ray segments the backward of this call is split into (``lp_renderer_backward_segments``; needs no
     GPU): 1 = one sweep per ray, > 1 = small batch, every block of 16 samples of a ray in its own workgroup."""
     _check_render_kwargs("backward_segments", _unused)
@@ -181,6 +204,8 @@ def backward_segments(rays: Rays, grid, decoder_params: DecoderParams, num_sampl
     a.rays.n_rays = int(rays.directions.shape[0])
     a.march.num_samples, a.march.num_samples_inf = int(num_samples), int(num_samples_inf)
     a.stop_neg_log_t = -math.log(stop_transmittance) if stop_transmittance and stop_transmittance > 0 else 0.0
+    a.kernel = int(kernel)
+    a.arithmetic = int(config.arithmetic if arithmetic is None else arithmetic)
     return int(_lib.lib().lp_renderer_backward_segments(ctypes.byref(a)))
 
 
@@ -189,15 +214,18 @@ _RELU_DUMP = None
 
 class relu_dump_recorder:
     """Test hook (``lp_renderer_backward_relu_dump``, include/lightplane_hip.h): inside the context every Renderer backward runs
-    the DUMP twin of its kernel and leaves the ReLU decisions it took in ``.dump`` -- int32 ``[n_rays, S_tot, 5]``: words 0..3 = trunk
-    layer 1, trunk layer 2, opacity hidden, colour hidden (bit f = unit f active), word 4 = 1 where the sample contributed.  Raises
-    for shapes without a dump twin (anything but the tuned bf16x3 family)."""
+    the DUMP twin of its kernel and leaves the ReLU decisions it took in ``.dump`` -- int32 ``[n_rays, S_tot, W]``,
+    ``W = lp_renderer_relu_dump_words``: per ReLU site of the decoder, in the reference's evaluation order, ``words_per_site`` words
+    (bit f of word b = unit 32 b + f active), then one flag word: 1 = the sample contributed, 2 = visited but beyond the ray's last
+    marched sample, 0 = never visited.  The tuned family: 4 sites x 1 word + flag = 5.  Raises for shapes without a dump twin (the
+    shape-generic kernels) and for a library built without -DLP_TEST_HOOKS."""
 
     def __init__(self):
         self.dump = None
+        self.words_per_site = 1
 
-    def reset(self, n_rays, s_tot, dev):
-        self.dump = torch.zeros(n_rays, s_tot, 5, dtype=torch.int32, device=dev)
+    def reset(self, n_rays, s_tot, words, dev):
+        self.dump = torch.zeros(n_rays, s_tot, words, dtype=torch.int32, device=dev)
         return self.dump
 
     def __enter__(self):
@@ -329,7 +357,12 @@ class LightplaneFunction(torch.autograd.Function):
         a.grad_mlp_params, a.grad_encoding = _lib.ptr(grad_params), _lib.ptr(grad_enc)
         with torch.cuda.device(dev):
             if _RELU_DUMP is not None:  # test hook (relu_dump_recorder): the DUMP twin of the same kernel
-                d = _RELU_DUMP.reset(directions.shape[0], cfg.num_samples + cfg.num_samples_inf, dev)
+                words = _lib.lib().lp_renderer_relu_dump_words(ctypes.byref(a))
+                if words < 0:
+                    _lib.check(words, "lp_renderer_relu_dump_words")
+                d = _RELU_DUMP.reset(directions.shape[0], cfg.num_samples + cfg.num_samples_inf, words, dev)
+                hid = max(cfg.dims_trunk[1:] + cfg.dims_opacity[1:-1] + cfg.dims_color[1:-1] + [cfg.channels])
+                _RELU_DUMP.words_per_site = 1 if _lib.lib().lp_renderer_kernel_family(ctypes.byref(a)) == 1 else (2 if hid > 32 else 1)
                 _lib.check(_lib.lib().lp_renderer_backward_relu_dump(ctypes.byref(a), d.data_ptr(), d.numel(), stream),
                            "lp_renderer_backward_relu_dump")
             else:
@@ -370,6 +403,7 @@ def lightplane_renderer(
     triton_num_warps: int = 4,  # ignored
     kernel: int = _lib.LP_KERNEL_AUTO,
     stop_transmittance: Optional[float] = None,
+    arithmetic: Optional[int] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Render ``rays`` through the grid-list ``grid`` (emission-absorption ray march).
 
@@ -393,17 +427,21 @@ def lightplane_renderer(
     the backward skips the same samples.  ``ray_length`` / ``feature`` then miss contributions bounded by
     ``stop_transmittance`` (times depth / colour) and the returned negative log transmittance is the value
     reached at the stop (``>= -log(stop_transmittance)``), i.e. alpha is exact to ``stop_transmittance``.
+
+    ``arithmetic`` (default ``config.arithmetic`` = ``LP_ARITH_DEFAULT``): ``_lib.LP_ARITH_FP32`` runs the backward in the
+    reference's arithmetic -- three bf16 limbs for every operand of the dX chains and fp32 weight-gradient products instead of
+    two-limb operands; shapes outside the tuned family then run the shape-generic fp32 kernels.
     """
     out = _render(rays, grid, decoder_params, num_samples, gain, num_samples_inf, mask_out_of_bounds_samples,
                   contract_coords, disparity_at_inf, inject_noise_sigma, inject_noise_seed, scaffold, color_grid,
-                  grid_sizes, color_grid_sizes, kernel, stop_transmittance)
+                  grid_sizes, color_grid_sizes, kernel, stop_transmittance, arithmetic=arithmetic)
     return out[0], out[1], out[2]
 
 
 def _render(rays: Rays, grid, decoder_params: DecoderParams, num_samples, gain, num_samples_inf=0,
             mask_out_of_bounds_samples=False, contract_coords=False, disparity_at_inf=1e-5, inject_noise_sigma=0.0,
             inject_noise_seed=None, scaffold=None, color_grid=None, grid_sizes=None, color_grid_sizes=None,
-            kernel=_lib.LP_KERNEL_AUTO, stop_transmittance=None, bg_color=None, alpha_mode=0):
+            kernel=_lib.LP_KERNEL_AUTO, stop_transmittance=None, bg_color=None, alpha_mode=0, arithmetic=None):
     """``lightplane_renderer`` plus the module front-end's fused epilogue: returns ``(ray_length, neg_log_t, feature,
     alpha)``; with ``bg_color [color_chn]`` the feature is composited over it (``+ T * bg``), with ``alpha_mode`` 1 / 2
     ``alpha`` is ``1 - T`` / ``log T`` (empty tensor otherwise) -- reference renderer_module.py:552-561, in-kernel."""
@@ -496,6 +534,7 @@ def _render(rays: Rays, grid, decoder_params: DecoderParams, num_samples, gain, 
         noise_seed=int(inject_noise_seed), scaffold_shape=scaffold_shape, kernel=int(kernel),
         stop_neg_log_t=stop_neg_log_t, n_grid_tensors=len(grid_tensors), n_color_tensors=len(color_tensors),
         grid_is_list=grid_is_list, alpha_mode=int(alpha_mode),
+        arithmetic=int(config.arithmetic if arithmetic is None else arithmetic),
     )
     return LightplaneFunction.apply(
         cfg, mlp_params, rays.encoding, rays.directions.contiguous(), rays.origins.contiguous(), grid_idx,

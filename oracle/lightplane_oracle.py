@@ -176,8 +176,12 @@ class relu_mask_forcer:
     piecewise-linear branch: a near-tie unit the kernel resolved the other way stops being a difference of O(1) in the
     gradient and becomes one of O(|pre-activation|) in the output (tests: ``test_flips_are_flips``)."""
 
-    def __init__(self, masks, keep=None):
+    def __init__(self, masks, keep=None, near_eps=None):
         self.masks, self.keep, self.k, self.n_forced = masks, keep, 0, 0
+        # what was forced, measured in THIS (the forced) evaluation: the largest |pre-activation| of a forced unit relative to its
+        # site's largest (a unit forced against a clear sign is not a near tie -- the caller's assertion), and, with ``near_eps``,
+        # how many units of the kept samples sit within that relative distance of zero (the pool forced units may come from)
+        self.near_eps, self.max_forced_margin, self.n_near_units, self.n_units = near_eps, 0.0, 0, 0
 
     def __enter__(self):
         global _RELU_FORCER
@@ -192,10 +196,21 @@ class relu_mask_forcer:
     def apply(self, x):
         m = self.masks[self.k]
         assert m.shape == x.shape, (self.k, tuple(m.shape), tuple(x.shape))
-        own = x.detach() > 0
+        xd = x.detach()
+        own = xd > 0
         if self.keep is not None:
             m = torch.where(self.keep[self.k], m, own)
-        self.n_forced += int((m != own).sum())
+        forced = m != own
+        nf = int(forced.sum())
+        self.n_forced += nf
+        ax = xd.abs()
+        scale = float(ax.max().clamp(min=1e-30))
+        if nf:
+            self.max_forced_margin = max(self.max_forced_margin, float(ax[forced].max()) / scale)
+        if self.near_eps is not None:
+            kept = torch.ones_like(own) if self.keep is None else self.keep[self.k].expand_as(own)
+            self.n_near_units += int((kept & (ax != 0) & (ax < self.near_eps * scale)).sum())
+            self.n_units += int(kept.sum())
         self.k += 1
         return x * m.to(x.dtype)
 

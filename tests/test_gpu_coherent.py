@@ -37,8 +37,8 @@ from lightplane_amd import _lib
 from oracle import lightplane_oracle as O
 from tests.synth import (cat_rays, grid_sizes_for, pinhole_crop, pinhole_rays, random_decoder, random_grids,
                          random_splatter_mlp)
-from tests.test_gpu_parity import (KERNEL_IDS, KERNELS, TieMasks, _assert_close, _dev, _rel_err, assert_grad_close, rel_l2,
-                                   run_hip_mlp_splatter, run_hip_renderer, run_hip_splatter, run_oracle_renderer)
+from tests.test_gpu_parity import (KERNEL_IDS, KERNELS, TieMasks, _assert_close, _dev, _rel_err, assert_grad_close, forced_oracle_check,
+                                   has_dump_twin, rel_l2, run_hip_mlp_splatter, run_hip_renderer, run_hip_splatter, run_oracle_renderer)
 
 pytestmark = pytest.mark.gpu
 F64 = torch.float64
@@ -124,6 +124,16 @@ def coherent_renderer_inputs(grid_name, image_name, mask_oob=True, num_samples=2
 
 
 def check_renderer(d, dev, kernel, tag, **extra):
+    """Outputs against the fp32 oracle at 1e-4.  Gradients: where the kernel that runs has a DUMP twin (both MFMA families) the
+    PROOF -- its own ReLU decisions forced onto the fp64 oracle, every forced unit a measured near tie, every entry at 1e-4
+    (forced_oracle_check); the shape-generic kernels keep the counted allowance of assert_grad_close."""
+    if kernel == _lib.LP_KERNEL_AUTO and has_dump_twin(d, **extra):
+        out = run_hip_renderer(d, dev, kernel, **extra)[0]
+        o_out = run_oracle_renderer(d)[0]
+        for nm, a, b in (("ray_length", out[0], o_out[0]), ("neg_log_t", out[1], o_out[1]), ("feature", out[2], o_out[2])):
+            _assert_close(f"{tag}: {nm}", a, b.detach().numpy())
+        forced_oracle_check(tag, d, dev, chunk=2048 if d["cfg"]["inject_noise_sigma"] == 0 else d["rays"].n_rays, **extra)
+        return
     out, gp, ge, gg, gc = run_hip_renderer(d, dev, kernel, **extra)
     o_out, o_gp, o_ge, o_gg, o_gc = run_oracle_renderer(d)       # the reference's arithmetic (fp32)
     for nm, a, b in (("ray_length", out[0], o_out[0]), ("neg_log_t", out[1], o_out[1]), ("feature", out[2], o_out[2])):

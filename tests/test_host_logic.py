@@ -13,7 +13,7 @@ from lightplane_amd import _lib, grids, params
 
 def test_library_loads_and_exports_every_declared_symbol():
     L = _lib.lib()
-    assert L.lp_version() == 205
+    assert L.lp_version() == 206
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "lightplane_hip.h")).read()
     declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(lp_[a-z_0-9]+)\s*\(", hdr, flags=re.M))
     assert declared == set(_lib.EXPORTS), f"header vs binding mismatch: {declared ^ set(_lib.EXPORTS)}"
@@ -328,6 +328,124 @@ def test_ray_shard_allreduce_logic_on_gloo():
     for p in procs:
         p.join(120)
     assert all(p.exitcode == 0 for p in procs) and len(ret) == 2
+
+
+def _gloo_worker8(rank, world_size, port, ret):
+    """World size 8 (one node's worth of ranks): the reduce-scatter + all-gather path with tails that do not divide by 8 and the
+    ray-shard bounds of 8 x 1080p -- the launch shape of BASELINE configs[3] / [4] (round-5 review, next 8)."""
+    import torch.distributed as dist
+    from lightplane_amd import parallel
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world_size)
+    try:
+        tri = sum(r + 1 for r in range(world_size))
+        for n in (0, 5, 8, 8 * 1000 + 7, 8 * 1000 + 1, 123457):
+            base = torch.arange(n, dtype=torch.float64) * 0.5 - 3.0
+            t = base * (rank + 1)
+            parallel._big_allreduce_(t, None)
+            assert torch.equal(t, base * tri), n
+        old = parallel.RS_AG_BYTES, parallel._supports_rs
+        parallel.RS_AG_BYTES, parallel._supports_rs = 64, (lambda t, pg=None: True)
+        try:  # through allreduce_sum_, a [rows, C] grid whose element count is not a multiple of 8, next to a small parameter vector
+            grid = torch.full((1001, 3), float(rank + 1))
+            par = torch.full((19,), 2.0 * (rank + 1))
+            parallel.allreduce_sum_([grid, par, None])
+            assert torch.equal(grid, torch.full((1001, 3), float(tri))) and torch.equal(par, torch.full((19,), 2.0 * tri))
+        finally:
+            parallel.RS_AG_BYTES, parallel._supports_rs = old
+        # 8 x 1080p rays over 8 ranks: contiguous, disjoint, complete; a count that does not divide leaves the last shard short
+        for n in (8 * 1920 * 1080, 8 * 1920 * 1080 - 5, 3):
+            lo, hi = parallel.shard_bounds(n, rank, world_size)
+            sizes = torch.zeros(world_size, dtype=torch.int64)
+            sizes[rank] = hi - lo
+            dist.all_reduce(sizes)
+            assert int(sizes.sum()) == n and int(sizes.max()) == -(-n // world_size)
+            bounds = torch.zeros(world_size, 2, dtype=torch.int64)
+            bounds[rank, 0], bounds[rank, 1] = lo, hi
+            dist.all_reduce(bounds)
+            assert bool((bounds[1:, 0] == bounds[:-1, 1]).all()) and int(bounds[0, 0]) == 0 and int(bounds[-1, 1]) == n
+        # gradients of a replicated tensor summed over the 8 ray shards
+        w = torch.ones(6, requires_grad=True)
+        (wv,) = parallel.replicate_with_grad_allreduce([w])
+        (wv.sum() * float(rank + 1)).backward()
+        assert torch.equal(w.grad, torch.full((6,), float(tri)))
+        ret[rank] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ray_shard_allreduce_logic_on_gloo_world_size_8():
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_gloo_worker8, args=(r, 8, port, ret)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    assert all(p.exitcode == 0 for p in procs) and len(ret) == 8
+
+
+def test_build_info_names_what_the_binary_was_built_from():
+    """lp_build_info(): the source hash of the tree the library was compiled from, its flags and the arithmetic of every backward
+    family -- what bench.py copies into its record (`arithmetic`, `build`) instead of a hand-written string."""
+    from lightplane_amd.csrc import build as B
+    info = _lib.build_info()
+    assert info["version"] == 206 and info["test_hooks"] in (0, 1)
+    assert info["src_hash"] == B.source_hash(), "liblightplane_hip.so was built from other sources than this tree: run lightplane_amd/csrc/build.py"
+    assert _lib.build_matches_tree() is True
+    assert info["tuned_bwd"]["dx_limbs"] in (2, 3) and "v_mfma_f32_16x16x" in info["tuned_bwd"]["dw"]
+    assert "-DLP_LOOP_DW_FP32" in info["flags"]["per_file"]["lp_renderer_loop_shallow.hip"]
+    import bench
+    text = bench.arithmetic_string(info)
+    assert ("two-limb" in text) == (info["tuned_bwd"]["dx_limbs"] == 2)
+    assert ("v_mfma_f32_16x16x32_bf16" in text) == ("bf16" in info["tuned_bwd"]["dw"])
+
+
+def test_arithmetic_selection_and_dump_words_without_gpu():
+    """LpRendererArgs.arithmetic: LP_ARITH_FP32 keeps the tuned family where it has such instantiations and selects the generic
+    fp32 kernels elsewhere; invalid values are refused; lp_renderer_relu_dump_words per family."""
+    from tests.synth import RENDERER_CASES
+    from lightplane_amd.renderer import relu_dump_words
+    by = {c.name: c for c in RENDERER_CASES}
+    d = by["triplane_basic"].build()
+    assert lp.kernel_family(d["rays"], d["grids"], d["decoder"]) == 1
+    assert lp.kernel_family(d["rays"], d["grids"], d["decoder"], arithmetic=_lib.LP_ARITH_FP32) == 1
+    assert lp.kernel_family(d["rays"], d["grids"], d["decoder"], arithmetic=_lib.LP_ARITH_FP32, num_samples_inf=65) == 0
+    assert lp.kernel_family(d["rays"], d["grids"], d["decoder"], kernel=_lib.LP_KERNEL_GENERIC) == 0
+    assert lp.backward_segments(d["rays"], d["grids"], d["decoder"], num_samples=64) > 1
+    assert lp.backward_segments(d["rays"], d["grids"], d["decoder"], num_samples=64, arithmetic=_lib.LP_ARITH_FP32) == 1
+    hooks = int(_lib.build_info()["test_hooks"])
+    assert relu_dump_words(d["rays"], d["grids"], d["decoder"]) == (5 if hooks else 0)
+    assert relu_dump_words(d["rays"], d["grids"], d["decoder"], arithmetic=_lib.LP_ARITH_FP32) == 0
+    assert relu_dump_words(d["rays"], d["grids"], d["decoder"], kernel=_lib.LP_KERNEL_GENERIC) == 0
+    dd = by["triplane_deep444"].build()      # 4 + 3 + 3 sites of one word
+    assert lp.kernel_family(dd["rays"], dd["grids"], dd["decoder"]) == 3
+    assert lp.kernel_family(dd["rays"], dd["grids"], dd["decoder"], arithmetic=_lib.LP_ARITH_FP32) == 0
+    assert relu_dump_words(dd["rays"], dd["grids"], dd["decoder"]) == (11 if hooks else 0)
+    dw = by["triplane_h64_c32"].build()      # 2 + 1 + 1 sites of two words
+    assert relu_dump_words(dw["rays"], dw["grids"], dw["decoder"]) == (9 if hooks else 0)
+    a = _empty_renderer_args()
+    a.arithmetic = 7
+    assert _lib.lib().lp_renderer_forward(ctypes.byref(a), None) == -1 and b"arithmetic" in _lib.lib().lp_last_error()
+
+
+def test_forcer_reports_what_it_forced():
+    """oracle.relu_mask_forcer measures what a forced-oracle proof is allowed to rest on: the largest relative |pre-activation| of a
+    unit forced against the oracle's own sign, and how many units sit that close to zero."""
+    from oracle import lightplane_oracle as O
+    x = torch.tensor([[1.0, -2.0, 1e-7, -3e-7, 0.5, 0.0]], dtype=torch.float64)
+    own = x > 0
+    m = own.clone()
+    m[0, 2] = False    # a near tie decided the other way
+    with O.relu_mask_forcer([m], near_eps=1e-6) as f:
+        y = O._relu(x)
+    assert f.n_forced == 1 and abs(f.max_forced_margin - 1e-7 / 2.0) < 1e-12 and f.n_near_units == 2 and f.n_units == 6
+    assert torch.equal(y, x * m.double())
+    m[0, 0] = False    # a unit with a CLEAR sign forced: the margin says so
+    with O.relu_mask_forcer([m], near_eps=1e-6) as f:
+        O._relu(x)
+    assert f.n_forced == 2 and f.max_forced_margin == 0.5
 
 
 def test_mlp_splatter_host_checks():
