@@ -115,6 +115,9 @@ RENDER_CFGS = {
     "h64_222": (256, 256, 128, 32, 128, "hidden 64: Renderer fwd+bwd, 256x256 rays, triplane 128^2x32ch, 128 samples, "
                                         "2-layer/64-hidden trunk/opacity/colour MLPs, 3 colour ch"),
 }
+RENDER_CFGS["refbench256"] = (256, 256, 256, 32, 32, "refbench256: the 256^2 row of the reference's own speed benchmark (tests/renderer_speed_benchmark.py:228-285) as a "
+                                                     "steady-state workload: 65 536 RANDOM rays (tests/utils.py:230-268) over three batch entries, triplane "
+                                                     "[3,32,32,32,32], 256 samples, 2/2/2 x 32 decoder with N(0, 0.01) parameters, disparity_at_inf 0.01")
 DECODER_SHAPES = {"h64_example_112": ((1, 1, 2), 64), "h64_222": ((2, 2, 2), 64)}  # everything else: 2/2/2 layers x 32 hidden
 HIDDEN, COLOR = 32, 3
 
@@ -133,13 +136,19 @@ class RendererWorkload:
         H, W, S, C, G, self.desc = RENDER_CFGS[name]
         self.S, self.C = S, C
         gen = torch.Generator().manual_seed(0)
-        self.sizes = grid_sizes_for((1, G, G, G, C), True)
+        random = name == "refbench256"  # incoherent rays, the reference benchmark's inputs
+        self.sizes = grid_sizes_for((3 if random else 1, G, G, G, C), True)
         self.grids_c = random_grids(gen, self.sizes)
         self.layers, self.hidden = DECODER_SHAPES.get(name, ((2, 2, 2), HIDDEN))
-        self.dec_c = random_decoder(gen, *self.layers, C, self.hidden, COLOR, std=0.15 if self.hidden == 32 else 0.1)
+        self.dec_c = random_decoder(gen, *self.layers, C, self.hidden, COLOR, std=0.01 if random else 0.15 if self.hidden == 32 else 0.1)
         gen_r = torch.Generator().manual_seed(100 + rank)
         az, el = camera_pose(name, rank)
-        self.rays_c = pinhole_rays(H, W, enc_dim=int(self.dec_c.n_hidden_color[0]), gen=gen_r, azimuth_deg=az, elevation_deg=el)
+        if random:
+            from tests.synth import random_rays
+            self.rays_c = random_rays(gen_r, H * W, 3, int(self.dec_c.n_hidden_color[0]))
+        else:
+            self.rays_c = pinhole_rays(H, W, enc_dim=int(self.dec_c.n_hidden_color[0]), gen=gen_r, azimuth_deg=az, elevation_deg=el)
+        self.render_kw = dict(disparity_at_inf=0.01) if random else {}
         n = H * W
         up = (torch.randn(n, generator=gen_r), torch.randn(n, generator=gen_r), torch.randn(n, COLOR, generator=gen_r))
         self.n_rays = n
@@ -186,7 +195,7 @@ class RendererWorkload:
             g, p = parallel.replicate_with_grad_allreduce([self.flat, self.params], self.pg)
         d = lp.DecoderParams(p, self.dec.n_hidden_trunk, self.dec.n_hidden_opacity, self.dec.n_hidden_color, COLOR)
         return lp.lightplane_renderer(self.rays, g, d, num_samples=self.S, gain=1.0, grid_sizes=self.sizes, kernel=self.kernel,
-                                      arithmetic=self.arithmetic)
+                                      arithmetic=self.arithmetic, **self.render_kw)
 
     def loss(self, out):
         return (out[0] * self.up[0]).sum() + (out[1] * self.up[1]).sum() + (out[2] * self.up[2]).sum()
@@ -943,7 +952,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: >= 0.5 s of work: 200 for cfg2 / cfg3, "
                                                             "10 for the 1080p workloads)")
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "1080p_s128", "cfg3", "small", "cfg5", "refbench", "refbench_splatter", "h64_example_112", "h64_222"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "1080p_s128", "cfg3", "small", "cfg5", "refbench", "refbench_splatter", "h64_example_112", "h64_222", "refbench256"])
     ap.add_argument("--refbench-max", type=float, default=None, help="refbench: largest image size (default 2048) / refbench_splatter: "
                                                                       "largest num_view (default 256)")
     ap.add_argument("--kernel", type=int, default=_lib.LP_KERNEL_AUTO)
@@ -952,7 +961,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the "
                                                        "multi-rank code path with several ranks on one GPU)")
     args = ap.parse_args()
-    big = args.workload in ("cfg4", "1080p_s128", "h64_example_112", "h64_222")
+    big = args.workload in ("cfg4", "1080p_s128", "h64_example_112", "h64_222", "refbench256")
     steps = args.steps if args.steps is not None else (2 if args.workload == "cfg5" else 10 if big else 200)
     warmup = args.warmup if args.warmup is not None else (1 if args.workload == "cfg5" else 2 if big else 10)
 

@@ -830,5 +830,6 @@ int renderer_bwd_bf3_c16(const LpRendererArgs& a, const MfmaParams& mp, int gm, 
 int renderer_bwd_bf3_c32(const LpRendererArgs& a, const MfmaParams& mp, int gm, hipStream_t stream);
 int renderer_bwd_bf3_f32(const LpRendererArgs& a, const MfmaParams& mp, int gm, hipStream_t stream);   // LP_ARITH_FP32
 int renderer_bwd_bf3_dump(const LpRendererArgs& a, const MfmaParams& mp, int gm, hipStream_t stream);  // mp.relu_dump set
+int debug_phase_cycles_c32(unsigned long long* out);  // developer builds with -DLP_PHASE_TIMING (the 32-channel unit's g_phase), else -1
 
 }  // namespace lp

@@ -11,4 +11,14 @@ int renderer_bwd_bf3_c32(const LpRendererArgs& a, const MfmaParams& mp, int gm, 
 #endif
 }
 
+#ifdef LP_PHASE_TIMING
+int debug_phase_cycles_c32(unsigned long long* out) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  unsigned long long z[16] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#else
+int debug_phase_cycles_c32(unsigned long long*) { return -1; }
+#endif
+
 }  // namespace lp

@@ -133,6 +133,31 @@ def split_decoder(mlp_params, n_hidden_trunk, n_hidden_opacity, n_hidden_color):
     )
 
 
+_GEOMETRY_DTYPE = None
+
+
+class geometry_dtype:
+    """Test diagnostics: while active, ``lightplane_renderer_naive`` computes the GEOMETRY of the march -- sample depths, interval
+    lengths, sample points, contraction, un-normalised coordinates, cell indices and interpolation weights -- in ``dtype`` (fp32: the
+    reference's own arithmetic, which DEFINES which cell a sample falls into and with what weights; the HIP kernels reproduce it,
+    tests/test_gpu_parity.py::test_corner_indices_bit_exact) whatever the dtype of the grids / parameters / ray encoding.  An fp64
+    oracle under it is "the reference's geometry, a wide decoder": what separates it from a kernel is the decoder's arithmetic alone,
+    not the 2^-24 x grid-extent round-off of a coordinate (1e-5 of a cell on a 128-cell axis -- as large as a ReLU near tie).  No
+    effect on any result outside the context."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _GEOMETRY_DTYPE
+        self._prev, _GEOMETRY_DTYPE = _GEOMETRY_DTYPE, self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        global _GEOMETRY_DTYPE
+        _GEOMETRY_DTYPE = self._prev
+
+
 _RELU_RECORDER = None
 
 
@@ -491,13 +516,18 @@ def lightplane_renderer_naive(
     color_grids = None if color_grid is None else _as_grid_list(color_grid, color_grid_sizes)
     n_rays = rays.directions.shape[0]
     tot = num_samples + num_samples_inf
-    depths = ray_depths(rays.near, rays.far, num_samples, num_samples_inf, disparity_at_inf)
+    near, far, directions, origins = rays.near, rays.far, rays.directions, rays.origins
+    gd = _GEOMETRY_DTYPE
+    if gd is not None and directions.dtype != gd:  # test diagnostics (geometry_dtype): the march's geometry in its own dtype
+        near, far, directions, origins = near.to(gd), far.to(gd), directions.to(gd), origins.to(gd)
+    depths = ray_depths(near, far, num_samples, num_samples_inf, disparity_at_inf)
     noise = None
     if inject_noise_sigma > 0.0:
         seed = 0 if inject_noise_seed is None else int(inject_noise_seed)
-        noise = sample_noise(n_rays, tot, seed, rays.directions.device).to(depths.dtype) * inject_noise_sigma
-    points = depths[..., None] * rays.directions[:, None] + rays.origins[:, None]
-    delta = ray_deltas(rays.near, rays.far, depths, num_samples)
+        noise = sample_noise(n_rays, tot, seed, rays.directions.device).to(rays.directions.dtype) * inject_noise_sigma
+    points = depths[..., None] * directions[:, None] + origins[:, None]  # (stays in the geometry dtype: cells and weights come from it)
+    delta = ray_deltas(near, far, depths, num_samples).to(rays.directions.dtype)
+    depths = depths.to(rays.directions.dtype)
     opacity, color = eval_decoder(
         points, grids, rays.grid_idx, decoder_params, rays.encoding, gain,
         mask_out_of_bounds_samples=mask_out_of_bounds_samples, noise=noise, scaffold=scaffold,

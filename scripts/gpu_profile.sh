@@ -29,9 +29,9 @@ for w in $WL; do
     1080p_s128) run 1080p_s128 5 1 ;;
     h64_222) run h64_222 20 1 ;;             # 2/2/2 x 64 on the two-block looped kernels (eight-wave forward)
     h64_example_112) run h64_example_112 20 1 ;;
-    cfg5)  # BASELINE configs[4] at its per-GPU size: kernel trace only (a step takes ~0.27 s)
-      rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg5 -o bench -- python $R/bench.py --workload cfg5 --no-cpu-baseline --no-extras --steps 3 --warmup 1 > $R/gpurun_out/prof_cfg5.txt 2>&1
-      tail -1 $R/gpurun_out/prof_cfg5.txt | cut -c1-300 ;;
+    cfg5) run cfg5 3 1 ;;                    # BASELINE configs[4] at its per-GPU size (a step takes ~0.27 s): kernel trace + counters of the
+                                             # render / splat kernels on the 256^3 x 32 grid (2.15 GB: the grid does NOT fit the caches)
+    refbench256) run refbench256 20 2 ;;     # the reference benchmark's 256^2 row: 65 536 RANDOM rays (incoherent scatter)
     loop)  # the headline workload through the layer-looped family (LP_LOOP=1: shallow two-waves-per-SIMD backward)
       export LP_LOOP=1
       rm -rf $R/gpurun_out/prof_loop $R/gpurun_out/pmc[1-4]_loop

@@ -306,7 +306,11 @@ def oracle_forced(d, dump, idx=None, chunk=2048, dtype=torch.float64, words_per_
             dd = copy.copy(dec)
             dd.mlp_params = params
             keep = [visited[lo:lo + chunk, :, None].expand(-1, -1, w) for w in widths]
-            with O.relu_mask_forcer([m[lo:lo + chunk] for m in masks], keep, near_eps=FORCED_TIE_K * TIE_EPS) as forcer:
+            # (geometry_dtype: the march's geometry -- cells, interpolation weights, interval lengths -- in the reference's fp32, as
+            # the kernels compute it; the fp64 part is the decoder.  With fp64 geometry a coordinate's 2^-24 x grid-extent round-off
+            # moves a pre-activation by up to 1e-5 of its site's largest on a 128-cell axis: the forced margins of the cfg-4 block
+            # measured 7e-6 .. 9.5e-6 that way, 3 .. 8 x what the decoder's own arithmetic explains.)
+            with O.geometry_dtype(torch.float32), O.relu_mask_forcer([m[lo:lo + chunk] for m in masks], keep, near_eps=FORCED_TIE_K * TIE_EPS) as forcer:
                 out = O.lightplane_renderer_naive(r, grids, dd, scaffold=scaffold, color_grid=cgrids, **d["cfg"])
             assert forcer.k == len(widths), f"the oracle evaluated {forcer.k} ReLU sites, the dump holds {len(widths)}"
             stats["n_forced"] += forcer.n_forced

@@ -128,6 +128,34 @@ def test_oracle_fp64_close_to_fp32():
         _close("fp32-vs-fp64", a, b, tol=1e-5)
 
 
+def test_geometry_dtype_keeps_the_references_cells_and_weights():
+    """oracle.geometry_dtype(fp32) under an fp64 run: the same cells / interpolation weights as the fp32 oracle (the geometry the
+    reference defines), a wide decoder on top -- outputs within fp32 round-off of both, and no effect outside the context."""
+    import copy
+    d = next(c for c in RENDERER_CASES if c.name == "voxel_inf_contract").build() if any(c.name == "voxel_inf_contract" for c in RENDERER_CASES) else RENDERER_CASES[0].build()
+
+    def run(dtype, geom=None):
+        r = copy.copy(d["rays"])
+        for f in ("directions", "origins", "near", "far", "encoding"):
+            setattr(r, f, getattr(r, f).to(dtype))
+        dec = copy.copy(d["decoder"])
+        dec.mlp_params = dec.mlp_params.to(dtype)
+        g = [x.to(dtype) for x in d["grids"]]
+        cg = None if d["color_grids"] is None else [x.to(dtype) for x in d["color_grids"]]
+        sc = None if d["scaffold"] is None else d["scaffold"].to(dtype)
+        if geom is None:
+            return O.lightplane_renderer_naive(r, g, dec, scaffold=sc, color_grid=cg, **d["cfg"])
+        with O.geometry_dtype(geom):
+            return O.lightplane_renderer_naive(r, g, dec, scaffold=sc, color_grid=cg, **d["cfg"])
+
+    a32, a64, mixed, again = run(torch.float32), run(torch.float64), run(torch.float64, torch.float32), run(torch.float64)
+    for x32, x64, xm, xa in zip(a32, a64, mixed, again):
+        assert xm.dtype == torch.float64 and torch.equal(x64, xa)
+        scale = float(x64.abs().max())
+        assert float((xm - x64).abs().max()) / scale < 2e-5 and float((xm - x32.double()).abs().max()) / scale < 2e-5
+    assert O._GEOMETRY_DTYPE is None
+
+
 def test_near_tie_masks_contain_every_fp32_vs_fp64_relu_flip():
     """The theory behind the GPU suite's tie masks (tests/test_gpu_parity.py TieMasks), checked on flips that are certainly
     flips: the oracle in fp32 against the same oracle in fp64 on a whole pinhole image.  Every `grad_grid` / `grad_encoding`
