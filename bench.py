@@ -148,7 +148,9 @@ class RendererWorkload:
             self.rays_c = random_rays(gen_r, H * W, 3, int(self.dec_c.n_hidden_color[0]))
         else:
             self.rays_c = pinhole_rays(H, W, enc_dim=int(self.dec_c.n_hidden_color[0]), gen=gen_r, azimuth_deg=az, elevation_deg=el)
-        self.render_kw = dict(disparity_at_inf=0.01) if random else {}
+        # (bench.py runs with check_inputs off -- no device sync in a timed step --, so "auto" cannot look at the rays: the random-ray
+        # workload names its march order; LP_BENCH_MARCH=rays for the A/B)
+        self.render_kw = dict(disparity_at_inf=0.01, march_order=os.environ.get("LP_BENCH_MARCH", "samples")) if random else {}
         n = H * W
         up = (torch.randn(n, generator=gen_r), torch.randn(n, generator=gen_r), torch.randn(n, COLOR, generator=gen_r))
         self.n_rays = n
@@ -365,7 +367,14 @@ def refbench_renderer(dev, sizes=None, kernel=_lib.LP_KERNEL_AUTO):
             return lp.lightplane_renderer(rays, grids, dec, num_samples=256, gain=1.0, disparity_at_inf=0.01, inject_noise_seed=0,
                                           kernel=kernel)
 
-        r = _ref_protocol(make_inputs, run, dev)
+        # the reference's call path checks grid_idx on the host (lightplane_renderer.py:464-467: a device sync per call); with it on,
+        # march_order "auto" sees that these rays are unrelated and marches samples per wavefront (no extra sync)
+        saved = lp.config.check_inputs
+        lp.config.check_inputs = True
+        try:
+            r = _ref_protocol(make_inputs, run, dev)
+        finally:
+            lp.config.check_inputs = saved
         r.update(num_rays=n, image_size=int(n ** 0.5),
                  Mrays_per_s_fwd_bwd=round(n / (r["t_fw_kernel_ms"] + r["t_bw_kernel_ms"]) / 1e3, 4))
         rows.append(r)
@@ -1000,7 +1009,7 @@ def main():
     global ARITHMETIC
     ARITHMETIC = arithmetic_string()
     lp.config.check_inputs = False  # the grid_idx range check is a host sync, not part of the op
-    if args.workload.startswith("refbench"):  # the reference's own benchmark tables (single GPU, its protocol; no timed-step loop)
+    if args.workload in ("refbench", "refbench_splatter"):  # the reference's own benchmark tables (single GPU, its protocol; no timed-step loop)
         assert world == 1, "refbench is a single-GPU table"
         if args.workload == "refbench":
             tab = refbench_renderer(dev, [x for x in REFBENCH_SIZES if x <= (args.refbench_max or 2048) + 1e-6], args.kernel)

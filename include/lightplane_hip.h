@@ -68,7 +68,8 @@ extern "C" {
                                   three)
                            0.2.6: LpRendererArgs.arithmetic (LP_ARITH_FP32: every product of the backward fp32-equivalent, selectable
                                   per call); lp_build_info(); lp_renderer_relu_dump_words() and dump twins for the layer-looped
-                                  family (the dump of family 1 keeps its five words per sample) */
+                                  family (the dump of family 1 keeps its five words per sample); LpRendererArgs.march_order
+                                  (LP_MARCH_SAMPLES_PER_WAVE: transposed march of the tuned backward for incoherent ray batches) */
 
 #define LP_MAX_GRIDS 8   /* grids per grid-list                         */
 #define LP_MAX_LAYERS 8  /* layers per MLP                              */
@@ -107,6 +108,18 @@ extern "C" {
  *                     instantiations for it; every other shape runs the shape-generic fp32 kernels (family 0: slow, exact). */
 #define LP_ARITH_DEFAULT 0
 #define LP_ARITH_FP32 1
+
+/* march order of the Renderer BACKWARD (LpRendererArgs.march_order; same results up to fp32 summation order).  The grid-gradient
+ * scatter merges the taps of consecutive lanes that fall into one cell into a single row-contiguous atomic:
+ *   LP_MARCH_RAYS_PER_WAVE     a wavefront = 32 consecutive rays at one sample: merges neighbouring rays (image-coherent batches:
+ *                              consecutive rays = neighbouring pixels).  Default.
+ *   LP_MARCH_SAMPLES_PER_WAVE  a wavefront = 32 consecutive samples of ONE ray (its rays one after the other): merges the samples a
+ *                              ray spends in one cell -- for batches of unrelated rays (random training batches; the reference's speed
+ *                              benchmark, tests/renderer_speed_benchmark.py:228-246), where every ray is its own run otherwise and
+ *                              the backward is bound by the chip's atomic rate.  Tuned family, plain configuration (no beyond-far
+ *                              samples, contraction, scaffold, noise, early termination), >= 32 samples; ignored elsewhere. */
+#define LP_MARCH_RAYS_PER_WAVE 0
+#define LP_MARCH_SAMPLES_PER_WAVE 1
 
 typedef struct LpGrid {
   int32_t B, D, H, W;  /* batch and spatial extent                         */
@@ -224,7 +237,7 @@ typedef struct LpRendererArgs {
    * Pass the same pointer to forward and backward, and only when lp_renderer_backward_segments() > 1. */
   float* seg_prefix;
   int32_t arithmetic;     /* LP_ARITH_* (backward only; the forward is fp32-equivalent in every mode) */
-  int32_t _pad;
+  int32_t march_order;    /* LP_MARCH_* (backward only): how (ray, sample) pairs are dealt to the lanes of a wavefront */
 } LpRendererArgs;
 
 typedef struct LpSplatterArgs {

@@ -28,6 +28,7 @@ def n_nlt_ckpt(num_samples: int, num_samples_inf: int) -> int:
 
 LP_KERNEL_AUTO, LP_KERNEL_GENERIC, LP_KERNEL_MFMA = 0, 1, 2
 LP_ARITH_DEFAULT, LP_ARITH_FP32 = 0, 1  # LpRendererArgs.arithmetic (include/lightplane_hip.h)
+LP_MARCH_RAYS_PER_WAVE, LP_MARCH_SAMPLES_PER_WAVE = 0, 1  # LpRendererArgs.march_order
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)
@@ -76,7 +77,7 @@ class LpRendererArgs(C.Structure):
         ("grad_encoding", C.c_void_p),
         ("grad_grid_list", C.c_void_p * LP_MAX_GRIDS), ("grad_color_grid_list", C.c_void_p * LP_MAX_GRIDS),
         ("bg_color", C.c_void_p), ("alpha", C.c_void_p), ("grad_alpha", C.c_void_p), ("alpha_mode", C.c_int32),
-        ("stop_neg_log_t", C.c_float), ("seg_prefix", C.c_void_p), ("arithmetic", C.c_int32), ("_pad", C.c_int32),
+        ("stop_neg_log_t", C.c_float), ("seg_prefix", C.c_void_p), ("arithmetic", C.c_int32), ("march_order", C.c_int32),
     ]
 
 

@@ -21,6 +21,12 @@
                        two-limb bf16 operands in the dX chains / weight gradients where the kernel family uses them (inside
                        1e-4 of the fp32 reference), 1 = ``LP_ARITH_FP32``, the reference's arithmetic (three limbs, fp32
                        weight-gradient products; shapes outside the tuned family then run the shape-generic fp32 kernels).
+``march_order``        how the Renderer BACKWARD deals (ray, sample) pairs to a wavefront (``LpRendererArgs.march_order``): "rays" = 32
+                       consecutive rays at one sample (its gradient scatter merges neighbouring rays: image-coherent batches),
+                       "samples" = 32 consecutive samples of one ray (merges the samples a ray spends in one cell: batches of
+                       unrelated rays, e.g. random training batches -- 3x on the reference's speed benchmark), "auto" (default) =
+                       "samples" when most consecutive rays of the batch share neither origin nor direction, decided together with
+                       the ``check_inputs`` device sync (no extra sync; "rays" when ``check_inputs`` is off).
 """
 import os
 
@@ -32,3 +38,4 @@ segment_forward: bool = os.environ.get("LIGHTPLANE_AMD_SEGMENT_FORWARD", "1") !=
 warn_generic_kernel: bool = os.environ.get("LIGHTPLANE_AMD_WARN_GENERIC", "1") != "0"
 stop_transmittance: float = float(os.environ.get("LIGHTPLANE_AMD_STOP_TRANSMITTANCE", "0"))
 arithmetic: int = int(os.environ.get("LIGHTPLANE_AMD_ARITHMETIC", "0"))
+march_order: str = os.environ.get("LIGHTPLANE_AMD_MARCH_ORDER", "auto")

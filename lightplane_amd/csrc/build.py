@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "liblightplane_hip.so")
 # (longest compiles first: the translation units are compiled in parallel)
-SOURCES = ["lp_renderer_loop.hip", "lp_renderer_loop_dump.hip", "lp_renderer_mfma_bwd.hip", "lp_renderer_mfma_bwd_dump.hip", "lp_renderer_mfma_bwd_c32.hip", "lp_renderer_mfma_bwd_aux.hip",
+SOURCES = ["lp_renderer_loop.hip", "lp_renderer_loop_dump.hip", "lp_renderer_mfma_bwd.hip", "lp_renderer_mfma_bwd_dump.hip", "lp_renderer_mfma_bwd_c32.hip", "lp_renderer_mfma_bwd_aux.hip", "lp_renderer_mfma_bwd_tm.hip",
            "lp_splatter_mlp_loop.hip", "lp_renderer_mfma.hip", "lp_renderer_loop_shallow.hip", "lp_renderer_loop_shallow_dump.hip",
            "lp_renderer_generic.hip", "lp_splatter.hip", "lp_splatter_mlp.hip", "lp_splatter_mlp_loop_shallow.hip", "lp_ray_embedding.hip", "lp_api.hip"]
 HEADERS = ["lp_device.h", "lp_host.h", "lp_mfma_common.h", "lp_generic_mlp.h", "lp_splat_walk.h", "lp_bf3.h", "lp_loop.h", "lp_renderer_loop.h",
@@ -49,6 +49,7 @@ FILE_FLAGS = {
     "lp_renderer_mfma_bwd_c32.hip": _BWD_FLAGS,
     "lp_renderer_mfma_bwd_aux.hip": _BWD_FLAGS,
     "lp_renderer_mfma_bwd_dump.hip": _BWD_FLAGS,
+    "lp_renderer_mfma_bwd_tm.hip": _BWD_FLAGS,
     # the shallow two-waves-per-SIMD backward of the layer-looped family: the same two switches take it from 49 spilled
     # registers to none (they cost the deep one-wave instantiations of lp_renderer_loop.hip 1-2 %, so those keep the defaults)
     # (-DLP_LOOP_DW_FP32: the two-waves-per-SIMD instantiations keep the fp32 weight-gradient quadrants -- with the bf16 ones of

@@ -131,6 +131,8 @@ static int check_renderer(const LpRendererArgs& a, bool backward) {
   if (!(a.stop_neg_log_t >= 0.0f)) return set_error(LP_EINVAL, "stop_neg_log_t must be >= 0 (0 = no early termination)");
   if (a.arithmetic != LP_ARITH_DEFAULT && a.arithmetic != LP_ARITH_FP32)
     return set_error(LP_EINVAL, "arithmetic %d is neither LP_ARITH_DEFAULT nor LP_ARITH_FP32", a.arithmetic);
+  if (a.march_order != LP_MARCH_RAYS_PER_WAVE && a.march_order != LP_MARCH_SAMPLES_PER_WAVE)
+    return set_error(LP_EINVAL, "march_order %d is neither LP_MARCH_RAYS_PER_WAVE nor LP_MARCH_SAMPLES_PER_WAVE", a.march_order);
   if (backward && a.stop_neg_log_t > 0.0f && !a.neg_log_t_ckpt)
     return set_error(LP_ENULL, "early termination needs neg_log_t_ckpt in the backward (it records where the forward stopped)");
   if ((rc = check_mlp("trunk", a.trunk, true))) return rc;

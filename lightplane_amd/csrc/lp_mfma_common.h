@@ -55,6 +55,7 @@ struct MfmaParams {
   // test hook (lp_renderer_backward_relu_dump): the ReLU decisions of the backward's recompute, [ray][sample][5] words -- t1, t2, o1,
   // c1 (bit f = unit f active) and 1 = "this sample was visited".  Only the DUMP instantiations read it.
   uint32_t* relu_dump;
+  int tm_rpw;  // transposed march (lp_renderer_mfma_bwd_tm.hip): rays per wave (1 .. 32, chosen at launch: small batches spread over the chip)
 };
 
 // LDS map (floats).  Weight matrices are kept ONCE, row-major [in][W_LD] with a padded row

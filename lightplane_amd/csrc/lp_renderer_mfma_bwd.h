@@ -830,6 +830,9 @@ int renderer_bwd_bf3_c16(const LpRendererArgs& a, const MfmaParams& mp, int gm, 
 int renderer_bwd_bf3_c32(const LpRendererArgs& a, const MfmaParams& mp, int gm, hipStream_t stream);
 int renderer_bwd_bf3_f32(const LpRendererArgs& a, const MfmaParams& mp, int gm, hipStream_t stream);   // LP_ARITH_FP32
 int renderer_bwd_bf3_dump(const LpRendererArgs& a, const MfmaParams& mp, int gm, hipStream_t stream);  // mp.relu_dump set
+// transposed march (LP_MARCH_SAMPLES_PER_WAVE): lp_renderer_mfma_bwd_tm.hip
+bool renderer_bwd_tm_supported(const LpRendererArgs& a);
+int renderer_bwd_bf3_tm_launch(const LpRendererArgs& a, const MfmaParams& mp, int gm, hipStream_t stream);
 int debug_phase_cycles_c32(unsigned long long* out);  // developer builds with -DLP_PHASE_TIMING (the 32-channel unit's g_phase), else -1
 
 }  // namespace lp

@@ -66,6 +66,7 @@ class _RendererCfg:
     grid_is_list: bool = False
     alpha_mode: int = 0            # fused module epilogue: 0 none, 1 alpha = 1 - T, 2 log T
     arithmetic: int = 0            # LP_ARITH_* of the backward (include/lightplane_hip.h)
+    march_order: int = 0           # LP_MARCH_* of the backward
 
 
 def _fill_args(cfg: _RendererCfg, grids, color_grids, mlp_params, directions, origins, grid_idx, near, far,
@@ -100,6 +101,7 @@ def _fill_args(cfg: _RendererCfg, grids, color_grids, mlp_params, directions, or
     a.stop_neg_log_t = float(cfg.stop_neg_log_t)
     a.alpha_mode = int(cfg.alpha_mode)
     a.arithmetic = int(cfg.arithmetic)
+    a.march_order = int(cfg.march_order)
     return a
 
 
@@ -151,7 +153,7 @@ def _shape_args(grid, decoder_params: DecoderParams, grid_sizes=None, color_grid
 _RENDER_KWARGS = frozenset((
     "num_samples", "gain", "mask_out_of_bounds_samples", "contract_coords", "disparity_at_inf", "inject_noise_sigma",
     "inject_noise_seed", "scaffold", "stop_transmittance", "regenerate_code", "triton_block_size", "triton_num_warps",
-    "allow_unsupported", "checkpointing", "use_naive_impl"))
+    "allow_unsupported", "checkpointing", "use_naive_impl", "march_order"))
 
 
 def _check_render_kwargs(fn: str, kw) -> None:
@@ -376,6 +378,29 @@ class LightplaneFunction(torch.autograd.Function):
         return (None, grad_params, grad_enc) + (None,) * 7 + tuple(gg) + tuple(gc)
 
 
+def check_inputs_and_choose_march(rays: Rays, grid_idx: torch.Tensor, B: int, march_order: Optional[str] = None) -> int:
+    """The ``grid_idx`` range check (``config.check_inputs``: the one device sync of a call, like the reference's min / max
+    asserts, lightplane_renderer.py:464-467) and, riding on the same sync, the backward's march order for "auto": image-coherent
+    batches -- consecutive rays share an origin (pinhole camera) or a direction (orthographic) -- march 32 rays per wavefront,
+    batches of unrelated rays 32 samples of one ray (``LP_MARCH_*``).  With ``check_inputs`` off "auto" is "rays" (no sync)."""
+    march_order = config.march_order if march_order is None else march_order
+    assert march_order in ("auto", "rays", "samples"), f"march_order has to be 'auto', 'rays' or 'samples' (got {march_order!r})"
+    march = _lib.LP_MARCH_SAMPLES_PER_WAVE if march_order == "samples" else _lib.LP_MARCH_RAYS_PER_WAVE
+    if config.check_inputs and grid_idx.numel() > 0:
+        lo, hi = torch.aminmax(grid_idx)
+        stats = [lo.float(), hi.float()]
+        if march_order == "auto" and grid_idx.numel() > 1:
+            o, dd = rays.origins, rays.directions
+            stats.append(((o[1:] == o[:-1]).all(dim=1) | (dd[1:] == dd[:-1]).all(dim=1)).float().mean())
+        vals = torch.stack(stats).tolist()
+        lo, hi = int(vals[0]), int(vals[1])
+        assert lo >= 0, f"Negative grid index: {lo}"
+        assert hi <= B - 1, f"A grid index is out of bounds ({hi} >= {B})"
+        if len(vals) > 2 and vals[2] < 0.5:
+            march = _lib.LP_MARCH_SAMPLES_PER_WAVE
+    return march
+
+
 def _decoder_dims(decoder_params: DecoderParams):
     return (int_list_of(decoder_params.n_hidden_trunk), int_list_of(decoder_params.n_hidden_opacity),
             int_list_of(decoder_params.n_hidden_color))
@@ -404,6 +429,7 @@ def lightplane_renderer(
     kernel: int = _lib.LP_KERNEL_AUTO,
     stop_transmittance: Optional[float] = None,
     arithmetic: Optional[int] = None,
+    march_order: Optional[str] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Render ``rays`` through the grid-list ``grid`` (emission-absorption ray march).
 
@@ -431,17 +457,21 @@ def lightplane_renderer(
     ``arithmetic`` (default ``config.arithmetic`` = ``LP_ARITH_DEFAULT``): ``_lib.LP_ARITH_FP32`` runs the backward in the
     reference's arithmetic -- three bf16 limbs for every operand of the dX chains and fp32 weight-gradient products instead of
     two-limb operands; shapes outside the tuned family then run the shape-generic fp32 kernels.
+
+    ``march_order`` (default ``config.march_order`` = "auto"): "rays" / "samples" / "auto" -- which pairs of (ray, sample) share a
+    wavefront in the backward, i.e. what its gradient scatter can merge (``LP_MARCH_*``, include/lightplane_hip.h): neighbouring
+    rays of an image, or consecutive samples of one ray (random ray batches).  Results agree up to fp32 summation order.
     """
     out = _render(rays, grid, decoder_params, num_samples, gain, num_samples_inf, mask_out_of_bounds_samples,
                   contract_coords, disparity_at_inf, inject_noise_sigma, inject_noise_seed, scaffold, color_grid,
-                  grid_sizes, color_grid_sizes, kernel, stop_transmittance, arithmetic=arithmetic)
+                  grid_sizes, color_grid_sizes, kernel, stop_transmittance, arithmetic=arithmetic, march_order=march_order)
     return out[0], out[1], out[2]
 
 
 def _render(rays: Rays, grid, decoder_params: DecoderParams, num_samples, gain, num_samples_inf=0,
             mask_out_of_bounds_samples=False, contract_coords=False, disparity_at_inf=1e-5, inject_noise_sigma=0.0,
             inject_noise_seed=None, scaffold=None, color_grid=None, grid_sizes=None, color_grid_sizes=None,
-            kernel=_lib.LP_KERNEL_AUTO, stop_transmittance=None, bg_color=None, alpha_mode=0, arithmetic=None):
+            kernel=_lib.LP_KERNEL_AUTO, stop_transmittance=None, bg_color=None, alpha_mode=0, arithmetic=None, march_order=None):
     """``lightplane_renderer`` plus the module front-end's fused epilogue: returns ``(ray_length, neg_log_t, feature,
     alpha)``; with ``bg_color [color_chn]`` the feature is composited over it (``+ T * bg``), with ``alpha_mode`` 1 / 2
     ``alpha`` is ``1 - T`` / ``log T`` (empty tensor otherwise) -- reference renderer_module.py:552-561, in-kernel."""
@@ -510,11 +540,7 @@ def _render(rays: Rays, grid, decoder_params: DecoderParams, num_samples, gain, 
 
     B = descs[0].B
     grid_idx = rays.grid_idx.to(torch.int32).contiguous()
-    if config.check_inputs and grid_idx.numel() > 0:
-        lo, hi = torch.aminmax(grid_idx)
-        lo, hi = int(lo), int(hi)
-        assert lo >= 0, f"Negative grid index: {lo}"
-        assert hi <= B - 1, f"A grid index is out of bounds ({hi} >= {B})"
+    march = check_inputs_and_choose_march(rays, grid_idx, B, march_order)
 
     scaffold_shape = None
     if scaffold is not None:
@@ -534,7 +560,7 @@ def _render(rays: Rays, grid, decoder_params: DecoderParams, num_samples, gain, 
         noise_seed=int(inject_noise_seed), scaffold_shape=scaffold_shape, kernel=int(kernel),
         stop_neg_log_t=stop_neg_log_t, n_grid_tensors=len(grid_tensors), n_color_tensors=len(color_tensors),
         grid_is_list=grid_is_list, alpha_mode=int(alpha_mode),
-        arithmetic=int(config.arithmetic if arithmetic is None else arithmetic),
+        arithmetic=int(config.arithmetic if arithmetic is None else arithmetic), march_order=int(march),
     )
     return LightplaneFunction.apply(
         cfg, mlp_params, rays.encoding, rays.directions.contiguous(), rays.origins.contiguous(), grid_idx,

@@ -435,3 +435,71 @@ def test_splatter_walk_touched_cells_equal_oracle(name):
         assert torch.equal(touched, wgrid > 0), (f"{name} grid {g}: touched cells differ in {int((touched != (wgrid > 0)).sum())} of "
                                                  f"{touched.numel()} cells")
         assert 0.2 * touched.numel() < int(touched.sum()) and bool((got >= 0).all())
+
+
+# --------------------------------------------------------------------------------------------------------------
+# transposed march of the tuned backward (LpRendererArgs.march_order = LP_MARCH_SAMPLES_PER_WAVE): batches of unrelated rays
+# --------------------------------------------------------------------------------------------------------------
+
+def _random_ray_case(n_rays, C, S, triplane=True, B=3, G=32, color_chn=3, seed=0, std=0.2, mask=False):
+    """The reference benchmark's kind of input (tests/renderer_speed_benchmark.py:228-246, tests/utils.py:230-268): random rays over
+    B batch entries of a coarse grid, 2/2/2 x 32 decoder."""
+    from tests.synth import random_rays
+    gen = torch.Generator().manual_seed(seed)
+    sizes = grid_sizes_for((B, G, G, G, C), triplane)
+    grids = random_grids(gen, sizes)
+    dec = random_decoder(gen, 2, 2, 2, C, 32, color_chn, std=std)
+    rays = random_rays(gen, n_rays, B, 32)
+    up = (torch.randn(n_rays, generator=gen), torch.randn(n_rays, generator=gen), torch.randn(n_rays, color_chn, generator=gen))
+    cfg = dict(num_samples=S, gain=1.0, num_samples_inf=0, mask_out_of_bounds_samples=mask, contract_coords=False, inject_noise_sigma=0.0,
+               inject_noise_seed=0)
+    return dict(rays=rays, grids=grids, color_grids=None, decoder=dec, scaffold=None, cfg=cfg, sizes=sizes, upstream=up)
+
+
+@pytest.mark.parametrize("n_rays,C,S,tri,cc,mask", [(4096, 32, 256, True, 3, False), (3000, 16, 100, True, 3, True), (2500, 32, 40, False, 4, False),
+                                                    (140000, 16, 33, True, 3, False), (777, 16, 32, False, 1, True)],
+                         ids=["refbench_like_c32_s256", "c16_s100_mask", "voxel_c32_rgba_s40", "140k_rays_32_per_wave_s33", "voxel_c16_tail_wave_s32"])
+def test_transposed_march_on_random_rays(n_rays, C, S, tri, cc, mask):
+    """march_order="samples" (one ray x 32 consecutive samples per wavefront: the run merge of the gradient scatter works along the
+    ray) against march_order="rays" of the same kernels' arithmetic -- same forward, same recompute, so the same ReLU decisions:
+    every gradient within 2e-5 -- and PROVEN against the fp64 oracle (its DUMP twin's decisions forced, every entry at 1e-4).
+    Ragged sample counts (a last block of 1 .. 8 samples), a last wave with fewer rays, 1 .. 32 rays per wave (small batches are
+    dealt over more workgroups), voxel and triplane scatter walks, three / four colour channels, masked samples."""
+    dev = _dev()
+    d = _random_ray_case(n_rays, C, S, triplane=tri, color_chn=cc, mask=mask, seed=n_rays % 97)
+    assert lp.kernel_family(d["rays"], d["grids"], d["decoder"]) == 1
+    ref = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO, march_order="rays")
+    got = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO, march_order="samples")
+    for a, b in zip(got[0], ref[0]):
+        assert torch.equal(a, b)  # (the forward does not depend on the backward's march order)
+    flat = lambda r: [("grad_mlp_params", r[1]), ("grad_encoding", r[2])] + [(f"grad_grid{i}", g) for i, g in enumerate(r[3])]  # noqa: E731
+    for (nm, a), (_, b) in zip(flat(got), flat(ref)):
+        err = float((a - b).abs().max() / b.abs().max())
+        assert err <= 2e-5, f"{nm}: samples-per-wave vs rays-per-wave {err:.3e}"
+    if n_rays <= 4096:
+        forced_oracle_check(f"transposed march {n_rays} rays C={C} S={S}", d, dev, march_order="samples")
+
+
+def test_march_order_auto_picks_by_ray_coherence():
+    """config.march_order = "auto": pinhole images march rays per wavefront, random rays samples per wavefront; decided with the
+    check_inputs sync, never when check_inputs is off; both give the oracle's gradients."""
+    from lightplane_amd.renderer import check_inputs_and_choose_march
+    from tests.synth import random_rays
+    dev = _dev()
+    gen = torch.Generator().manual_seed(3)
+    img = pinhole_rays(32, 32, enc_dim=32, gen=gen).to(dev)
+    rnd = random_rays(gen, 1024, 2, 32).to(dev)
+    assert lp.config.check_inputs and lp.config.march_order == "auto"
+    assert check_inputs_and_choose_march(img, img.grid_idx.int(), 2) == _lib.LP_MARCH_RAYS_PER_WAVE
+    assert check_inputs_and_choose_march(rnd, rnd.grid_idx.int(), 2) == _lib.LP_MARCH_SAMPLES_PER_WAVE
+    assert check_inputs_and_choose_march(rnd, rnd.grid_idx.int(), 2, "rays") == _lib.LP_MARCH_RAYS_PER_WAVE
+    try:
+        lp.config.check_inputs = False
+        assert check_inputs_and_choose_march(rnd, rnd.grid_idx.int(), 2) == _lib.LP_MARCH_RAYS_PER_WAVE
+    finally:
+        lp.config.check_inputs = True
+    d = _random_ray_case(2048, 16, 64, seed=5)
+    got = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO)          # auto -> samples per wavefront
+    ref = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO, march_order="rays")
+    for a, b in zip([got[1], got[2]] + list(got[3]), [ref[1], ref[2]] + list(ref[3])):
+        assert float((a - b).abs().max() / b.abs().max()) <= 2e-5
