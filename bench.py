@@ -344,6 +344,19 @@ def _ref_protocol(make_inputs, run, dev, n_reruns=5, n_warmup=2):
     return res
 
 
+def _device_random_rays(gen, n, batch, enc_dim, dev):
+    """tests/utils.py:230-268 of the reference: its benchmark draws the rays ON the device (torch.randn(..., device=device)); so does
+    this (a CPU draw + copy leaves the GPU idle for milliseconds between the protocol's synchronisations)."""
+    rn = lambda *shape: torch.randn(*shape, device=dev, generator=gen)  # noqa: E731
+    grid_idx = torch.randint(0, batch, (n,), device=dev, generator=gen, dtype=torch.long)
+    origins = rn(n, 3) / 3.0
+    directions = -origins + rn(n, 3) * 0.1
+    near = rn(n) * 0.1 + 0.1
+    far = rn(n).abs() * 0.1 + 3.0
+    enc = None if enc_dim is None else rn(n, enc_dim)
+    return lp.Rays(directions=directions, origins=origins, grid_idx=grid_idx, near=near, far=far, encoding=enc)
+
+
 def refbench_renderer(dev, sizes=None, kernel=_lib.LP_KERNEL_AUTO):
     """tests/renderer_speed_benchmark.py:228-285 on this implementation: grid [3,32,32,32,32] as a triplane (three batch entries),
     2/2/2 x 32 decoder with N(0, 0.01) parameters (tests/utils.py:349), 256 samples, random rays (tests/utils.py:230-268)."""
@@ -358,7 +371,7 @@ def refbench_renderer(dev, sizes=None, kernel=_lib.LP_KERNEL_AUTO):
             grids = [g.to(dev).requires_grad_(True) for g in random_grids(gen, gsz)]
             dec = random_decoder(gen, 2, 2, 2, 32, 32, 3, std=0.01)
             params = dec.mlp_params.to(dev).requires_grad_(True)
-            rays = random_rays(gen, n, 3, 32).to(dev)
+            rays = _device_random_rays(torch.Generator(device=dev).manual_seed(it), n, 3, 32, dev)
             rays.encoding.requires_grad_(True)
             return rays, grids, lp.DecoderParams(params, dec.n_hidden_trunk, dec.n_hidden_opacity, dec.n_hidden_color, 3)
 
@@ -394,10 +407,9 @@ def refbench_splatter(dev, views=None):
         n = 128 * 128 * nv
 
         def make_inputs(it):
-            gen = torch.Generator().manual_seed(it)
-            rays = random_rays(gen, n, 1, None)
-            rays.encoding = torch.rand(n, 64, generator=gen)
-            rays = rays.to(dev)
+            gen = torch.Generator(device=dev).manual_seed(it)
+            rays = _device_random_rays(gen, n, 1, None, dev)
+            rays.encoding = torch.rand(n, 64, device=dev, generator=gen)
             rays.encoding.requires_grad_(True)
             return rays
 

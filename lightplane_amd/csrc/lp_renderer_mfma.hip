@@ -263,10 +263,6 @@ bool renderer_mfma_f32_supported(const LpRendererArgs& a) {
 int renderer_mfma_segments(const LpRendererArgs& a) {
   static const int forced = getenv("LP_SEGMENTS") ? atoi(getenv("LP_SEGMENTS")) : -1;
   if (forced == 0 || a.arithmetic != LP_ARITH_DEFAULT) return 1;
-  // the transposed march deals small batches over the chip by rays per wave: no segments
-  if (a.march_order == LP_MARCH_SAMPLES_PER_WAVE && a.march.num_samples >= 32 && !(a.noise_sigma > 0.0f) && !a.march.contract_coords &&
-      !a.scaffold)
-    return 1;
   if (a.march.num_samples_inf != 0 || a.stop_neg_log_t > 0.0f) return 1;
   const int n_seg = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
   if (n_seg < 2) return 1;

@@ -510,9 +510,11 @@ static int launch_tm_gm(const LpRendererArgs& a, const MfmaParams& mp, int gm, h
   }
 }
 
-// the transposed march covers: PLAIN, checkpoints present, at least one full block of samples, one sweep per ray
+// the transposed march covers: PLAIN, checkpoints present, at least one full block of samples.  (A small batch's forward may have
+// marched segments in parallel -- seg_prefix -- which this backward does not need: it deals a small batch over the chip by rays per
+// wave, and every ray's samples lie in one wave.)
 bool renderer_bwd_tm_supported(const LpRendererArgs& a) {
-  return bwd_is_plain(a) && a.neg_log_t_ckpt != nullptr && a.march.num_samples >= 32 && !a.seg_prefix && a.arithmetic == LP_ARITH_DEFAULT;
+  return bwd_is_plain(a) && a.neg_log_t_ckpt != nullptr && a.march.num_samples >= 32 && a.arithmetic == LP_ARITH_DEFAULT;
 }
 
 int renderer_bwd_bf3_tm_launch(const LpRendererArgs& a, const MfmaParams& mp, int gm, hipStream_t stream) {

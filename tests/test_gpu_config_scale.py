@@ -472,6 +472,7 @@ def test_transposed_march_on_random_rays(n_rays, C, S, tri, cc, mask):
     got = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO, march_order="samples")
     for a, b in zip(got[0], ref[0]):
         assert torch.equal(a, b)  # (the forward does not depend on the backward's march order)
+    assert lp.backward_segments(d["rays"], d["grids"], d["decoder"], num_samples=S) == (1 if n_rays > 32768 else (S + 15) // 16)  # small batches: segmented forward
     flat = lambda r: [("grad_mlp_params", r[1]), ("grad_encoding", r[2])] + [(f"grad_grid{i}", g) for i, g in enumerate(r[3])]  # noqa: E731
     for (nm, a), (_, b) in zip(flat(got), flat(ref)):
         err = float((a - b).abs().max() / b.abs().max())
