@@ -118,6 +118,9 @@ RENDER_CFGS = {
 RENDER_CFGS["refbench256"] = (256, 256, 256, 32, 32, "refbench256: the 256^2 row of the reference's own speed benchmark (tests/renderer_speed_benchmark.py:228-285) as a "
                                                      "steady-state workload: 65 536 RANDOM rays (tests/utils.py:230-268) over three batch entries, triplane "
                                                      "[3,32,32,32,32], 256 samples, 2/2/2 x 32 decoder with N(0, 0.01) parameters, disparity_at_inf 0.01")
+RENDER_CFGS["cfg5_render"] = (135, 1920, 256, 32, 256, "cfg5 render leg alone: Renderer fwd+bwd, 135x1920 rays of a 1080p camera, VOXEL grid 256^3x32ch (2.15 GB: 8x the "
+                                                         "Infinity Cache), 256 samples, 2-layer/32-hidden MLPs -- the launch the grid-tile-staging question is about")
+VOXEL_CFGS = ("cfg5_render",)
 DECODER_SHAPES = {"h64_example_112": ((1, 1, 2), 64), "h64_222": ((2, 2, 2), 64)}  # everything else: 2/2/2 layers x 32 hidden
 HIDDEN, COLOR = 32, 3
 
@@ -129,7 +132,7 @@ def camera_pose(name, rank):
 
 
 class RendererWorkload:
-    def __init__(self, name, rank, dev, pg, kernel, arithmetic=_lib.LP_ARITH_DEFAULT, with_loss=False):
+    def __init__(self, name, rank, dev, pg, kernel, arithmetic=_lib.LP_ARITH_DEFAULT, with_loss=False, march_order=None):
         from tests.synth import grid_sizes_for, pinhole_rays, random_decoder, random_grids
 
         self.name, self.pg, self.kernel, self.arithmetic, self.with_loss = name, pg, kernel, arithmetic, with_loss
@@ -137,8 +140,11 @@ class RendererWorkload:
         self.S, self.C = S, C
         gen = torch.Generator().manual_seed(0)
         random = name == "refbench256"  # incoherent rays, the reference benchmark's inputs
-        self.sizes = grid_sizes_for((3 if random else 1, G, G, G, C), True)
-        self.grids_c = random_grids(gen, self.sizes)
+        self.sizes = grid_sizes_for((3 if random else 1, G, G, G, C), name not in VOXEL_CFGS)
+        if name in VOXEL_CFGS:  # (2.15 GB: drawn on the device, in slices)
+            self.grids_c = None
+        else:
+            self.grids_c = random_grids(gen, self.sizes)
         self.layers, self.hidden = DECODER_SHAPES.get(name, ((2, 2, 2), HIDDEN))
         self.dec_c = random_decoder(gen, *self.layers, C, self.hidden, COLOR, std=0.01 if random else 0.15 if self.hidden == 32 else 0.1)
         gen_r = torch.Generator().manual_seed(100 + rank)
@@ -150,12 +156,18 @@ class RendererWorkload:
             self.rays_c = pinhole_rays(H, W, enc_dim=int(self.dec_c.n_hidden_color[0]), gen=gen_r, azimuth_deg=az, elevation_deg=el)
         # (bench.py runs with check_inputs off -- no device sync in a timed step --, so "auto" cannot look at the rays: the random-ray
         # workload names its march order; LP_BENCH_MARCH=rays for the A/B)
-        self.render_kw = dict(disparity_at_inf=0.01, march_order=os.environ.get("LP_BENCH_MARCH", "samples")) if random else {}
+        self.render_kw = dict(disparity_at_inf=0.01, march_order=march_order or os.environ.get("LP_BENCH_MARCH", "samples")) if random else {}
         n = H * W
         up = (torch.randn(n, generator=gen_r), torch.randn(n, generator=gen_r), torch.randn(n, COLOR, generator=gen_r))
         self.n_rays = n
         self.rays = self.rays_c.to(dev)
-        self.flat, _ = lp.flatten_grid([g.to(dev) for g in self.grids_c])
+        if self.grids_c is None:
+            gd = torch.Generator(device=dev).manual_seed(0)
+            self.flat = torch.empty(G * G * G, C, device=dev)
+            for z in range(0, G * G * G, 1 << 22):
+                self.flat[z:z + (1 << 22)] = torch.randn(min(1 << 22, G * G * G - z), C, device=dev, generator=gd)
+        else:
+            self.flat, _ = lp.flatten_grid([g.to(dev) for g in self.grids_c])
         self.flat.requires_grad_(True)
         self.params = self.dec_c.mlp_params.to(dev).requires_grad_(True)
         self.rays.encoding.requires_grad_(True)
@@ -165,7 +177,7 @@ class RendererWorkload:
 
     # bytes/ray = S*K*C*4 gathered (fwd) ; the same re-gathered + the same as atomic payload (bwd) ; + ray I/O
     def algorithmic_bytes(self):
-        per_sample = 12 * self.C * 4  # triplane: 3 planes x 4 corners
+        per_sample = (8 if self.name in VOXEL_CFGS else 12) * self.C * 4  # triplane: 3 planes x 4 corners; voxel grid: 8 corners
         return self.n_rays * (self.S * per_sample + 184), self.n_rays * (self.S * per_sample * 2 + 316)
 
     def mlp_flops_fwdbwd(self):
@@ -591,6 +603,8 @@ def counter_clock_ghz(v):
 def issue_bound(v, kname, dw_f32_mfma=None):
     """Issue cycles per SIMD of one launch from its instruction counts (see binding_ceiling)."""
     valu, mfma = v["SQ_INSTS_VALU"], v["SQ_INSTS_MFMA"]
+    if "renderer_bwd_bf3_tm" in kname:  # transposed march: bf16 pipe only (two-limb dX, bf16 dW quadrants)
+        return valu * 4.0 / N_SIMD
     if "renderer_bwd_bf3" in kname and kname.count(",") >= 6:
         # the tuned backward since round 5 (<C, GM, PLAIN, NC, NW, SEG, DUMP, F32>): its weight-gradient products run on the bf16 pipe
         # too (v_mfma_f32_16x16x32_bf16) -- no MFMA serialises with the VALU any more -- unless it is an LP_ARITH_FP32 instantiation
@@ -956,6 +970,10 @@ EXTRAS = (  # key in `extras`, leg
     ("joint_cfg5_one_gpu", lambda dev, k: measure_cfg5(dev, k)),
     ("renderer_h64_example_112", lambda dev, k: measure_extra("h64_example_112", dev, k, 5)),
     ("renderer_h64_222", lambda dev, k: measure_extra("h64_222", dev, k, 5)),
+    # 65 536 RANDOM rays (the reference benchmark's 256^2 row as a steady-state workload): the backward's transposed march
+    # (samples per wavefront), and the rays-per-wavefront kernel of rounds 1-5 on the same input for the A/B
+    ("renderer_refbench256_random_rays", lambda dev, k: measure_extra("refbench256", dev, k, 10, march_order="samples")),
+    ("renderer_refbench256_random_rays_march_rays", lambda dev, k: measure_extra("refbench256", dev, k, 5, march_order="rays")),
     # the reference's own benchmark axes (its protocol: wall time incl. host side, fresh inputs per rerun)
     ("refbench_renderer", lambda dev, k: refbench_renderer(dev, [256, 1024], k)),
     ("refbench_splatter", lambda dev, k: refbench_splatter(dev, [1, 16])),
@@ -973,7 +991,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: >= 0.5 s of work: 200 for cfg2 / cfg3, "
                                                             "10 for the 1080p workloads)")
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "1080p_s128", "cfg3", "small", "cfg5", "refbench", "refbench_splatter", "h64_example_112", "h64_222", "refbench256"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "1080p_s128", "cfg3", "small", "cfg5", "refbench", "refbench_splatter", "h64_example_112", "h64_222", "refbench256", "cfg5_render"])
     ap.add_argument("--refbench-max", type=float, default=None, help="refbench: largest image size (default 2048) / refbench_splatter: "
                                                                       "largest num_view (default 256)")
     ap.add_argument("--kernel", type=int, default=_lib.LP_KERNEL_AUTO)
@@ -982,7 +1000,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the "
                                                        "multi-rank code path with several ranks on one GPU)")
     args = ap.parse_args()
-    big = args.workload in ("cfg4", "1080p_s128", "h64_example_112", "h64_222", "refbench256")
+    big = args.workload in ("cfg4", "1080p_s128", "h64_example_112", "h64_222", "refbench256", "cfg5_render")
     steps = args.steps if args.steps is not None else (2 if args.workload == "cfg5" else 10 if big else 200)
     warmup = args.warmup if args.warmup is not None else (1 if args.workload == "cfg5" else 2 if big else 10)
 

@@ -116,8 +116,8 @@ extern "C" {
  *   LP_MARCH_SAMPLES_PER_WAVE  a wavefront = 32 consecutive samples of ONE ray (its rays one after the other): merges the samples a
  *                              ray spends in one cell -- for batches of unrelated rays (random training batches; the reference's speed
  *                              benchmark, tests/renderer_speed_benchmark.py:228-246), where every ray is its own run otherwise and
- *                              the backward is bound by the chip's atomic rate.  Tuned family, plain configuration (no beyond-far
- *                              samples, contraction, scaffold, noise, early termination), >= 32 samples; ignored elsewhere. */
+ *                              the backward is bound by the chip's atomic rate.  Tuned family, no beyond-far samples, no early
+ *                              termination, >= 32 samples; ignored elsewhere (the rays-per-wavefront kernels run). */
 #define LP_MARCH_RAYS_PER_WAVE 0
 #define LP_MARCH_SAMPLES_PER_WAVE 1
 

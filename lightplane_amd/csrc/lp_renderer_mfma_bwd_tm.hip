@@ -21,8 +21,8 @@
 //  * the ray encoding is wave-uniform: cb = b_c1 + W_c1^T enc and enc live in a 256-byte record per wave; the colour layer's weight
 //    gradient takes X = e + enc directly (no per-ray epilogue product), d enc = W_c1 sum_s d hc is formed once per ray after a
 //    cross-lane reduction.
-// Scope: the PLAIN configuration (no beyond-far samples, contraction, scaffold, noise, early termination), one sweep per ray,
-// four-wave workgroups, default arithmetic.  Selected by LpRendererArgs.march_order == LP_MARCH_SAMPLES_PER_WAVE (the Python
+// Scope: no beyond-far samples, no early termination (opacity noise, contraction, scaffold and the out-of-bounds mask are covered:
+// PLAIN = false), at least 32 samples, four-wave workgroups, default arithmetic.  Selected by LpRendererArgs.march_order == LP_MARCH_SAMPLES_PER_WAVE (the Python
 // front-end sets it for batches whose consecutive rays do not share an origin, see lightplane_amd/renderer.py).
 #include "lp_renderer_mfma_bwd.h"
 
@@ -53,7 +53,7 @@ struct TmLds {
   static_assert(2 * TOTAL <= 160 * 1024, "two workgroups per CU");
 };
 
-template <int C, int GM, int NC, bool DUMP = false>
+template <int C, int GM, int NC, bool PLAIN, bool DUMP = false>
 __global__ void __launch_bounds__(256, 2) renderer_bwd_bf3_tm(const LpRendererArgs a, const MfmaParams mp) {
   using M = Lds;
   using R = LdsBf3Rm<C>;
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_bf3_tm(const LpRendererAr
 
   auto sample_of = [&](int blk_s) { const int s = blk_s * 32 + r; return s < S ? s : S - 1; };  // (lanes beyond S re-do the last sample, dead)
   Sample<C> nx;
-  fetch_sample<C, GM, false, true>(a, sm, ray, sample_of(bs), h, nx);
+  fetch_sample<C, GM, false, PLAIN>(a, sm, ray, sample_of(bs), h, nx);
   const int n_it = rpw * n_blk;
   for (int it = 0; it < n_it; ++it) {
     if (new_ray) {  // wave-uniform: per-ray scalars, cb = b_c1 + W_c1^T enc and enc into the wave's record
@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_bf3_tm(const LpRendererAr
     }
     const int s = bs * 32 + r;
     const bool on = s < S;
-    const float depth = nx.depth, x = nx.x, y = nx.y, z = nx.z;
+    const float depth = nx.depth, occ = nx.occ, x = nx.x, y = nx.y, z = nx.z;
     const int b_cur = ray.b;
     float x0[C / 2];
 #pragma unroll
@@ -216,10 +216,12 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_bf3_tm(const LpRendererAr
 
     // ---------------- compositing, backward: wave scans along the ray ----------------
     const int sc = on ? s : S - 1;
-    const float depth_prev = ray.near_t + lin01((sc > 0) ? sc - 1 : 0, S) * (ray.far_t - ray.near_t);
+    const float depth_prev = PLAIN ? ray.near_t + lin01((sc > 0) ? sc - 1 : 0, S) * (ray.far_t - ray.near_t)
+                                   : sample_depth_tab((sc > 0) ? sc - 1 : 0, a.march, ray.near_t, ray.far_t, sm + M::INF);
     const float delta = (sc == 0) ? delta0 : depth - depth_prev;
-    const float raw = hd.raw_o;
-    const float opacity = a.gain * softplus_f(raw);
+    float raw = hd.raw_o;
+    if (!PLAIN && a.noise_sigma > 0.0f) raw = raw + sample_noise(rid, sc, a.rays.n_rays, S, a.noise_seed) * a.noise_sigma;
+    const float opacity = a.gain * softplus_f(raw) * occ;
     const float od = on ? opacity * delta : 0.0f;
     float n_hi = 0.0f, n_lo = 0.0f;  // -log T behind the previous block: the forward's checkpoint (a float pair)
     if (bs > 0) {
@@ -239,7 +241,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_bf3_tm(const LpRendererAr
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       sg[c] = (c < NC) ? sigmoid_f(hd.raw_c[c]) : 0.0f;
-      if (c < NC) p_i = fmaf(gfeat[c], sg[c], p_i);
+      if (c < NC) p_i = fmaf(gfeat[c], sg[c] * occ, p_i);
     }
     p_i = on ? p_i : 0.0f;
     float p_up = __shfl_down(p_i, 1, 32);          // p of the next (farther) sample
@@ -251,10 +253,10 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_bf3_tm(const LpRendererAr
     const float next_suffix_carry = __shfl(suffix, 0, 32);
     const float next_p_carry = __shfl(p_i, 0, 32);
     const bool contrib = valid && on;
-    const float dro = contrib ? d_a * delta * a.gain * d_softplus_f(raw) : 0.0f;
+    const float dro = contrib ? d_a * delta * a.gain * occ * d_softplus_f(raw) : 0.0f;
     float drc[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) drc[c] = (c < NC && contrib) ? w * gfeat[c] * sg[c] * (1.0f - sg[c]) : 0.0f;
+    for (int c = 0; c < 4; ++c) drc[c] = (c < NC && contrib) ? w * gfeat[c] * occ * sg[c] * (1.0f - sg[c]) : 0.0f;
 
     // ---------------- output layers of the heads (VALU) ----------------
     float dhc[16];
@@ -387,7 +389,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_bf3_tm(const LpRendererAr
     }
     LP_SCHED_FENCE();
     __builtin_amdgcn_s_setprio(0);
-    const bool live = contrib;
+    const bool live = contrib && !(a.march.mask_out_of_bounds && !point_in_bounds(x, y, z));  // a masked sample scatters nothing
 
     // ---------------- the ray is done: d enc = W_c1 D, D = the ray's sum of d hc over lanes and blocks ----------------
     suffix_carry = next_suffix_carry;
@@ -420,7 +422,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_bf3_tm(const LpRendererAr
       new_ray = false;
     }
     // ---------------- next iteration's samples + grid gradient of this one ----------------
-    if (it + 1 < n_it) fetch_sample<C, GM, true, true>(a, sm, ray, sample_of(bs), h, nx);
+    if (it + 1 < n_it) fetch_sample<C, GM, true, PLAIN>(a, sm, ray, sample_of(bs), h, nx);
     LP_SCHED_FENCE();
     if (gg && !(mp.dbg & 2)) {
       if constexpr (GM == GM_TRIPLANE) {
@@ -475,7 +477,7 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_bf3_tm(const LpRendererAr
   }
 }
 
-template <int C, int GM, int NC, bool DUMP>
+template <int C, int GM, int NC, bool PLAIN, bool DUMP>
 static int launch_tm(const LpRendererArgs& a, const MfmaParams& mp_, hipStream_t stream) {
   // rays per wave: 32 once the batch fills two rounds of resident workgroups (2 per CU); a smaller batch is spread over the chip --
   // every workgroup pays the weight staging and the dW flush once, so not below 1 024 workgroups' worth
@@ -486,35 +488,38 @@ static int launch_tm(const LpRendererArgs& a, const MfmaParams& mp_, hipStream_t
   if (forced >= 1 && forced <= RAYS_PER_WAVE) rpw = forced;
   mp.tm_rpw = rpw;
   constexpr size_t lds = (size_t)TmLds<C>::TOTAL;
-  const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_bf3_tm<C, GM, NC, DUMP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_bf3_tm<C, GM, NC, PLAIN, DUMP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   const unsigned nb = (unsigned)((a.rays.n_rays + WAVES * rpw - 1) / (WAVES * rpw));
-  hipLaunchKernelGGL((renderer_bwd_bf3_tm<C, GM, NC, DUMP>), dim3(nb), dim3(256), lds, stream, a, mp);
+  hipLaunchKernelGGL((renderer_bwd_bf3_tm<C, GM, NC, PLAIN, DUMP>), dim3(nb), dim3(256), lds, stream, a, mp);
   return LP_OK;
 }
-template <int C, int GM>
+template <int C, int GM, bool PLAIN>
 static int launch_tm_nc(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t stream) {
 #ifdef LP_TEST_HOOKS
-  if (mp.relu_dump) return a.color_chn <= 3 ? launch_tm<C, GM, 3, true>(a, mp, stream) : launch_tm<C, GM, 4, true>(a, mp, stream);
+  if (mp.relu_dump) return a.color_chn <= 3 ? launch_tm<C, GM, 3, PLAIN, true>(a, mp, stream) : launch_tm<C, GM, 4, PLAIN, true>(a, mp, stream);
 #else
   if (mp.relu_dump) return set_error(LP_EUNSUPPORTED, "relu dump: this library was built without -DLP_TEST_HOOKS (no DUMP twins)");
 #endif
-  return a.color_chn <= 3 ? launch_tm<C, GM, 3, false>(a, mp, stream) : launch_tm<C, GM, 4, false>(a, mp, stream);
+  return a.color_chn <= 3 ? launch_tm<C, GM, 3, PLAIN, false>(a, mp, stream) : launch_tm<C, GM, 4, PLAIN, false>(a, mp, stream);
 }
 template <int C>
 static int launch_tm_gm(const LpRendererArgs& a, const MfmaParams& mp, int gm, hipStream_t stream) {
+  const bool plain = bwd_is_plain(a);
   switch (gm) {
-    case GM_TRIPLANE: return launch_tm_nc<C, GM_TRIPLANE>(a, mp, stream);
-    case GM_VOXEL: return launch_tm_nc<C, GM_VOXEL>(a, mp, stream);
-    default: return launch_tm_nc<C, GM_GENERIC>(a, mp, stream);
+    case GM_TRIPLANE: return plain ? launch_tm_nc<C, GM_TRIPLANE, true>(a, mp, stream) : launch_tm_nc<C, GM_TRIPLANE, false>(a, mp, stream);
+    case GM_VOXEL: return plain ? launch_tm_nc<C, GM_VOXEL, true>(a, mp, stream) : launch_tm_nc<C, GM_VOXEL, false>(a, mp, stream);
+    default: return plain ? launch_tm_nc<C, GM_GENERIC, true>(a, mp, stream) : launch_tm_nc<C, GM_GENERIC, false>(a, mp, stream);
   }
 }
 
-// the transposed march covers: PLAIN, checkpoints present, at least one full block of samples.  (A small batch's forward may have
+// the transposed march covers: no beyond-far samples (<= 64 would fit the table, but their -log T jumps by orders of magnitude per
+// sample: the in-block scan is not the place for them), no early termination, checkpoints present, at least one full block of samples.  (A small batch's forward may have
 // marched segments in parallel -- seg_prefix -- which this backward does not need: it deals a small batch over the chip by rays per
 // wave, and every ray's samples lie in one wave.)
 bool renderer_bwd_tm_supported(const LpRendererArgs& a) {
-  return bwd_is_plain(a) && a.neg_log_t_ckpt != nullptr && a.march.num_samples >= 32 && a.arithmetic == LP_ARITH_DEFAULT;
+  return a.march.num_samples_inf == 0 && !(a.stop_neg_log_t > 0.0f) && a.neg_log_t_ckpt != nullptr && a.march.num_samples >= 32 &&
+         a.arithmetic == LP_ARITH_DEFAULT;
 }
 
 int renderer_bwd_bf3_tm_launch(const LpRendererArgs& a, const MfmaParams& mp, int gm, hipStream_t stream) {

@@ -31,7 +31,8 @@ for w in $WL; do
     h64_example_112) run h64_example_112 20 1 ;;
     cfg5) run cfg5 3 1 ;;                    # BASELINE configs[4] at its per-GPU size (a step takes ~0.27 s): kernel trace + counters of the
                                              # render / splat kernels on the 256^3 x 32 grid (2.15 GB: the grid does NOT fit the caches)
-    refbench256) run refbench256 20 2 ;;     # the reference benchmark's 256^2 row: 65 536 RANDOM rays (incoherent scatter)
+    refbench256) run refbench256 20 2 ;;
+    cfg5_render) run cfg5_render 5 1 ;;      # the render leg of cfg 5 alone (voxel 256^3 x 32 ch)     # the reference benchmark's 256^2 row: 65 536 RANDOM rays (incoherent scatter)
     loop)  # the headline workload through the layer-looped family (LP_LOOP=1: shallow two-waves-per-SIMD backward)
       export LP_LOOP=1
       rm -rf $R/gpurun_out/prof_loop $R/gpurun_out/pmc[1-4]_loop

@@ -22,6 +22,7 @@ CMD = {"cfg2": "python bench.py --workload cfg2 --no-cpu-baseline --no-extras --
        "1080p_s128": "python bench.py --workload 1080p_s128 --no-cpu-baseline --no-extras --steps 5 --warmup 3",
        "cfg5": "python bench.py --workload cfg5 --no-cpu-baseline --no-extras --steps 3 --warmup 3",
        "refbench256": "python bench.py --workload refbench256 --no-cpu-baseline --no-extras --steps 20 --warmup 3",
+       "cfg5_render": "python bench.py --workload cfg5_render --no-cpu-baseline --no-extras --steps 5 --warmup 3",
        "loop": "LP_LOOP=1 python bench.py --workload cfg2 --no-cpu-baseline --no-extras --steps 200 --warmup 3",
        "h64_222": "python bench.py --workload h64_222 --no-cpu-baseline --no-extras --steps 20 --warmup 3",
        "h64_example_112": "python bench.py --workload h64_example_112 --no-cpu-baseline --no-extras --steps 20 --warmup 3"}

@@ -441,7 +441,7 @@ def test_splatter_walk_touched_cells_equal_oracle(name):
 # transposed march of the tuned backward (LpRendererArgs.march_order = LP_MARCH_SAMPLES_PER_WAVE): batches of unrelated rays
 # --------------------------------------------------------------------------------------------------------------
 
-def _random_ray_case(n_rays, C, S, triplane=True, B=3, G=32, color_chn=3, seed=0, std=0.2, mask=False):
+def _random_ray_case(n_rays, C, S, triplane=True, B=3, G=32, color_chn=3, seed=0, std=0.2, mask=False, rich=False):
     """The reference benchmark's kind of input (tests/renderer_speed_benchmark.py:228-246, tests/utils.py:230-268): random rays over
     B batch entries of a coarse grid, 2/2/2 x 32 decoder."""
     from tests.synth import random_rays
@@ -453,23 +453,34 @@ def _random_ray_case(n_rays, C, S, triplane=True, B=3, G=32, color_chn=3, seed=0
     up = (torch.randn(n_rays, generator=gen), torch.randn(n_rays, generator=gen), torch.randn(n_rays, color_chn, generator=gen))
     cfg = dict(num_samples=S, gain=1.0, num_samples_inf=0, mask_out_of_bounds_samples=mask, contract_coords=False, inject_noise_sigma=0.0,
                inject_noise_seed=0)
-    return dict(rays=rays, grids=grids, color_grids=None, decoder=dec, scaffold=None, cfg=cfg, sizes=sizes, upstream=up)
+    scaffold = None
+    if rich:  # the non-PLAIN instantiations: opacity noise, contraction, an occupancy scaffold
+        cfg.update(contract_coords=True, inject_noise_sigma=0.4, inject_noise_seed=17)
+        scaffold = (torch.rand(B, 6, 5, 7, generator=gen) > 0.3).float()
+    return dict(rays=rays, grids=grids, color_grids=None, decoder=dec, scaffold=scaffold, cfg=cfg, sizes=sizes, upstream=up)
 
 
-@pytest.mark.parametrize("n_rays,C,S,tri,cc,mask", [(4096, 32, 256, True, 3, False), (3000, 16, 100, True, 3, True), (2500, 32, 40, False, 4, False),
-                                                    (140000, 16, 33, True, 3, False), (777, 16, 32, False, 1, True)],
-                         ids=["refbench_like_c32_s256", "c16_s100_mask", "voxel_c32_rgba_s40", "140k_rays_32_per_wave_s33", "voxel_c16_tail_wave_s32"])
-def test_transposed_march_on_random_rays(n_rays, C, S, tri, cc, mask):
+@pytest.mark.parametrize("n_rays,C,S,tri,cc,mask,rich", [(4096, 32, 256, True, 3, False, False), (3000, 16, 100, True, 3, True, False),
+                                                         (2500, 32, 40, False, 4, False, False), (140000, 16, 33, True, 3, False, False),
+                                                         (777, 16, 32, False, 1, True, False), (3100, 16, 70, True, 3, False, True),
+                                                         (2100, 32, 64, False, 4, False, True)],
+                         ids=["refbench_like_c32_s256", "c16_s100_mask", "voxel_c32_rgba_s40", "140k_rays_32_per_wave_s33", "voxel_c16_tail_wave_s32",
+                              "c16_s70_noise_contract_scaffold", "voxel_c32_rgba_s64_noise_contract_scaffold"])
+def test_transposed_march_on_random_rays(n_rays, C, S, tri, cc, mask, rich):
     """march_order="samples" (one ray x 32 consecutive samples per wavefront: the run merge of the gradient scatter works along the
     ray) against march_order="rays" of the same kernels' arithmetic -- same forward, same recompute, so the same ReLU decisions:
     every gradient within 2e-5 -- and PROVEN against the fp64 oracle (its DUMP twin's decisions forced, every entry at 1e-4).
     Ragged sample counts (a last block of 1 .. 8 samples), a last wave with fewer rays, 1 .. 32 rays per wave (small batches are
     dealt over more workgroups), voxel and triplane scatter walks, three / four colour channels, masked samples."""
     dev = _dev()
-    d = _random_ray_case(n_rays, C, S, triplane=tri, color_chn=cc, mask=mask, seed=n_rays % 97)
+    d = _random_ray_case(n_rays, C, S, triplane=tri, color_chn=cc, mask=mask, seed=n_rays % 97, rich=rich)
     assert lp.kernel_family(d["rays"], d["grids"], d["decoder"]) == 1
     ref = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO, march_order="rays")
     got = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO, march_order="samples")
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:  # the transposed-march kernel is what ran (never a silent fall-back)
+        run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO, march_order="samples")
+    assert any("renderer_bwd_bf3_tm" in e.name for e in prof.events()), "march_order='samples' did not launch the transposed-march backward"
     for a, b in zip(got[0], ref[0]):
         assert torch.equal(a, b)  # (the forward does not depend on the backward's march order)
     assert lp.backward_segments(d["rays"], d["grids"], d["decoder"], num_samples=S) == (1 if n_rays > 32768 else (S + 15) // 16)  # small batches: segmented forward
@@ -478,7 +489,7 @@ def test_transposed_march_on_random_rays(n_rays, C, S, tri, cc, mask):
         err = float((a - b).abs().max() / b.abs().max())
         assert err <= 2e-5, f"{nm}: samples-per-wave vs rays-per-wave {err:.3e}"
     if n_rays <= 4096:
-        forced_oracle_check(f"transposed march {n_rays} rays C={C} S={S}", d, dev, march_order="samples")
+        forced_oracle_check(f"transposed march {n_rays} rays C={C} S={S}", d, dev, chunk=n_rays if rich else 2048, march_order="samples")
 
 
 def test_march_order_auto_picks_by_ray_coherence():
