@@ -18,6 +18,7 @@ namespace lp {
 
 static thread_local char g_err[512] = "";
 thread_local uint32_t* g_relu_dump = nullptr;  // test hook, see lp_host.h
+thread_local const char* g_last_backward = "";
 
 int set_error(int code, const char* fmt, ...) {
   va_list ap;
@@ -351,6 +352,7 @@ int lp_renderer_backward(const LpRendererArgs* args, void* stream) {
   if (a.kernel == LP_KERNEL_MFMA && fam == 0)
     return set_error(LP_EUNSUPPORTED, "MFMA renderer kernel unavailable for this shape: %s", why);
   if (fam == 1 && a.kernel != LP_KERNEL_GENERIC) return renderer_backward_mfma(a, (hipStream_t)stream);
+  g_last_backward = (fam == 3 && a.kernel != LP_KERNEL_GENERIC) ? "layer-looped family" : "shape-generic kernels";
   if (fam == 3 && a.kernel != LP_KERNEL_GENERIC) return renderer_backward_loop(a, (hipStream_t)stream);
   return renderer_backward_generic(a, (hipStream_t)stream);
 }
@@ -443,6 +445,11 @@ int lp_splatter_backward(const LpSplatterArgs* args_, void* stream) {
   }
   return splatter_backward_launch(*args, (hipStream_t)stream);
 }
+
+/* developer / test hook (not part of include/lightplane_hip.h): which Renderer backward the calling thread launched last --
+ * "tuned family, rays per wavefront", "tuned family, samples per wavefront (transposed march)", "layer-looped family",
+ * "shape-generic kernels" (static strings) */
+const char* lp_debug_last_renderer_backward(void) { return g_last_backward; }
 
 /* developer hook (not part of include/lightplane_hip.h): per-phase cycle totals of the MFMA backward,
  * only in builds with -DLP_PHASE_TIMING (returns -1 otherwise) */

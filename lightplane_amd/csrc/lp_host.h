@@ -14,6 +14,8 @@ int check_launch(const char* what);
 // test hook (lp_renderer_backward_relu_dump, lp_api.hip): while non-NULL, the MFMA backwards launch their DUMP twins, which also
 // write the ReLU decisions of the recompute here.  Thread-local; NULL in every product call.
 extern thread_local uint32_t* g_relu_dump;
+// developer / test hook (lp_debug_last_renderer_backward, lp_api.hip): which backward the calling thread launched last
+extern thread_local const char* g_last_backward;
 
 // generic (shape-agnostic) kernels: lp_renderer_generic.hip
 int renderer_forward_generic(const LpRendererArgs& a, hipStream_t stream);

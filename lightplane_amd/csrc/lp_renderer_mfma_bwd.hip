@@ -14,7 +14,11 @@ int renderer_backward_mfma2(const LpRendererArgs& a, const MfmaParams& mp, int g
 #ifdef LP_DEV_ONE
   rc = renderer_bwd_bf3_c16(a, mp, gm, stream);
 #else
-  if (a.march_order == LP_MARCH_SAMPLES_PER_WAVE && renderer_bwd_tm_supported(a)) rc = renderer_bwd_bf3_tm_launch(a, mp, gm, stream);
+  g_last_backward = "tuned family, rays per wavefront";
+  if (a.march_order == LP_MARCH_SAMPLES_PER_WAVE && renderer_bwd_tm_supported(a)) {
+    g_last_backward = "tuned family, samples per wavefront (transposed march)";
+    rc = renderer_bwd_bf3_tm_launch(a, mp, gm, stream);
+  }
   else if (mp.relu_dump) rc = renderer_bwd_bf3_dump(a, mp, gm, stream);                    // test hook
   else if (a.arithmetic == LP_ARITH_FP32) rc = renderer_bwd_bf3_f32(a, mp, gm, stream);     // the reference's arithmetic, per call
   else if (a.grid.channels == 16) rc = renderer_bwd_bf3_c16(a, mp, gm, stream);

@@ -479,12 +479,13 @@ __global__ void __launch_bounds__(256, 2) renderer_bwd_bf3_tm(const LpRendererAr
 
 template <int C, int GM, int NC, bool PLAIN, bool DUMP>
 static int launch_tm(const LpRendererArgs& a, const MfmaParams& mp_, hipStream_t stream) {
-  // rays per wave: 32 once the batch fills two rounds of resident workgroups (2 per CU); a smaller batch is spread over the chip --
-  // every workgroup pays the weight staging and the dW flush once, so not below 1 024 workgroups' worth
+  // rays per wave: 32 once the batch fills one round of resident workgroups (2 per CU = 512); a smaller batch is spread over the chip
+  // with fewer rays per wave (every workgroup pays the weight staging and the dW flush once).  Measured on 65 536 random rays
+  // (refbench256, fwd + bwd): 32 rays per wave 7.15 ms, 16: 7.52, 8: 7.78, 4: 8.86 (profiles/r06_transposed_march.txt)
   MfmaParams mp = mp_;
   static const int forced = getenv("LP_TM_RPW") ? atoi(getenv("LP_TM_RPW")) : 0;
   int rpw = RAYS_PER_WAVE;
-  while (rpw > 1 && (a.rays.n_rays + WAVES * rpw - 1) / (WAVES * rpw) < 1024) rpw >>= 1;
+  while (rpw > 1 && (a.rays.n_rays + WAVES * rpw - 1) / (WAVES * rpw) < 512) rpw >>= 1;
   if (forced >= 1 && forced <= RAYS_PER_WAVE) rpw = forced;
   mp.tm_rpw = rpw;
   constexpr size_t lds = (size_t)TmLds<C>::TOTAL;
