@@ -839,6 +839,8 @@ def measure_cfg5(dev, kernel, reps=2):
     peak_mb = reference_protocol_peak_mb(wl, dev)
     obs = observed_kernels(wl, 1)
     roof = wl.roofline(fwd_ms, bwd_ms)
+    roof["binding"] = soft(cfg5_binding)
+    roof["grid_tile_staging"] = GRID_TILE_STAGING
     out = {"workload": wl.desc, "rays": wl.n_rays, "splat_rays": wl.splat_rays.n_rays, "render_rays": wl.cam.n_rays,
            "fwd_ms": round(fwd_ms, 3), "bwd_ms": round(bwd_ms, 3), "Mrays_per_s_fwd_bwd": round(wl.n_rays / (fwd_ms + bwd_ms) / 1e3, 4),
            "reps": reps, "peak_bwd_mem_mb": round(peak_mb, 1), "roofline": roof,
@@ -935,13 +937,56 @@ def relabel(roof):
 
 GRID_TILE_STAGING = {
     "built": False,
-    "why": ("north_star names LDS staging of grid tiles; measured instead of built.  cfg-2 backward: FETCH_SIZE ~10 MB per launch against "
-            "12.9 GB of algorithmic gather bytes (the 786 KB grid is L1 / L2 resident; L2->fabric traffic is 0.06x the algorithmic bytes), "
-            "the gather phase is 3.7 k of 31.9 k cycles per wave-sample (profiles/r05_backward_phase_cycles.txt) while VALU issue "
-            "is ~0.6 of the kernel time; a 128-ray workgroup's footprint on an edge-on plane spans 131 KB (more than the LDS left beside "
-            "the weight images) and is camera dependent.  MLP weights ARE LDS staged (bf16x3 limb images)."),
-    "evidence": ["profiles/r05_pmc_summary.json", "profiles/r05_backward_phase_cycles.txt"],
+    "decision": "waived on evidence at the configuration where it could matter",
+    "why": ("north_star names LDS staging of grid tiles.  Decided with counters on cfg 5's render leg, the one launch whose grid does NOT fit "
+            "any cache (voxel 256^3 x 32 ch = 2.15 GB: 8x the Infinity Cache, 500x the L2; 135 x 1920 rays, 256 samples): L2 -> fabric fetch "
+            "traffic of the forward is 0.17 GB per launch against 67.9 GB of algorithmic gather bytes (0.0025x), of the backward 0.23 GB "
+            "(+ 0.60 GB of merged atomic segments) against 135.9 GB (0.006x); the backward's fetch phase is 4.2 k of 33.8 k cycles per "
+            "wave-sample (12.5 %).  The round-5 review's criterion -- build it if fetch traffic > 1.5x algorithmic or the fetch phase > 25 % "
+            "of the sample -- is missed by three orders of magnitude / a factor two: image-coherent rays re-read the rows their neighbours "
+            "(lanes, and the previous sample) just pulled into the 32 KB L1 / 4 MB L2, which is exactly the reuse a staged tile would "
+            "capture; a 128-ray workgroup's footprint (131 KB on an edge-on plane) would not fit the LDS left beside the weight images "
+            "anyway.  cfg 2: FETCH_SIZE ~12 MB per backward launch against 12.9 GB.  Incoherent rays get their locality from the "
+            "transposed march instead (consecutive samples of one ray per wavefront).  MLP weights ARE LDS staged (bf16x3 limb images)."),
+    "evidence": ["profiles/r06_pmc_summary.json (cfg5: / cfg5_render: entries)", "profiles/r06_cfg5_render_phase_cycles.txt",
+                 "profiles/r06_kernel_stats_cfg5.csv"],
 }
+
+
+def cfg5_binding(observed=None):
+    """What binds the four kernels of cfg 5 (committed counter passes of `bench.py --workload cfg5`, profiles/rNN_pmc_summary.json):
+    per kernel the L2 -> fabric traffic against the algorithmic bytes of SURVEY 8(d), the atomic-segment rate of the splat walk and
+    the issue fraction of the render backward.  None when no counters are committed."""
+    ns, nr, S, C = 13 * 512 * 512, 135 * 1920, 256, 32
+    alg = {"splat_fwd_walk": ns * S * (8 * C * 4 + 8 * 4), "splat_bwd_walk": ns * S * 8 * C * 4,
+           "renderer_fwd": nr * S * 8 * C * 4, "renderer_bwd": nr * S * 8 * C * 4 * 2}
+    d0 = os.path.join(REPO, "profiles")
+    files = [f for f in glob.glob(os.path.join(d0, "r*_pmc_summary.json")) if _PMC_FILE.search(os.path.basename(f))]
+    files.sort(key=lambda f: int(_PMC_FILE.search(os.path.basename(f)).group(1)), reverse=True)
+    for f in files:
+        d = json.load(open(f))
+        ent = {k.split(": ", 1)[1]: v for k, v in d.items() if k.startswith("cfg5: ") and "FETCH_SIZE" in v}
+        if not ent:
+            continue
+        out = {"source": os.path.relpath(f, REPO) + " (committed counter passes, not this run)", "kernels": {}}
+        for kn, v in ent.items():
+            key = next((a for a in alg if a in kn), None)
+            if key is None:
+                continue
+            ms = (v.get("trace_duration_ns") or v.get("pmc_duration_ns") or 0.0) / 1e6
+            e = {"ms": round(ms, 3), "fetch_gb": round(v["FETCH_SIZE"] * 1024 / 1e9, 3), "write_gb": round(v.get("WRITE_SIZE", 0.0) * 1024 / 1e9, 3),
+                 "algorithmic_gb": round(alg[key] / 1e9, 1),
+                 "fabric_traffic_over_algorithmic": round((v["FETCH_SIZE"] + v.get("WRITE_SIZE", 0.0)) * 1024 / alg[key], 4)}
+            if key == "splat_fwd_walk" and ms:
+                segs = v["WRITE_SIZE"] * 1024 / 64.0
+                e.update(kind="atomic segments", segments_per_launch=round(segs), frac_segments=round(segs / (ms * 1e-3) / ATOMIC_SEGMENTS_PER_S, 4))
+            elif v.get("SQ_INSTS_VALU") and ms:
+                clk = counter_clock_ghz(v) or CLOCK_GHZ
+                e.update(kind="issue", frac_issue=round(v["SQ_INSTS_VALU"] * 4.0 / N_SIMD / (clk * 1e6) / ms, 4))
+            out["kernels"][kn] = e
+        out["kind"] = "per kernel: splat forward walk = atomic segments; the others = instruction issue; fabric traffic << algorithmic bytes everywhere"
+        return out
+    return None
 
 
 def soft(fn, *a, **kw):
@@ -1114,7 +1159,13 @@ def main():
         roof["traffic"] = traffic
         roof["dominant_kernel"] = dom
         if dom and dom in observed:
-            roof["dominant_kernel_ms"] = round(observed[dom]["mean_ms"], 4)
+            # one kernel, three clocks -- named, so that they cannot be mistaken for one another: torch.profiler's device timeline of
+            # this run (instrumented: runs ~5-10 % long), HIP events around the whole backward of this run (`bwd_ms`, what `achieved`
+            # uses), and rocprofv3's kernel trace of the committed profile pass
+            roof["dominant_kernel_ms_torch_profiler"] = round(observed[dom]["mean_ms"], 4)
+            pv, _, _ = pmc_entry(args.workload, dom)
+            if pv and pv.get("trace_duration_ns"):
+                roof["dominant_kernel_ms_rocprof_committed"] = round(pv["trace_duration_ns"] / 1e6, 4)
         roof["binding"] = soft(binding_ceiling, args.workload, wl, fwd_ms, bwd_ms, observed)
         relabel(roof)
         roof["traffic_source"] = (f"{src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, NOT measured in "
