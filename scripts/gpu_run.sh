@@ -37,7 +37,7 @@ for step in "$@"; do
           echo "$(basename $f): $(LIGHTPLANE_AMD_LIB=$PWD/$f timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras $arg 2>&1 | tail -1 |
             python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], "Mrays/s fwd", d["fwd_ms"], "bwd", d["bwd_ms"])' 2>&1 | tail -1)"
         done; done > "$log" 2>&1 ;;
-    profile) bash scripts/gpu_profile.sh ${arg//,/ } > "$log" 2>&1; python scripts/summarize_profiles.py ${LP_ROUND:-r04} >> "$log" 2>&1 ;;
+    profile) bash scripts/gpu_profile.sh ${arg//,/ } > "$log" 2>&1; python scripts/summarize_profiles.py ${LP_ROUND:-r06} ${arg:-cfg2,cfg3,cfg4} >> "$log" 2>&1 ;;  # (only the workloads profiled here: the round's other entries stay)
     py) timeout 900 python scripts/$arg > "$log" 2>&1; echo "rc=$?" >> "$log" ;;
     hip) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 scripts/$arg -o /tmp/probe_bin > "$log" 2>&1 && timeout 300 /tmp/probe_bin >> "$log" 2>&1 ;;
     *) echo "unknown step $step"; continue ;;
