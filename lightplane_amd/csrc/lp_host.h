@@ -27,6 +27,8 @@ bool renderer_mfma_supported(const LpRendererArgs& a, const char** why);
 int renderer_forward_mfma(const LpRendererArgs& a, hipStream_t stream);
 int renderer_backward_mfma(const LpRendererArgs& a, hipStream_t stream);
 int renderer_mfma_segments(const LpRendererArgs& a);  // segments of the segment-parallel backward (1 = none)
+bool renderer_tm_eligible(const LpRendererArgs& a);                        // these arguments may march samples per wavefront (forward and backward)
+int renderer_tm_rays_per_wave(const LpRendererArgs& a, int resident_workgroups);  // rays per wave of that march (1 .. 32)
 bool renderer_mfma_f32_supported(const LpRendererArgs& a);  // the tuned family has an LP_ARITH_FP32 instantiation for these arguments
 int renderer_forward_combine_launch(const LpRendererArgs& a, int seg_blocks, hipStream_t stream);  // chains the segments of a segmented forward
 

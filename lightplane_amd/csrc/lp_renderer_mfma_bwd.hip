@@ -15,7 +15,7 @@ int renderer_backward_mfma2(const LpRendererArgs& a, const MfmaParams& mp, int g
   rc = renderer_bwd_bf3_c16(a, mp, gm, stream);
 #else
   g_last_backward = "tuned family, rays per wavefront";
-  if (a.march_order == LP_MARCH_SAMPLES_PER_WAVE && renderer_bwd_tm_supported(a)) {
+  if (renderer_bwd_tm_supported(a)) {
     g_last_backward = "tuned family, samples per wavefront (transposed march)";
     rc = renderer_bwd_bf3_tm_launch(a, mp, gm, stream);
   }

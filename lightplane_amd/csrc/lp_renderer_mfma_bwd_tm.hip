@@ -483,10 +483,7 @@ static int launch_tm(const LpRendererArgs& a, const MfmaParams& mp_, hipStream_t
   // with fewer rays per wave (every workgroup pays the weight staging and the dW flush once).  Measured on 65 536 random rays
   // (refbench256, fwd + bwd): 32 rays per wave 7.15 ms, 16: 7.52, 8: 7.78, 4: 8.86 (profiles/r06_transposed_march.txt)
   MfmaParams mp = mp_;
-  static const int forced = getenv("LP_TM_RPW") ? atoi(getenv("LP_TM_RPW")) : 0;
-  int rpw = RAYS_PER_WAVE;
-  while (rpw > 1 && (a.rays.n_rays + WAVES * rpw - 1) / (WAVES * rpw) < 512) rpw >>= 1;
-  if (forced >= 1 && forced <= RAYS_PER_WAVE) rpw = forced;
+  const int rpw = renderer_tm_rays_per_wave(a, 512);
   mp.tm_rpw = rpw;
   constexpr size_t lds = (size_t)TmLds<C>::TOTAL;
   const hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_bf3_tm<C, GM, NC, PLAIN, DUMP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -519,8 +516,7 @@ static int launch_tm_gm(const LpRendererArgs& a, const MfmaParams& mp, int gm, h
 // marched segments in parallel -- seg_prefix -- which this backward does not need: it deals a small batch over the chip by rays per
 // wave, and every ray's samples lie in one wave.)
 bool renderer_bwd_tm_supported(const LpRendererArgs& a) {
-  return a.march.num_samples_inf == 0 && !(a.stop_neg_log_t > 0.0f) && a.neg_log_t_ckpt != nullptr && a.march.num_samples >= 32 &&
-         a.arithmetic == LP_ARITH_DEFAULT;
+  return renderer_tm_eligible(a) && a.neg_log_t_ckpt != nullptr && a.arithmetic == LP_ARITH_DEFAULT;
 }
 
 int renderer_bwd_bf3_tm_launch(const LpRendererArgs& a, const MfmaParams& mp, int gm, hipStream_t stream) {

@@ -198,9 +198,11 @@ def relu_dump_words(rays: Rays, grid, decoder_params: DecoderParams, grid_sizes=
 
 def backward_segments(rays: Rays, grid, decoder_params: DecoderParams, num_samples: int, num_samples_inf: int = 0,
                       grid_sizes=None, color_grid=None, color_grid_sizes=None, stop_transmittance: float = 0.0,
-                      kernel: int = _lib.LP_KERNEL_AUTO, arithmetic: Optional[int] = None, **_unused) -> int:
+                      kernel: int = _lib.LP_KERNEL_AUTO, arithmetic: Optional[int] = None, march_order: str = "rays", **_unused) -> int:
     """Number of ray segments the backward of this call is split into (``lp_renderer_backward_segments``; needs no
-    GPU): 1 = one sweep per ray, > 1 = small batch, every block of 16 samples of a ray in its own workgroup."""
+    GPU): 1 = one sweep per ray, > 1 = small batch, every block of 16 samples of a ray in its own workgroup.  ``march_order``
+    "samples" (the transposed march, where it applies) never segments: it deals a small batch over the chip by rays per wave."""
+    _unused.pop("march_order", None)
     _check_render_kwargs("backward_segments", _unused)
     a = _shape_args(grid, decoder_params, grid_sizes, color_grid, color_grid_sizes)
     a.rays.n_rays = int(rays.directions.shape[0])
@@ -208,6 +210,7 @@ def backward_segments(rays: Rays, grid, decoder_params: DecoderParams, num_sampl
     a.stop_neg_log_t = -math.log(stop_transmittance) if stop_transmittance and stop_transmittance > 0 else 0.0
     a.kernel = int(kernel)
     a.arithmetic = int(config.arithmetic if arithmetic is None else arithmetic)
+    a.march_order = _lib.LP_MARCH_SAMPLES_PER_WAVE if march_order == "samples" else _lib.LP_MARCH_RAYS_PER_WAVE
     return int(_lib.lib().lp_renderer_backward_segments(ctypes.byref(a)))
 
 

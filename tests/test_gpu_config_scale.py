@@ -481,9 +481,11 @@ def test_transposed_march_on_random_rays(n_rays, C, S, tri, cc, mask, rich):
     last = _lib.lib().lp_debug_last_renderer_backward
     last.restype = ctypes.c_char_p
     assert b"transposed march" in last(), f"march_order='samples' did not launch the transposed-march backward: {last()}"  # never a silent fall-back
-    for a, b in zip(got[0], ref[0]):
-        assert torch.equal(a, b)  # (the forward does not depend on the backward's march order)
-    assert lp.backward_segments(d["rays"], d["grids"], d["decoder"], num_samples=S) == (1 if n_rays > 32768 else (S + 15) // 16)  # small batches: segmented forward
+    for nm, a, b in zip(("ray_length", "neg_log_t", "feature"), got[0], ref[0]):  # the transposed forward: same samples, a scan instead of a loop
+        _assert_close(f"transposed forward vs rays-per-wavefront forward: {nm}", a, b.detach().cpu().numpy(), tol=3e-6)
+    scaff = dict(scaffold=d["scaffold"]) if rich else {}
+    assert lp.backward_segments(d["rays"], d["grids"], d["decoder"], **d["cfg"], **scaff) == (1 if n_rays > 32768 else (S + 15) // 16)
+    assert lp.backward_segments(d["rays"], d["grids"], d["decoder"], march_order="samples", **d["cfg"], **scaff) == 1  # dealt by rays per wave instead
     flat = lambda r: [("grad_mlp_params", r[1]), ("grad_encoding", r[2])] + [(f"grad_grid{i}", g) for i, g in enumerate(r[3])]  # noqa: E731
     for (nm, a), (_, b) in zip(flat(got), flat(ref)):
         err = float((a - b).abs().max() / b.abs().max())
