@@ -18,7 +18,7 @@ namespace lp {
 
 static thread_local char g_err[512] = "";
 thread_local uint32_t* g_relu_dump = nullptr;  // test hook, see lp_host.h
-thread_local const char* g_last_backward = "";
+const char* volatile g_last_backward = "";
 
 int set_error(int code, const char* fmt, ...) {
   va_list ap;
@@ -446,7 +446,7 @@ int lp_splatter_backward(const LpSplatterArgs* args_, void* stream) {
   return splatter_backward_launch(*args, (hipStream_t)stream);
 }
 
-/* developer / test hook (not part of include/lightplane_hip.h): which Renderer backward the calling thread launched last --
+/* developer / test hook (not part of include/lightplane_hip.h): which Renderer backward the process launched last --
  * "tuned family, rays per wavefront", "tuned family, samples per wavefront (transposed march)", "layer-looped family",
  * "shape-generic kernels" (static strings) */
 const char* lp_debug_last_renderer_backward(void) { return g_last_backward; }

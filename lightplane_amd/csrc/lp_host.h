@@ -14,8 +14,10 @@ int check_launch(const char* what);
 // test hook (lp_renderer_backward_relu_dump, lp_api.hip): while non-NULL, the MFMA backwards launch their DUMP twins, which also
 // write the ReLU decisions of the recompute here.  Thread-local; NULL in every product call.
 extern thread_local uint32_t* g_relu_dump;
-// developer / test hook (lp_debug_last_renderer_backward, lp_api.hip): which backward the calling thread launched last
-extern thread_local const char* g_last_backward;
+// developer / test hook (lp_debug_last_renderer_backward, lp_api.hip): which Renderer backward the PROCESS launched last (autograd runs
+// the backward on its own thread: a thread-local would be invisible to the caller; a plain pointer to a static string -- a race between
+// two launching threads only makes the answer one of the two)
+extern const char* volatile g_last_backward;
 
 // generic (shape-agnostic) kernels: lp_renderer_generic.hip
 int renderer_forward_generic(const LpRendererArgs& a, hipStream_t stream);
