@@ -28,7 +28,8 @@ def pytest_terminal_summary(terminalreporter):
     if FORCED_EVENTS:
         terminalreporter.write_sep("-", f"forced-oracle proofs: {len(FORCED_EVENTS)}")
         for e in FORCED_EVENTS:
-            terminalreporter.write_line(f"forced-oracle {e['name']}: {e['forced_units']} units forced over {e['visited_samples']} samples; "
+            terminalreporter.write_line(f"forced-oracle {e['name']}: {e['forced_units']} units forced over {e['visited_samples']} samples "
+                                        f"(largest forced margin {e.get('max_forced_margin', 0.0):.1e}, {e.get('near_tie_units')} near-tie units in the oracle); "
                                         f"worst {max(e['worst'].values()):.2e} ({max(e['worst'], key=e['worst'].get)})")
         if os.path.isdir(out):
             import json
