@@ -25,8 +25,8 @@
                        consecutive rays at one sample (its gradient scatter merges neighbouring rays: image-coherent batches),
                        "samples" = 32 consecutive samples of one ray (merges the samples a ray spends in one cell: batches of
                        unrelated rays, e.g. random training batches -- 3x on the reference's speed benchmark), "auto" (default) =
-                       "samples" when most consecutive rays of the batch share neither origin nor direction, decided together with
-                       the ``check_inputs`` device sync (no extra sync; "rays" when ``check_inputs`` is off).
+                       "samples" unless most consecutive rays of the batch are neighbours (directions within 5 %, origins within
+                       0.05), decided together with the ``check_inputs`` device sync (no extra sync; "rays" when ``check_inputs`` is off).
 """
 import os
 

@@ -383,9 +383,11 @@ class LightplaneFunction(torch.autograd.Function):
 
 def check_inputs_and_choose_march(rays: Rays, grid_idx: torch.Tensor, B: int, march_order: Optional[str] = None) -> int:
     """The ``grid_idx`` range check (``config.check_inputs``: the one device sync of a call, like the reference's min / max
-    asserts, lightplane_renderer.py:464-467) and, riding on the same sync, the backward's march order for "auto": image-coherent
-    batches -- consecutive rays share an origin (pinhole camera) or a direction (orthographic) -- march 32 rays per wavefront,
-    batches of unrelated rays 32 samples of one ray (``LP_MARCH_*``).  With ``check_inputs`` off "auto" is "rays" (no sync)."""
+    asserts, lightplane_renderer.py:464-467) and, riding on the same sync, the march order for "auto": a batch is image-coherent
+    when most consecutive rays are NEIGHBOURS -- directions within 5 % of each other and origins within 0.05 scene units (pinhole
+    rows: same origin, one pixel of angle; orthographic rows: same direction, one pixel of offset) -- and marches 32 rays per
+    wavefront; unrelated rays (random rays, but also random PIXELS of one camera: same origin, unrelated directions) march 32
+    samples of one ray (``LP_MARCH_*``).  With ``check_inputs`` off "auto" is "rays" (no sync)."""
     march_order = config.march_order if march_order is None else march_order
     assert march_order in ("auto", "rays", "samples"), f"march_order has to be 'auto', 'rays' or 'samples' (got {march_order!r})"
     march = _lib.LP_MARCH_SAMPLES_PER_WAVE if march_order == "samples" else _lib.LP_MARCH_RAYS_PER_WAVE
@@ -394,7 +396,8 @@ def check_inputs_and_choose_march(rays: Rays, grid_idx: torch.Tensor, B: int, ma
         stats = [lo.float(), hi.float()]
         if march_order == "auto" and grid_idx.numel() > 1:
             o, dd = rays.origins, rays.directions
-            stats.append(((o[1:] == o[:-1]).all(dim=1) | (dd[1:] == dd[:-1]).all(dim=1)).float().mean())
+            near = ((dd[1:] - dd[:-1]).norm(dim=1) <= 0.05 * dd[1:].norm(dim=1)) & ((o[1:] - o[:-1]).norm(dim=1) <= 0.05)
+            stats.append(near.float().mean())
         vals = torch.stack(stats).tolist()
         lo, hi = int(vals[0]), int(vals[1])
         assert lo >= 0, f"Negative grid index: {lo}"

@@ -501,12 +501,14 @@ def test_march_order_auto_picks_by_ray_coherence():
     from tests.synth import random_rays
     dev = _dev()
     gen = torch.Generator().manual_seed(3)
-    img = pinhole_rays(32, 32, enc_dim=32, gen=gen).to(dev)
+    img = pinhole_rays(128, 128, enc_dim=32, gen=gen).to(dev)
     rnd = random_rays(gen, 1024, 2, 32).to(dev)
     assert lp.config.check_inputs and lp.config.march_order == "auto"
     assert check_inputs_and_choose_march(img, img.grid_idx.int(), 2) == _lib.LP_MARCH_RAYS_PER_WAVE
     assert check_inputs_and_choose_march(rnd, rnd.grid_idx.int(), 2) == _lib.LP_MARCH_SAMPLES_PER_WAVE
     assert check_inputs_and_choose_march(rnd, rnd.grid_idx.int(), 2, "rays") == _lib.LP_MARCH_RAYS_PER_WAVE
+    shuffled = img[torch.randperm(img.n_rays, generator=gen).to(dev)]   # random PIXELS of one camera: same origin, unrelated directions
+    assert check_inputs_and_choose_march(shuffled, shuffled.grid_idx.int(), 2) == _lib.LP_MARCH_SAMPLES_PER_WAVE
     try:
         lp.config.check_inputs = False
         assert check_inputs_and_choose_march(rnd, rnd.grid_idx.int(), 2) == _lib.LP_MARCH_RAYS_PER_WAVE

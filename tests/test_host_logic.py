@@ -430,6 +430,33 @@ def test_arithmetic_selection_and_dump_words_without_gpu():
     assert _lib.lib().lp_renderer_forward(ctypes.byref(a), None) == -1 and b"arithmetic" in _lib.lib().lp_last_error()
 
 
+def test_march_order_heuristic_without_gpu():
+    """march_order "auto": neighbouring rays (an image in scanline order) march rays per wavefront; unrelated rays -- random rays, and
+    random PIXELS of one camera -- samples per wavefront; explicit orders are taken as given; no look when check_inputs is off."""
+    from lightplane_amd.renderer import check_inputs_and_choose_march
+    from tests.synth import pinhole_rays, random_rays
+    gen = torch.Generator().manual_seed(0)
+    img = pinhole_rays(96, 128, enc_dim=32, gen=gen)
+    shuffled = img[torch.randperm(img.n_rays, generator=gen)]
+    rnd = random_rays(gen, 2048, 3, 32)
+    R, S = _lib.LP_MARCH_RAYS_PER_WAVE, _lib.LP_MARCH_SAMPLES_PER_WAVE
+    gi = lambda r: r.grid_idx.to(torch.int32)  # noqa: E731
+    assert lp.config.check_inputs
+    assert check_inputs_and_choose_march(img, gi(img), 1) == R
+    assert check_inputs_and_choose_march(shuffled, gi(shuffled), 1) == S
+    assert check_inputs_and_choose_march(rnd, gi(rnd), 3) == S
+    assert check_inputs_and_choose_march(rnd, gi(rnd), 3, "rays") == R and check_inputs_and_choose_march(img, gi(img), 1, "samples") == S
+    with pytest.raises(AssertionError, match="out of bounds"):
+        check_inputs_and_choose_march(rnd, gi(rnd), 2)
+    with pytest.raises(AssertionError, match="march_order"):
+        check_inputs_and_choose_march(rnd, gi(rnd), 3, "diagonal")
+    try:
+        lp.config.check_inputs = False
+        assert check_inputs_and_choose_march(rnd, gi(rnd), 3) == R
+    finally:
+        lp.config.check_inputs = True
+
+
 def test_forcer_reports_what_it_forced():
     """oracle.relu_mask_forcer measures what a forced-oracle proof is allowed to rest on: the largest relative |pre-activation| of a
     unit forced against the oracle's own sign, and how many units sit that close to zero."""
