@@ -428,7 +428,12 @@ def refbench_splatter(dev, views=None):
         def run(rays):
             return lp.lightplane_splatter(rays, sizes, num_samples=96, mask_out_of_bounds_samples=True)
 
-        r = _ref_protocol(make_inputs, run, dev)
+        saved = lp.config.check_inputs  # (the reference's call path checks grid_idx with a device sync; "auto" march order rides on it)
+        lp.config.check_inputs = True
+        try:
+            r = _ref_protocol(make_inputs, run, dev)
+        finally:
+            lp.config.check_inputs = saved
         r.update(num_view=nv, num_rays=n, Mrays_per_s_fwd_bwd=round(n / (r["t_fw_kernel_ms"] + r["t_bw_kernel_ms"]) / 1e3, 4))
         rows.append(r)
     return {"benchmark": "reference tests/splatter_speed_benchmark.py:200-247: 128^2 x num_view random rays x 64 ch -> voxel "

@@ -255,7 +255,9 @@ typedef struct LpSplatterArgs {
   LpMlp mlp;               /* dims[0] == encoding_dim == input_grid.channels,
                               dims[last] == out.channels                          */
   int32_t kernel;
-  int32_t _pad;
+  int32_t march_order;     /* LP_MARCH_* (plain Splatter forward): LP_MARCH_SAMPLES_PER_WAVE walks 32 consecutive samples of ONE ray per
+                              wavefront instead of 32 rays -- for batches of unrelated rays (reference tests/splatter_speed_benchmark.py):
+                              the run merge of the atomic walk then works along the ray.  0 = rays per wavefront (image-coherent batches) */
   /* backward */
   const float* grad_out;   /* [rows, C] gradient w.r.t. the NORMALISED output grid */
   const float* weight;     /* [rows] un-clamped splat weights saved by forward     */

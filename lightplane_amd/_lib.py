@@ -86,7 +86,7 @@ class LpSplatterArgs(C.Structure):
         ("rays", LpRays), ("march", LpMarch), ("out", LpGridList),
         ("out_feature", C.c_void_p), ("out_weight", C.c_void_p),
         ("input_grid", LpGridList), ("mlp_params", C.c_void_p), ("n_mlp_params", C.c_int64),
-        ("mlp", LpMlp), ("kernel", C.c_int32), ("_pad", C.c_int32),
+        ("mlp", LpMlp), ("kernel", C.c_int32), ("march_order", C.c_int32),
         ("grad_out", C.c_void_p), ("weight", C.c_void_p), ("grad_encoding", C.c_void_p),
         ("grad_input_grid", C.c_void_p), ("grad_mlp_params", C.c_void_p),
         ("grad_input_grid_list", C.c_void_p * LP_MAX_GRIDS),

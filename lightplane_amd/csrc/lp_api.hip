@@ -180,6 +180,8 @@ static int check_renderer(const LpRendererArgs& a, bool backward) {
 
 static int check_splatter(const LpSplatterArgs& a, bool backward) {
   int rc;
+  if (a.march_order != LP_MARCH_RAYS_PER_WAVE && a.march_order != LP_MARCH_SAMPLES_PER_WAVE)
+    return set_error(LP_EINVAL, "march_order %d is neither LP_MARCH_RAYS_PER_WAVE nor LP_MARCH_SAMPLES_PER_WAVE", a.march_order);
   if ((rc = check_rays(a.rays, true))) return rc;
   if ((rc = check_march(a.march))) return rc;
   if ((rc = check_grid_list("out", a.out, true))) return rc;

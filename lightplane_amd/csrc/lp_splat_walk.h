@@ -15,6 +15,14 @@ struct SplatSrcRegs {
     for (int i = 0; i < 8; ++i) out[i] = enc[j][8 * c8 + i];
   }
 };
+template <int CPL>
+struct SplatSrcConst {  // every item of the walk splats the same vector (the samples of ONE ray: transposed march)
+  float v[CPL];
+  LP_DEV void load8(int j, int, float (&out)[8]) const {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = v[j];
+  }
+};
 struct SplatSrcLds {  // tile [channel][ld] in LDS
   const float* tile;
   int ld, sub;

@@ -70,9 +70,16 @@ __global__ void __launch_bounds__(256) splat_fwd_kernel(const LpSplatterArgs a) 
 // ---------------------------------------------------------------------------------------
 // RPW rays per wave (16: twice as many waves in flight for the same ray count -- the walk is a
 // latency-bound scalar loop, and 256x256 rays are only 2048 waves of 32).
-template <int C, int RPW>
+// (Enc: enc[j][item] -- a register array [C / 16][RPW] of the wave's rays, or SplatEncConst for the transposed march)
+template <int CPL>
+struct SplatEncConst {
+  float v[CPL];
+  struct Row { float x; LP_DEV float operator[](int) const { return x; } };
+  LP_DEV Row operator[](int j) const { return Row{v[j]}; }
+};
+template <int C, int RPW, class Enc>
 LP_DEV void splat_walk(float* feat, float* wgt, const LpGrid& g, int b, float x, float y, float z, bool live,
-                       int lane, const float (&enc)[C / 16][RPW], float* wT, int dbg) {
+                       int lane, const Enc& enc, float* wT, int dbg) {
   constexpr int CPL = C / 16;        // channels per lane: 16 lanes per tap slot, four slots per pass
   constexpr int NQ = 64 / RPW;       // lanes per ray in the lane = ray layout
   constexpr int SPQ = 8 / NQ;        // tap-weight slots each of them writes
@@ -220,6 +227,51 @@ __global__ void __launch_bounds__(256) splat_fwd_walk_kernel(const LpSplatterArg
         splat_walk_vox<C, RPW, SplatSrcRegs<CPL, RPW>, true, WLD>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, SplatSrcRegs<CPL, RPW>{enc}, wT, dbg);
       else
         splat_walk<C, RPW>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, enc, wT, dbg);
+    }
+  }
+}
+
+// Forward walk with a TRANSPOSED MARCH (LpSplatterArgs.march_order == LP_MARCH_SAMPLES_PER_WAVE): a wave = ONE ray x 32 consecutive
+// samples, its rays one after the other.  For batches of unrelated rays (the reference's splatter_speed_benchmark.py draws random
+// rays): with lane = ray every ray is its own run -- 8 corner rows x C / 16 segments + 8 weight segments per ray-sample --, with lane =
+// sample the same walk (run heads by ballot, carried columns, weight windows) merges the samples a ray spends in one cell and carries
+// the shared face when it steps to a neighbour.  The splatted vector is constant along a ray: no transposition through LDS, no
+// [channel][ray] register array; `rpw` rays per wave (a small batch is dealt over the chip by it).
+template <int C>
+__global__ void __launch_bounds__(256) splat_fwd_ray_kernel(const LpSplatterArgs a, int dbg, int rpw) {
+  constexpr int CPL = C / 16;
+  constexpr int WLD = 32 + 8;
+  __shared__ __attribute__((aligned(16))) float lds[4][8 * WLD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31;
+  float* wT = lds[wave];
+  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
+  const int n_blk = (s_tot + 31) >> 5;
+  const bool contract = a.march.contract_coords != 0;
+  const bool mask = a.march.mask_out_of_bounds != 0;
+  const int64_t ray0 = ((int64_t)blockIdx.x * 4 + wave) * rpw;
+  for (int k = 0; k < rpw; ++k) {
+    const int64_t rid = ray0 + k;
+    if (rid >= a.rays.n_rays) break;  // wave-uniform
+    const Ray ray = load_ray(a.rays, rid);
+    SplatSrcConst<CPL> src;
+    SplatEncConst<CPL> enc;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) src.v[j] = enc.v[j] = a.rays.encoding[rid * C + (lane & 15) + 16 * j];
+    for (int bs = 0; bs < n_blk; ++bs) {
+      const int s = bs * 32 + r;
+      const int sc = s < s_tot ? s : s_tot - 1;
+      const float depth = sample_depth(sc, a.march, ray.near_t, ray.far_t);
+      float x, y, z;
+      sample_point(ray, depth, contract, x, y, z);
+      const bool live = s < s_tot && !(mask && !point_in_bounds(x, y, z));
+      for (int g = 0; g < a.out.n_grids; ++g) {
+        const LpGrid& og = a.out.grids[g];
+        if (og.D > 1 && og.H > 1 && og.W > 1 && !(dbg & 4))
+          splat_walk_vox<C, 32, SplatSrcConst<CPL>, true, WLD>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, src, wT, dbg);
+        else
+          splat_walk<C, 32>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, enc, wT, dbg);
+      }
     }
   }
 }
@@ -482,6 +534,19 @@ int splatter_forward_launch(const LpSplatterArgs& a, hipStream_t stream) {
     // (profiles/r04_splat_fwd_rpw32_ab.txt); LP_SPLAT_RPW=16 selects the 16-ray waves (A/B, tests)
     static const int rpw = getenv("LP_SPLAT_RPW") ? atoi(getenv("LP_SPLAT_RPW")) : 32;
     static const int dbg = getenv("LP_SPLAT_DEBUG") ? atoi(getenv("LP_SPLAT_DEBUG")) : 0;  // timing experiments
+    static const bool tm_off = getenv("LP_TM_OFF") != nullptr;
+    if (a.march_order == LP_MARCH_SAMPLES_PER_WAVE && !tm_off) {  // batches of unrelated rays: one ray x 32 samples per wavefront
+      if (a.rays.n_rays == 0) return LP_OK;
+      static const int forced = getenv("LP_TM_RPW") ? atoi(getenv("LP_TM_RPW")) : 0;
+      int rays_pw = 32;  // (rays per wave: fewer while the batch leaves workgroup slots idle -- 4 workgroups per CU)
+      while (rays_pw > 1 && (a.rays.n_rays + 4 * rays_pw - 1) / (4 * rays_pw) < 1024) rays_pw >>= 1;
+      if (forced >= 1 && forced <= 32) rays_pw = forced;
+      const unsigned blocks = (unsigned)((a.rays.n_rays + 4 * rays_pw - 1) / (4 * rays_pw));
+      if (Cw == 64) hipLaunchKernelGGL((splat_fwd_ray_kernel<64>), dim3(blocks), dim3(256), 0, stream, a, dbg, rays_pw);
+      else if (Cw == 32) hipLaunchKernelGGL((splat_fwd_ray_kernel<32>), dim3(blocks), dim3(256), 0, stream, a, dbg, rays_pw);
+      else hipLaunchKernelGGL((splat_fwd_ray_kernel<16>), dim3(blocks), dim3(256), 0, stream, a, dbg, rays_pw);
+      return check_launch("splat_fwd_ray_kernel");
+    }
     const int rpw_eff = Cw == 64 ? 16 : rpw;
     const unsigned ray_blocks = (unsigned)((a.rays.n_rays + 4 * rpw_eff - 1) / (4 * rpw_eff));
     if (ray_blocks == 0) return LP_OK;

@@ -50,6 +50,7 @@ class _SplatterCfg:
     kernel: int = 0
     in_is_list: bool = False   # the input grid-list arrives as one tensor per grid (zero-copy) instead of a flat tensor
     n_in_tensors: int = 1
+    march_order: int = 0       # LP_MARCH_* of the plain Splatter's forward walk
 
 
 def _fill_args(cfg: _SplatterCfg, directions, origins, grid_idx, near, far, feature, mlp_params=None,
@@ -66,6 +67,7 @@ def _fill_args(cfg: _SplatterCfg, directions, origins, grid_idx, near, far, feat
         a.n_mlp_params = mlp_params.numel()
         a.mlp = _lib.make_mlp(cfg.mlp_dims, 0)
         a.kernel = int(cfg.kernel)
+    a.march_order = int(cfg.march_order)
     return a
 
 
@@ -178,20 +180,19 @@ class LightplaneMLPSplatterFunction(torch.autograd.Function):
         return (grad_feature, grad_params) + (None,) * 6 + tuple(gi)
 
 
-def _prep_rays(rays: Rays, B: int):
+def _prep_rays(rays: Rays, B: int, march_order: Optional[str] = "rays"):
+    """Device / dtype checks, the ``grid_idx`` range check and (riding on its sync) the march order of the forward walk
+    (``renderer.check_inputs_and_choose_march``).  Returns (march order, ray tensors)."""
+    from .renderer import check_inputs_and_choose_march
     _lib.check_tensors(
         rays.encoding.device,
         {"rays.directions": rays.directions, "rays.origins": rays.origins, "rays.near": rays.near,
          "rays.far": rays.far, "rays.encoding": rays.encoding},
         {"rays.grid_idx": rays.grid_idx})
     grid_idx = rays.grid_idx.to(torch.int32).contiguous()
-    if config.check_inputs and grid_idx.numel() > 0:
-        lo, hi = torch.aminmax(grid_idx)
-        lo, hi = int(lo), int(hi)
-        assert lo >= 0, f"Negative grid index: {lo}"
-        assert hi <= B - 1, f"A grid index is out of bounds ({hi} >= {B})"
-    return (rays.directions.contiguous(), rays.origins.contiguous(), grid_idx, rays.near.contiguous(),
-            rays.far.contiguous())
+    march = check_inputs_and_choose_march(rays, grid_idx, B, march_order)
+    return march, (rays.directions.contiguous(), rays.origins.contiguous(), grid_idx, rays.near.contiguous(),
+                   rays.far.contiguous())
 
 
 def lightplane_splatter(
@@ -208,6 +209,7 @@ def lightplane_splatter(
     triton_block_size: int = 16,  # ignored
     triton_num_warps: int = 4,  # ignored
     process_group=None,
+    march_order: Optional[str] = None,
 ):
     """Splat ``rays.encoding`` into a zero-initialised grid-list of shape ``output_grid_size``.
 
@@ -216,6 +218,10 @@ def lightplane_splatter(
     result is ``features / clamp(weights, 1e-5)``.  Arguments / returns follow the reference's
     ``lightplane_splatter`` (lightplane/lightplane_splatter.py:31-164): a list of
     ``[B, D, H, W, C]`` tensors, or the flat ``[sum BDHW, C]`` tensor if ``return_list=False``.
+
+    ``march_order`` ("auto" / "rays" / "samples", default ``config.march_order``): which (ray, sample) pairs share a wavefront of
+    the forward walk -- 32 neighbouring rays (image-coherent batches) or 32 consecutive samples of one ray (unrelated rays, e.g. the
+    reference's ``tests/splatter_speed_benchmark.py``); see ``lightplane_renderer``.  Same result up to fp32 summation order.
     """
     sizes = sizes_to_list(output_grid_size)
     descs, channels, n_rows = make_grid_descs(sizes)
@@ -226,7 +232,8 @@ def lightplane_splatter(
     cfg = _SplatterCfg(descs, channels, n_rows, int(num_samples), int(num_samples_inf),
                        bool(mask_out_of_bounds_samples), bool(contract_coords), float(disparity_at_inf),
                        process_group)
-    out = LightplaneSplatterFunction.apply(rays.encoding, cfg, *_prep_rays(rays, descs[0].B))
+    cfg.march_order, ray_tensors = _prep_rays(rays, descs[0].B, march_order)
+    out = LightplaneSplatterFunction.apply(rays.encoding, cfg, *ray_tensors)
     if return_list:
         return list(unflatten_grid(out, sizes))
     return out
@@ -296,7 +303,7 @@ def lightplane_mlp_splatter(
     cfg = _SplatterCfg(descs, channels, n_rows, int(num_samples), int(num_samples_inf),
                        bool(mask_out_of_bounds_samples), bool(contract_coords), float(disparity_at_inf),
                        process_group, in_descs, in_channels, in_n_rows, dims, int(kernel), in_is_list, len(in_tensors))
-    out = LightplaneMLPSplatterFunction.apply(rays.encoding, flat_params, cfg, *_prep_rays(rays, descs[0].B),
+    out = LightplaneMLPSplatterFunction.apply(rays.encoding, flat_params, cfg, *_prep_rays(rays, descs[0].B)[1],
                                               *in_tensors)
     if return_list:
         return list(unflatten_grid(out, sizes))

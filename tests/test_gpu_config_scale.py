@@ -519,3 +519,44 @@ def test_march_order_auto_picks_by_ray_coherence():
     ref = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO, march_order="rays")
     for a, b in zip([got[1], got[2]] + list(got[3]), [ref[1], ref[2]] + list(ref[3])):
         assert float((a - b).abs().max() / b.abs().max()) <= 2e-5
+
+
+@pytest.mark.parametrize("n_rays,C,S,tri,mask,n_inf", [(4096, 64, 96, False, True, 0), (3000, 32, 70, False, False, 3), (2000, 16, 40, True, True, 0),
+                                                        (70000, 32, 33, False, False, 0), (500, 64, 20, True, False, 0)],
+                         ids=["refbench_like_c64_s96_mask", "voxel_c32_s70_inf3", "triplane_c16_s40_mask", "70k_rays_voxel_c32_s33", "triplane_c64_s20_short_march"])
+def test_splatter_transposed_march_on_random_rays(n_rays, C, S, tri, mask, n_inf):
+    """The Splatter's forward walk with march_order="samples" (one ray x 32 consecutive samples per wavefront: the atomic walk merges
+    along the ray) on batches of unrelated rays -- the reference's splatter_speed_benchmark.py kind of input: the normalised output
+    grids and grad_encoding against march_order="rays" (same arithmetic per (ray, sample), another summation order) and, for the
+    small cases, against the oracle.  Voxel (carried columns, weight windows) and plane walks, 16 / 32 / 64 channels, ragged last
+    blocks, beyond-far samples, a march shorter than one block."""
+    from tests.synth import random_rays
+    dev = _dev()
+    gen = torch.Generator().manual_seed(n_rays % 89)
+    B, G = 2, 24
+    sizes = grid_sizes_for((B, G, G + 2, G - 4, C), tri)
+    rays = random_rays(gen, n_rays, B, None)
+    rays.encoding = torch.rand(n_rays, C, generator=gen)
+    up = [torch.randn(*s, generator=gen) for s in sizes]
+    cfg = dict(num_samples=S, num_samples_inf=n_inf, mask_out_of_bounds_samples=mask, contract_coords=n_inf > 0)
+
+    def run(order):
+        r = rays.to(dev)
+        r.encoding = r.encoding.clone().requires_grad_(True)
+        out = lp.lightplane_splatter(r, sizes, march_order=order, **cfg)
+        sum((o * u.to(dev)).sum() for o, u in zip(out, up)).backward()
+        return out, r.encoding.grad
+
+    ref_out, ref_ge = run("rays")
+    got_out, got_ge = run("samples")
+    for i, (a, b) in enumerate(zip(got_out, ref_out)):
+        _assert_close(f"splat out{i}: samples-per-wave vs rays-per-wave", a, b.detach().cpu().numpy(), tol=2e-5)
+    _assert_close("grad_encoding: samples-per-wave vs rays-per-wave", got_ge, ref_ge.cpu().numpy(), tol=2e-5)
+    if n_rays <= 4096:
+        r = copy.copy(rays)
+        r.encoding = rays.encoding.clone().requires_grad_(True)
+        o_out = O.lightplane_splatter_naive(r, sizes, **cfg)
+        sum((o * u).sum() for o, u in zip(o_out, up)).backward()
+        for i, (a, b) in enumerate(zip(got_out, o_out)):
+            _assert_close(f"splat out{i} vs oracle", a, b.detach().numpy())
+        _assert_close("grad_encoding vs oracle", got_ge, r.encoding.grad.numpy())
