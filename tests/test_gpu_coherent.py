@@ -652,16 +652,16 @@ sys.path.insert(0, {root!r})
 import pytest
 sys.exit(pytest.main([{root!r} + "/tests/test_gpu_coherent.py", {root!r} + "/tests/test_gpu_config_scale.py", {root!r} + "/tests/test_gpu_parity.py",
                       "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k",
-                      "test_segmented_backward or test_1080p_backward_block or test_flips_are_flips or cfg2_sized or test_cfg2_full_batch"]))
+                      "test_segmented_backward or test_flips_are_flips or cfg2_sized or c16_s128"]))
 """
 
 
 def test_coherent_and_config_scale_cases_through_the_transposed_march():
     """LIGHTPLANE_AMD_MARCH_ORDER=samples sends every eligible launch (tuned family, >= 32 samples, no beyond-far samples) through the
-    transposed march -- also the IMAGE-COHERENT ones the default would march rays per wavefront: the headline launch (all 65 536
-    rays, proof included), the real 1080p launches, the 16 segmented-backward cases (it replaces the segment-parallel march there)
-    and the proof cases, in a child process.  (The whole GPU suite passes that way but for two tests that assert the default's
-    kernel name / setting: gpurun_out/r06k_2_testsall.log.)"""
+    transposed march -- also the IMAGE-COHERENT ones the default would march rays per wavefront: a real 1080p launch, the 16
+    segmented-backward cases (it replaces the segment-parallel march there), the cfg-2-sized properties and the proof cases, in a
+    child process.  (The WHOLE GPU suite passes that way -- the headline launch with all 65 536 rays and its proof included -- but
+    for two tests that assert the default's kernel name / setting: profiles/r06_transposed_march.txt, section 5.)"""
     r = subprocess.run([sys.executable, "-c", _TM_CHILD.format(root=ROOT)], cwd=ROOT, env=dict(os.environ, LIGHTPLANE_AMD_MARCH_ORDER="samples"),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
