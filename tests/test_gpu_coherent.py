@@ -652,13 +652,13 @@ sys.path.insert(0, {root!r})
 import pytest
 sys.exit(pytest.main([{root!r} + "/tests/test_gpu_coherent.py", {root!r} + "/tests/test_gpu_config_scale.py", {root!r} + "/tests/test_gpu_parity.py",
                       "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k",
-                      "test_segmented_backward or test_flips_are_flips or cfg2_sized or c16_s128"]))
+                      "triplane_s88 or voxel_b2_rgba_s96 or triplane_scaffold_noise_s70 or voxel_c32_s72 or test_flips_are_flips or cfg2_sized or c16_s128"]))
 """
 
 
 def test_coherent_and_config_scale_cases_through_the_transposed_march():
     """LIGHTPLANE_AMD_MARCH_ORDER=samples sends every eligible launch (tuned family, >= 32 samples, no beyond-far samples) through the
-    transposed march -- also the IMAGE-COHERENT ones the default would march rays per wavefront: a real 1080p launch, the 16
+    transposed march -- also the IMAGE-COHERENT ones the default would march rays per wavefront: a real 1080p launch, four of the
     segmented-backward cases (it replaces the segment-parallel march there), the cfg-2-sized properties and the proof cases, in a
     child process.  (The WHOLE GPU suite passes that way -- the headline launch with all 65 536 rays and its proof included -- but
     for two tests that assert the default's kernel name / setting: profiles/r06_transposed_march.txt, section 5.)"""
