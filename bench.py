@@ -157,6 +157,9 @@ class RendererWorkload:
         # (bench.py runs with check_inputs off -- no device sync in a timed step --, so "auto" cannot look at the rays: the random-ray
         # workload names its march order; LP_BENCH_MARCH=rays for the A/B)
         self.render_kw = dict(disparity_at_inf=0.01, march_order=march_order or os.environ.get("LP_BENCH_MARCH", "samples")) if random else {}
+        # (... and likewise the row length of the image: with check_inputs on the front-end detects it by itself; LP_BENCH_NO_ROW_HINT=1 for the A/B)
+        if not random and not os.environ.get("LP_BENCH_NO_ROW_HINT"):
+            self.render_kw["rays_per_row"] = W
         n = H * W
         up = (torch.randn(n, generator=gen_r), torch.randn(n, generator=gen_r), torch.randn(n, COLOR, generator=gen_r))
         self.n_rays = n
@@ -246,6 +249,7 @@ class SplatterWorkload:
         from tests.synth import pinhole_rays
 
         self.pg, self.S, self.C, self.G = pg, 256, 32, 128
+        self.row = None if os.environ.get("LP_BENCH_NO_ROW_HINT") else image[1]  # rays per image row (detected by the front-end when check_inputs is on)
         gen = torch.Generator().manual_seed(100 + rank)
         az, el = camera_pose("cfg2", rank)
         self.rays_c = pinhole_rays(image[0], image[1], gen=gen, azimuth_deg=az, elevation_deg=el)
@@ -265,7 +269,7 @@ class SplatterWorkload:
 
     def forward(self, replicated=True):
         return lp.lightplane_splatter(self.rays, self.sizes, num_samples=self.S, return_list=False,
-                                      process_group=self.pg if replicated else None)
+                                      process_group=self.pg if replicated else None, rays_per_row=self.row)
 
     def loss(self, out):
         return (out * self.up).sum()
@@ -483,12 +487,15 @@ class JointWorkload:
 
     def forward(self, replicated=True):
         pg = self.pg if replicated else None
-        grid = lp.lightplane_splatter(self.splat_rays, self.sizes, num_samples=self.S, return_list=False, process_group=pg)
+        row = not os.environ.get("LP_BENCH_NO_ROW_HINT")
+        grid = lp.lightplane_splatter(self.splat_rays, self.sizes, num_samples=self.S, return_list=False, process_group=pg,
+                                      rays_per_row=self.img if row else None)
         p = self.params
         if replicated:  # the splatted grid is a replicated tensor consumed by ray shards: its gradient is summed over the GPUs
             grid, p = parallel.replicate_with_grad_allreduce([grid, self.params], self.pg, exclusive_grads=True)  # consumed by the Renderer only
         d = lp.DecoderParams(p, self.dec_c.n_hidden_trunk, self.dec_c.n_hidden_opacity, self.dec_c.n_hidden_color, 3)
-        return lp.lightplane_renderer(self.cam, grid, d, num_samples=self.S, gain=1.0, grid_sizes=self.sizes, kernel=self.kernel)
+        return lp.lightplane_renderer(self.cam, grid, d, num_samples=self.S, gain=1.0, grid_sizes=self.sizes, kernel=self.kernel,
+                                      rays_per_row=1920 if row else None)
 
     def loss(self, out):
         return out[0].sum() + out[1].sum() + out[2].sum()

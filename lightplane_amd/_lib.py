@@ -48,7 +48,7 @@ class LpGridList(C.Structure):
 class LpRays(C.Structure):
     _fields_ = [("n_rays", C.c_int64), ("directions", C.c_void_p), ("origins", C.c_void_p),
                 ("grid_idx", C.c_void_p), ("near_t", C.c_void_p), ("far_t", C.c_void_p),
-                ("encoding", C.c_void_p), ("encoding_dim", C.c_int32), ("_pad", C.c_int32)]
+                ("encoding", C.c_void_p), ("encoding_dim", C.c_int32), ("row_length", C.c_int32)]
 
 
 class LpMarch(C.Structure):
@@ -246,8 +246,9 @@ def current_stream(device: torch.device) -> Optional[int]:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def make_rays(directions, origins, grid_idx_i32, near, far, encoding) -> LpRays:
+def make_rays(directions, origins, grid_idx_i32, near, far, encoding, row_length: int = 0) -> LpRays:
     r = LpRays()
+    r.row_length = int(row_length)
     r.n_rays = directions.shape[0]
     r.directions, r.origins = ptr(directions), ptr(origins)
     r.grid_idx, r.near_t, r.far_t = ptr(grid_idx_i32), ptr(near), ptr(far)

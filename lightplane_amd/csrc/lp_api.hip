@@ -105,6 +105,7 @@ static int check_rays(const LpRays& r, bool need_encoding) {
   if (!r.directions || !r.origins || !r.grid_idx || !r.near_t || !r.far_t)
     return set_error(LP_ENULL, "rays: directions/origins/grid_idx/near/far must be non-NULL");
   if (need_encoding && !r.encoding) return set_error(LP_ENULL, "rays.encoding is NULL");
+  if (r.row_length < 0) return set_error(LP_EINVAL, "rays.row_length %d < 0 (0 = unknown)", r.row_length);
   if (r.encoding_dim < 0 || r.encoding_dim > LP_MAX_WIDTH)
     return set_error(LP_EUNSUPPORTED, "rays.encoding_dim %d outside [0, %d]", r.encoding_dim, LP_MAX_WIDTH);
   return LP_OK;

@@ -340,8 +340,8 @@ splat_bwd_walk_kernel(const LpSplatterArgs a, int n_seg) {
   float* wT = lds[wave];
   const int blk = (int)blockIdx.x / n_seg, seg = (int)blockIdx.x - blk * n_seg;  // (ray block, segment of the march)
   const int64_t ray0 = ((int64_t)blk * 4 + wave) * RPW;
-  const int64_t ray_id = ray0 + r;
-  const bool valid = ray_id < a.rays.n_rays;
+  const bool valid = ray0 + r < a.rays.n_rays;
+  const int64_t ray_id = patch_ray_index(ray0 + r, a.rays.n_rays, a.rays.row_length);  // (row_length: 2 x 4 / 4 x 4 pixel patches per wave)
   const int64_t rid = valid ? ray_id : 0;
   const Ray ray = load_ray(a.rays, rid);
   float acc[CPL][RPW];
@@ -444,7 +444,7 @@ splat_bwd_walk_kernel(const LpSplatterArgs a, int n_seg) {
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
       if (grp == 0 && ray0 + i < a.rays.n_rays) {
-        float* dst = a.grad_encoding + (ray0 + i) * C + sub + 16 * j;
+        float* dst = a.grad_encoding + patch_ray_index(ray0 + i, a.rays.n_rays, a.rays.row_length) * C + sub + 16 * j;
         if (n_seg > 1) atomic_add_f32(dst, v);  // the segments of a ray add up (the launcher zero-fills)
         else *dst = v;
       }

@@ -67,6 +67,7 @@ class _RendererCfg:
     alpha_mode: int = 0            # fused module epilogue: 0 none, 1 alpha = 1 - T, 2 log T
     arithmetic: int = 0            # LP_ARITH_* of the backward (include/lightplane_hip.h)
     march_order: int = 0           # LP_MARCH_* of the backward
+    row_length: int = 0            # LpRays.row_length: rays per image row (0 = unknown)
 
 
 def _fill_args(cfg: _RendererCfg, grids, color_grids, mlp_params, directions, origins, grid_idx, near, far,
@@ -74,7 +75,7 @@ def _fill_args(cfg: _RendererCfg, grids, color_grids, mlp_params, directions, or
     """``grids`` / ``color_grids``: tuples of tensors -- ONE flat ``[rows, C]`` tensor, or one ``[B, D, H, W, C]`` tensor
     per grid (zero-copy grid-list: per-grid base pointers in the ABI)."""
     a = _lib.LpRendererArgs()
-    a.rays = _lib.make_rays(directions, origins, grid_idx, near, far, encoding)
+    a.rays = _lib.make_rays(directions, origins, grid_idx, near, far, encoding, cfg.row_length)
     a.grid = _lib.make_grid_list(list(grids) if cfg.grid_is_list else grids[0], cfg.descs, cfg.channels, cfg.n_rows)
     if cfg.color_descs is not None:
         a.color_grid = _lib.make_grid_list(list(color_grids) if cfg.grid_is_list else color_grids[0], cfg.color_descs,
@@ -381,30 +382,62 @@ class LightplaneFunction(torch.autograd.Function):
         return (None, grad_params, grad_enc) + (None,) * 7 + tuple(gg) + tuple(gc)
 
 
-def check_inputs_and_choose_march(rays: Rays, grid_idx: torch.Tensor, B: int, march_order: Optional[str] = None) -> int:
+def _neighbours(a, b, da, db):
+    """Rays (origin a, direction da) and (b, db) are pixel neighbours: directions within 5 %, origins within 0.05 scene units."""
+    return ((da - db).norm(dim=-1) <= 0.05 * da.norm(dim=-1)) & ((a - b).norm(dim=-1) <= 0.05)
+
+
+def check_inputs_and_plan(rays: Rays, grid_idx: torch.Tensor, B: int, march_order: Optional[str] = None,
+                          rays_per_row: Optional[int] = None):
     """The ``grid_idx`` range check (``config.check_inputs``: the one device sync of a call, like the reference's min / max
-    asserts, lightplane_renderer.py:464-467) and, riding on the same sync, the march order for "auto": a batch is image-coherent
-    when most consecutive rays are NEIGHBOURS -- directions within 5 % of each other and origins within 0.05 scene units (pinhole
-    rows: same origin, one pixel of angle; orthographic rows: same direction, one pixel of offset) -- and marches 32 rays per
-    wavefront; unrelated rays (random rays, but also random PIXELS of one camera: same origin, unrelated directions) march 32
-    samples of one ray (``LP_MARCH_*``).  With ``check_inputs`` off "auto" is "rays" (no sync)."""
+    asserts, lightplane_renderer.py:464-467) and, riding on the same sync, what the kernels should know about the ORDER of the
+    batch.  Returns ``(march order, rays per image row)``:
+    * march order for "auto": a batch is image-coherent when most consecutive rays are NEIGHBOURS -- directions within 5 % of each
+      other and origins within 0.05 scene units (pinhole rows: same origin, one pixel of angle; orthographic rows: same direction,
+      one pixel of offset) -- and marches 32 rays per wavefront; unrelated rays (random rays, but also random PIXELS of one camera:
+      same origin, unrelated directions) march 32 samples of one ray (``LP_MARCH_*``);
+    * rays per row (``LpRays.row_length``; 0 = unknown) unless given: the neighbour chain of a scanline-ordered image breaks exactly
+      at the row ends -- first break at W - 1, N / W - 1 breaks in all -- and ray W is a neighbour of ray 0 (the pixel below).
+    With ``check_inputs`` off nothing is looked at: "auto" is "rays", the row length is what the caller says (or unknown)."""
     march_order = config.march_order if march_order is None else march_order
     assert march_order in ("auto", "rays", "samples"), f"march_order has to be 'auto', 'rays' or 'samples' (got {march_order!r})"
     march = _lib.LP_MARCH_SAMPLES_PER_WAVE if march_order == "samples" else _lib.LP_MARCH_RAYS_PER_WAVE
-    if config.check_inputs and grid_idx.numel() > 0:
+    n = int(grid_idx.numel())
+    row_length = 0
+    if rays_per_row is not None:
+        row_length = int(rays_per_row)
+        assert row_length >= 0 and (row_length == 0 or n % row_length == 0), (
+            f"rays_per_row = {rays_per_row} does not divide the {n} rays of the batch")
+    if config.check_inputs and n > 0:
         lo, hi = torch.aminmax(grid_idx)
         stats = [lo.float(), hi.float()]
-        if march_order == "auto" and grid_idx.numel() > 1:
+        look = n > 1 and (march_order == "auto" or rays_per_row is None)
+        if look:
             o, dd = rays.origins, rays.directions
-            near = ((dd[1:] - dd[:-1]).norm(dim=1) <= 0.05 * dd[1:].norm(dim=1)) & ((o[1:] - o[:-1]).norm(dim=1) <= 0.05)
-            stats.append(near.float().mean())
-        vals = torch.stack(stats).tolist()
+            near = _neighbours(o[1:], o[:-1], dd[1:], dd[:-1])
+            brk = ~near
+            first = brk.float().argmax()                      # first row end (0 if the chain never breaks)
+            below = torch.clamp(first + 1, max=n - 1)           # the ray one row below ray 0, if rows are first + 1 long
+            vert = _neighbours(o[0], o[below], dd[0], dd[below])
+            stats += [near.float().mean(), first.float(), brk.sum().float(), vert.float()]
+        vals = torch.stack(stats).tolist()   # the one device sync of the call
         lo, hi = int(vals[0]), int(vals[1])
         assert lo >= 0, f"Negative grid index: {lo}"
         assert hi <= B - 1, f"A grid index is out of bounds ({hi} >= {B})"
-        if len(vals) > 2 and vals[2] < 0.5:
-            march = _lib.LP_MARCH_SAMPLES_PER_WAVE
-    return march
+        if look:
+            coherent = vals[2] >= 0.5
+            if march_order == "auto" and not coherent:
+                march = _lib.LP_MARCH_SAMPLES_PER_WAVE
+            if rays_per_row is None and coherent:
+                w, n_brk = int(vals[3]) + 1, int(vals[4])
+                if n_brk > 0 and w >= 8 and n % w == 0 and n // w >= 4 and n_brk == n // w - 1 and vals[5] > 0.5:
+                    row_length = w
+    return march, row_length
+
+
+def check_inputs_and_choose_march(rays: Rays, grid_idx: torch.Tensor, B: int, march_order: Optional[str] = None) -> int:
+    """``check_inputs_and_plan(...)[0]``: the march order alone."""
+    return check_inputs_and_plan(rays, grid_idx, B, march_order, rays_per_row=0)[0]
 
 
 def _decoder_dims(decoder_params: DecoderParams):
@@ -436,6 +469,7 @@ def lightplane_renderer(
     stop_transmittance: Optional[float] = None,
     arithmetic: Optional[int] = None,
     march_order: Optional[str] = None,
+    rays_per_row: Optional[int] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Render ``rays`` through the grid-list ``grid`` (emission-absorption ray march).
 
@@ -467,17 +501,24 @@ def lightplane_renderer(
     ``march_order`` (default ``config.march_order`` = "auto"): "rays" / "samples" / "auto" -- which pairs of (ray, sample) share a
     wavefront in the backward, i.e. what its gradient scatter can merge (``LP_MARCH_*``, include/lightplane_hip.h): neighbouring
     rays of an image, or consecutive samples of one ray (random ray batches).  Results agree up to fp32 summation order.
+
+    ``rays_per_row`` (default: detected together with the march order when ``config.check_inputs`` is on, else unknown): the batch is
+    made of image rows in scanline order, this many consecutive rays each.  A hint (``LpRays.row_length``): the tuned kernels then
+    give every wavefront an 8 x 4 pixel patch instead of 32 pixels of one row -- the rays it merges and gathers for are neighbours
+    in both image directions (+5 % on the headline configuration).  Per-ray results do not depend on it.
     """
     out = _render(rays, grid, decoder_params, num_samples, gain, num_samples_inf, mask_out_of_bounds_samples,
                   contract_coords, disparity_at_inf, inject_noise_sigma, inject_noise_seed, scaffold, color_grid,
-                  grid_sizes, color_grid_sizes, kernel, stop_transmittance, arithmetic=arithmetic, march_order=march_order)
+                  grid_sizes, color_grid_sizes, kernel, stop_transmittance, arithmetic=arithmetic, march_order=march_order,
+                  rays_per_row=rays_per_row)
     return out[0], out[1], out[2]
 
 
 def _render(rays: Rays, grid, decoder_params: DecoderParams, num_samples, gain, num_samples_inf=0,
             mask_out_of_bounds_samples=False, contract_coords=False, disparity_at_inf=1e-5, inject_noise_sigma=0.0,
             inject_noise_seed=None, scaffold=None, color_grid=None, grid_sizes=None, color_grid_sizes=None,
-            kernel=_lib.LP_KERNEL_AUTO, stop_transmittance=None, bg_color=None, alpha_mode=0, arithmetic=None, march_order=None):
+            kernel=_lib.LP_KERNEL_AUTO, stop_transmittance=None, bg_color=None, alpha_mode=0, arithmetic=None, march_order=None,
+            rays_per_row=None):
     """``lightplane_renderer`` plus the module front-end's fused epilogue: returns ``(ray_length, neg_log_t, feature,
     alpha)``; with ``bg_color [color_chn]`` the feature is composited over it (``+ T * bg``), with ``alpha_mode`` 1 / 2
     ``alpha`` is ``1 - T`` / ``log T`` (empty tensor otherwise) -- reference renderer_module.py:552-561, in-kernel."""
@@ -546,7 +587,7 @@ def _render(rays: Rays, grid, decoder_params: DecoderParams, num_samples, gain, 
 
     B = descs[0].B
     grid_idx = rays.grid_idx.to(torch.int32).contiguous()
-    march = check_inputs_and_choose_march(rays, grid_idx, B, march_order)
+    march, row_length = check_inputs_and_plan(rays, grid_idx, B, march_order, rays_per_row)
 
     scaffold_shape = None
     if scaffold is not None:
@@ -566,7 +607,7 @@ def _render(rays: Rays, grid, decoder_params: DecoderParams, num_samples, gain, 
         noise_seed=int(inject_noise_seed), scaffold_shape=scaffold_shape, kernel=int(kernel),
         stop_neg_log_t=stop_neg_log_t, n_grid_tensors=len(grid_tensors), n_color_tensors=len(color_tensors),
         grid_is_list=grid_is_list, alpha_mode=int(alpha_mode),
-        arithmetic=int(config.arithmetic if arithmetic is None else arithmetic), march_order=int(march),
+        arithmetic=int(config.arithmetic if arithmetic is None else arithmetic), march_order=int(march), row_length=int(row_length),
     )
     return LightplaneFunction.apply(
         cfg, mlp_params, rays.encoding, rays.directions.contiguous(), rays.origins.contiguous(), grid_idx,

@@ -51,12 +51,13 @@ class _SplatterCfg:
     in_is_list: bool = False   # the input grid-list arrives as one tensor per grid (zero-copy) instead of a flat tensor
     n_in_tensors: int = 1
     march_order: int = 0       # LP_MARCH_* of the plain Splatter's forward walk
+    row_length: int = 0        # LpRays.row_length: rays per image row (0 = unknown)
 
 
 def _fill_args(cfg: _SplatterCfg, directions, origins, grid_idx, near, far, feature, mlp_params=None,
                input_grid=None) -> _lib.LpSplatterArgs:
     a = _lib.LpSplatterArgs()
-    a.rays = _lib.make_rays(directions, origins, grid_idx, near, far, feature)
+    a.rays = _lib.make_rays(directions, origins, grid_idx, near, far, feature, cfg.row_length)
     a.march = _lib.make_march(cfg.num_samples, cfg.num_samples_inf, cfg.mask_out_of_bounds_samples,
                               cfg.contract_coords, cfg.disparity_at_inf)
     a.out = _lib.make_grid_list(None, cfg.descs, cfg.channels, cfg.n_rows)
@@ -180,17 +181,17 @@ class LightplaneMLPSplatterFunction(torch.autograd.Function):
         return (grad_feature, grad_params) + (None,) * 6 + tuple(gi)
 
 
-def _prep_rays(rays: Rays, B: int, march_order: Optional[str] = "rays"):
-    """Device / dtype checks, the ``grid_idx`` range check and (riding on its sync) the march order of the forward walk
-    (``renderer.check_inputs_and_choose_march``).  Returns (march order, ray tensors)."""
-    from .renderer import check_inputs_and_choose_march
+def _prep_rays(rays: Rays, B: int, march_order: Optional[str] = "rays", rays_per_row: Optional[int] = 0):
+    """Device / dtype checks, the ``grid_idx`` range check and (riding on its sync) the march order of the forward walk and the
+    row length of an image batch (``renderer.check_inputs_and_plan``).  Returns ((march order, row length), ray tensors)."""
+    from .renderer import check_inputs_and_plan
     _lib.check_tensors(
         rays.encoding.device,
         {"rays.directions": rays.directions, "rays.origins": rays.origins, "rays.near": rays.near,
          "rays.far": rays.far, "rays.encoding": rays.encoding},
         {"rays.grid_idx": rays.grid_idx})
     grid_idx = rays.grid_idx.to(torch.int32).contiguous()
-    march = check_inputs_and_choose_march(rays, grid_idx, B, march_order)
+    march = check_inputs_and_plan(rays, grid_idx, B, march_order, rays_per_row)
     return march, (rays.directions.contiguous(), rays.origins.contiguous(), grid_idx, rays.near.contiguous(),
                    rays.far.contiguous())
 
@@ -210,6 +211,7 @@ def lightplane_splatter(
     triton_num_warps: int = 4,  # ignored
     process_group=None,
     march_order: Optional[str] = None,
+    rays_per_row: Optional[int] = None,
 ):
     """Splat ``rays.encoding`` into a zero-initialised grid-list of shape ``output_grid_size``.
 
@@ -222,6 +224,8 @@ def lightplane_splatter(
     ``march_order`` ("auto" / "rays" / "samples", default ``config.march_order``): which (ray, sample) pairs share a wavefront of
     the forward walk -- 32 neighbouring rays (image-coherent batches) or 32 consecutive samples of one ray (unrelated rays, e.g. the
     reference's ``tests/splatter_speed_benchmark.py``); see ``lightplane_renderer``.  Same result up to fp32 summation order.
+    ``rays_per_row``: rays per image row of a scanline-ordered batch (detected with the input check unless given; a hint for the
+    backward walk, which then gathers for 2 x 4 pixel patches per wavefront; see ``lightplane_renderer``).
     """
     sizes = sizes_to_list(output_grid_size)
     descs, channels, n_rows = make_grid_descs(sizes)
@@ -232,7 +236,7 @@ def lightplane_splatter(
     cfg = _SplatterCfg(descs, channels, n_rows, int(num_samples), int(num_samples_inf),
                        bool(mask_out_of_bounds_samples), bool(contract_coords), float(disparity_at_inf),
                        process_group)
-    cfg.march_order, ray_tensors = _prep_rays(rays, descs[0].B, march_order)
+    (cfg.march_order, cfg.row_length), ray_tensors = _prep_rays(rays, descs[0].B, march_order, rays_per_row)
     out = LightplaneSplatterFunction.apply(rays.encoding, cfg, *ray_tensors)
     if return_list:
         return list(unflatten_grid(out, sizes))

@@ -560,3 +560,50 @@ def test_splatter_transposed_march_on_random_rays(n_rays, C, S, tri, mask, n_inf
         for i, (a, b) in enumerate(zip(got_out, o_out)):
             _assert_close(f"splat out{i} vs oracle", a, b.detach().numpy())
         _assert_close("grad_encoding vs oracle", got_ge, r.encoding.grad.numpy())
+
+
+@pytest.mark.parametrize("H,W,C,tri,S", [(64, 64, 16, True, 24), (50, 72, 32, False, 20), (135, 96, 16, True, 40), (256, 256, 16, True, 128)],
+                         ids=["64x64_triplane", "50x72_voxel_tail_rows", "135x96_segmented", "cfg2_image"])
+def test_row_length_hint_gives_the_same_rays_their_same_results(H, W, C, tri, S):
+    """LpRays.row_length (rays_per_row / auto-detected): the tuned kernels deal 8 x 4 pixel patches to a wavefront instead of 32
+    pixels of one row.  Per-ray outputs are computed by the same instructions whatever lane a ray sits in: BIT-IDENTICAL; gradients
+    agree up to the order of the fp32 atomics.  Image heights that are no multiple of four (the last rows keep their scanline
+    order), a segmented small batch, the headline image; detection by the front-end; the Splatter's backward walk."""
+    from lightplane_amd.renderer import check_inputs_and_plan
+    dev = _dev()
+    gen = torch.Generator().manual_seed(H + W)
+    sizes = grid_sizes_for((1, 20, 24, 28, C), tri) if S < 100 else grid_sizes_for((1, 64, 64, 64, C), True)
+    grids = random_grids(gen, sizes)
+    dec = random_decoder(gen, 2, 2, 2, C, 32, 3, std=0.2)
+    rays = pinhole_rays(H, W, enc_dim=32, gen=gen, azimuth_deg=25.0, elevation_deg=20.0)
+    n = rays.n_rays
+    up = (torch.randn(n, generator=gen), torch.randn(n, generator=gen), torch.randn(n, 3, generator=gen))
+    cfg = dict(num_samples=S, gain=1.0, num_samples_inf=0, mask_out_of_bounds_samples=False, contract_coords=False, inject_noise_sigma=0.0,
+               inject_noise_seed=0)
+    d = dict(rays=rays, grids=grids, color_grids=None, decoder=dec, scaffold=None, cfg=cfg, sizes=sizes, upstream=up)
+    assert check_inputs_and_plan(rays.to(dev), rays.grid_idx.int().to(dev), 1) == (_lib.LP_MARCH_RAYS_PER_WAVE, W)   # detected
+    ref = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO, rays_per_row=0)
+    got = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO, rays_per_row=W)
+    auto = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO)
+    for a, b, c in zip(got[0], ref[0], auto[0]):
+        assert torch.equal(a, b) and torch.equal(c, b)
+    for nm, a, b in [("grad_mlp_params", got[1], ref[1]), ("grad_encoding", got[2], ref[2])] + [(f"grad_grid{i}", x, y) for i, (x, y) in enumerate(zip(got[3], ref[3]))]:
+        err = float((a - b).abs().max() / b.abs().max())
+        assert err <= 2e-5, f"{nm}: with vs without the row-length hint {err:.3e}"
+    # the Splatter: forward unchanged, backward walk with 2 x 4 pixel patches
+    srays = pinhole_rays(H, W, gen=gen, azimuth_deg=25.0, elevation_deg=20.0)
+    srays.encoding = torch.rand(n, C, generator=gen)
+    ssz = [[1, 18, 20, 16, C]]
+    sup = torch.randn(*ssz[0], generator=gen).to(dev)
+
+    def splat(row):
+        r = srays.to(dev)
+        r.encoding = r.encoding.clone().requires_grad_(True)
+        (out,) = lp.lightplane_splatter(r, ssz, num_samples=S, rays_per_row=row)
+        (out * sup).sum().backward()
+        return out, r.encoding.grad
+
+    o0, g0 = splat(0)
+    o1, g1 = splat(W)
+    _assert_close("splat out", o1, o0.detach().cpu().numpy(), tol=2e-5)
+    _assert_close("splat grad_encoding", g1, g0.cpu().numpy(), tol=2e-5)
