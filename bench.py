@@ -157,9 +157,7 @@ class RendererWorkload:
         # (bench.py runs with check_inputs off -- no device sync in a timed step --, so "auto" cannot look at the rays: the random-ray
         # workload names its march order; LP_BENCH_MARCH=rays for the A/B)
         self.render_kw = dict(disparity_at_inf=0.01, march_order=march_order or os.environ.get("LP_BENCH_MARCH", "samples")) if random else {}
-        # (... and likewise the row length of the image: with check_inputs on the front-end detects it by itself; LP_BENCH_NO_ROW_HINT=1 for the A/B)
-        if not random and not os.environ.get("LP_BENCH_NO_ROW_HINT"):
-            self.render_kw["rays_per_row"] = W
+
         n = H * W
         up = (torch.randn(n, generator=gen_r), torch.randn(n, generator=gen_r), torch.randn(n, COLOR, generator=gen_r))
         self.n_rays = n
@@ -494,8 +492,7 @@ class JointWorkload:
         if replicated:  # the splatted grid is a replicated tensor consumed by ray shards: its gradient is summed over the GPUs
             grid, p = parallel.replicate_with_grad_allreduce([grid, self.params], self.pg, exclusive_grads=True)  # consumed by the Renderer only
         d = lp.DecoderParams(p, self.dec_c.n_hidden_trunk, self.dec_c.n_hidden_opacity, self.dec_c.n_hidden_color, 3)
-        return lp.lightplane_renderer(self.cam, grid, d, num_samples=self.S, gain=1.0, grid_sizes=self.sizes, kernel=self.kernel,
-                                      rays_per_row=1920 if row else None)
+        return lp.lightplane_renderer(self.cam, grid, d, num_samples=self.S, gain=1.0, grid_sizes=self.sizes, kernel=self.kernel)
 
     def loss(self, out):
         return out[0].sum() + out[1].sum() + out[2].sum()

@@ -151,10 +151,11 @@ typedef struct LpRays {
                                Splatter: splatted feature) */
   int32_t encoding_dim;
   int32_t row_length;       /* > 0: the batch is made of image rows in scanline order, row_length consecutive rays each (neighbouring
-                               pixels).  A hint (0 = unknown; ABI 0.2.6, the former padding): the tuned Renderer kernels and the
-                               Splatter's backward walk then deal 8 x 4 / 2 x 4 PIXEL PATCHES to a wavefront -- four image rows walked
-                               column by column, alternating direction -- instead of 32 / 8 pixels of one row, so that the rays a wave
-                               merges and gathers for are neighbours in both image directions.  Results are per ray and unchanged. */
+                               pixels).  A hint (0 = unknown; ABI 0.2.6, the former padding): the Splatter's backward walk then deals
+                               2 x 4 PIXEL PATCHES to a wavefront -- four image rows walked column by column, alternating direction --
+                               instead of 8 pixels of one row: the rays a wave gathers for are neighbours in both image directions
+                               (cfg 3 backward -14 %).  Results are per ray and unchanged.  (The Renderer kernels ignore it: dealt
+                               8 x 4 patches they measured SLOWER -- profiles/r06_ray_order.txt.) */
 } LpRays;
 
 /* ray-march schedule: reference naive_renderer.py:218-257, ray_util.py:48-58 */

@@ -41,8 +41,8 @@ LP_DEV Ray load_ray(const LpRays& r, int64_t i) {
 
 // linspace(0,1,S)[i], scalar torch formula: i < S/2 ? i*step : 1 - (S-1-i)*step
 // LpRays.row_length: which ray a wave's item `idx` (block * rays-per-block + lane order) works on.  The batch is cut into bands of
-// four image rows; a band's 4 W rays are walked column by column, alternating direction (a snake): 32 consecutive items = an 8 x 4
-// pixel patch whose neighbours in the walk are pixel neighbours.  A bijection of [0, n_rays): the tail that is not a whole band
+// four image rows; a band's 4 W rays are walked column by column, alternating direction (a snake): 8 consecutive items = a 2 x 4
+// pixel patch whose neighbours in the walk are pixel neighbours (used by the Splatter's backward walk).  A bijection of [0, n_rays): the tail that is not a whole band
 // keeps its scanline order.  Measured on reordered inputs before it moved in here: scripts/bench_ray_order.py,
 // profiles/r06_ray_order.txt.
 LP_DEV int64_t patch_ray_index(int64_t idx, int64_t n_rays, int W) {

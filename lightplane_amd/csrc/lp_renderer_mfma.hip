@@ -59,9 +59,8 @@ __global__ void __launch_bounds__(256, OCC) renderer_fwd_bf3(const LpRendererArg
   const int n_seg = SEGF ? (a.march.num_samples + seg_len - 1) / seg_len : 1;
   const int blk = SEGF ? (int)blockIdx.x / n_seg : (int)blockIdx.x;
   const int seg = SEGF ? (int)blockIdx.x - blk * n_seg : 0;
-  const int64_t item = ((int64_t)blk * WAVES + wave) * RAYS_PER_WAVE + r;
-  const bool valid = item < a.rays.n_rays;
-  const int64_t ray_id = patch_ray_index(item, a.rays.n_rays, a.rays.row_length);  // (row_length: 8 x 4 pixel patches per wave)
+  const int64_t ray_id = ((int64_t)blk * WAVES + wave) * RAYS_PER_WAVE + r;
+  const bool valid = ray_id < a.rays.n_rays;
   const int64_t rid = valid ? ray_id : 0;
   const Ray ray = load_ray(a.rays, rid);
   float cb[16];  // per-ray pre-activation of the colour hidden layer (replaces the ray encoding in the loop)

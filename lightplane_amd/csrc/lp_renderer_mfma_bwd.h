@@ -221,9 +221,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) renderer_bwd_bf3(con
   const int n_seg = seg_on ? (a.march.num_samples + seg_len - 1) / seg_len : 1;  // workgroups per 128 rays
   const int blk = seg_on ? (int)blockIdx.x / n_seg : (int)blockIdx.x;
   const int seg = seg_on ? (int)blockIdx.x - blk * n_seg : 0;
-  const int64_t item = ((int64_t)blk * WAVES3 + wave) * RAYS_PER_WAVE + r;
-  const bool valid = item < a.rays.n_rays;
-  const int64_t ray_id = patch_ray_index(item, a.rays.n_rays, a.rays.row_length);  // (row_length: 8 x 4 pixel patches per wave)
+  const int64_t ray_id = ((int64_t)blk * WAVES3 + wave) * RAYS_PER_WAVE + r;
+  const bool valid = ray_id < a.rays.n_rays;
   const int64_t rid = valid ? ray_id : 0;
   const Ray ray = load_ray(a.rays, rid);
   const int s_tot = a.march.num_samples + a.march.num_samples_inf;

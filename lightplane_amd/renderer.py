@@ -503,9 +503,8 @@ def lightplane_renderer(
     rays of an image, or consecutive samples of one ray (random ray batches).  Results agree up to fp32 summation order.
 
     ``rays_per_row`` (default: detected together with the march order when ``config.check_inputs`` is on, else unknown): the batch is
-    made of image rows in scanline order, this many consecutive rays each.  A hint (``LpRays.row_length``): the tuned kernels then
-    give every wavefront an 8 x 4 pixel patch instead of 32 pixels of one row -- the rays it merges and gathers for are neighbours
-    in both image directions (+5 % on the headline configuration).  Per-ray results do not depend on it.
+    made of image rows in scanline order, this many consecutive rays each (``LpRays.row_length``).  The Renderer kernels ignore the
+    hint today (dealt 8 x 4 pixel patches they measured slower, profiles/r06_ray_order.txt); the Splatter's backward walk uses it.
     """
     out = _render(rays, grid, decoder_params, num_samples, gain, num_samples_inf, mask_out_of_bounds_samples,
                   contract_coords, disparity_at_inf, inject_noise_sigma, inject_noise_seed, scaffold, color_grid,

@@ -565,10 +565,11 @@ def test_splatter_transposed_march_on_random_rays(n_rays, C, S, tri, mask, n_inf
 @pytest.mark.parametrize("H,W,C,tri,S", [(64, 64, 16, True, 24), (50, 72, 32, False, 20), (135, 96, 16, True, 40), (256, 256, 16, True, 128)],
                          ids=["64x64_triplane", "50x72_voxel_tail_rows", "135x96_segmented", "cfg2_image"])
 def test_row_length_hint_gives_the_same_rays_their_same_results(H, W, C, tri, S):
-    """LpRays.row_length (rays_per_row / auto-detected): the tuned kernels deal 8 x 4 pixel patches to a wavefront instead of 32
-    pixels of one row.  Per-ray outputs are computed by the same instructions whatever lane a ray sits in: BIT-IDENTICAL; gradients
-    agree up to the order of the fp32 atomics.  Image heights that are no multiple of four (the last rows keep their scanline
-    order), a segmented small batch, the headline image; detection by the front-end; the Splatter's backward walk."""
+    """LpRays.row_length (rays_per_row / auto-detected): the Splatter's backward walk deals 2 x 4 pixel patches to a wavefront
+    instead of 8 pixels of one row; the Renderer accepts the hint and ignores it (profiles/r06_ray_order.txt).  Per-ray results do
+    not depend on it: Renderer outputs BIT-IDENTICAL, gradients equal up to the order of the fp32 atomics.  Image heights that are no
+    multiple of four (the last rows keep their scanline order), a segmented small batch, the headline image; detection by the
+    front-end."""
     from lightplane_amd.renderer import check_inputs_and_plan
     dev = _dev()
     gen = torch.Generator().manual_seed(H + W)
