@@ -173,7 +173,7 @@ LP_DEV void splat_walk(float* feat, float* wgt, const LpGrid& g, int b, float x,
 }
 
 template <int C, int RPW>
-__global__ void __launch_bounds__(256) splat_fwd_walk_kernel(const LpSplatterArgs a, int dbg, int n_seg) {
+__global__ void __launch_bounds__(256) splat_fwd_walk_kernel(const LpSplatterArgs a, int dbg, int n_seg, int grp) {
   constexpr int LD = RPW + 4;  // row stride of the transposed encoding tile [channel][ray]
   constexpr int NQ = 64 / RPW;
   constexpr int CPL = C / 16;
@@ -182,9 +182,14 @@ __global__ void __launch_bounds__(256) splat_fwd_walk_kernel(const LpSplatterArg
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane / RPW, r = lane % RPW;
   float* tile = lds[wave];
-  // small batches: blockIdx = (ray block, segment of the march) -- samples are independent, so a segment is just a
-  // sub-range of the sample loop (splat_segments() on the host)
-  const int blk = (int)blockIdx.x / n_seg, seg = (int)blockIdx.x - blk * n_seg;
+  // blockIdx = (ray block, segment of the march) -- samples are independent, so a segment is just a subset of the sample loop
+  // launch order: groups of `grp` ray blocks; inside a group segment after segment, every ray block of the group for each
+  const int n_blk = (int)gridDim.x / n_seg;
+  const int per_group = grp * n_seg;
+  const int gi = (int)blockIdx.x / per_group, gl = (int)blockIdx.x - gi * per_group;
+  const int g_size = (n_blk - gi * grp < grp) ? n_blk - gi * grp : grp;  // (the last group may be short)
+  const int seg = gl / g_size;
+  const int blk = gi * grp + (gl - seg * g_size);
   const int64_t ray_id = ((int64_t)blk * 4 + wave) * RPW + r;
   const bool valid = ray_id < a.rays.n_rays;
   const int64_t rid = valid ? ray_id : 0;
@@ -214,9 +219,14 @@ __global__ void __launch_bounds__(256) splat_fwd_walk_kernel(const LpSplatterArg
   const int s_tot = a.march.num_samples + a.march.num_samples_inf;
   const bool contract = a.march.contract_coords != 0;
   const bool mask = a.march.mask_out_of_bounds != 0;
+  // segment `seg` takes the samples seg, seg + n_seg, ...: interleaved, not a contiguous range (splat_forward_segments() on the host);
+  // (dbg & 8: contiguous ranges, the A/B)
+  const bool interleaved = !(dbg & 8);
   const int per_seg = (s_tot + n_seg - 1) / n_seg;
-  const int s_lo = seg * per_seg, s_hi = (s_lo + per_seg < s_tot) ? s_lo + per_seg : s_tot;
-  for (int s = s_lo; s < s_hi; ++s) {
+  const int s_lo = interleaved ? seg : seg * per_seg;
+  const int s_hi = interleaved ? s_tot : ((s_lo + per_seg < s_tot) ? s_lo + per_seg : s_tot);
+  const int s_step = interleaved ? n_seg : 1;
+  for (int s = s_lo; s < s_hi; s += s_step) {
     const float depth = sample_depth(s, a.march, ray.near_t, ray.far_t);
     float x, y, z;
     sample_point(ray, depth, contract, x, y, z);
@@ -329,12 +339,16 @@ __global__ void __launch_bounds__(256) splat_bwd_kernel(const LpSplatterArgs a) 
 // RPW = rays per wave: 16 (default), or 8 -- half the per-lane accumulators and batch buffers, so twice the waves fit a SIMD
 // and twice the gathers are in flight, for the price of the per-sample geometry being amortised over 8 rays instead of 16
 // (LP_SPLAT_BWD_RPW, measured in DESIGN.md 4.4).
+// The 64 / RPW lanes of a ray each take ONE SAMPLE of a block of 64 / RPW consecutive samples (round 6): the per-sample geometry
+// (depth, point, tap set: ~60 % of the instructions of a VALU-bound kernel when every lane of a ray repeated it for the same sample)
+// is computed once per (ray, sample); the walk then goes through the block's samples, reading the tap rows of sample j from the lanes
+// j RPW .. and its weights from table j.
 template <int C, int B, int RPW = 16>
 __global__ void __launch_bounds__(256, RPW == 8 ? (C < 32 ? 4 : (C < 64 ? 3 : 2)) : ((B == 4 && C < 64) ? 3 : 2))
 splat_bwd_walk_kernel(const LpSplatterArgs a, int n_seg) {
   static_assert(RPW == 16 || (RPW == 8 && B == 8), "rays per wave: 16, or 8 with one batch of 8");
-  constexpr int CPL = C / 16, NQ = 64 / RPW, SPQ = 8 / NQ;
-  __shared__ __attribute__((aligned(16))) float lds[4][8 * RPW];
+  constexpr int CPL = C / 16, NQ = 64 / RPW;
+  __shared__ __attribute__((aligned(16))) float lds[4][NQ * 8 * RPW];  // per wave: [sample of the block][tap][ray]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane / RPW, r = lane % RPW, sub = lane & 15, grp = lane >> 4;
   float* wT = lds[wave];
@@ -354,11 +368,12 @@ splat_bwd_walk_kernel(const LpSplatterArgs a, int n_seg) {
   const bool mask_oob = a.march.mask_out_of_bounds != 0;
   const int per_seg = (s_tot + n_seg - 1) / n_seg;
   const int s_lo = seg * per_seg, s_hi = (s_lo + per_seg < s_tot) ? s_lo + per_seg : s_tot;
-  for (int s = s_lo; s < s_hi; ++s) {
-    const float depth = sample_depth(s, a.march, ray.near_t, ray.far_t);
+  for (int sb = s_lo; sb < s_hi; sb += NQ) {
+    const int s = sb + q;  // this lane's sample of the block
+    const float depth = sample_depth(s < s_tot ? s : s_tot - 1, a.march, ray.near_t, ray.far_t);
     float x, y, z;
     sample_point(ray, depth, contract, x, y, z);
-    const bool live = valid && !(mask_oob && !point_in_bounds(x, y, z));
+    const bool live = valid && s < s_hi && !(mask_oob && !point_in_bounds(x, y, z));
     for (int g = 0; g < a.out.n_grids; ++g) {
       TapSet tp;
       grid_tapset<true>(a.out.grids[g], ray.b, x, y, z, tp);
@@ -368,69 +383,71 @@ splat_bwd_walk_kernel(const LpSplatterArgs a, int n_seg) {
         for (int k = 0; k < 8; ++k) tp.w[k] = 0.0f;
       }
 #pragma unroll
-      for (int i = 0; i < SPQ; ++i) {
-        float v = tp.w[i];
-#pragma unroll
-        for (int qq = 1; qq < NQ; ++qq) v = (q == qq) ? tp.w[qq * SPQ + i] : v;
-        wT[(q * SPQ + i) * RPW + r] = v;
-      }
+      for (int k = 0; k < 8; ++k) wT[(q * 8 + k) * RPW + r] = tp.w[k];
       const int row0 = tp.row0;
       const int ok = (int)tp.ok;
       const int prow_ = lane_prev(row0), pok_ = lane_prev(ok);  // all lanes enabled: see run_head()
       const bool head = run_head(r, row0, prow_, ok, pok_);
-      const unsigned mask = ((unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head)) | (B == 8 ? 0x101u : 0x1111u)) &
-                            ((1u << RPW) - 1u);
+      const unsigned long long heads = (unsigned long long)__ballot(head);
+      const unsigned long long lives = (unsigned long long)__ballot(ok != 0);
       const int koff = (grp & 1) * tp.sv + (grp >> 1) * tp.st;
       const unsigned bit_lo = 1u << (2 * grp), bit_hi = 2u << (2 * grp);
-      const float4* wlo = reinterpret_cast<const float4*>(wT + (2 * grp) * RPW);
-      const float4* whi = reinterpret_cast<const float4*>(wT + (2 * grp + 1) * RPW);
+      const int n_here = (s_hi - sb < NQ) ? s_hi - sb : NQ;
+#pragma unroll 1
+      for (int js = 0; js < n_here; ++js) {
+        const int l0 = js * RPW;  // first lane of sample js of the block
+        if (((lives >> l0) & ((1ull << RPW) - 1ull)) == 0ull) continue;  // no ray of the wave touches the grid at this sample
+        const unsigned mask = ((unsigned)(heads >> l0) | (B == 8 ? 0x101u : 0x1111u)) & ((1u << RPW) - 1u);
+        const float4* wlo = reinterpret_cast<const float4*>(wT + (js * 8 + 2 * grp) * RPW);
+        const float4* whi = reinterpret_cast<const float4*>(wT + (js * 8 + 2 * grp + 1) * RPW);
 #pragma unroll
-      for (int cb = 0; cb < RPW / B; ++cb) {
-        // columns of the runs that start in this batch of B rays (the first ray of a batch is forced to be a
-        // run head: a run crossing a batch boundary is simply read again)
-        float glo[B][CPL], ghi[B][CPL], ilo[B], ihi[B];
+        for (int cb = 0; cb < RPW / B; ++cb) {
+          // columns of the runs that start in this batch of B rays (the first ray of a batch is forced to be a
+          // run head: a run crossing a batch boundary is simply read again)
+          float glo[B][CPL], ghi[B][CPL], ilo[B], ihi[B];
 #pragma unroll
-        for (int i = 0; i < B; ++i) {
-          const int rr = B * cb + i;
-          if ((mask >> rr) & 1u) {
-            const int s_row = __builtin_amdgcn_readlane(row0, rr);
-            const unsigned s_ok = (unsigned)__builtin_amdgcn_readlane(ok, rr);
-            const int64_t row = (int64_t)(s_row + koff);
-            const bool l_ok = (s_ok & bit_lo) != 0, h_ok = (s_ok & bit_hi) != 0;
-            ilo[i] = l_ok ? a.weight[row] : 1.0f;
-            ihi[i] = h_ok ? a.weight[row + 1] : 1.0f;
+          for (int i = 0; i < B; ++i) {
+            const int rr = B * cb + i;
+            if ((mask >> rr) & 1u) {
+              const int s_row = __builtin_amdgcn_readlane(row0, l0 + rr);
+              const unsigned s_ok = (unsigned)__builtin_amdgcn_readlane(ok, l0 + rr);
+              const int64_t row = (int64_t)(s_row + koff);
+              const bool l_ok = (s_ok & bit_lo) != 0, h_ok = (s_ok & bit_hi) != 0;
+              ilo[i] = l_ok ? a.weight[row] : 1.0f;
+              ihi[i] = h_ok ? a.weight[row + 1] : 1.0f;
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) {
-              glo[i][j] = l_ok ? a.grad_out[row * C + sub + 16 * j] : 0.0f;
-              ghi[i][j] = h_ok ? a.grad_out[(row + 1) * C + sub + 16 * j] : 0.0f;
+              for (int j = 0; j < CPL; ++j) {
+                glo[i][j] = l_ok ? a.grad_out[row * C + sub + 16 * j] : 0.0f;
+                ghi[i][j] = h_ok ? a.grad_out[(row + 1) * C + sub + 16 * j] : 0.0f;
+              }
             }
           }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        float w0[B], w1[B];
+          __builtin_amdgcn_sched_barrier(0);
+          float w0[B], w1[B];
 #pragma unroll
-        for (int i4 = 0; i4 < B / 4; ++i4) {
-          const float4 a4 = wlo[(B / 4) * cb + i4], b4 = whi[(B / 4) * cb + i4];
-          w0[4 * i4 + 0] = a4.x; w0[4 * i4 + 1] = a4.y; w0[4 * i4 + 2] = a4.z; w0[4 * i4 + 3] = a4.w;
-          w1[4 * i4 + 0] = b4.x; w1[4 * i4 + 1] = b4.y; w1[4 * i4 + 2] = b4.z; w1[4 * i4 + 3] = b4.w;
-        }
-        float cl[CPL], ch[CPL];
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) cl[j] = ch[j] = 0.0f;
-#pragma unroll
-        for (int i = 0; i < B; ++i) {
-          const int rr = B * cb + i;
-          if ((mask >> rr) & 1u) {
-            // gradient of out = feat / max(weight, 1e-5) w.r.t. feat (weights carry no gradient)
-            const float il = 1.0f / fmaxf(ilo[i], 1e-5f), ih = 1.0f / fmaxf(ihi[i], 1e-5f);
-#pragma unroll
-            for (int j = 0; j < CPL; ++j) {
-              cl[j] = glo[i][j] * il;
-              ch[j] = ghi[i][j] * ih;
-            }
+          for (int i4 = 0; i4 < B / 4; ++i4) {
+            const float4 a4 = wlo[(B / 4) * cb + i4], b4 = whi[(B / 4) * cb + i4];
+            w0[4 * i4 + 0] = a4.x; w0[4 * i4 + 1] = a4.y; w0[4 * i4 + 2] = a4.z; w0[4 * i4 + 3] = a4.w;
+            w1[4 * i4 + 0] = b4.x; w1[4 * i4 + 1] = b4.y; w1[4 * i4 + 2] = b4.z; w1[4 * i4 + 3] = b4.w;
           }
+          float cl[CPL], ch[CPL];
 #pragma unroll
-          for (int j = 0; j < CPL; ++j) acc[j][rr] = fmaf(w1[i], ch[j], fmaf(w0[i], cl[j], acc[j][rr]));
+          for (int j = 0; j < CPL; ++j) cl[j] = ch[j] = 0.0f;
+#pragma unroll
+          for (int i = 0; i < B; ++i) {
+            const int rr = B * cb + i;
+            if ((mask >> rr) & 1u) {
+              // gradient of out = feat / max(weight, 1e-5) w.r.t. feat (weights carry no gradient)
+              const float il = 1.0f / fmaxf(ilo[i], 1e-5f), ih = 1.0f / fmaxf(ihi[i], 1e-5f);
+#pragma unroll
+              for (int j = 0; j < CPL; ++j) {
+                cl[j] = glo[i][j] * il;
+                ch[j] = ghi[i][j] * ih;
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) acc[j][rr] = fmaf(w1[i], ch[j], fmaf(w0[i], cl[j], acc[j][rr]));
+          }
         }
       }
     }
@@ -504,25 +521,46 @@ __global__ void __launch_bounds__(256) hash_randn_kernel(const int32_t* x1, cons
     }                                                                                          \
   } while (0)
 
-// Small batches: a wave marches 16 rays one sample after the other, so fewer than ~16 k rays leave most of the chip idle.
+// Small batches (BACKWARD): a wave marches its rays one sample after the other, so fewer than ~16 k rays leave most of the chip idle.
 // The samples of a ray are independent in the Splatter, so the march is cut into segments of at least 16 samples, as many
 // as bring the launch to ~3 workgroups per CU (LP_SPLAT_SEGMENTS=1 switches it off).  Walk kernels on MI355X, 256 samples
-// into a 128^3 x 32 grid (scripts/bench_small_batch.py --splatter, profiles/r02_small_batch.txt): 4 096 rays forward
-// 1.31 -> 0.28 ms, backward 1.19 -> 0.23 ms; 16 384 rays 1.29 -> 0.89 / 1.16 -> 0.81 ms; at 32 768 rays (512 ray blocks)
-// two segments no longer pay for the backward (1.17 -> 1.29 ms), hence the 768.
-// The FORWARD also gains from a few segments on mid-sized batches (more waves in flight behind the atomics): cfg 3 (1 024 ray
-// blocks, 256 samples) forward 2.42 ms with one segment, 2.35 with two, 2.26 with three, 2.33 with four; its backward loses
-// (2.33 -> 2.43 .. 2.69 ms) -- hence `forward`: up to three segments while the launch stays within 3 072 workgroups.
-static int splat_segments(const LpSplatterArgs& a, unsigned ray_blocks, bool forward = false) {
+// into a 128^3 x 32 grid (scripts/bench_small_batch.py --splatter, profiles/r02_small_batch.txt): 4 096 rays backward
+// 1.19 -> 0.23 ms; 16 384 rays 1.16 -> 0.81 ms; at 32 768 rays (512 ray blocks) two segments no longer pay (1.17 -> 1.29 ms),
+// hence the 768.
+static int splat_segments(const LpSplatterArgs& a, unsigned ray_blocks) {
   static const int forced = getenv("LP_SPLAT_SEGMENTS") ? atoi(getenv("LP_SPLAT_SEGMENTS")) : 0;
   const int s_tot = a.march.num_samples + a.march.num_samples_inf;
   int n = forced > 0 ? forced : (int)(768u / (ray_blocks ? ray_blocks : 1u));
-  if (forced <= 0 && forward && n <= 1) {  // measured up to three; four was already slower (385..768 ray blocks must not get 4..7)
-    n = (int)(3072u / (ray_blocks ? ray_blocks : 1u));
-    if (n > 3) n = 3;
-  }
   if (n > s_tot / 16) n = s_tot / 16;
   return n < 1 ? 1 : n;
+}
+
+// FORWARD walk (round 6, profiles/r06_splat_launch_order.txt): the march of every ray block is dealt to up to 32 workgroups that take
+// INTERLEAVED samples (segment g: samples g, g + n, ...; at least 8 each).  Rounds 2-5 cut it into <= 3 CONTIGUOUS ranges: the samples
+// in front of and behind the grid cost a fraction of those inside, the middle range's waves ran alone for most of the launch (average
+// wave lifetime 31 % of the kernel's) -- cfg 3 forward 2.18 ms.  Interleaved and fine-grained every workgroup gets the same mix; and the
+// ORDER the (ray block, segment) workgroups are issued in decides how far apart in time the atomics to one grid row are:
+//   * segment-major (all ray blocks at segment 0, then at segment 1, ...): the chip works on ONE depth phase of the whole image at a time
+//     -- cfg 3 forward 1.63 ms (20.4 Mrays/s fwd+bwd from 17.3); right while the grid is small enough to stay cached between
+//     phases and a phase of the whole batch is short;
+//   * ray-block-major (the segments of a ray block side by side): right for grids far beyond the caches (cfg 5, 256^3 x 32 = 2.15 GB:
+//     forward 149.8 -> 139.4 ms; segment-major 157) and for very large batches (1024^2 rays: every phase re-reads all encodings).
+// Measured on nine image / grid shapes; the rule below picks the faster order on each.  LP_SPLAT_FWD_SEGMENTS / LP_SPLAT_FWD_GROUP: A/B.
+static int splat_forward_segments(const LpSplatterArgs& a) {
+  static const int forced = getenv("LP_SPLAT_FWD_SEGMENTS") ? atoi(getenv("LP_SPLAT_FWD_SEGMENTS")) : 0;
+  const int s_tot = a.march.num_samples + a.march.num_samples_inf;
+  int n = forced > 0 ? forced : s_tot / 8;
+  if (forced <= 0 && n > 32) n = 32;
+  if (n > s_tot) n = s_tot;
+  return n < 1 ? 1 : n;
+}
+// ray blocks per launch group: inside a group the workgroups are issued segment after segment (group = every ray block: segment-major;
+// group = 1: ray-block-major)
+static int splat_forward_group(const LpSplatterArgs& a, unsigned ray_blocks) {
+  static const int forced = getenv("LP_SPLAT_FWD_GROUP") ? atoi(getenv("LP_SPLAT_FWD_GROUP")) : 0;
+  if (forced > 0) return forced;
+  const double grid_bytes = (double)a.out.n_rows * (double)a.out.channels * 4.0;
+  return (grid_bytes <= 1.0e9 && ray_blocks <= 4096u) ? (int)ray_blocks : 1;
 }
 
 int splatter_forward_launch(const LpSplatterArgs& a, hipStream_t stream) {
@@ -550,14 +588,15 @@ int splatter_forward_launch(const LpSplatterArgs& a, hipStream_t stream) {
     const int rpw_eff = Cw == 64 ? 16 : rpw;
     const unsigned ray_blocks = (unsigned)((a.rays.n_rays + 4 * rpw_eff - 1) / (4 * rpw_eff));
     if (ray_blocks == 0) return LP_OK;
-    const int n_seg = splat_segments(a, ray_blocks, true);
+    const int n_seg = splat_forward_segments(a);
     const unsigned blocks = ray_blocks * (unsigned)n_seg;
+    const int grp = splat_forward_group(a, ray_blocks);
     // (64 channels -- the reference's own speed benchmark splats into [1,160,160,160,64] -- : four channels per lane)
-    if (Cw == 64) hipLaunchKernelGGL((splat_fwd_walk_kernel<64, 16>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg);
-    else if (Cw == 16 && rpw == 32) hipLaunchKernelGGL((splat_fwd_walk_kernel<16, 32>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg);
-    else if (Cw == 16) hipLaunchKernelGGL((splat_fwd_walk_kernel<16, 16>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg);
-    else if (rpw == 32) hipLaunchKernelGGL((splat_fwd_walk_kernel<32, 32>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg);
-    else hipLaunchKernelGGL((splat_fwd_walk_kernel<32, 16>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg);
+    if (Cw == 64) hipLaunchKernelGGL((splat_fwd_walk_kernel<64, 16>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg, grp);
+    else if (Cw == 16 && rpw == 32) hipLaunchKernelGGL((splat_fwd_walk_kernel<16, 32>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg, grp);
+    else if (Cw == 16) hipLaunchKernelGGL((splat_fwd_walk_kernel<16, 16>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg, grp);
+    else if (rpw == 32) hipLaunchKernelGGL((splat_fwd_walk_kernel<32, 32>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg, grp);
+    else hipLaunchKernelGGL((splat_fwd_walk_kernel<32, 16>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg, grp);
     return check_launch("splat_fwd_walk_kernel");
   }
   LP_SPLAT_DISPATCH(splat_fwd_kernel);
