@@ -73,7 +73,7 @@ LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, floa
   const int prow_ = lane_prev(row0), pok_ = lane_prev(ok);  // all lanes enabled: see run_head()
   const bool head = run_head(r, row0, prow_, ok, pok_);
   const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head));
-  {
+  if (!(dbg & 64)) {
     // merge axis A (wave-uniform): the axis of the first cell change of this walk
     int A = 0;
     if (mask & ~1u) {
@@ -93,6 +93,7 @@ LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, floa
     const float4* wlo = reinterpret_cast<const float4*>(wT + k_lo * WLD);
     const float4* whi = reinterpret_cast<const float4*>(wT + k_hi * WLD);
     const int64_t hi_off = (int64_t)sA * C;
+    const unsigned lane_off = (unsigned)(koff * C + sub);  // this lane's float inside the block of rows that starts at row0
     // slots on the near / far side along A (all four corner pairs): a column is only carried over if the old
     // and the new cell agree on its validity (a masked or padding ray in the neighbouring cell has ok == 0)
     const unsigned lo_slots = A == 0 ? 0x55u : (A == 1 ? 0x33u : 0x0Fu);
@@ -119,34 +120,35 @@ LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, floa
           const int n_row = __builtin_amdgcn_readlane(row0, rr);
           const int n_cell = __builtin_amdgcn_readlane(cell, rr);
           const int d = n_cell - s_cell, dr = n_row - s_row;  // dr: also tells grids of different batch entries apart
-          float* dst = feat + (int64_t)(s_row + koff) * C + sub;
           const unsigned n_ok = (unsigned)__builtin_amdgcn_readlane(ok, rr);
-          if (d == step && dr == sA && ((n_ok & lo_slots) << sh) == (s_ok & (lo_slots << sh))) {
-            // +1 along A: the far column becomes the near one
+          // up == 0: +1 along A, the far column becomes the near one; down == 0: -1 along A.  A column is only carried over if the old and
+          // the new cell agree on its validity.  (One integer per case, kept opaque: a conjunction of wave-uniform compares is lowered to
+          // lane-mask logic -- s_cselect_b64 / s_and_b64 vcc / s_cbranch_vccnz, three times the scalar instructions of s_cmp + s_cbranch_scc;
+          // the walks are bound by their instruction count, profiles/r06_splat_launch_order.txt.)
+          int up = (d ^ step) | (dr ^ sA) | (int)(((n_ok & lo_slots) << sh) ^ (s_ok & (lo_slots << sh)));
+          int down = (d ^ -step) | (dr ^ -sA) | (int)(((s_ok & lo_slots) << sh) ^ (n_ok & (lo_slots << sh)));
+          up = __builtin_amdgcn_readfirstlane(up);
+          down = __builtin_amdgcn_readfirstlane(down);
+          asm volatile("" : "+s"(up), "+s"(down));
+          float* const rowp = feat + (int64_t)s_row * C;  // (wave-uniform: scalar base + per-lane 32-bit offset)
+          if (down != 0) {  // the near column is left behind
             if ((s_ok & bit_lo) && on) {
 #pragma unroll
-              for (int j = 0; j < CPL; ++j) atomic_add_f32(dst + 16 * j, lo[j]);
+              for (int j = 0; j < CPL; ++j) atomic_add_f32(rowp + lane_off + 16 * j, lo[j]);
             }
-#pragma unroll
-            for (int j = 0; j < CPL; ++j) { lo[j] = hi[j]; hi[j] = 0.0f; }
-          } else if (d == -step && dr == -sA && ((s_ok & lo_slots) << sh) == (n_ok & (lo_slots << sh))) {  // -1 along A
+          }
+          if (up != 0) {  // the far column is left behind
             if ((s_ok & bit_hi) && on) {
 #pragma unroll
-              for (int j = 0; j < CPL; ++j) atomic_add_f32(dst + hi_off + 16 * j, hi[j]);
+              for (int j = 0; j < CPL; ++j) atomic_add_f32(rowp + hi_off + lane_off + 16 * j, hi[j]);
             }
+          }
+          const bool is_up = up == 0, is_down = down == 0;
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) { hi[j] = lo[j]; lo[j] = 0.0f; }
-          } else {
-            if ((s_ok & bit_lo) && on) {
-#pragma unroll
-              for (int j = 0; j < CPL; ++j) atomic_add_f32(dst + 16 * j, lo[j]);
-            }
-            if ((s_ok & bit_hi) && on) {
-#pragma unroll
-              for (int j = 0; j < CPL; ++j) atomic_add_f32(dst + hi_off + 16 * j, hi[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < CPL; ++j) lo[j] = hi[j] = 0.0f;
+          for (int j = 0; j < CPL; ++j) {
+            const float l = lo[j], h = hi[j];
+            lo[j] = is_up ? h : 0.0f;
+            hi[j] = is_down ? l : 0.0f;
           }
           s_row = n_row;
           s_cell = n_cell;
@@ -160,17 +162,17 @@ LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, floa
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    float* dst = feat + (int64_t)(s_row + koff) * C + sub;
+    float* const rowp = feat + (int64_t)s_row * C;
     if ((s_ok & bit_lo) && on) {
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) atomic_add_f32(dst + 16 * j, lo[j]);
+      for (int j = 0; j < CPL; ++j) atomic_add_f32(rowp + lane_off + 16 * j, lo[j]);
     }
     if ((s_ok & bit_hi) && on) {
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) atomic_add_f32(dst + hi_off + 16 * j, hi[j]);
+      for (int j = 0; j < CPL; ++j) atomic_add_f32(rowp + hi_off + lane_off + 16 * j, hi[j]);
     }
   }
-  if (!SPLAT) return;  // the Renderer's gradient scatter has no weight grid
+  if (!SPLAT || (dbg & 32)) return;  // the Renderer's gradient scatter has no weight grid  (dbg & 32 / 64: timing experiments)
   // unit weights: x-neighbouring rows are neighbouring floats of the weight grid, so a 16-cell window of x per
   // (y, z) pair is kept in the lanes (lane = pair * 16 + x - window base) and written with ONE atomic
   // instruction of four 64-byte segments when the walk leaves it -- the per-run version issued four segments
@@ -181,6 +183,10 @@ LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, floa
     const float4* whi = reinterpret_cast<const float4*>(wT + (2 * grp + 1) * WLD);
     const int W = g.W;
     float acc = 0.0f;
+    // (an opaque copy of the head mask: with the same value visibly tested in both walks the compiler keeps all 32 head bits of the
+    // first walk as lane masks in 64 scalar registers and tests each bit twice there)
+    unsigned mask_w = (unsigned)__builtin_amdgcn_readfirstlane((int)mask);
+    asm volatile("; head mask of the weight walk" : "+s"(mask_w));
     int s_row = __builtin_amdgcn_readlane(row0, 0);
     int s_iu = __builtin_amdgcn_readlane(iu, 0);
     int wb = ((s_iu & 15) == 15) ? s_iu : (s_iu & ~15);  // window base (x of lane sub == 0)
@@ -195,11 +201,14 @@ LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, floa
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int rr = 8 * c8 + i;
-        if (rr > 0 && ((mask >> rr) & 1u)) {
+        if (rr > 0 && ((mask_w >> rr) & 1u)) {
           const int n_row = __builtin_amdgcn_readlane(row0, rr);
           const int n_iu = __builtin_amdgcn_readlane(iu, rr);
-          const bool same_line = (n_row - n_iu) == rowb;
-          if (!(same_line && n_iu >= wb && n_iu + 1 < wb + 16)) {
+          // (same (y, z) line and 0 <= n_iu - wb <= 14; one opaque integer, as above)
+          int leave = ((n_row - n_iu) ^ rowb) | (int)((unsigned)(n_iu - wb) >= 15u);
+          leave = __builtin_amdgcn_readfirstlane(leave);
+          asm volatile("" : "+s"(leave));
+          if (leave != 0) {
             const int xl = wb + sub;
             if (acc != 0.0f && xl >= 0 && xl < W && on) atomic_add_f32(wgt + (int64_t)(rowb + koff + xl), acc);
             acc = 0.0f;
