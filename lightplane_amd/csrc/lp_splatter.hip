@@ -366,9 +366,11 @@ splat_bwd_walk_kernel(const LpSplatterArgs a, int n_seg) {
   const int s_tot = a.march.num_samples + a.march.num_samples_inf;
   const bool contract = a.march.contract_coords != 0;
   const bool mask_oob = a.march.mask_out_of_bounds != 0;
-  const int per_seg = (s_tot + n_seg - 1) / n_seg;
-  const int s_lo = seg * per_seg, s_hi = (s_lo + per_seg < s_tot) ? s_lo + per_seg : s_tot;
-  for (int sb = s_lo; sb < s_hi; sb += NQ) {
+  // segment `seg` takes the sample blocks seg, seg + n_seg, ... (interleaved like the forward's samples: contiguous ranges give the
+  // segment in the middle of the march all the samples inside the grid -- cfg 3 backward 0.88 -> 0.71 ms with the same three segments;
+  // the segments of a ray block stay side by side in the launch: issued segment-major the gather loses its L2 locality, 0.89 ms)
+  const int s_hi = s_tot;
+  for (int sb = seg * NQ; sb < s_hi; sb += NQ * n_seg) {
     const int s = sb + q;  // this lane's sample of the block
     const float depth = sample_depth(s < s_tot ? s : s_tot - 1, a.march, ray.near_t, ray.far_t);
     float x, y, z;
@@ -647,8 +649,10 @@ int splatter_backward_launch(const LpSplatterArgs& a, hipStream_t stream) {
       const uint64_t cap = (uint64_t)n_simd * occ, waves = (uint64_t)ray_blocks * 4;
       const int s_tot = a.march.num_samples + a.march.num_samples_inf;
       if (waves >= cap && waves <= 16 * cap) {
+        // (round 6: the segments take INTERLEAVED sample blocks, so more of them also even out the work of a wave -- a launch of up to
+        // four rounds starts at three segments whatever its round arithmetic says: 256^2 rays x 16 ch, exactly two rounds: 0.80 -> 0.65 ms)
         const int cand[5] = {1, 2, 3, 4, 6};
-        for (int i = 0; i < 5; ++i) {
+        for (int i = (waves <= 4 * cap) ? 2 : 0; i < 5; ++i) {
           const int n = cand[i];
           if (n > 1 && s_tot / n < 16) break;
           const uint64_t tot = waves * n, rounds = (tot + cap - 1) / cap;

@@ -28,6 +28,22 @@ for H, W, G, C, S in CASES:
     for _ in range(n):
         f()
     e1.record(); torch.cuda.synchronize()
-    out[f"{H}x{W}->{G}^3x{C},S{S}"] = round(e0.elapsed_time(e1) / n, 4)
+    fwd = e0.elapsed_time(e1) / n
+    # backward (gather walk): LP_SPLAT_SEGMENTS forces its segment count
+    rays.encoding.requires_grad_(True)
+    up = torch.randn(G ** 3, C, device=dev)
+    def fb():
+        rays.encoding.grad = None
+        (f() * up).sum().backward()
+    for _ in range(3):
+        fb()
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(n):
+        fb()
+    e1.record(); torch.cuda.synchronize()
+    out[f"{H}x{W}->{G}^3x{C},S{S}"] = (round(fwd, 4), round(e0.elapsed_time(e1) / n - fwd, 4))
+    rays.encoding.requires_grad_(False)
+    del up
     torch.cuda.empty_cache()
-print(json.dumps({"seg": os.environ.get("LP_SPLAT_FWD_SEGMENTS"), "grp": os.environ.get("LP_SPLAT_FWD_GROUP"), "fwd_ms": out}))
+print(json.dumps({"seg": os.environ.get("LP_SPLAT_FWD_SEGMENTS"), "grp": os.environ.get("LP_SPLAT_FWD_GROUP"), "bwd_seg": os.environ.get("LP_SPLAT_SEGMENTS"),
+                  "fwd_bwd_ms": out}))  # (bwd = step - fwd: includes the loss kernels)
