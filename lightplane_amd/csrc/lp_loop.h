@@ -29,7 +29,11 @@ struct LoopLayer {
 inline int loop_layer_bytes(int rows_in, int cols) { return ((rows_in + 31) / 32) * ((cols + 31) / 32) * LOOP_BLK; }
 
 LP_DEV constexpr int pi16l(int m) { return m < 4 ? 2 * m : (m < 12 ? 2 * (m - 4) + 1 : 2 * (m - 8)); }
+#ifdef LP_TIMING_NO_BARRIER  // timing experiment (wrong results): what the workgroup barriers of the dW rounds cost
+LP_DEV void lds_barrier_l() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
 LP_DEV void lds_barrier_l() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // staging
