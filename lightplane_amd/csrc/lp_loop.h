@@ -271,16 +271,47 @@ inline namespace dw_fp32 {
 // Backward of one layer: dW (workgroup-shared quadrants) and dX.  x = the layer's input activation, dy = upstream gradient
 // (already masked by the layer's own ReLU).  Publishes the X / dY tiles of one block pair, runs the dX chain while the LDS
 // writes land, then barrier -> quadrant -> barrier per block pair.
+// z_delta (two-block layers, bf16 quadrants): byte distance from the dY tile to a THIRD tile of the wave's area, 0 = there is none.
+// With it both dY blocks of a layer are published at once and an X block once per input block: a 64 x 64 layer stores 4 tiles behind 4
+// barriers instead of 8 behind 8 (every (ib, ob) pair used to re-publish its X and dY block).
 template <int NB, int DXL = 3>
 LP_DEV void loop_layer_bwd(const char* lbase, const LoopLayer& L, int lane, float* xt, float* yt, const float* wave0, int stride,
                            int a_off, int b_off, bool want_params, bool want_dx, const float (&x)[NB][16], const float (&dy)[NB][16],
-                           LoopDw<NB>& dw, f32x16 (&dx)[NB]) {
+                           LoopDw<NB>& dw, f32x16 (&dx)[NB], int z_delta = 0) {
   const int h = lane >> 5, r = lane & 31;
   const int in_blocks = (L.rows_in + 31) >> 5;
 #if LP_LOOP_DW_BF16
   // (a_off / b_off are BYTE offsets of the supplier addresses here, see the callers)
   char* const xrow = reinterpret_cast<char*>(xt) + rm_off(loop_rho(r), 4 * h);
   char* const yrow = reinterpret_cast<char*>(yt) + rm_off(loop_rho(r), 4 * h);
+  if constexpr (NB == 2) {
+    if (z_delta != 0) {  // (workgroup-uniform)
+      const bool two_out = L.ob > 1;
+      if (want_params) {
+        limb_tile_store<2>(xrow, x[0]);
+        limb_tile_store<2>(yrow, dy[0]);
+        if (two_out) limb_tile_store<2>(yrow + z_delta, dy[1]);
+      }
+      if (want_dx) loop_layer_dx<NB, DXL>(lbase, L, lane, dy, dx);
+      if (want_params) {
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib) {
+          if (ib < in_blocks) {  // workgroup-uniform
+            if (ib > 0) limb_tile_store<2>(xrow, x[ib]);  // (behind the closing barrier of the previous input block)
+            lds_barrier_l();
+            float db_unused = 0.0f;
+            dw.q[ib][0] = loop_dw_quadrant_bf(reinterpret_cast<const char*>(wave0), stride * 4, a_off, b_off, dw.q[ib][0],
+                                              ib == 0 ? dw.db[0] : db_unused, ib == 0, lane);
+            if (two_out)
+              dw.q[ib][1] = loop_dw_quadrant_bf(reinterpret_cast<const char*>(wave0), stride * 4, a_off, b_off + z_delta, dw.q[ib][1],
+                                                ib == 0 ? dw.db[1] : db_unused, ib == 0, lane);
+            lds_barrier_l();
+          }
+        }
+      }
+      return;
+    }
+  }
   if (want_params) {
     limb_tile_store<2>(xrow, x[0]);
     limb_tile_store<2>(yrow, dy[0]);

@@ -44,6 +44,9 @@ struct LoopParams {
   // per ReLU site in the reference's evaluation order, then the visited flag (include/lightplane_hip.h).  Only the DUMP twins read it.
   uint32_t* relu_dump;
   int dump_words;
+  // per-wave LDS area of the backward: floats per wave, and the byte distance from the dY tile to the third tile of two-block layers
+  // (0 = none: the decoder's images leave no room), see loop_layer_bwd
+  int tile_stride, z_delta;
 };
 
 // per-wave LDS area behind the images (floats)
@@ -53,6 +56,10 @@ struct LoopTile {
   static constexpr int TS = 2 * 32 * LT_LD;    // [5][32]: d raw_o, d raw_c[0..3] by ray
   static constexpr int WT = TS + 5 * 32;       // [8][32]: the scatter's weight table when C = 64 (its dx0 tile [64][36] spans X and dY)
   static constexpr int PER_WAVE = WT + 8 * 32;
+  // third tile of the two-block backward (hidden 64, bf16 quadrants): starts at TS -- TS and WT are idle during the layer rounds -- and
+  // ends Z_EXTRA floats behind PER_WAVE
+  static constexpr int ZT = TS;
+  static constexpr int Z_EXTRA = ZT + 2 * rm_bytes(32) / 4 - PER_WAVE;
 };
 
 
@@ -342,7 +349,9 @@ __global__ void __launch_bounds__(256, (NB == 1 && MT <= 2 && MH <= 1 && !WC) ? 
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int h = lane >> 5, r = lane & 31;
   float* const wave0 = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + lp.img_end);
-  float* const wv = wave0 + wave * T::PER_WAVE;
+  const int PW = (NB == 2 && LP_LOOP_DW_BF16) ? lp.tile_stride : T::PER_WAVE;  // floats per wave
+  const int zd = (NB == 2 && LP_LOOP_DW_BF16) ? lp.z_delta : 0;
+  float* const wv = wave0 + wave * PW;
   float* const xt = wv + T::XT;
   float* const yt = wv + T::YT;
   float* const ts = wv + T::TS;
@@ -377,7 +386,7 @@ __global__ void __launch_bounds__(256, (NB == 1 && MT <= 2 && MH <= 1 && !WC) ? 
   int s_begin = 0;
 #pragma unroll
   for (int v = 0; v < WAVES; ++v) {
-    const int sv = (int)wave0[v * T::PER_WAVE + T::TS];
+    const int sv = (int)wave0[v * PW + T::TS];
     s_begin = sv > s_begin ? sv : s_begin;
   }
   __syncthreads();  // ts[] is reused by the sample loop
@@ -683,7 +692,7 @@ __global__ void __launch_bounds__(256, (NB == 1 && MT <= 2 && MH <= 1 && !WC) ? 
       f32x16 dxc[NB];
 #pragma unroll
       for (int b = 0; b < NB; ++b) dxc[b] = (f32x16){0};
-      loop_layer_bwd<NB, DXL>(lbase, lp.co, lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, true, hc, dyc, dw_co, dxc);
+      loop_layer_bwd<NB, DXL>(lbase, lp.co, lane, xt, yt, wave0, PW, a_off, b_off, want_params, true, hc, dyc, dw_co, dxc, zd);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
 #pragma unroll
@@ -718,14 +727,14 @@ __global__ void __launch_bounds__(256, (NB == 1 && MT <= 2 && MH <= 1 && !WC) ? 
 #pragma unroll
         for (int b = 0; b < NB; ++b) dx[b] = (f32x16){0};
         if (l > 0) {
-          loop_layer_bwd<NB, DXL>(lbase, lp.c[l], lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, true, cA[l > 0 ? l - 1 : 0], g, dw_c[l], dx);
+          loop_layer_bwd<NB, DXL>(lbase, lp.c[l], lane, xt, yt, wave0, PW, a_off, b_off, want_params, true, cA[l > 0 ? l - 1 : 0], g, dw_c[l], dx, zd);
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) g[b][q] = (cA[l > 0 ? l - 1 : 0][b][q] > 0.0f) ? dx[b][q] : 0.0f;
           }
         } else {
-          loop_layer_bwd<NB, DXL>(lbase, lp.c[0], lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, true, cin, g, dw_c[0], dx);
+          loop_layer_bwd<NB, DXL>(lbase, lp.c[0], lane, xt, yt, wave0, PW, a_off, b_off, want_params, true, cin, g, dw_c[0], dx, zd);
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
 #pragma unroll
@@ -782,14 +791,14 @@ __global__ void __launch_bounds__(256, (NB == 1 && MT <= 2 && MH <= 1 && !WC) ? 
 #pragma unroll
         for (int b = 0; b < NB; ++b) dx[b] = (f32x16){0};
         if (l > 0) {
-          loop_layer_bwd<NB, DXL>(lbase, lp.o[l], lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, true, oA[l > 0 ? l - 1 : 0], g, dw_o[l], dx);
+          loop_layer_bwd<NB, DXL>(lbase, lp.o[l], lane, xt, yt, wave0, PW, a_off, b_off, want_params, true, oA[l > 0 ? l - 1 : 0], g, dw_o[l], dx, zd);
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) g[b][q] = (oA[l > 0 ? l - 1 : 0][b][q] > 0.0f) ? dx[b][q] : 0.0f;
           }
         } else {
-          loop_layer_bwd<NB, DXL>(lbase, lp.o[0], lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, true, e, g, dw_o[0], dx);
+          loop_layer_bwd<NB, DXL>(lbase, lp.o[0], lane, xt, yt, wave0, PW, a_off, b_off, want_params, true, e, g, dw_o[0], dx, zd);
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
 #pragma unroll
@@ -812,14 +821,14 @@ __global__ void __launch_bounds__(256, (NB == 1 && MT <= 2 && MH <= 1 && !WC) ? 
 #pragma unroll
         for (int b = 0; b < NB; ++b) dx[b] = (f32x16){0};
         if (l > 0) {
-          loop_layer_bwd<NB, DXL>(lbase, lp.t[l], lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, true, tA[l > 0 ? l - 1 : 0], g, dw_t[l], dx);
+          loop_layer_bwd<NB, DXL>(lbase, lp.t[l], lane, xt, yt, wave0, PW, a_off, b_off, want_params, true, tA[l > 0 ? l - 1 : 0], g, dw_t[l], dx, zd);
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) g[b][q] = (tA[l > 0 ? l - 1 : 0][b][q] > 0.0f) ? dx[b][q] : 0.0f;
           }
         } else {
-          loop_layer_bwd<NB, DXL>(lbase, lp.t[0], lane, xt, yt, wave0, T::PER_WAVE, a_off, b_off, want_params, gg, xin, g, dw_t[0], dx);
+          loop_layer_bwd<NB, DXL>(lbase, lp.t[0], lane, xt, yt, wave0, PW, a_off, b_off, want_params, gg, xin, g, dw_t[0], dx, zd);
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
 #pragma unroll

@@ -129,6 +129,14 @@ static LoopParams loop_params(const LpRendererArgs& a) {
   p.seg_fwd = 0;
   p.relu_dump = g_relu_dump;  // test hook (NULL in every product call)
   p.dump_words = NB * ((tg ? 2 : p.n_t) + p.n_o + p.n_c) + 1;
+  // the two-block backward's third tile (loop_layer_bwd): when the images leave the room  (LP_LOOP_NO_ZTILE: A/B)
+  static const bool no_z = getenv("LP_LOOP_NO_ZTILE") != nullptr;
+  p.tile_stride = LoopTile::PER_WAVE;
+  p.z_delta = 0;
+  if (NB == 2 && !no_z && (size_t)p.img_end + (size_t)WAVES * (LoopTile::PER_WAVE + LoopTile::Z_EXTRA) * 4 <= 160 * 1024) {
+    p.tile_stride = LoopTile::PER_WAVE + LoopTile::Z_EXTRA;
+    p.z_delta = (LoopTile::ZT - LoopTile::YT) * 4;
+  }
   return p;
 }
 
@@ -166,7 +174,7 @@ static int loop_seg_blocks(const LpRendererArgs& a, unsigned ray_blocks, unsigne
 }
 
 static size_t loop_lds_bytes(const LoopParams& p, bool backward) {
-  return (size_t)p.img_end + (backward ? (size_t)WAVES * LoopTile::PER_WAVE * 4 : 0);
+  return (size_t)p.img_end + (backward ? (size_t)WAVES * p.tile_stride * 4 : 0);
 }
 
 bool renderer_loop_fits(const LpRendererArgs& a) {
