@@ -343,8 +343,16 @@ __global__ void __launch_bounds__(256) splat_bwd_kernel(const LpSplatterArgs a) 
 // (depth, point, tap set: ~60 % of the instructions of a VALU-bound kernel when every lane of a ray repeated it for the same sample)
 // is computed once per (ray, sample); the walk then goes through the block's samples, reading the tap rows of sample j from the lanes
 // j RPW .. and its weights from table j.
+// waves per SIMD the 8-ray backward walk is compiled for, 32 / 16 channels (32: four since round 6 -- 128 registers, 19 spilled: cfg 3
+// backward 0.707 -> 0.687 ms, cfg 5 49.8 -> 47.5 ms against three waves without spills)
+#ifndef LP_SBW_OCC32
+#define LP_SBW_OCC32 4
+#endif
+#ifndef LP_SBW_OCC16
+#define LP_SBW_OCC16 4
+#endif
 template <int C, int B, int RPW = 16>
-__global__ void __launch_bounds__(256, RPW == 8 ? (C < 32 ? 4 : (C < 64 ? 3 : 2)) : ((B == 4 && C < 64) ? 3 : 2))
+__global__ void __launch_bounds__(256, RPW == 8 ? (C < 32 ? LP_SBW_OCC16 : (C < 64 ? LP_SBW_OCC32 : 2)) : ((B == 4 && C < 64) ? 3 : 2))
 splat_bwd_walk_kernel(const LpSplatterArgs a, int n_seg) {
   static_assert(RPW == 16 || (RPW == 8 && B == 8), "rays per wave: 16, or 8 with one batch of 8");
   constexpr int CPL = C / 16, NQ = 64 / RPW;
