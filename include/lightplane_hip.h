@@ -347,9 +347,10 @@ int lp_renderer_corner_rows(const LpRendererArgs* args, int64_t* rows, void* str
  * instruction sequence, stores added), which also writes the ReLU decisions of the backward's decoder recompute:
  * dump[(ray * S_tot + sample) * 5 + {0: trunk layer 1, 1: trunk layer 2 (the trunk output), 2: opacity hidden, 3: colour
  * hidden}] = bit f set when unit f is active, word 4 = 1 (sample contributed), 2 (visited, not contributing: beyond the ray's
- * last marched sample), 0 (never visited).  dump_words must be n_rays * S_tot * lp_renderer_relu_dump_words(args).  The tuned
- * bf16x3 family (kernel family 1, RGB, four-wave workgroups) and the layer-looped family (3) have dump twins: LP_EUNSUPPORTED
- * otherwise, and in a library built without -DLP_TEST_HOOKS (lp_build_info() "test_hooks": 0).  The tests force these decisions onto the
+ * last marched sample), 0 (never visited).  dump_words must be n_rays * S_tot * lp_renderer_relu_dump_words(args).  Every kernel
+ * family has dump twins -- the tuned bf16x3 family (1; four-wave workgroups, default arithmetic), the layer-looped family (3) and the
+ * shape-generic kernels (0): LP_EUNSUPPORTED for LP_ARITH_FP32, for the tuned family's eight-wave workgroups (> 64 beyond-far samples)
+ * and in a library built without -DLP_TEST_HOOKS (lp_build_info() "test_hooks": 0).  The tests force these decisions onto the
  * fp64 oracle and require every gradient entry within 1e-4 (tests/test_gpu_config_scale.py::test_flips_are_flips). */
 int lp_renderer_backward_relu_dump(const LpRendererArgs* args, uint32_t* dump, int64_t dump_words, void* stream);
 /* Words per (ray, sample) of that dump for these arguments (shapes only, no launch), or LP_EUNSUPPORTED:
@@ -358,7 +359,8 @@ int lp_renderer_backward_relu_dump(const LpRendererArgs* args, uint32_t* dump, i
  *     channels), sites in the reference's evaluation order (naive_renderer.py:328-501) -- single grid-list: trunk layers 1 .. n_t,
  *     opacity hidden layers, colour hidden layers; two-grid decoder: relu(sampled feature), opacity hidden layers, relu(sampled
  *     colour feature), colour hidden layers -- word k * NB + b holds units 32 b .. 32 b + 31 of site k, the last word the
- *     visited flag (1 / 2 / 0 as above). */
+ *     visited flag (1 / 2 / 0 as above);
+ *   family 0 (shape-generic, also LP_KERNEL_GENERIC): the same layout with NB = ceil(widest site / 32). */
 int lp_renderer_relu_dump_words(const LpRendererArgs* args);
 
 #ifdef __cplusplus

@@ -379,7 +379,7 @@ int lp_renderer_relu_dump_words(const LpRendererArgs* args) {
     return 5;
   }
   if (fam == 3) return renderer_loop_dump_words(*args);
-  return set_error(LP_EUNSUPPORTED, "relu dump: the shape-generic kernels have no dump twin");
+  return renderer_generic_dump_words(*args);  // (the shape-generic backward: ceil(widest site / 32) words per site)
 }
 
 int lp_renderer_backward_relu_dump(const LpRendererArgs* args, uint32_t* dump, int64_t dump_words, void* stream) {

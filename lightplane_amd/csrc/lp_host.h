@@ -41,6 +41,7 @@ int renderer_loop_segments(const LpRendererArgs& a);  // segments of the segment
 int renderer_forward_loop(const LpRendererArgs& a, hipStream_t stream);
 int renderer_backward_loop(const LpRendererArgs& a, hipStream_t stream);
 int renderer_loop_dump_words(const LpRendererArgs& a);  // words per (ray, sample) of the ReLU dump
+int renderer_generic_dump_words(const LpRendererArgs& a);  // ... of the shape-generic backward (sites x ceil(widest site / 32) + 1)
 // per-translation-unit arithmetic reports for lp_build_info() (JSON fragments, static storage)
 const char* build_info_tuned_bwd();
 const char* build_info_tuned_bwd_aux();

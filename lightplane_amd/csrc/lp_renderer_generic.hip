@@ -33,6 +33,10 @@ struct GenArgs {
   GenPlan p;
   int stage_ld;        // LDS staging row stride (floats), bwd only
   int lds_param_accum; // 1: accumulate weight grads in LDS, flush once per block
+  // test hook (lp_renderer_backward_relu_dump, DUMP twin only): [ray][sample][dump_words] words -- dump_wps words per ReLU site in the
+  // reference's evaluation order, then the visited flag
+  uint32_t* relu_dump;
+  int dump_words, dump_wps;
 };
 
 // Full decoder of one sample.  Fills act[] per plan; returns the raw opacity (pre noise).
@@ -154,7 +158,9 @@ __global__ void __launch_bounds__(64) renderer_fwd_generic(const GenArgs ga) {
 // backward
 // ---------------------------------------------------------------------------------------
 
-template <int ACT_CAP, bool LDS_ACC>
+// DUMP (test hook, instantiated under -DLP_TEST_HOOKS): the ReLU decisions of the recompute are also written to ga.relu_dump -- same
+// instruction sequence, stores added.
+template <int ACT_CAP, bool LDS_ACC, bool DUMP = false>
 __global__ void __launch_bounds__(64) renderer_bwd_generic(const GenArgs ga) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const LpRendererArgs& a = ga.a;
@@ -223,6 +229,31 @@ __global__ void __launch_bounds__(64) renderer_bwd_generic(const GenArgs ga) {
     float occ = 1.0f;
     if (a.scaffold) occ = scaffold_lookup(a.scaffold, a.scaffold_shape, ray.b, x, y, z);
     float raw = decode(ga, ray, x, y, z, enc, act);
+    if constexpr (DUMP) {
+      // sites in the reference's evaluation order (naive_renderer.py:328-501): single grid-list: trunk layers, opacity hidden layers,
+      // colour hidden layers; two-grid decoder: relu(feature), opacity hidden layers, relu(colour feature), colour hidden layers.
+      // An activation (two-grid: the raw sample) is > 0 exactly where the unit is active -- the test every mask of this backward applies.
+      uint32_t* const dsite = ga.relu_dump + (rid * (int64_t)s_tot + s) * ga.dump_words;
+      int k = 0;
+      auto put = [&](int off, int width) {
+        for (int w0 = 0; w0 < ga.dump_wps; ++w0) {
+          unsigned m = 0;
+          for (int b = 0; b < 32; ++b) {
+            const int c = 32 * w0 + b;
+            if (c < width && act[off + c] > 0.0f) m |= 1u << b;
+          }
+          if (valid) dsite[k * ga.dump_wps + w0] = m;
+        }
+        ++k;
+      };
+      if (two_grids) put(p.x0, C);
+      else
+        for (int l = 0; l < a.trunk.n_layers; ++l) put(p.trunk[l], a.trunk.dims[l + 1]);
+      for (int l = 0; l + 1 < a.opacity.n_layers; ++l) put(p.op[l], a.opacity.dims[l + 1]);
+      if (two_grids) put(p.cx0, C);
+      for (int l = 0; l + 1 < a.color.n_layers; ++l) put(p.col[l], a.color.dims[l + 1]);
+      if (valid) dsite[k * ga.dump_wps] = 1u;  // (this kernel marches every sample up to the forward's last one: visited = contributed)
+    }
     if (a.noise_sigma > 0.0f)
       raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
     const float sp = softplus_f(raw);
@@ -368,6 +399,8 @@ int renderer_forward_generic(const LpRendererArgs& a, hipStream_t stream) {
   const int total = make_plan(a, ga.p);
   ga.stage_ld = 0;
   ga.lds_param_accum = 0;
+  ga.relu_dump = nullptr;
+  ga.dump_words = ga.dump_wps = 0;
   const unsigned blocks = (unsigned)((a.rays.n_rays + 63) / 64);
   if (blocks == 0) return LP_OK;
   if (total <= 256)
@@ -379,9 +412,38 @@ int renderer_forward_generic(const LpRendererArgs& a, hipStream_t stream) {
   return check_launch("renderer_fwd_generic");
 }
 
+// ReLU dump of the shape-generic backward: sites and words per site (include/lightplane_hip.h, lp_renderer_relu_dump_words)
+static void generic_dump_shape(const LpRendererArgs& a, int& n_sites, int& wps) {
+  const bool two = a.color_grid.n_grids > 0;
+  int maxw = 1;
+  n_sites = 0;
+  auto site = [&](int w) { ++n_sites; maxw = w > maxw ? w : maxw; };
+  if (two) { site(a.grid.channels); site(a.grid.channels); }
+  else for (int l = 0; l < a.trunk.n_layers; ++l) site(a.trunk.dims[l + 1]);
+  for (int l = 0; l + 1 < a.opacity.n_layers; ++l) site(a.opacity.dims[l + 1]);
+  for (int l = 0; l + 1 < a.color.n_layers; ++l) site(a.color.dims[l + 1]);
+  wps = (maxw + 31) / 32;
+}
+int renderer_generic_dump_words(const LpRendererArgs& a) {
+#ifdef LP_TEST_HOOKS
+  int n_sites, wps;
+  generic_dump_shape(a, n_sites, wps);
+  return n_sites * wps + 1;
+#else
+  (void)a;
+  return set_error(LP_EUNSUPPORTED, "relu dump: the library was built without -DLP_TEST_HOOKS");
+#endif
+}
+
 int renderer_backward_generic(const LpRendererArgs& a, hipStream_t stream) {
   GenArgs ga;
   ga.a = a;
+  ga.relu_dump = g_relu_dump;  // test hook (NULL in every product call)
+  {
+    int n_sites;
+    generic_dump_shape(a, n_sites, ga.dump_wps);
+    ga.dump_words = n_sites * ga.dump_wps + 1;
+  }
   const int total = make_plan(a, ga.p);
   int maxw = a.grid.channels;
   const LpMlp* ms[3] = {&a.trunk, &a.opacity, &a.color};
@@ -404,6 +466,24 @@ int renderer_backward_generic(const LpRendererArgs& a, hipStream_t stream) {
     if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e)); \
     hipLaunchKernelGGL((renderer_bwd_generic<CAP, ACC>), dim3(blocks), dim3(64), lds, stream, ga); \
   } while (0)
+#ifdef LP_TEST_HOOKS
+  if (ga.relu_dump) {  // the DUMP twins
+#define LP_LAUNCH_BWD_DUMP(CAP, ACC)                                                                    \
+  do {                                                                                                  \
+    hipError_t e = hipFuncSetAttribute((const void*)renderer_bwd_generic<CAP, ACC, true>,               \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+    if (e != hipSuccess) return set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));     \
+    hipLaunchKernelGGL((renderer_bwd_generic<CAP, ACC, true>), dim3(blocks), dim3(64), lds, stream, ga); \
+  } while (0)
+    if (total <= 256) {
+      if (lds_acc) LP_LAUNCH_BWD_DUMP(256, true); else LP_LAUNCH_BWD_DUMP(256, false);
+    } else {
+      if (lds_acc) LP_LAUNCH_BWD_DUMP(1024, true); else LP_LAUNCH_BWD_DUMP(1024, false);
+    }
+#undef LP_LAUNCH_BWD_DUMP
+    return check_launch("renderer_bwd_generic (dump)");
+  }
+#endif
   if (total <= 256) {
     if (lds_acc) LP_LAUNCH_BWD(256, true); else LP_LAUNCH_BWD(256, false);
   } else {

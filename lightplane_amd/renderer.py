@@ -184,8 +184,8 @@ def kernel_family(rays: Rays, grid, decoder_params: DecoderParams, grid_sizes=No
 def relu_dump_words(rays: Rays, grid, decoder_params: DecoderParams, grid_sizes=None, color_grid=None, color_grid_sizes=None,
                     num_samples_inf: int = 0, kernel: int = _lib.LP_KERNEL_AUTO, arithmetic: Optional[int] = None, **_unused) -> int:
     """Words per (ray, sample) of the ReLU dump of these shapes (``lp_renderer_relu_dump_words``; test hook, needs no GPU), or 0
-    where the kernel that would run has no DUMP twin (shape-generic kernels, LP_ARITH_FP32, the tuned family's eight-wave
-    workgroups, a library built without -DLP_TEST_HOOKS)."""
+    where the kernel that would run has no DUMP twin (LP_ARITH_FP32, the tuned family's eight-wave workgroups, a library built
+    without -DLP_TEST_HOOKS)."""
     _check_render_kwargs("relu_dump_words", _unused)
     if not int(_lib.build_info().get("test_hooks", 0)):
         return 0
@@ -223,8 +223,9 @@ class relu_dump_recorder:
     the DUMP twin of its kernel and leaves the ReLU decisions it took in ``.dump`` -- int32 ``[n_rays, S_tot, W]``,
     ``W = lp_renderer_relu_dump_words``: per ReLU site of the decoder, in the reference's evaluation order, ``words_per_site`` words
     (bit f of word b = unit 32 b + f active), then one flag word: 1 = the sample contributed, 2 = visited but beyond the ray's last
-    marched sample, 0 = never visited.  The tuned family: 4 sites x 1 word + flag = 5.  Raises for shapes without a dump twin (the
-    shape-generic kernels) and for a library built without -DLP_TEST_HOOKS."""
+    marched sample, 0 = never visited.  The tuned family: 4 sites x 1 word + flag = 5; the shape-generic kernels: ceil(widest site / 32)
+    words per site.  Raises where there is no dump twin (LP_ARITH_FP32, the tuned family's eight-wave workgroups) and for a library
+    built without -DLP_TEST_HOOKS."""
 
     def __init__(self):
         self.dump = None
@@ -367,8 +368,11 @@ class LightplaneFunction(torch.autograd.Function):
                 if words < 0:
                     _lib.check(words, "lp_renderer_relu_dump_words")
                 d = _RELU_DUMP.reset(directions.shape[0], cfg.num_samples + cfg.num_samples_inf, words, dev)
-                hid = max(cfg.dims_trunk[1:] + cfg.dims_opacity[1:-1] + cfg.dims_color[1:-1] + [cfg.channels])
-                _RELU_DUMP.words_per_site = 1 if _lib.lib().lp_renderer_kernel_family(ctypes.byref(a)) == 1 else (2 if hid > 32 else 1)
+                # ReLU sites in the reference's evaluation order (include/lightplane_hip.h): every kernel family writes the same number
+                # of words for each of them, then the flag word
+                n_sites = (2 if color_grids else len(cfg.dims_trunk) - 1) + max(len(cfg.dims_opacity) - 2, 0) + max(len(cfg.dims_color) - 2, 0)
+                assert n_sites > 0 and (words - 1) % n_sites == 0, (words, n_sites)
+                _RELU_DUMP.words_per_site = (words - 1) // n_sites
                 _lib.check(_lib.lib().lp_renderer_backward_relu_dump(ctypes.byref(a), d.data_ptr(), d.numel(), stream),
                            "lp_renderer_backward_relu_dump")
             else:

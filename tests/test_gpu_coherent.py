@@ -124,15 +124,15 @@ def coherent_renderer_inputs(grid_name, image_name, mask_oob=True, num_samples=2
 
 
 def check_renderer(d, dev, kernel, tag, **extra):
-    """Outputs against the fp32 oracle at 1e-4.  Gradients: where the kernel that runs has a DUMP twin (both MFMA families) the
-    PROOF -- its own ReLU decisions forced onto the fp64 oracle, every forced unit a measured near tie, every entry at 1e-4
-    (forced_oracle_check); the shape-generic kernels keep the counted allowance of assert_grad_close."""
-    if kernel == _lib.LP_KERNEL_AUTO and has_dump_twin(d, **extra):
+    """Outputs against the fp32 oracle at 1e-4.  Gradients: where the kernel that runs has a DUMP twin (every family since round 6,
+    the shape-generic kernels included) the PROOF -- its own ReLU decisions forced onto the fp64 oracle, every forced unit a measured
+    near tie, every entry at 1e-4 (forced_oracle_check); the counted allowance of assert_grad_close is left to early termination."""
+    if has_dump_twin(d, kernel=kernel, **extra):
         out = run_hip_renderer(d, dev, kernel, **extra)[0]
         o_out = run_oracle_renderer(d)[0]
         for nm, a, b in (("ray_length", out[0], o_out[0]), ("neg_log_t", out[1], o_out[1]), ("feature", out[2], o_out[2])):
             _assert_close(f"{tag}: {nm}", a, b.detach().numpy())
-        forced_oracle_check(tag, d, dev, chunk=2048 if d["cfg"]["inject_noise_sigma"] == 0 else d["rays"].n_rays, **extra)
+        forced_oracle_check(tag, d, dev, chunk=2048 if d["cfg"]["inject_noise_sigma"] == 0 else d["rays"].n_rays, kernel=kernel, **extra)
         return
     out, gp, ge, gg, gc = run_hip_renderer(d, dev, kernel, **extra)
     o_out, o_gp, o_ge, o_gg, o_gc = run_oracle_renderer(d)       # the reference's arithmetic (fp32)

@@ -25,7 +25,7 @@ import lightplane_amd as lp
 from lightplane_amd import _lib
 from oracle import lightplane_oracle as O
 from tests.synth import baseline_cfg1, cfg2_inputs, grid_sizes_for, pinhole_rays, random_decoder, random_grids
-from tests.test_gpu_parity import _assert_close, _dev, assert_grad_close, forced_oracle_check, run_hip_renderer
+from tests.test_gpu_parity import _assert_close, _dev, assert_grad_close, forced_oracle_check, relu_site_widths, run_hip_renderer
 
 pytestmark = pytest.mark.gpu
 F64 = torch.float64
@@ -96,14 +96,8 @@ def test_baseline_cfg1_exact(golden_dir):
         for nm, a, b in (("ray_length", out[0], o_out[0]), ("neg_log_t", out[1], o_out[1]), ("feature", out[2], o_out[2])):
             _assert_close(f"cfg1 {tag}: {nm}/oracle", a, b.numpy())
             _assert_close(f"cfg1 {tag}: {nm}/golden", a, z[nm])
-        if kernel == _lib.LP_KERNEL_AUTO:  # the tuned family: the proof (its ReLU decisions forced onto the fp64 oracle)
-            forced_oracle_check("cfg1 auto", d, dev)
-            continue
-        _, q_gp, q_ge, q_gg = oracle_chunked(d, dtype=F64)
-        for nm, a, b, c, n in (("grad_mlp_params", gp, o_gp, q_gp, 4 * 32), ("grad_encoding", ge, o_ge, q_ge, 32),
-                               ("grad_grid0", gg[0], o_gg[0], q_gg[0], 8 * 16)):
-            assert_grad_close(f"cfg1 {tag}: {nm}/oracle", a, b.numpy(), n, want64=c.numpy())
-            assert_grad_close(f"cfg1 {tag}: {nm}/golden", a, z[nm], n, want64=c.numpy())
+        # gradients: the proof for both kernels (the kernel's own ReLU decisions forced onto the fp64 oracle, every entry at 1e-4)
+        forced_oracle_check(f"cfg1 {tag}", d, dev, kernel=kernel)
 
 
 @pytest.mark.parametrize("C,G,S", [(16, 64, 128), (32, 128, 64), (32, 128, 256)], ids=["c16_s128", "c32_s64", "cfg4_c32_s256"])
@@ -204,16 +198,18 @@ def test_cfg2_fp32_arithmetic_agrees_with_default():
 
 
 def test_relu_dump_refuses_kernels_without_a_twin():
-    """The MFMA families have dump twins; the shape-generic kernels and the LP_ARITH_FP32 instantiations do not and must refuse
-    loudly (never a silent production launch)."""
-    from lightplane_amd.renderer import relu_dump_recorder
+    """Every kernel family has dump twins; the LP_ARITH_FP32 instantiations do not and must refuse loudly (never a silent production
+    launch).  The shape-generic twin writes ceil(widest site / 32) words per site."""
+    from lightplane_amd.renderer import relu_dump_recorder, relu_dump_words
     from tests.synth import RENDERER_CASES
     dev = _dev()
     d = next(c for c in RENDERER_CASES if c.name == "triplane_deep444").build()
-    for kw in (dict(kernel=_lib.LP_KERNEL_GENERIC), dict(kernel=_lib.LP_KERNEL_AUTO, arithmetic=_lib.LP_ARITH_FP32)):
-        with relu_dump_recorder():
-            with pytest.raises(_lib.LightplaneHipError, match="relu dump"):
-                run_hip_renderer(d, dev, kw.pop("kernel"), **kw)
+    with relu_dump_recorder():
+        with pytest.raises(_lib.LightplaneHipError, match="relu dump"):
+            run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO, arithmetic=_lib.LP_ARITH_FP32)
+    n_sites = len(relu_site_widths(d))
+    assert relu_dump_words(d["rays"], d["grids"], d["decoder"], kernel=_lib.LP_KERNEL_GENERIC) == n_sites * 1 + 1   # hidden 32
+    forced_oracle_check("deep444 generic", d, dev, kernel=_lib.LP_KERNEL_GENERIC)
 
 
 INDEX_CASES = {

@@ -215,14 +215,14 @@ def assert_grad_close(name, got, want, entries_per_sample, tol=1e-4, want64=None
                 + f"; {n_off - n_un} more explained by the fp64 oracle; allowed count {allowed}; relative L2 {l2:.3e} (allowed 1e-3)")
 
 
-def has_dump_twin(d, **extra):
-    """The kernel LP_KERNEL_AUTO runs for this case has a DUMP twin (both MFMA families; not the shape-generic kernels, not the
-    tuned family's eight-wave workgroups, not early termination -- the oracle marches every sample)."""
+def has_dump_twin(d, kernel=_lib.LP_KERNEL_AUTO, **extra):
+    """The kernel that runs this case has a DUMP twin (every family since round 6: tuned, layer-looped, shape-generic; not the tuned
+    family's eight-wave workgroups, not LP_ARITH_FP32, not early termination -- the oracle marches every sample)."""
     if extra.get("stop_transmittance"):
         return False
     from lightplane_amd.renderer import relu_dump_words
     return relu_dump_words(d["rays"], d["grids"], d["decoder"], color_grid=d.get("color_grids"),
-                           num_samples_inf=d["cfg"].get("num_samples_inf", 0)) > 0
+                           num_samples_inf=d["cfg"].get("num_samples_inf", 0), kernel=kernel) > 0
 
 
 def relu_site_widths(d):
@@ -250,13 +250,13 @@ def unpack_relu_dump(dump, widths, words_per_site=1):
     return masks, d[..., -1] != 0
 
 
-def run_hip_renderer_with_dump(d, dev, **extra):
+def run_hip_renderer_with_dump(d, dev, kernel=_lib.LP_KERNEL_AUTO, **extra):
     """The production backward AND the same backward through the DUMP twin of its kernel (ReLU decisions recorded).
     Returns (production results, dump, words per site)."""
     from lightplane_amd.renderer import relu_dump_recorder
-    prod = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO, **extra)
+    prod = run_hip_renderer(d, dev, kernel, **extra)
     with relu_dump_recorder() as rec:
-        twin = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO, **extra)
+        twin = run_hip_renderer(d, dev, kernel, **extra)
     assert rec.dump is not None, "the backward did not go through the dump hook"
     # the twin is the same template with stores added: same arithmetic, so its gradients equal the production launch's up to
     # the order of the fp32 atomics
@@ -332,7 +332,7 @@ def oracle_forced(d, dump, idx=None, chunk=2048, dtype=torch.float64, words_per_
 FORCED_EVENTS = []  # one record per forced-oracle check; printed by conftest.pytest_terminal_summary
 
 
-def forced_oracle_check(name, d, dev, idx=None, tol=1e-4, chunk=2048, **extra):
+def forced_oracle_check(name, d, dev, idx=None, tol=1e-4, chunk=2048, kernel=_lib.LP_KERNEL_AUTO, **extra):
     """THE PROOF behind the ReLU-flip allowance (round-4 review, next 2): the production backward's own ReLU decisions, read
     back from the DUMP twin of its kernel, are forced onto the fp64 oracle; then EVERY entry of every gradient family and every
     output has to meet the north_star bar outright -- no allowance, no second oracle, no mask.  Whatever separated the kernel
@@ -342,7 +342,7 @@ def forced_oracle_check(name, d, dev, idx=None, tol=1e-4, chunk=2048, **extra):
     oracle and forcing them all would hide it.  So every forced unit has to be a near tie in the fp64 oracle -- its |pre-activation|
     at most FORCED_TIE_K * TIE_EPS of its site's largest one -- and there cannot be more forced units than the oracle has units
     that close to zero."""
-    prod, dump, wps = run_hip_renderer_with_dump(d, dev, **extra)
+    prod, dump, wps = run_hip_renderer_with_dump(d, dev, kernel, **extra)
     out, gp, ge, gg, gc = prod
     f_out, f_gp, f_ge, f_gg, f_gc, st = oracle_forced(d, dump, idx, chunk=chunk, words_per_site=wps)
     sel = (lambda t: t) if idx is None else (lambda t: t[idx.to(t.device)])

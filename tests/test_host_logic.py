@@ -418,13 +418,14 @@ def test_arithmetic_selection_and_dump_words_without_gpu():
     hooks = int(_lib.build_info()["test_hooks"])
     assert relu_dump_words(d["rays"], d["grids"], d["decoder"]) == (5 if hooks else 0)
     assert relu_dump_words(d["rays"], d["grids"], d["decoder"], arithmetic=_lib.LP_ARITH_FP32) == 0
-    assert relu_dump_words(d["rays"], d["grids"], d["decoder"], kernel=_lib.LP_KERNEL_GENERIC) == 0
+    assert relu_dump_words(d["rays"], d["grids"], d["decoder"], kernel=_lib.LP_KERNEL_GENERIC) == (5 if hooks else 0)  # the generic twin
     dd = by["triplane_deep444"].build()      # 4 + 3 + 3 sites of one word
     assert lp.kernel_family(dd["rays"], dd["grids"], dd["decoder"]) == 3
     assert lp.kernel_family(dd["rays"], dd["grids"], dd["decoder"], arithmetic=_lib.LP_ARITH_FP32) == 0
     assert relu_dump_words(dd["rays"], dd["grids"], dd["decoder"]) == (11 if hooks else 0)
     dw = by["triplane_h64_c32"].build()      # 2 + 1 + 1 sites of two words
     assert relu_dump_words(dw["rays"], dw["grids"], dw["decoder"]) == (9 if hooks else 0)
+    assert relu_dump_words(dw["rays"], dw["grids"], dw["decoder"], kernel=_lib.LP_KERNEL_GENERIC) == (9 if hooks else 0)  # ceil(64 / 32) words
     a = _empty_renderer_args()
     a.arithmetic = 7
     assert _lib.lib().lp_renderer_forward(ctypes.byref(a), None) == -1 and b"arithmetic" in _lib.lib().lp_last_error()
