@@ -36,6 +36,10 @@ def pytest_terminal_summary(terminalreporter):
             with open(os.path.join(out, "forced_oracle.json"), "w") as f:
                 json.dump(FORCED_EVENTS, f, indent=1)
     if not FLIP_EVENTS:
+        if FORCED_EVENTS and os.path.isdir(out):  # a GPU run that took no allowance says so in its record
+            import json
+            with open(os.path.join(out, "flip_allowance.json"), "w") as f:
+                json.dump([], f)
         return
     terminalreporter.write_sep("-", f"ReLU-flip allowance taken {len(FLIP_EVENTS)} time(s)")
     for e in FLIP_EVENTS:
