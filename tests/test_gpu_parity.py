@@ -272,8 +272,8 @@ def run_hip_renderer_with_dump(d, dev, kernel=_lib.LP_KERNEL_AUTO, **extra):
 
 
 FORCED_TIE_K = 1  # a unit the kernel decided against the fp64 oracle's sign has to be a near tie IN the oracle: |pre-activation| <=
-                  # FORCED_TIE_K * TIE_EPS = 1e-6 of its site's largest one.  Measured over the suite's 140 proofs (oracle on the reference's
-                  # fp32 geometry): at most 12 forced units per launch, largest margin 3.5e-8 -- the round-off of an fp32-equivalent dot
+                  # FORCED_TIE_K * TIE_EPS = 1e-6 of its site's largest one.  Measured over the suite's 160 proofs (oracle on the reference's
+                  # fp32 geometry): at most 22 forced units per launch, largest margin 3.5e-8 -- the round-off of an fp32-equivalent dot
                   # product of 16-64 terms whose inputs carry the round-off of up to seven earlier layers (profiles/r06_forced_oracle.json)
 
 
