@@ -172,7 +172,9 @@ LP_DEV void splat_walk(float* feat, float* wgt, const LpGrid& g, int b, float x,
   }
 }
 
-template <int C, int RPW>
+// W2 (all output grids voxel grids, C a multiple of 32): the voxel walk with two carry axes (splat_walk_vox2, lp_splat_walk.h) --
+// lane = channel of 32, lane group = corner along the third axis
+template <int C, int RPW, bool W2 = false>
 __global__ void __launch_bounds__(256) splat_fwd_walk_kernel(const LpSplatterArgs a, int dbg, int n_seg, int grp) {
   constexpr int LD = RPW + 4;  // row stride of the transposed encoding tile [channel][ray]
   constexpr int NQ = 64 / RPW;
@@ -205,10 +207,12 @@ __global__ void __launch_bounds__(256) splat_fwd_walk_kernel(const LpSplatterArg
     tile[(c0 + 2) * LD + r] = valid ? v.z : 0.0f;
     tile[(c0 + 3) * LD + r] = valid ? v.w : 0.0f;
   }
-  float enc[CPL][RPW];  // channels (lane & 15) + 16 j of all rays
+  constexpr int LPG = W2 ? 32 : 16;   // lanes (= channels) per lane group
+  constexpr int NJ = C / LPG;
+  float enc[NJ][RPW];  // channels (lane & (LPG - 1)) + LPG j of all rays
 #pragma unroll
-  for (int jc = 0; jc < CPL; ++jc) {
-    const float4* src = reinterpret_cast<const float4*>(tile + ((lane & 15) + 16 * jc) * LD);
+  for (int jc = 0; jc < NJ; ++jc) {
+    const float4* src = reinterpret_cast<const float4*>(tile + ((lane & (LPG - 1)) + LPG * jc) * LD);
 #pragma unroll
     for (int j = 0; j < RPW / 4; ++j) {
       const float4 v = src[j];
@@ -233,10 +237,14 @@ __global__ void __launch_bounds__(256) splat_fwd_walk_kernel(const LpSplatterArg
     const bool live = valid && !(mask && !point_in_bounds(x, y, z));
     for (int g = 0; g < a.out.n_grids; ++g) {
       const LpGrid& og = a.out.grids[g];
-      if (og.D > 1 && og.H > 1 && og.W > 1 && !(dbg & 4))
-        splat_walk_vox<C, RPW, SplatSrcRegs<CPL, RPW>, true, WLD>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, SplatSrcRegs<CPL, RPW>{enc}, wT, dbg);
-      else
-        splat_walk<C, RPW>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, enc, wT, dbg);
+      if constexpr (W2) {
+        splat_walk_vox2<C, RPW, WLD>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, enc, wT, dbg);
+      } else {
+        if (og.D > 1 && og.H > 1 && og.W > 1 && !(dbg & 4))
+          splat_walk_vox<C, RPW, SplatSrcRegs<CPL, RPW>, true, WLD>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, SplatSrcRegs<CPL, RPW>{enc}, wT, dbg);
+        else
+          splat_walk<C, RPW>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, enc, wT, dbg);
+      }
     }
   }
 }
@@ -602,7 +610,13 @@ int splatter_forward_launch(const LpSplatterArgs& a, hipStream_t stream) {
     const unsigned blocks = ray_blocks * (unsigned)n_seg;
     const int grp = splat_forward_group(a, ray_blocks);
     // (64 channels -- the reference's own speed benchmark splats into [1,160,160,160,64] -- : four channels per lane)
-    if (Cw == 64) hipLaunchKernelGGL((splat_fwd_walk_kernel<64, 16>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg, grp);
+    // voxel grids only, 32 / 64 channels: the walk with two carry axes  (LP_SPLAT_WALK2=0: the one-axis walk, A/B)
+    static const bool walk2 = getenv("LP_SPLAT_WALK2") == nullptr || atoi(getenv("LP_SPLAT_WALK2")) != 0;
+    bool all_voxel = walk2 && !(dbg & 4);
+    for (int g = 0; g < a.out.n_grids; ++g) all_voxel = all_voxel && a.out.grids[g].D > 1 && a.out.grids[g].H > 1 && a.out.grids[g].W > 1;
+    if (all_voxel && Cw == 64) hipLaunchKernelGGL((splat_fwd_walk_kernel<64, 16, true>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg, grp);
+    else if (all_voxel && Cw == 32 && rpw == 32) hipLaunchKernelGGL((splat_fwd_walk_kernel<32, 32, true>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg, grp);
+    else if (Cw == 64) hipLaunchKernelGGL((splat_fwd_walk_kernel<64, 16>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg, grp);
     else if (Cw == 16 && rpw == 32) hipLaunchKernelGGL((splat_fwd_walk_kernel<16, 32>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg, grp);
     else if (Cw == 16) hipLaunchKernelGGL((splat_fwd_walk_kernel<16, 16>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg, grp);
     else if (rpw == 32) hipLaunchKernelGGL((splat_fwd_walk_kernel<32, 32>), dim3(blocks), dim3(256), 0, stream, a, dbg, n_seg, grp);
