@@ -243,9 +243,9 @@ LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, floa
 // lane = channel of 32: a +-1 step along A or B flushes the two columns left behind, a diagonal step three, and what stays is
 // re-labelled.  Same segments per flushed column as before (two rows of C x 4 bytes per atomic instruction).
 // enc[j][i]: channel (lane & 31) + 32 j of ray i.  Splatter forward only (SPLAT convention, unit weights by the caller).
-template <int C, int RPW, int WLD>
+template <int C, int RPW, int WLD, class Enc>
 LP_DEV void splat_walk_vox_feat2(float* feat, const LpGrid& g, int row0, int cell, int ok, int su, int sv, int st, unsigned mask,
-                                 int lane, const float (&enc)[C / 32][RPW], const float* wT, int dbg) {
+                                 int lane, const Enc& enc, const float* wT, int dbg) {
   static_assert(C % 32 == 0, "32 channels per lane group");
   constexpr int CPL = C / 32;
   const int ch = lane & 31, gc = lane >> 5;
@@ -373,9 +373,10 @@ LP_DEV void splat_walk_vox_feat2(float* feat, const LpGrid& g, int row0, int cel
 
 // the Splatter forward's voxel walk with two carry axes: tap set, weight table, run heads -- as splat_walk_vox --, then the feature walk
 // above and the unit-weight walk
-template <int C, int RPW, int WLD>
+// (Enc: enc[j][i] = channel (lane & 31) + 32 j of item i -- a register array [C / 32][RPW], or SplatEncConst for the transposed march)
+template <int C, int RPW, int WLD, class Enc>
 LP_DEV void splat_walk_vox2(float* feat, float* wgt, const LpGrid& g, int b, float x, float y, float z, bool live, int lane,
-                            const float (&enc)[C / 32][RPW], float* wT, int dbg) {
+                            const Enc& enc, float* wT, int dbg) {
   constexpr int NQ = 64 / RPW;
   constexpr int SPQ = 8 / NQ;
   const int q = lane / RPW, r = lane % RPW;
@@ -397,7 +398,7 @@ LP_DEV void splat_walk_vox2(float* feat, float* wgt, const LpGrid& g, int b, flo
   const int prow_ = lane_prev(row0), pok_ = lane_prev(ok);  // all lanes enabled: see run_head()
   const bool head = run_head(r, row0, prow_, ok, pok_);
   const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head));
-  if (!(dbg & 64)) splat_walk_vox_feat2<C, RPW, WLD>(feat, g, row0, tp.cell, ok, tp.su, tp.sv, tp.st, mask, lane, enc, wT, dbg);
+  if (!(dbg & 64)) splat_walk_vox_feat2<C, RPW, WLD, Enc>(feat, g, row0, tp.cell, ok, tp.su, tp.sv, tp.st, mask, lane, enc, wT, dbg);
   if (dbg & 32) return;
   splat_walk_vox_weights<RPW, WLD>(wgt, g, row0, tp.iu, tp.sv, tp.st, mask, lane, wT, dbg);
 }

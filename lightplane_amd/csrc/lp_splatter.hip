@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256) splat_fwd_walk_kernel(const LpSplatterArg
     for (int g = 0; g < a.out.n_grids; ++g) {
       const LpGrid& og = a.out.grids[g];
       if constexpr (W2) {
-        splat_walk_vox2<C, RPW, WLD>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, enc, wT, dbg);
+        splat_walk_vox2<C, RPW, WLD, float[NJ][RPW]>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, enc, wT, dbg);
       } else {
         if (og.D > 1 && og.H > 1 && og.W > 1 && !(dbg & 4))
           splat_walk_vox<C, RPW, SplatSrcRegs<CPL, RPW>, true, WLD>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, SplatSrcRegs<CPL, RPW>{enc}, wT, dbg);
@@ -255,9 +255,12 @@ __global__ void __launch_bounds__(256) splat_fwd_walk_kernel(const LpSplatterArg
 // sample the same walk (run heads by ballot, carried columns, weight windows) merges the samples a ray spends in one cell and carries
 // the shared face when it steps to a neighbour.  The splatted vector is constant along a ray: no transposition through LDS, no
 // [channel][ray] register array; `rpw` rays per wave (a small batch is dealt over the chip by it).
-template <int C>
+// W2 (all output grids voxel grids, 32 / 64 channels): the voxel walk with two carry axes -- a ray steps along all three grid axes in
+// the proportions of its direction, one carry axis catches the dominant one only
+template <int C, bool W2 = false>
 __global__ void __launch_bounds__(256) splat_fwd_ray_kernel(const LpSplatterArgs a, int dbg, int rpw) {
-  constexpr int CPL = C / 16;
+  constexpr int LPG = W2 ? 32 : 16;
+  constexpr int CPL = C / LPG;
   constexpr int WLD = 32 + 8;
   __shared__ __attribute__((aligned(16))) float lds[4][8 * WLD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -275,7 +278,7 @@ __global__ void __launch_bounds__(256) splat_fwd_ray_kernel(const LpSplatterArgs
     SplatSrcConst<CPL> src;
     SplatEncConst<CPL> enc;
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) src.v[j] = enc.v[j] = a.rays.encoding[rid * C + (lane & 15) + 16 * j];
+    for (int j = 0; j < CPL; ++j) src.v[j] = enc.v[j] = a.rays.encoding[rid * C + (lane & (LPG - 1)) + LPG * j];
     for (int bs = 0; bs < n_blk; ++bs) {
       const int s = bs * 32 + r;
       const int sc = s < s_tot ? s : s_tot - 1;
@@ -285,10 +288,14 @@ __global__ void __launch_bounds__(256) splat_fwd_ray_kernel(const LpSplatterArgs
       const bool live = s < s_tot && !(mask && !point_in_bounds(x, y, z));
       for (int g = 0; g < a.out.n_grids; ++g) {
         const LpGrid& og = a.out.grids[g];
-        if (og.D > 1 && og.H > 1 && og.W > 1 && !(dbg & 4))
-          splat_walk_vox<C, 32, SplatSrcConst<CPL>, true, WLD>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, src, wT, dbg);
-        else
-          splat_walk<C, 32>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, enc, wT, dbg);
+        if constexpr (W2) {
+          splat_walk_vox2<C, 32, WLD, SplatEncConst<CPL>>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, enc, wT, dbg);
+        } else {
+          if (og.D > 1 && og.H > 1 && og.W > 1 && !(dbg & 4))
+            splat_walk_vox<C, 32, SplatSrcConst<CPL>, true, WLD>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, src, wT, dbg);
+          else
+            splat_walk<C, 32>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, enc, wT, dbg);
+        }
       }
     }
   }
@@ -598,7 +605,12 @@ int splatter_forward_launch(const LpSplatterArgs& a, hipStream_t stream) {
       while (rays_pw > 1 && (a.rays.n_rays + 4 * rays_pw - 1) / (4 * rays_pw) < 1024) rays_pw >>= 1;
       if (forced >= 1 && forced <= 32) rays_pw = forced;
       const unsigned blocks = (unsigned)((a.rays.n_rays + 4 * rays_pw - 1) / (4 * rays_pw));
-      if (Cw == 64) hipLaunchKernelGGL((splat_fwd_ray_kernel<64>), dim3(blocks), dim3(256), 0, stream, a, dbg, rays_pw);
+      static const bool walk2r = getenv("LP_SPLAT_WALK2") == nullptr || atoi(getenv("LP_SPLAT_WALK2")) != 0;
+      bool all_vox = walk2r && !(dbg & 4);
+      for (int g = 0; g < a.out.n_grids; ++g) all_vox = all_vox && a.out.grids[g].D > 1 && a.out.grids[g].H > 1 && a.out.grids[g].W > 1;
+      if (all_vox && Cw == 64) hipLaunchKernelGGL((splat_fwd_ray_kernel<64, true>), dim3(blocks), dim3(256), 0, stream, a, dbg, rays_pw);
+      else if (all_vox && Cw == 32) hipLaunchKernelGGL((splat_fwd_ray_kernel<32, true>), dim3(blocks), dim3(256), 0, stream, a, dbg, rays_pw);
+      else if (Cw == 64) hipLaunchKernelGGL((splat_fwd_ray_kernel<64>), dim3(blocks), dim3(256), 0, stream, a, dbg, rays_pw);
       else if (Cw == 32) hipLaunchKernelGGL((splat_fwd_ray_kernel<32>), dim3(blocks), dim3(256), 0, stream, a, dbg, rays_pw);
       else hipLaunchKernelGGL((splat_fwd_ray_kernel<16>), dim3(blocks), dim3(256), 0, stream, a, dbg, rays_pw);
       return check_launch("splat_fwd_ray_kernel");
