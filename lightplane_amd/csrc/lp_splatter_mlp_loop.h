@@ -23,7 +23,9 @@ struct SplatLoopParams {
   LoopLayer l[SLOOP_MAX];
   int inf;                     // float offset of the beyond-far table in the small block
   int img_end;                 // bytes before the per-wave tiles
-  int n_seg;                   // small batches: segments the march is cut into (blockIdx = (128 rays, segment))
+  int n_seg;                   // segments the march is cut into (blockIdx = (ray block, segment))
+  int fwd_group;               // forward: > 0 = INTERLEAVED samples per segment (g, g + n_seg, ...), issued in groups of this many ray
+                               // blocks segment after segment (lp_splatter.hip, splat_forward_segments / _group); 0 = contiguous ranges
   int dbg;
 };
 
@@ -189,7 +191,14 @@ __global__ void __launch_bounds__(64 * NW, 2) splat_mlp_fwd_loop(const LpSplatte
   float* const wv = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + sp.img_end) + wave * T::PER_WAVE;
   float* const vt = wv + T::XT;
   float* const wT = wv + T::WT;
-  const int blk = (int)blockIdx.x / sp.n_seg, seg = (int)blockIdx.x - blk * sp.n_seg;
+  // (ray block, segment): the plain Splatter's forward launch shape (splat_fwd_walk_kernel) -- interleaved samples, grouped issue order
+  const int grp = sp.fwd_group > 0 ? sp.fwd_group : 1;
+  const int n_blk = (int)gridDim.x / sp.n_seg;
+  const int per_group = grp * sp.n_seg;
+  const int gi = (int)blockIdx.x / per_group, gl = (int)blockIdx.x - gi * per_group;
+  const int g_size = (n_blk - gi * grp < grp) ? n_blk - gi * grp : grp;
+  const int seg = gl / g_size;
+  const int blk = gi * grp + (gl - seg * g_size);
   const int64_t ray_id = ((int64_t)blk * NW + wave) * RAYS_PER_WAVE + r;
   const bool valid = ray_id < a.rays.n_rays;
   const int64_t rid = valid ? ray_id : 0;
@@ -198,9 +207,12 @@ __global__ void __launch_bounds__(64 * NW, 2) splat_mlp_fwd_loop(const LpSplatte
   sloop_load_encoding<E>(a, rid, h, enc);
   const int s_tot = a.march.num_samples + a.march.num_samples_inf;
   const bool mask = a.march.mask_out_of_bounds != 0;
+  const bool interleaved = sp.fwd_group > 0;
   const int per_seg = (s_tot + sp.n_seg - 1) / sp.n_seg;
-  const int s_lo = seg * per_seg, s_hi = (s_lo + per_seg < s_tot) ? s_lo + per_seg : s_tot;
-  for (int s = s_lo; s < s_hi; ++s) {
+  const int s_lo = interleaved ? seg : seg * per_seg;
+  const int s_hi = interleaved ? s_tot : ((s_lo + per_seg < s_tot) ? s_lo + per_seg : s_tot);
+  const int s_step = interleaved ? sp.n_seg : 1;
+  for (int s = s_lo; s < s_hi; s += s_step) {
     Sample<E> sm;
     fetch_sample<E, GM_GENERIC, true>(rv, geo, ray, s, h, sm);
     const bool live = valid && !(mask && !point_in_bounds(sm.x, sm.y, sm.z));
@@ -434,6 +446,7 @@ static SplatLoopParams sloop_params(const LpSplatterArgs& a, int NB) {
   static const int dbg = getenv("LP_MFMA_DEBUG") ? atoi(getenv("LP_MFMA_DEBUG")) : 0;
   p.dbg = dbg;
   p.n_seg = 1;
+  p.fwd_group = 0;
   return p;
 }
 
@@ -481,6 +494,21 @@ static int sloop_launch(K kernel, const LpSplatterArgs& a, hipStream_t stream, b
   int n_seg = forced > 0 ? forced : (int)(256u / (nb ? nb : 1u));
   if (n_seg > s_tot / 16) n_seg = s_tot / 16;
   if (n_seg < 1) n_seg = 1;
+  p.fwd_group = 0;
+  if (!backward) {
+    // forward: as the plain Splatter's (lp_splatter.hip: interleaved segments of >= 16 samples here -- every workgroup stages the MLP's
+    // limb images --, segment-major while the output grid is cache-sized; LP_SPLAT_FWD_SEGMENTS / LP_SPLAT_FWD_GROUP: A/B, 0 group = rounds 2-5)
+    static const int forced_f = getenv("LP_SPLAT_FWD_SEGMENTS") ? atoi(getenv("LP_SPLAT_FWD_SEGMENTS")) : 0;
+    static const int forced_g = getenv("LP_SPLAT_FWD_GROUP") ? atoi(getenv("LP_SPLAT_FWD_GROUP")) : -1;
+    if (forced_g != 0) {
+      n_seg = forced_f > 0 ? forced_f : s_tot / 16;
+      if (forced_f <= 0 && n_seg > 16) n_seg = 16;
+      if (n_seg > s_tot) n_seg = s_tot;
+      if (n_seg < 1) n_seg = 1;
+      const double grid_bytes = (double)a.out.n_rows * (double)a.out.channels * 4.0;
+      p.fwd_group = forced_g > 0 ? forced_g : ((grid_bytes <= 1.0e9 && nb <= 4096u) ? (int)nb : 1);
+    }
+  }
   p.n_seg = n_seg;
   if (backward && n_seg > 1 && a.grad_encoding) {
     const hipError_t e2 = hipMemsetAsync(a.grad_encoding, 0, (size_t)a.rays.n_rays * a.mlp.dims[0] * sizeof(float), stream);
