@@ -243,7 +243,10 @@ LP_DEV void splat_walk_vox(float* feat, float* wgt, const LpGrid& g, int b, floa
 // lane = channel of 32: a +-1 step along A or B flushes the two columns left behind, a diagonal step three, and what stays is
 // re-labelled.  Same segments per flushed column as before (two rows of C x 4 bytes per atomic instruction).
 // enc[j][i]: channel (lane & 31) + 32 j of ray i.  Splatter forward only (SPLAT convention, unit weights by the caller).
-template <int C, int RPW, int WLD, class Enc>
+// DIAG: also diagonal steps over the two carry axes, as two successive unit steps through a virtual cell (three of four columns leave).
+// Pays for rays marched along (the transposed march: -6 % on the reference's splatter benchmark), not for image rows (cfg 5 -1 %, cfg 3 + 3 %:
+// the second pass through the step code costs every run head a loop).
+template <int C, int RPW, int WLD, class Enc, bool DIAG = false>
 LP_DEV void splat_walk_vox_feat2(float* feat, const LpGrid& g, int row0, int cell, int ok, int su, int sv, int st, unsigned mask,
                                  int lane, const Enc& enc, const float* wT, int dbg) {
   static_assert(C % 32 == 0, "32 channels per lane group");
@@ -288,6 +291,16 @@ LP_DEV void splat_walk_vox_feat2(float* feat, const LpGrid& g, int row0, int cel
     codev = (along_a && da == -1 && dr == -sA && okAm) ? 1 : codev;
     codev = (along_b && db == 1 && dr == sB && okBp) ? 2 : codev;
     codev = (along_b && db == -1 && dr == -sB && okBm) ? 3 : codev;
+    // a DIAGONAL step over A and B = the A step into a virtual intermediate cell, then the B step: three of the four columns leave, the one
+    // both cells share stays (its validity has to agree: old column ((da + 1) / 2, (db + 1) / 2) against the new one on the other side).
+    // Second step in bits 3..: 2 / 3 as above, 7 = none.
+    const int oa = (da + 1) >> 1, ob = (db + 1) >> 1;
+    const int so = oa * bA + ob * bB, sn = (1 - oa) * bA + (1 - ob) * bB;    // slot of that column (+ 0 / bX) in the old / new cell
+    const int bX = 1 << X;
+    const unsigned pair = 1u | (1u << bX);                                   // the two corners of a column along the third axis
+    const bool okD = ((pok >> so) & pair) == ((uok >> sn) & pair);
+    const bool diag = dx == 0 && packable && (da == 1 || da == -1) && (db == 1 || db == -1) && dr == da * sA + db * sB && okD;
+    codev = (DIAG && diag) ? ((da > 0 ? 0 : 1) | ((db > 0 ? 2 : 3) << 3)) : (codev | (7 << 3));
   }
   const int k00 = gc << X;
   const unsigned bit[2][2] = {{1u << k00, 1u << (k00 + bB)}, {1u << (k00 + bA), 1u << (k00 + bA + bB)}};
@@ -329,27 +342,38 @@ LP_DEV void splat_walk_vox_feat2(float* feat, const LpGrid& g, int row0, int cel
     for (int i = 0; i < 8; ++i) {
       const int rr = 8 * c8 + i;
       if (rr > 0 && ((mask >> rr) & 1u)) {
-        const int code = __builtin_amdgcn_readlane(codev, rr);
-        if (code == 0) {         // +1 along A: the columns a = 0 are left behind, a = 1 becomes a = 0
-          flush(0, 0); flush(0, 1);
+        const int code2 = __builtin_amdgcn_readlane(codev, rr);
+        int code = code2 & 7;
+#pragma unroll 1
+        for (int pass = 0; pass < (DIAG ? 2 : 1); ++pass) {
+          if (code == 0) {         // +1 along A: the columns a = 0 are left behind, a = 1 becomes a = 0
+            flush(0, 0); flush(0, 1);
 #pragma unroll
-          for (int j = 0; j < CPL; ++j) { acc[0][0][j] = acc[1][0][j]; acc[0][1][j] = acc[1][1][j]; acc[1][0][j] = acc[1][1][j] = 0.0f; }
-        } else if (code == 1) {  // -1 along A
-          flush(1, 0); flush(1, 1);
+            for (int j = 0; j < CPL; ++j) { acc[0][0][j] = acc[1][0][j]; acc[0][1][j] = acc[1][1][j]; acc[1][0][j] = acc[1][1][j] = 0.0f; }
+          } else if (code == 1) {  // -1 along A
+            flush(1, 0); flush(1, 1);
 #pragma unroll
-          for (int j = 0; j < CPL; ++j) { acc[1][0][j] = acc[0][0][j]; acc[1][1][j] = acc[0][1][j]; acc[0][0][j] = acc[0][1][j] = 0.0f; }
-        } else if (code == 2) {  // +1 along B
-          flush(0, 0); flush(1, 0);
+            for (int j = 0; j < CPL; ++j) { acc[1][0][j] = acc[0][0][j]; acc[1][1][j] = acc[0][1][j]; acc[0][0][j] = acc[0][1][j] = 0.0f; }
+          } else if (code == 2) {  // +1 along B
+            flush(0, 0); flush(1, 0);
 #pragma unroll
-          for (int j = 0; j < CPL; ++j) { acc[0][0][j] = acc[0][1][j]; acc[1][0][j] = acc[1][1][j]; acc[0][1][j] = acc[1][1][j] = 0.0f; }
-        } else if (code == 3) {  // -1 along B
-          flush(0, 1); flush(1, 1);
+            for (int j = 0; j < CPL; ++j) { acc[0][0][j] = acc[0][1][j]; acc[1][0][j] = acc[1][1][j]; acc[0][1][j] = acc[1][1][j] = 0.0f; }
+          } else if (code == 3) {  // -1 along B
+            flush(0, 1); flush(1, 1);
 #pragma unroll
-          for (int j = 0; j < CPL; ++j) { acc[0][1][j] = acc[0][0][j]; acc[1][1][j] = acc[1][0][j]; acc[0][0][j] = acc[1][0][j] = 0.0f; }
-        } else {
-          flush(0, 0); flush(0, 1); flush(1, 0); flush(1, 1);
+            for (int j = 0; j < CPL; ++j) { acc[0][1][j] = acc[0][0][j]; acc[1][1][j] = acc[1][0][j]; acc[0][0][j] = acc[1][0][j] = 0.0f; }
+          } else {
+            flush(0, 0); flush(0, 1); flush(1, 0); flush(1, 1);
 #pragma unroll
-          for (int j = 0; j < CPL; ++j) acc[0][0][j] = acc[0][1][j] = acc[1][0][j] = acc[1][1][j] = 0.0f;
+            for (int j = 0; j < CPL; ++j) acc[0][0][j] = acc[0][1][j] = acc[1][0][j] = acc[1][1][j] = 0.0f;
+          }
+          if (!DIAG || (code2 >> 3) == 7) break;   // (the usual case: one step)
+          // the virtual intermediate cell of a diagonal step: one over along A; the columns that came along keep their validity, the
+          // other side is empty (nothing to flush from it)
+          const bool up = (code2 & 7) == 0;
+          s_row += up ? sA : -sA;
+          s_ok = up ? ((s_ok & (mA0 << bA)) >> bA) : ((s_ok & mA0) << bA);
+          code = code2 >> 3;
         }
         s_row = __builtin_amdgcn_readlane(row0, rr);
         s_ok = (unsigned)__builtin_amdgcn_readlane(ok, rr);
@@ -374,7 +398,7 @@ LP_DEV void splat_walk_vox_feat2(float* feat, const LpGrid& g, int row0, int cel
 // the Splatter forward's voxel walk with two carry axes: tap set, weight table, run heads -- as splat_walk_vox --, then the feature walk
 // above and the unit-weight walk
 // (Enc: enc[j][i] = channel (lane & 31) + 32 j of item i -- a register array [C / 32][RPW], or SplatEncConst for the transposed march)
-template <int C, int RPW, int WLD, class Enc>
+template <int C, int RPW, int WLD, class Enc, bool DIAG = false>
 LP_DEV void splat_walk_vox2(float* feat, float* wgt, const LpGrid& g, int b, float x, float y, float z, bool live, int lane,
                             const Enc& enc, float* wT, int dbg) {
   constexpr int NQ = 64 / RPW;
@@ -398,7 +422,7 @@ LP_DEV void splat_walk_vox2(float* feat, float* wgt, const LpGrid& g, int b, flo
   const int prow_ = lane_prev(row0), pok_ = lane_prev(ok);  // all lanes enabled: see run_head()
   const bool head = run_head(r, row0, prow_, ok, pok_);
   const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(head));
-  if (!(dbg & 64)) splat_walk_vox_feat2<C, RPW, WLD, Enc>(feat, g, row0, tp.cell, ok, tp.su, tp.sv, tp.st, mask, lane, enc, wT, dbg);
+  if (!(dbg & 64)) splat_walk_vox_feat2<C, RPW, WLD, Enc, DIAG>(feat, g, row0, tp.cell, ok, tp.su, tp.sv, tp.st, mask, lane, enc, wT, dbg);
   if (dbg & 32) return;
   splat_walk_vox_weights<RPW, WLD>(wgt, g, row0, tp.iu, tp.sv, tp.st, mask, lane, wT, dbg);
 }

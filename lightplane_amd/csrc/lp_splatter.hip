@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(256) splat_fwd_ray_kernel(const LpSplatterArgs
       for (int g = 0; g < a.out.n_grids; ++g) {
         const LpGrid& og = a.out.grids[g];
         if constexpr (W2) {
-          splat_walk_vox2<C, 32, WLD, SplatEncConst<CPL>>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, enc, wT, dbg);
+          splat_walk_vox2<C, 32, WLD, SplatEncConst<CPL>, true>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, enc, wT, dbg);
         } else {
           if (og.D > 1 && og.H > 1 && og.W > 1 && !(dbg & 4))
             splat_walk_vox<C, 32, SplatSrcConst<CPL>, true, WLD>(a.out_feature, a.out_weight, og, ray.b, x, y, z, live, lane, src, wT, dbg);
