@@ -70,16 +70,32 @@ LP_DEV void splat_walk_vox_weights(float* wgt, const LpGrid& g, int row0, int iu
         if (rr > 0 && ((mask_w >> rr) & 1u)) {
           const int n_row = __builtin_amdgcn_readlane(row0, rr);
           const int n_iu = __builtin_amdgcn_readlane(iu, rr);
-          // (same (y, z) line and 0 <= n_iu - wb <= 14; one opaque integer, as above)
-          int leave = ((n_row - n_iu) ^ rowb) | (int)((unsigned)(n_iu - wb) >= 15u);
+          // (same (y, z) line and 0 <= n_iu - wb <= 14: nothing to do; one opaque integer per case, as above)
+          const int dl = (n_row - n_iu) - rowb;                       // how the window's (y0, z0) line moves
+          const int out_x = (int)((unsigned)(n_iu - wb) >= 15u);
+          int leave = dl | out_x;
+          // a step of one line along y or z inside the window's x range (round 6: views oblique to the grid take it at most run heads):
+          // the two pairs on the far side become the near ones -- only the two left behind are written (two segments instead of four)
+          int carry = out_x | (int)!(dl == tp.sv || dl == -tp.sv || dl == tp.st || dl == -tp.st);
           leave = __builtin_amdgcn_readfirstlane(leave);
-          asm volatile("" : "+s"(leave));
+          carry = __builtin_amdgcn_readfirstlane(carry);
+          asm volatile("" : "+s"(leave), "+s"(carry));
           if (leave != 0) {
             const int xl = wb + sub;
-            if (acc != 0.0f && xl >= 0 && xl < W && on) atomic_add_f32(wgt + (int64_t)(rowb + koff + xl), acc);
-            acc = 0.0f;
-            wb = ((n_iu & 15) == 15) ? n_iu : (n_iu & ~15);
-            rowb = n_row - n_iu;
+            if (carry == 0) {
+              const bool along_y = dl == tp.sv || dl == -tp.sv;
+              const int side = along_y ? (grp & 1) : (grp >> 1);      // this lane's corner bit along the stepping axis
+              const bool behind = side == (dl > 0 ? 0 : 1);
+              if (behind && acc != 0.0f && xl >= 0 && xl < W && on) atomic_add_f32(wgt + (int64_t)(rowb + koff + xl), acc);
+              const float other = __shfl_xor(acc, along_y ? 16 : 32);
+              acc = behind ? other : 0.0f;                            // (the lanes left behind take over the line that stays)
+              rowb += dl;
+            } else {
+              if (acc != 0.0f && xl >= 0 && xl < W && on) atomic_add_f32(wgt + (int64_t)(rowb + koff + xl), acc);
+              acc = 0.0f;
+              wb = ((n_iu & 15) == 15) ? n_iu : (n_iu & ~15);
+              rowb = n_row - n_iu;
+            }
           }
           m0 = (wb + sub) == n_iu;
           m1 = (wb + sub) == n_iu + 1;
