@@ -8,7 +8,8 @@ import lightplane_amd as lp
 from tests.synth import pinhole_rays, random_splatter_mlp
 
 dev = torch.device("cuda:0"); lp.config.check_inputs = False
-CASES = [(256, 256, 64, 128, 32, 2, 32, 128), (256, 256, 64, 128, 32, 3, 64, 128), (128, 128, 32, 64, 16, 2, 32, 64)]
+CASES = [(256, 256, 64, 128, 32, 2, 32, 128), (256, 256, 64, 128, 32, 3, 64, 128), (128, 128, 32, 64, 16, 2, 32, 64),
+         (256, 256, 64, 128, 32, 2, 32, 256)]  # (the last one: the launch of rounds 2-5's version of this script, profiles/r02_other_workloads.txt)
 for H, W, Gi, Go, E, nl, hid, S in CASES:
     gen = torch.Generator().manual_seed(H + Go)
     rays = pinhole_rays(H, W, gen=gen, azimuth_deg=25.0, elevation_deg=20.0)
