@@ -356,6 +356,7 @@ SPLATS = {
     "triplane32_c16": ((1, 32, 32, 32, 16), True, 1),
     "voxel20_c32_b2": ((2, 20, 18, 22, 32), False, 2),
     "voxel24_c16": ((1, 24, 24, 24, 16), False, 1),
+    "voxel18_c64": ((1, 18, 20, 16, 64), False, 1),   # 64 channels: 16-ray waves, two registers per lane in the two-axis walk
 }
 
 
