@@ -421,6 +421,27 @@ def test_splatter_coherent_image(name, image, mask):
     check_splatter(d, _dev(), f"{name}/{image}/mask={mask}")
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_splatter_random_cameras(seed):
+    """The voxel walks' carries under cameras at RANDOM angles to the grid (round 6: two carry axes chosen per wave-sample, weight
+    windows carried over y / z steps, segments of interleaved samples): images of 40 x 56 pixels, non-cubic grids, 16 / 32 / 64
+    channels, one or two batch entries, with and without the out-of-bounds mask -- outputs and grad_encoding against the oracle."""
+    gen = torch.Generator().manual_seed(1000 + seed)
+    rnd = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))
+    C = (32, 64, 16, 32)[seed % 4]
+    batch = 1 + (seed % 3 == 2)
+    base = (batch, rnd(10, 26), rnd(10, 26), rnd(10, 26), C)
+    out_sizes = grid_sizes_for(base, False)
+    parts = [pinhole_rays(40, 56, grid_idx=b, azimuth_deg=float(torch.rand(1, generator=gen)) * 360.0,
+                          elevation_deg=float(torch.rand(1, generator=gen)) * 120.0 - 60.0) for b in range(batch)]
+    rays = parts[0] if batch == 1 else cat_rays(parts)
+    rays.encoding = torch.rand(rays.n_rays, C, generator=gen)
+    d = dict(rays=rays, out_sizes=out_sizes, mlp=None, in_grids=None, in_sizes=None,
+             cfg=dict(num_samples=rnd(20, 45), num_samples_inf=0, mask_out_of_bounds_samples=bool(seed & 1), contract_coords=False),
+             upstream=[torch.randn(*sz, generator=gen) for sz in out_sizes])
+    check_splatter(d, _dev(), f"random camera {seed}: grid {base}")
+
+
 @pytest.mark.parametrize("name", list(SPLATS))
 @pytest.mark.parametrize("num_samples", [37, 70])
 def test_splatter_segmented_march(name, num_samples):
