@@ -24,7 +24,7 @@ from .rays import Rays, calc_harmonic_embedding, calc_harmonic_embedding_dim, ji
 from . import config  # noqa: E402
 from .renderer import LightplaneFunction, backward_segments, kernel_family, lightplane_renderer  # noqa: E402
 from .splatter import (LightplaneMLPSplatterFunction, LightplaneSplatterFunction, lightplane_mlp_splatter,  # noqa: E402
-                       lightplane_splatter)
+                       lightplane_splatter, mlp_splatter_kernel_family)
 from .modules import LightplaneMLPSplatter, LightplaneRenderer, LightplaneSplatter  # noqa: E402
 # The reference's sub-module import paths (`from lightplane.mlp_utils import DecoderParams`, tests/renderer_speed_benchmark.py:30)
 # exist as alias modules (re-exports only).  Two of them are named like the functions they hold, exactly as in the reference
@@ -40,7 +40,7 @@ from .splatter import lightplane_splatter  # noqa: E402,F811
 __all__ = [
     "lightplane_renderer", "lightplane_splatter", "lightplane_mlp_splatter", "LightplaneRenderer",
     "LightplaneSplatter", "LightplaneMLPSplatter", "LightplaneFunction", "LightplaneSplatterFunction",
-    "LightplaneMLPSplatterFunction", "config", "kernel_family", "backward_segments",
+    "LightplaneMLPSplatterFunction", "config", "kernel_family", "mlp_splatter_kernel_family", "backward_segments",
     "Rays", "DecoderParams", "SplatterParams", "init_decoder_params", "init_splatter_params",
     "flatten_decoder_params", "flatten_splatter_params", "flattened_decoder_params_to_list",
     "flattened_triton_decoder_to_list", "get_triton_function_input_dims", "flatten_grid",

@@ -19,6 +19,21 @@ extern thread_local uint32_t* g_relu_dump;
 // two launching threads only makes the answer one of the two)
 extern const char* volatile g_last_backward;
 
+// The MFMA kernels index grid rows with 32-bit integers and address them as a 64-bit base + row * C * 4 (+ a 32-bit byte offset for
+// the corner inside the cell): any grid-list whose every grid ends below row 2^31 of the tensor that holds it, and whose z-slice
+// (H x W rows: the farthest corner of a cell) stays below 2 GB.  No limit on the byte size -- a 256^3 x 32 grid per batch element
+// is 2.1 GB, and batches of them are what 288 GB of HBM are for.  (Rounds 2-6 excluded grid-lists of 4 GB or more: the per-slot
+// scatter walk formed a 32-bit byte offset from the tensor's base.)
+inline bool grid_list_rows_ok(const LpGridList& gl) {
+  if (gl.n_rows >= ((int64_t)1 << 31)) return false;
+  for (int g = 0; g < gl.n_grids; ++g) {
+    const LpGrid& d = gl.grids[g];
+    if (d.row_offset + (int64_t)d.B * d.D * d.H * d.W >= ((int64_t)1 << 31)) return false;
+    if (((int64_t)d.H * d.W + d.W + 1) * gl.channels * 4 >= ((int64_t)1 << 31)) return false;
+  }
+  return true;
+}
+
 // generic (shape-agnostic) kernels: lp_renderer_generic.hip
 int renderer_forward_generic(const LpRendererArgs& a, hipStream_t stream);
 int renderer_backward_generic(const LpRendererArgs& a, hipStream_t stream);

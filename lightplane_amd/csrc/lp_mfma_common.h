@@ -323,12 +323,13 @@ constexpr int DX_LD = 36;  // row stride of the transposed dx0 tile [channel][ra
 template <int C>
 LP_DEV void flush_run(float* gg, int s_row, unsigned s_ok, int koff, unsigned kbit, int sub, const float (&run)[C / 16],
                       int dbg) {
-  // 32-bit byte offset from the uniform base (grid-lists below 4 GB only, see renderer_mfma_supported)
-  const unsigned off = (unsigned)(s_row + koff) * (unsigned)(C * 4) + (unsigned)(sub * 4);
+  // the run's row goes into the scalar base (64-bit: grid-lists of any size below 2^31 rows), the lane part -- this slot's corner
+  // offset inside the cell, this lane's channel -- stays a 32-bit byte offset (a corner is at most one z-slice + one line away)
   if ((s_ok & kbit) && !(dbg & 1)) {
+    char* const rb = reinterpret_cast<char*>(gg) + (int64_t)s_row * (C * 4);
+    const unsigned lane_off = (unsigned)koff * (unsigned)(C * 4) + (unsigned)(sub * 4);
 #pragma unroll
-    for (int j = 0; j < C / 16; ++j)
-      atomic_add_f32(reinterpret_cast<float*>(reinterpret_cast<char*>(gg) + off + 64 * j), run[j]);
+    for (int j = 0; j < C / 16; ++j) atomic_add_f32(reinterpret_cast<float*>(rb + lane_off + 64 * j), run[j]);
   }
 }
 

@@ -10,7 +10,7 @@ namespace lp {
 // ---------------------------------------------------------------------------------------------------------------
 static int loop_nb(int H, int C = 16) { return (H <= 32 && C <= 32) ? 1 : 2; }
 
-// Shape family: grid-list(s) with C in {16, 32} channels below 4 GB; trunk of 1..4 layers, or none with a separate colour
+// Shape family: grid-list(s) with C in {16, 32} channels below 2^31 rows (any byte size); trunk of 1..4 layers, or none with a separate colour
 // grid-list; heads of 1..4 layers; every hidden width equal to H in {16, 32} -- or, on the two-block instantiation (H = 64, or
 // C = 64 grid channels with any of the three widths): at most 2 trunk layers, heads of at most 2 layers, <= 4 colour channels, a
 // colour grid only with C <= 32; <= 256 beyond-far samples.
@@ -40,8 +40,8 @@ bool renderer_loop_supported(const LpRendererArgs& a, const char** why) {
   if (C == 64 && tg) { *why = "64 grid channels with a separate colour grid"; return false; }
   if (a.color_chn > 32) { *why = "more than 32 colour channels"; return false; }
   if (a.color_chn > 4 && (H == 64 || C == 64)) { *why = "more than 4 colour channels with hidden width 64 / 64 grid channels"; return false; }
-  if (a.grid.n_rows * C * 4 >= (int64_t)1 << 32) { *why = "grid-list of 4 GB or more"; return false; }
-  if (tg && a.color_grid.n_rows * C * 4 >= (int64_t)1 << 32) { *why = "colour grid-list of 4 GB or more"; return false; }
+  if (!grid_list_rows_ok(a.grid)) { *why = "grid-list of 2^31 rows or more (or a grid slice of 2 GB or more)"; return false; }
+  if (tg && !grid_list_rows_ok(a.color_grid)) { *why = "colour grid-list of 2^31 rows or more (or a grid slice of 2 GB or more)"; return false; }
   if (a.march.num_samples_inf > LOOP_N_INF) { *why = "more than 256 beyond-far samples"; return false; }
   return true;
 }

@@ -276,7 +276,7 @@ int renderer_forward_combine_launch(const LpRendererArgs& a, int seg_blocks, hip
 // host side
 // ---------------------------------------------------------------------------------------
 
-// Shape family of these kernels: grid-list(s) with C in {16, 32} channels below 4 GB; trunk of 1 or 2 layers -- or
+// Shape family of these kernels: grid-list(s) with C in {16, 32} channels below 2^31 rows (any byte size); trunk of 1 or 2 layers -- or
 // none with a separate colour grid-list (the reference's two-grid decoder: the heads read relu(sampled feature)
 // of their own grid) --, opacity / colour heads of 1 or 2 layers, every hidden width equal to H in {16, 32};
 // <= 4 colour channels.  The default shape (2/2/2 layers, H = 32, one grid-list) runs the tuned kernels; the
@@ -302,8 +302,8 @@ bool renderer_mfma_supported(const LpRendererArgs& a, const char** why) {
   if (H != 16 && H != 32) { *why = "hidden width other than 16 / 32"; return false; }
   if (!same) { *why = "hidden widths differ between layers"; return false; }
   if (a.color_chn > 4) { *why = "more than 4 colour channels"; return false; }
-  if (a.grid.n_rows * C * 4 >= (int64_t)1 << 32) { *why = "grid-list of 4 GB or more"; return false; }
-  if (tg && a.color_grid.n_rows * C * 4 >= (int64_t)1 << 32) { *why = "colour grid-list of 4 GB or more"; return false; }
+  if (!grid_list_rows_ok(a.grid)) { *why = "grid-list of 2^31 rows or more (or a grid slice of 2 GB or more)"; return false; }
+  if (tg && !grid_list_rows_ok(a.color_grid)) { *why = "colour grid-list of 2^31 rows or more (or a grid slice of 2 GB or more)"; return false; }
   if (a.march.num_samples_inf > MAX_INF) { *why = "more than 256 beyond-far samples"; return false; }
   // the tuned kernels are written for ONE decoder shape; the flex / two-grid subsets this family used to take (fp32-MFMA
   // kernels with run-time layer flags) belong to the layer-looped family since round 4

@@ -16,7 +16,7 @@ bool splatter_mlp_loop_supported(const LpSplatterArgs& a) {
     if (!width_ok(m.dims[l]) || m.dims[l] != m.dims[1]) return false;
   const int CO = m.dims[m.n_layers];
   if (CO != 16 && CO != 32) return false;
-  if (a.input_grid.n_rows * m.dims[0] * 4 >= (int64_t)1 << 32) return false;  // 32-bit scatter offsets
+  if (!grid_list_rows_ok(a.input_grid)) return false;  // 32-bit row indices
   if (a.out.n_rows >= (int64_t)1 << 31) return false;
   if (a.march.num_samples_inf > LOOP_N_INF) return false;
   const SplatLoopParams p = sloop_params(a, sloop_nb(a));

@@ -120,7 +120,7 @@ def _warn_if_generic(a, cfg: _RendererCfg) -> None:
         _warned_shapes.add(key)
         warnings.warn(
             "lightplane_amd: this decoder shape runs on the shape-generic Renderer kernels (10-100x slower). The "
-            "MFMA families cover grid channels 16/32, grid-lists below 4 GB, trunk 1-4 (0 with a separate colour grid) / "
+            "MFMA families cover grid channels 16/32, grid-lists below 2^31 rows, trunk 1-4 (0 with a separate colour grid) / "
             "opacity 1-4 / colour 1-4 layers with ONE hidden width of 16 or 32 and <= 32 colour channels, or up to 2/2/2 "
             "layers with hidden width 64 and / or 64 grid channels and <= 4 colour channels (a separate colour grid only with 16 / 32 "
             "grid channels); at most 256 "

@@ -243,6 +243,19 @@ def lightplane_splatter(
     return out
 
 
+def mlp_splatter_kernel_family(output_grid_size, mlp_params: SplatterParams, input_grid_sizes, num_samples_inf: int = 0) -> int:
+    """Kernel family that runs an MLP-Splatter of these shapes: 3 = layer-looped MFMA family (2-4 layers, widths 16 / 32 / 64),
+    0 = shape-generic kernels (``lp_splatter_kernel_family``: shapes only, needs no GPU)."""
+    descs, channels, n_rows = make_grid_descs(sizes_to_list(output_grid_size))
+    in_descs, in_channels, in_n_rows = make_grid_descs(sizes_to_list(input_grid_sizes))
+    a = _lib.LpSplatterArgs()
+    a.march = _lib.make_march(1, int(num_samples_inf), False, False, 1e-5)
+    a.out = _lib.make_grid_list(None, descs, channels, n_rows)
+    a.input_grid = _lib.make_grid_list(None, in_descs, in_channels, in_n_rows)
+    a.mlp = _lib.make_mlp(int_list_of(mlp_params.n_hidden), 0)
+    return int(_lib.lib().lp_splatter_kernel_family(ctypes.byref(a)))
+
+
 def lightplane_mlp_splatter(
     rays: Rays,
     output_grid_size,

@@ -591,6 +591,17 @@ def test_kernel_family_selection():
             assert L.lp_splatter_kernel_family(ctypes.byref(a)) == 3, (n_layers, feat)
     a.mlp = _lib.make_mlp([32, 64, 48, 32], 0)  # hidden widths differ: shape-generic kernels
     assert L.lp_splatter_kernel_family(ctypes.byref(a)) == 0
+    # grid-lists of 4 GB and more stay on the matrix cores (lp_host.h grid_list_rows_ok: rows are 32-bit, bytes are not;
+    # tests/test_gpu_large_grid.py runs them): a batch of four 256^3 x 32 scenes (8.6 GB), the layer-looped family on 17 GB of 16
+    # channels, an MLP-Splatter reading 8.6 GB; 2^31 rows and more are the shape-generic kernels'
+    dec = random_decoder(gen, 2, 2, 2, 32, 32, 3)
+    assert kernel_family(None, None, dec, grid_sizes=[[4, 256, 256, 256, 32]]) == 1
+    assert kernel_family(None, None, dec, grid_sizes=grid_sizes_for((40, 1024, 1024, 1024, 32), True)) == 1   # 3 x 5.4 GB of planes
+    assert kernel_family(None, None, random_decoder(gen, 3, 2, 2, 16, 16, 3), grid_sizes=[[16, 256, 256, 256, 16]]) == 3
+    assert kernel_family(None, None, random_decoder(gen, 2, 2, 2, 16, 32, 3), grid_sizes=[[128, 256, 256, 256, 16]]) == 0  # 2^31 rows
+    from lightplane_amd.params import SplatterParams
+    sp = SplatterParams(torch.zeros(1), torch.tensor([32, 32, 32]))
+    assert lp.mlp_splatter_kernel_family([[4, 64, 64, 64, 32]], sp, [[4, 256, 256, 256, 32]]) == 3
 
 
 def test_extension_and_absent_names():
