@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define LP_VERSION 206 /* 0.2.0: per-grid base pointers (zero-copy grid-lists), fused bg-colour / alpha epilogue,
+#define LP_VERSION 207 /* 0.2.0: per-grid base pointers (zero-copy grid-lists), fused bg-colour / alpha epilogue,
                            ray-embedding entry points; grad replicas removed
                            0.2.1: segment-parallel backward for small batches (LpRendererArgs.seg_prefix)
                            0.2.2: no struct change; lp_*_kernel_family() report family 3 (layer-looped MFMA kernels: Renderer
@@ -69,7 +69,11 @@ extern "C" {
                            0.2.6: LpRendererArgs.arithmetic (LP_ARITH_FP32: every product of the backward fp32-equivalent, selectable
                                   per call); lp_build_info(); lp_renderer_relu_dump_words() and dump twins for the layer-looped
                                   family (the dump of family 1 keeps its five words per sample); LpRendererArgs.march_order
-                                  (LP_MARCH_SAMPLES_PER_WAVE: transposed march of the tuned backward for incoherent ray batches) */
+                                  (LP_MARCH_SAMPLES_PER_WAVE: transposed march of the tuned backward for incoherent ray batches)
+                           0.2.7: no struct change; LP_SEG_LEN 16 -> 8: LpRendererArgs.seg_prefix holds a record per 8 samples
+                                  (lp_renderer_backward_segments() returns ceil(S / 8) for a small batch): batches of up to ~2 000 rays
+                                  are dealt to the CUs in 8-sample segments, larger ones in 16-sample segments as before; the MFMA
+                                  families take grid-lists of any byte size below 2^31 rows (were: below 4 GB) */
 
 #define LP_MAX_GRIDS 8   /* grids per grid-list                         */
 #define LP_MAX_LAYERS 8  /* layers per MLP                              */
@@ -83,8 +87,9 @@ extern "C" {
  * the final -log T) -- the backward starts there (see stop_neg_log_t).
  * O(N) memory: 2 * (ceil(S/LP_NLT_CKPT) + S_inf + 1) floats per ray. */
 #define LP_NLT_CKPT 32
-/* samples per ray segment of the segment-parallel backward (LpRendererArgs.seg_prefix) */
-#define LP_SEG_LEN 16
+/* samples per state record of the segment-parallel march of a small batch (LpRendererArgs.seg_prefix); a workgroup marches one or more
+ * such blocks (16 before 0.2.7) */
+#define LP_SEG_LEN 8
 
 /* error codes (negative; positive values are hipError_t) */
 #define LP_OK 0

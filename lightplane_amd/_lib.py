@@ -18,6 +18,7 @@ LP_MAX_GRIDS = 8
 LP_MAX_LAYERS = 8
 LP_MAX_WIDTH = 128
 LP_NLT_CKPT = 32
+LP_SEG_LEN = 8   # samples per state record of a small batch's segment-parallel march (lightplane_hip.h; 16 before ABI 0.2.7)
 
 
 def n_nlt_ckpt(num_samples: int, num_samples_inf: int) -> int:

@@ -9,7 +9,7 @@
                        kernel and the background / alpha epilogue inside the render kernel (2 launches instead of
                        ~17).  Off: the reference's PyTorch op chain around the functional renderer.  Default on.
 ``segment_backward``   small Renderer batches (<= 32 768 rays, default decoder shape): the backward sweeps every
-                       block of 16 samples of a ray in its own workgroup, from running sums the forward saves per block
+                       block of LP_SEG_LEN = 8 samples of a ray (two blocks once the batch has more than ~2 000 rays) in its own workgroup, from running sums the forward saves per block
                        (32 B per ray and block).  Default on.
 ``segment_forward``    the forward of such a batch marches the segments in parallel too (one workgroup per 128 rays and
                        segment + a combine pass; outputs differ from the single sweep by rounding, ~1e-7).  Default on.

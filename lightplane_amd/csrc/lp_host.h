@@ -1,6 +1,7 @@
 // lp_host.h -- host-side glue shared by the translation units of liblightplane_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "../../include/lightplane_hip.h"
 
@@ -32,6 +33,25 @@ inline bool grid_list_rows_ok(const LpGridList& gl) {
     if (((int64_t)d.H * d.W + d.W + 1) * gl.channels * 4 >= ((int64_t)1 << 31)) return false;
   }
   return true;
+}
+
+// LP_SEG_LEN-sample blocks per segment of a segment-parallel launch (small batches: forward and backward of both MFMA families).
+// Every workgroup pays the weight staging and, in the backward, the dW flush once, and workgroups that share a CU share its SIMDs:
+//  * as many 16-sample segments (two blocks) as keep the launch within ONE round of resident workgroups -- measured
+//    (scripts/bench_small_batch.py, S = 128, tuned backward): 16-sample segments 4 096 rays 0.39 ms / 16 384 rays 1.13 ms, 32-sample
+//    segments 0.51 / 0.88 ms;
+//  * 8-sample segments (one block, ABI 0.2.7; LP_SEG_LEN was 16 before) only while even they leave at most one workgroup per CU: the
+//    reference example's decoder (2/2/2 x 64) on 1 024 random rays 0.89 -> 0.56 ms per training step, 2/2/2 x 32 0.50 -> 0.35 ms; on
+//    4 096 rays, where 16-sample segments already give every CU a workgroup, 8-sample ones were 18 % SLOWER (0.73 -> 0.86 ms:
+//    profiles/r06_train_step.txt).
+// LP_SEG_BLOCKS (developer knob) forces the number of blocks.
+inline int seg_blocks_for(unsigned ray_blocks, int n_rec, unsigned resident) {
+  static const int forced = getenv("LP_SEG_BLOCKS") ? atoi(getenv("LP_SEG_BLOCKS")) : 0;
+  if (forced > 0) return forced < n_rec ? forced : n_rec;
+  if (n_rec <= 1 || (uint64_t)ray_blocks * (uint64_t)n_rec <= 256u) return 1;
+  int m = 2;
+  while (m < n_rec && (uint64_t)ray_blocks * (uint64_t)((n_rec + m - 1) / m) > resident) m += 2;
+  return m < n_rec ? m : n_rec;
 }
 
 // generic (shape-agnostic) kernels: lp_renderer_generic.hip

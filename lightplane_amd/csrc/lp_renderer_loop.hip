@@ -162,15 +162,11 @@ int renderer_loop_segments(const LpRendererArgs& a) {
   return n_seg;
 }
 
-// LP_SEG_LEN-sample blocks per segment: as many segments as keep the launch within one round of resident workgroups (every
-// workgroup stages up to 69 KB of limb images and flushes its dW once)
+// LP_SEG_LEN-sample blocks per segment: seg_blocks_for() (lp_host.h) -- every workgroup stages up to 69 KB of limb images and flushes
+// its dW once
 static int loop_seg_blocks(const LpRendererArgs& a, unsigned ray_blocks, unsigned resident = 256u) {
-  static const int forced = getenv("LP_SEG_BLOCKS") ? atoi(getenv("LP_SEG_BLOCKS")) : 0;
   const int n_rec = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
-  int m = 1;
-  while (m < n_rec && (uint64_t)ray_blocks * ((n_rec + m - 1) / m) > resident) ++m;
-  if (forced > 0) m = forced < n_rec ? forced : n_rec;
-  return m;
+  return seg_blocks_for(ray_blocks, n_rec, resident);
 }
 
 static size_t loop_lds_bytes(const LoopParams& p, bool backward) {

@@ -424,10 +424,7 @@ static int launch_fwd(const LpRendererArgs& a, const MfmaParams& mp, hipStream_t
     if (a.seg_prefix && seg_fwd && !a.seg_forward_off) {
       MfmaParams ms = mp;
       const int n_rec = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
-      static const int forced = getenv("LP_SEG_BLOCKS") ? atoi(getenv("LP_SEG_BLOCKS")) : 0;
-      int m = 1;
-      while (m < n_rec && (uint64_t)n_blocks(a) * ((n_rec + m - 1) / m) > 512u) ++m;
-      if (forced > 0) m = forced < n_rec ? forced : n_rec;
+      const int m = seg_blocks_for(n_blocks(a), n_rec, 512u);
       ms.seg_blocks = m;
       const unsigned nb = n_blocks(a) * (unsigned)((n_rec + m - 1) / m);
       if (a.color_chn <= 3 && !no_nc3) {

@@ -757,15 +757,9 @@ static int launch_bwd3w(const LpRendererArgs& a, const MfmaParams& mp_, hipStrea
   const unsigned ray_blocks = (unsigned)((a.rays.n_rays + NW * RAYS_PER_WAVE - 1) / (NW * RAYS_PER_WAVE));
   unsigned segs = 1;
   if (SEG) {
-    // as many segments as keep the launch within one round of resident workgroups (2 per CU): every workgroup pays
-    // the weight staging and the dW flush once, so a second round costs more than longer segments do.  Measured
-    // (scripts/bench_small_batch.py, S = 128): 16-sample segments 4 096 rays 0.39 ms / 16 384 rays 1.13 ms, 32-sample
-    // segments 0.51 / 0.88 ms.
-    static const int forced = getenv("LP_SEG_BLOCKS") ? atoi(getenv("LP_SEG_BLOCKS")) : 0;
+    // blocks per segment: seg_blocks_for() (lp_host.h); two workgroups per CU are resident
     const int n_rec = (a.march.num_samples + LP_SEG_LEN - 1) / LP_SEG_LEN;
-    int m = 1;
-    while (m < n_rec && (uint64_t)ray_blocks * ((n_rec + m - 1) / m) > 512u) ++m;
-    if (forced > 0) m = forced < n_rec ? forced : n_rec;
+    const int m = seg_blocks_for(ray_blocks, n_rec, 512u);
     mp.seg_blocks = m;
     segs = (unsigned)((n_rec + m - 1) / m);
   }

@@ -201,7 +201,7 @@ def backward_segments(rays: Rays, grid, decoder_params: DecoderParams, num_sampl
                       grid_sizes=None, color_grid=None, color_grid_sizes=None, stop_transmittance: float = 0.0,
                       kernel: int = _lib.LP_KERNEL_AUTO, arithmetic: Optional[int] = None, march_order: str = "rays", **_unused) -> int:
     """Number of ray segments the backward of this call is split into (``lp_renderer_backward_segments``; needs no
-    GPU): 1 = one sweep per ray, > 1 = small batch, every block of 16 samples of a ray in its own workgroup.  ``march_order``
+    GPU): 1 = one sweep per ray, > 1 = small batch, the number of state records per ray (one per LP_SEG_LEN = 8 samples; a workgroup sweeps one or two such blocks).  ``march_order``
     "samples" (the transposed march, where it applies) never segments: it deals a small batch over the chip by rays per wave."""
     _unused.pop("march_order", None)
     _check_render_kwargs("backward_segments", _unused)

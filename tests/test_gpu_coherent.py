@@ -243,7 +243,7 @@ def test_renderer_coherent_early_termination_exact_when_off():
         "triplane_16k_rays_s80", "voxel_c32_s72", "voxel_flex_h16_s50", "two_grid_s66", "mixed_h64_s50", "voxel_c32_h64_scaffold_s40", "two_grid_h64_s66",
         "deep444_s72", "deep342_c32_scaffold_noise_s50", "deep_two_grid_s66"])
 def test_segmented_backward(grid, num_samples, kw):
-    """4 096-ray image, S > 16: the backward runs one workgroup per (128 rays, block of 16 samples) and has to agree with
+    """4 096-ray image, S > 16: the backward runs one workgroup per (128 rays, one or two blocks of LP_SEG_LEN = 8 samples) and has to agree with
     the oracle AND with the one-workgroup-per-128-rays sweep of the same kernel (same recompute, so no ReLU-flip slack:
     1e-5 of the largest entry)."""
     dev = _dev()
@@ -255,7 +255,7 @@ def test_segmented_backward(grid, num_samples, kw):
     d = coherent_renderer_inputs(grid, image, num_samples=num_samples, seed=3 if num_samples == 33 else 11, **kw)
     if noise:
         d["cfg"] = dict(d["cfg"], inject_noise_sigma=0.3, inject_noise_seed=5)
-    n_seg = (num_samples + 15) // 16
+    n_seg = -(-num_samples // _lib.LP_SEG_LEN)
     assert lp.backward_segments(d["rays"], d["grids"], d["decoder"], color_grid=d["color_grids"], **d["cfg"]) == n_seg
     assert lp.config.segment_backward
     try:
@@ -332,15 +332,15 @@ def test_segmented_march_with_fused_epilogue(alpha_mode):
 def test_segmented_backward_is_not_used_where_it_cannot_be():
     d = coherent_renderer_inputs("triplane24_c16", "64x64_axis", num_samples=64)
     q = lambda **over: lp.backward_segments(d["rays"], d["grids"], d["decoder"], **dict(d["cfg"], **over))
-    assert q() == 4
-    assert q(num_samples=16) == 1
+    assert q() == 8
+    assert q(num_samples=8) == 1
     assert q(num_samples_inf=2) == 1                                                    # beyond-far samples
     d32 = coherent_renderer_inputs("voxel20_c32", "64x64_axis", num_samples=64)        # C = 32: the same kernels
-    assert lp.backward_segments(d32["rays"], d32["grids"], d32["decoder"], **d32["cfg"]) == 4
+    assert lp.backward_segments(d32["rays"], d32["grids"], d32["decoder"], **d32["cfg"]) == 8
     dflex = coherent_renderer_inputs("triplane24_c16", "64x64_axis", num_samples=64, hidden=16)  # flex family: the same
-    assert lp.backward_segments(dflex["rays"], dflex["grids"], dflex["decoder"], **dflex["cfg"]) == 4
+    assert lp.backward_segments(dflex["rays"], dflex["grids"], dflex["decoder"], **dflex["cfg"]) == 8
     dwide = coherent_renderer_inputs("triplane24_c16", "64x64_axis", num_samples=64, hidden=64)  # hidden 64: the same
-    assert lp.backward_segments(dwide["rays"], dwide["grids"], dwide["decoder"], **dwide["cfg"]) == 4
+    assert lp.backward_segments(dwide["rays"], dwide["grids"], dwide["decoder"], **dwide["cfg"]) == 8
     assert lp.backward_segments(dwide["rays"], dwide["grids"], dwide["decoder"], **dict(dwide["cfg"], num_samples_inf=1)) == 1
     big = pinhole_rays(256, 256, enc_dim=32, gen=torch.Generator().manual_seed(0))      # 65 536 rays fill the chip
     assert lp.backward_segments(big, d["grids"], d["decoder"], **d["cfg"]) == 1

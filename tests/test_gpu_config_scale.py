@@ -480,7 +480,7 @@ def test_transposed_march_on_random_rays(n_rays, C, S, tri, cc, mask, rich):
     for nm, a, b in zip(("ray_length", "neg_log_t", "feature"), got[0], ref[0]):  # the transposed forward: same samples, a scan instead of a loop
         _assert_close(f"transposed forward vs rays-per-wavefront forward: {nm}", a, b.detach().cpu().numpy(), tol=3e-6)
     scaff = dict(scaffold=d["scaffold"]) if rich else {}
-    assert lp.backward_segments(d["rays"], d["grids"], d["decoder"], **d["cfg"], **scaff) == (1 if n_rays > 32768 else (S + 15) // 16)
+    assert lp.backward_segments(d["rays"], d["grids"], d["decoder"], **d["cfg"], **scaff) == (1 if n_rays > 32768 else -(-S // _lib.LP_SEG_LEN))
     assert lp.backward_segments(d["rays"], d["grids"], d["decoder"], march_order="samples", **d["cfg"], **scaff) == 1  # dealt by rays per wave instead
     flat = lambda r: [("grad_mlp_params", r[1]), ("grad_encoding", r[2])] + [(f"grad_grid{i}", g) for i, g in enumerate(r[3])]  # noqa: E731
     for (nm, a), (_, b) in zip(flat(got), flat(ref)):

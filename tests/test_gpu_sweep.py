@@ -237,7 +237,7 @@ def test_renderer_segmented_sweep(i):
     dev = _dev()
     import os
     if not os.environ.get("LP_LOOP"):  # (LP_LOOP=1 sends the default shape through the layer-looped family: one sweep per ray)
-        assert lp.backward_segments(d["rays"], d["grids"], d["decoder"], **d["cfg"]) == (case.num_samples + 15) // 16
+        assert lp.backward_segments(d["rays"], d["grids"], d["decoder"], **d["cfg"]) == -(-case.num_samples // _lib.LP_SEG_LEN)
     out, gp, ge, gg, _ = run_hip_renderer(d, dev, _lib.LP_KERNEL_AUTO)
     o_out, o_gp, o_ge, o_gg, _ = run_oracle_renderer64(d)
     r_out, r_gp, r_ge, r_gg, _ = run_oracle_renderer(d)

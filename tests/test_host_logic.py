@@ -13,7 +13,7 @@ from lightplane_amd import _lib, grids, params
 
 def test_library_loads_and_exports_every_declared_symbol():
     L = _lib.lib()
-    assert L.lp_version() == 206
+    assert L.lp_version() == 207
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "lightplane_hip.h")).read()
     declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(lp_[a-z_0-9]+)\s*\(", hdr, flags=re.M))
     assert declared == set(_lib.EXPORTS), f"header vs binding mismatch: {declared ^ set(_lib.EXPORTS)}"
@@ -181,12 +181,13 @@ def test_abi_v2_validation_without_gpu():
 
 
 def test_backward_segments_query_without_gpu():
-    """lp_renderer_backward_segments (ABI 0.2.1) looks at shapes only: blocks of 16 samples for a small batch of the
-    default decoder shape with 16 channels, 1 everywhere else."""
+    """lp_renderer_backward_segments (ABI 0.2.1) looks at shapes only: blocks of LP_SEG_LEN = 8 samples (16 before 0.2.7) for a small
+    batch of the default decoder shape with 16 channels, 1 everywhere else."""
     L = _lib.lib()
     a = _empty_renderer_args()
     a.rays.n_rays = 4096
-    for s, want in ((8, 1), (16, 1), (17, 2), (64, 4), (65, 5), (256, 16)):
+    assert _lib.LP_SEG_LEN == 8
+    for s, want in ((8, 1), (9, 2), (16, 2), (17, 3), (64, 8), (65, 9), (256, 32)):
         a.march.num_samples = s
         assert L.lp_renderer_backward_segments(ctypes.byref(a)) == want
     a.march.num_samples = 128
@@ -202,7 +203,7 @@ def test_backward_segments_query_without_gpu():
     a.kernel = _lib.LP_KERNEL_GENERIC
     assert L.lp_renderer_backward_segments(ctypes.byref(a)) == 1
     a.kernel = _lib.LP_KERNEL_AUTO
-    assert L.lp_renderer_backward_segments(ctypes.byref(a)) == 8
+    assert L.lp_renderer_backward_segments(ctypes.byref(a)) == 16
     # zero rays with a prefix buffer: validated, nothing launched
     a.rays.n_rays = 0
     a.seg_prefix = 0x1000
@@ -223,12 +224,12 @@ def test_backward_segments_python_query_covers_every_mfma_family():
         dec = random_decoder(gen, *layers, input_chn=C, hidden_chn=hidden, color_chn=3, use_separate_color_grid=sep)
         return lp.backward_segments(rays, grids, dec, color_grid=cgrids, **dict(dict(num_samples=64), **kw))
 
-    assert q() == 4 and q(C=32) == 4
-    assert q(layers=(1, 1, 1), hidden=16) == 4          # flex
-    assert q(layers=(0, 2, 2), sep=True) == 4           # two-grid decoder
-    assert q(C=32, hidden=64) == 4                      # hidden 64: two-block looped kernels
-    assert q(layers=(3, 2, 2)) == 4                     # layer-looped family
-    assert q(num_samples=16) == 1 and q(num_samples_inf=2) == 1 and q(stop_transmittance=0.01) == 1
+    assert q() == 8 and q(C=32) == 8
+    assert q(layers=(1, 1, 1), hidden=16) == 8          # flex
+    assert q(layers=(0, 2, 2), sep=True) == 8           # two-grid decoder
+    assert q(C=32, hidden=64) == 8                      # hidden 64: two-block looped kernels
+    assert q(layers=(3, 2, 2)) == 8                     # layer-looped family
+    assert q(num_samples=8) == 1 and q(num_samples_inf=2) == 1 and q(stop_transmittance=0.01) == 1
     assert lp.kernel_family(rays, random_grids(gen, grid_sizes_for((1, 8, 8, 8, 16), True)),
                             random_decoder(gen, 3, 2, 2, input_chn=16, hidden_chn=32, color_chn=3)) == 3
 
@@ -391,7 +392,7 @@ def test_build_info_names_what_the_binary_was_built_from():
     family -- what bench.py copies into its record (`arithmetic`, `build`) instead of a hand-written string."""
     from lightplane_amd.csrc import build as B
     info = _lib.build_info()
-    assert info["version"] == 206 and info["test_hooks"] in (0, 1)
+    assert info["version"] == 207 and info["test_hooks"] in (0, 1)
     assert info["src_hash"] == B.source_hash(), "liblightplane_hip.so was built from other sources than this tree: run lightplane_amd/csrc/build.py"
     assert _lib.build_matches_tree() is True
     assert info["tuned_bwd"]["dx_limbs"] in (2, 3) and "v_mfma_f32_16x16x" in info["tuned_bwd"]["dw"]
