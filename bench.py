@@ -837,6 +837,54 @@ def measure_extra(name, dev, kernel, reps, **kw):
     return out
 
 
+def measure_train_step(dev, kernel, reps=50):
+    """The reference example's TRAINING ITERATION (its examples/fit_single_scene.py with examples/config/synthetic_overfit.json:
+    --n_rays 4096 RANDOM rays per iteration, triplane 128^2 x 32 ch, S = 128, scaffold, mask_out_of_bounds_samples, decoder
+    2/2/2 x 64): forward + MSE loss + backward issued back to back, events over ``reps`` iterations (scripts/bench_train_step.py is
+    the standalone form with more sizes / both march orders; profiles/r06_train_step.txt)."""
+    from tests.synth import grid_sizes_for, random_decoder, random_grids
+    C, G, S, H = 32, 128, 128, 64
+    gen = torch.Generator().manual_seed(0)
+    dec0 = random_decoder(gen, 2, 2, 2, C, H, 3, std=0.15)
+    params = dec0.mlp_params.to(dev).requires_grad_(True)
+    dec = lp.DecoderParams(params, dec0.n_hidden_trunk, dec0.n_hidden_opacity, dec0.n_hidden_color, 3)
+    grids = [g.to(dev).requires_grad_(True) for g in random_grids(gen, grid_sizes_for((1, G, G, G, C), True))]
+    scaffold = (torch.rand(1, G, G, G, generator=gen) < 0.35).float().to(dev)
+    out = {"workload": "reference examples/fit_single_scene.py + config/synthetic_overfit.json: n RANDOM rays per iteration, triplane "
+                       "128^2 x 32 ch, S = 128, scaffold, decoder 2/2/2 x 64 (layer-looped family); forward + MSE loss + backward",
+           "reps": reps, "rows": []}
+    for n in (1024, 4096, 16384):
+        o = torch.randn(n, 3, generator=gen) * 0.1 + torch.tensor([0.0, 0.0, 2.7])
+        d = torch.nn.functional.normalize(torch.rand(n, 3, generator=gen) * 2 - 1 - o, dim=-1)
+        rays = lp.Rays(directions=d.to(dev), origins=o.to(dev), grid_idx=torch.zeros(n, dtype=torch.int32, device=dev),
+                       near=torch.full((n,), 1.0, device=dev), far=torch.full((n,), 4.4, device=dev),
+                       encoding=torch.randn(n, H, generator=gen).to(dev).requires_grad_(True))
+        target = torch.rand(n, 3, generator=gen).to(dev)
+
+        def step():
+            params.grad = rays.encoding.grad = None
+            for g in grids:
+                g.grad = None
+            feat = lp.lightplane_renderer(rays, grids, dec, num_samples=S, gain=1.0, scaffold=scaffold, mask_out_of_bounds_samples=True,
+                                          kernel=kernel)[2]
+            ((feat - target) ** 2).mean().backward()
+
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            step()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / reps
+        out["rows"].append({"rays": n, "ms_per_iteration": round(ms, 4), "Mrays_per_s_fwd_bwd": round(n / ms / 1e3, 4)})
+    out["Mrays_per_s_fwd_bwd"] = out["rows"][1]["Mrays_per_s_fwd_bwd"]  # the example's default: 4 096 rays
+    torch.cuda.empty_cache()
+    return out
+
+
 def measure_cfg5(dev, kernel, reps=2):
     """BASELINE configs[4] at its per-GPU size on ONE GPU (13 views of 512 x 512 x 32 ch -> 256^3 x 32 ch voxel grid, 135 x 1920
     camera rows rendered from it at 256 samples, end-to-end backward through the render, the normalisation and the splat):
@@ -1024,6 +1072,8 @@ EXTRAS = (  # key in `extras`, leg
     ("joint_cfg5_one_gpu", lambda dev, k: measure_cfg5(dev, k)),
     ("renderer_h64_example_112", lambda dev, k: measure_extra("h64_example_112", dev, k, 5)),
     ("renderer_h64_222", lambda dev, k: measure_extra("h64_222", dev, k, 5)),
+    # the reference example's training iteration: 1 024 / 4 096 / 16 384 RANDOM rays through the example's decoder (latency-bound)
+    ("renderer_train_step_example_h64", lambda dev, k: measure_train_step(dev, k)),
     # 65 536 RANDOM rays (the reference benchmark's 256^2 row as a steady-state workload): the backward's transposed march
     # (samples per wavefront), and the rays-per-wavefront kernel of rounds 1-5 on the same input for the A/B
     ("renderer_refbench256_random_rays", lambda dev, k: measure_extra("refbench256", dev, k, 10, march_order="samples")),
