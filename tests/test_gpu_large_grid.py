@@ -61,6 +61,7 @@ def _render(rays, grids, dec, dev, cfg, up, **extra):
 
 
 def _close(name, got, want, tol=2e-5):
+    got, want = got.detach(), want.detach()
     sc = float(want.abs().max()) + 1e-30
     e = float((got - want).abs().max()) / sc
     assert e <= tol, f"{name}: {e:.3e} of the largest entry"
@@ -195,3 +196,33 @@ def test_mlp_splatter_input_grid_beyond_4gb():
     assert float(gg_s.abs().max()) > 0
     _close("grad_input_grid[last element]", gg_b[b], gg_s[0])
     assert float(gg_b[:b].abs().max()) == 0.0
+
+
+def test_renderer_forward_on_a_136gb_grid_list():
+    """Rows are 32-bit: the largest grid-list the MFMA kernels take is just below 2^31 rows -- 127 scenes of 256^3 x 16 channels = 136 GB
+    in ONE tensor (an MI355X has 288 GB).  Forward only (its gradient would be another 136 GB): rays at the last scene give the outputs
+    of that scene alone, bit for bit."""
+    dev = _dev()
+    shape = (256, 256, 256, 16)
+    batch = 127
+    need = batch * 256 ** 3 * 16 * 4
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < need + (8 << 30):
+        pytest.skip(f"needs {need / 2**30:.0f} GiB of free HBM, {free / 2**30:.0f} GiB are free")
+    gen = torch.Generator().manual_seed(21)
+    big, small = _big_and_small(gen, shape, batch, dev)
+    assert big.numel() // 16 < (1 << 31) <= (batch + 1) * 256 ** 3
+    dec = random_decoder(gen, 2, 2, 2, 16, 32, 3, std=0.15)
+    params = dec.mlp_params.to(dev)
+    hdec = lp.DecoderParams(params, dec.n_hidden_trunk, dec.n_hidden_opacity, dec.n_hidden_color, dec.color_chn)
+    h, w = 48, 64
+    r_big, r_small = _rays(h, w, batch - 1, 32, dev), _rays(h, w, 0, 32, dev)
+    assert lp.kernel_family(r_big, [big], dec) == 1
+    with torch.no_grad():
+        o_b = lp.lightplane_renderer(r_big, [big], hdec, **CFG)
+        o_s = lp.lightplane_renderer(r_small, [small], hdec, **CFG)
+    for i, (a, b) in enumerate(zip(o_b, o_s)):
+        assert torch.equal(a, b), f"output {i}"
+    assert float(o_s[2].abs().max()) > 0
+    del big
+    torch.cuda.empty_cache()
