@@ -70,6 +70,8 @@ elif what == "renderer":
                   (0, 2, 2, 32, 32, 128, True), (0, 1, 1, 16, 16, 64, True), (0, 2, 1, 32, 32, 128, True)]
     if os.environ.get("SHAPESET") == "h64":  # the 2/2/2 x 64 decoder on both BASELINE grid shapes (two-block looped kernels)
         shapes = [(2, 2, 2, 64, 16, 64, False), (2, 2, 2, 64, 32, 128, False), (0, 2, 2, 64, 16, 64, True), (0, 2, 2, 64, 32, 128, True)]
+    if os.environ.get("SHAPESET") == "deep64":  # hidden 64 with more than two layers per MLP: the shape-generic kernels (NPIX=128 keeps it short)
+        shapes = [(2, 2, 2, 64, 32, 128, False), (3, 2, 2, 64, 32, 128, False), (3, 3, 3, 64, 32, 128, False), (4, 4, 4, 64, 32, 128, False)]
     only = os.environ.get("SHAPES")  # e.g. SHAPES="4/2/4,4/4/4": only these layer triples
     for (nt, no, nc, H, C, G, sep) in shapes:
         if only and f"{nt}/{no}/{nc}" not in only.split(","):
