@@ -7,9 +7,33 @@
 namespace lp {
 
 // y[o] = b[o] + sum_i x[i] * W[i*ldw + o], o < n_out.  x, y: private arrays.
+// Blocks of eight outputs; every output is the chain b + x[0] w[0] + x[1] w[1] + ... in this order.  Full blocks run without a
+// per-output test: the eight weight loads of a row are issued together and waited for once (round 6, late: the guarded form below --
+// kept for the last, partial block -- compiled to eight load / s_waitcnt vmcnt(0) / v_fma triples behind eight scalar branches per
+// row, i.e. eight serial memory round trips per eight FMAs: ~1 000 cycles per row of a 64-wide layer, 150x the MFMA families' time per
+// MAC).  Same operations in the same order: results are bit-identical.
 LP_DEV void dense(const float* __restrict__ W, const float* __restrict__ b, int d_in, int ldw,
                   int n_out, const float* x, float* y, bool relu) {
-  for (int o0 = 0; o0 < n_out; o0 += 8) {
+  int o0 = 0;
+  for (; o0 + 8 <= n_out; o0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = b[o0 + k];
+    const float* w = W + o0;
+#pragma unroll 8
+    for (int i = 0; i < d_in; ++i) {  // (eight rows = 16 dwordx4 loads in flight: a wave of these kernels is alone on its SIMD, ILP is all it has)
+      const float xi = x[i];
+      float wv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) wv[k] = w[k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = fmaf(xi, wv[k], acc[k]);
+      w += ldw;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) y[o0 + k] = relu ? fmaxf(acc[k], 0.0f) : acc[k];
+  }
+  if (o0 < n_out) {  // the last, partial block
     float acc[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = (o0 + k < n_out) ? b[o0 + k] : 0.0f;
@@ -26,10 +50,51 @@ LP_DEV void dense(const float* __restrict__ W, const float* __restrict__ b, int 
   }
 }
 
-// dx[i] = sum_o dy[o] * W[i*ldw + o]  (o < n_out)
+// dx[i] = sum_o dy[o] * W[i*ldw + o]  (o < n_out): every dx[i] is the chain dy[0] w[0] + dy[1] w[1] + ... in this order.  Four rows at
+// a time over four outputs at a time: 4 + 16 loads in flight before 16 FMAs on four independent chains (the plain double loop was one
+// load pair and one dependent FMA per round trip); the per-row order is unchanged -- bit-identical results.
 LP_DEV void dense_bwd_input(const float* __restrict__ W, int d_in, int ldw, int n_out,
                             const float* dy, float* dx) {
-  for (int i = 0; i < d_in; ++i) {
+  int i = 0;
+  for (; i + 4 <= d_in; i += 4) {
+    const float* w0 = W + (int64_t)i * ldw;
+    const float* w1 = w0 + ldw;
+    const float* w2 = w1 + ldw;
+    const float* w3 = w2 + ldw;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int o = 0;
+#pragma unroll 4
+    for (; o + 4 <= n_out; o += 4) {
+      float d[4], a0[4], a1[4], a2[4], a3[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        d[k] = dy[o + k];
+        a0[k] = w0[o + k];
+        a1[k] = w1[o + k];
+        a2[k] = w2[o + k];
+        a3[k] = w3[o + k];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s0 = fmaf(d[k], a0[k], s0);
+        s1 = fmaf(d[k], a1[k], s1);
+        s2 = fmaf(d[k], a2[k], s2);
+        s3 = fmaf(d[k], a3[k], s3);
+      }
+    }
+    for (; o < n_out; ++o) {
+      const float d = dy[o];
+      s0 = fmaf(d, w0[o], s0);
+      s1 = fmaf(d, w1[o], s1);
+      s2 = fmaf(d, w2[o], s2);
+      s3 = fmaf(d, w3[o], s3);
+    }
+    dx[i] = s0;
+    dx[i + 1] = s1;
+    dx[i + 2] = s2;
+    dx[i + 3] = s3;
+  }
+  for (; i < d_in; ++i) {
     const float* w = W + (int64_t)i * ldw;
     float s = 0.0f;
     for (int o = 0; o < n_out; ++o) s = fmaf(dy[o], w[o], s);
@@ -110,20 +175,61 @@ LP_DEV void accum(float* target, float v) {
     atomic_add_f32(target, v);
 }
 
+// Every entry (i, o) is the chain X[0][i] Y[0][o] + X[1][i] Y[1][o] + ... over the 64 rays in this order.  A lane works on FOUR entries
+// at a time (e, e + 64, e + 128, e + 192: four independent chains) and four rays per step: 32 LDS reads in flight before 16 FMAs
+// (round 6, late: the one-entry form issued two reads, waited, and did one dependent FMA -- an LDS round trip per FMA, 4 096 of them
+// per lane and 64 x 64 layer: ~170 of the ~200 ms of a 3/2/2 x 64 backward on 16 384 rays).  Same operations in the same order per
+// entry: bit-identical results.
 template <bool LDS_ACC>
 LP_DEV void wave_outer(const float* Xs, const float* Ys, int ld, int d_in, int ldw, int n_out,
                        float* gW, float* gb, int lane) {
   __syncthreads();
   const int n = d_in * n_out;
-  for (int e = lane; e < n; e += 64) {
-    const int i = e / n_out, o = e - i * n_out;
-    float s = 0.0f;
-    for (int r = 0; r < 64; ++r) s = fmaf(Xs[r * ld + i], Ys[r * ld + o], s);
-    accum<LDS_ACC>(gW + (int64_t)i * ldw + o, s);
+  for (int e0 = lane; e0 < n; e0 += 256) {
+    const float* xp[4];
+    const float* yp[4];
+    int64_t dst[4];
+    bool ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = e0 + 64 * j;
+      ok[j] = e < n;
+      const int ee = ok[j] ? e : e0;
+      const int i = ee / n_out, o = ee - i * n_out;
+      xp[j] = Xs + i;
+      yp[j] = Ys + o;
+      dst[j] = (int64_t)i * ldw + o;
+    }
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int r = 0; r < 64; r += 4) {
+      float xv[4][4], yv[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xv[q][j] = xp[j][(r + q) * ld];
+          yv[q][j] = yp[j][(r + q) * ld];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] = fmaf(xv[q][j], yv[q][j], s[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (ok[j]) accum<LDS_ACC>(gW + dst[j], s[j]);
   }
   for (int o = lane; o < n_out; o += 64) {
     float s = 0.0f;
-    for (int r = 0; r < 64; ++r) s += Ys[r * ld + o];
+    for (int r = 0; r < 64; r += 8) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = Ys[(r + q) * ld + o];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += v[q];
+    }
     accum<LDS_ACC>(gb + o, s);
   }
   __syncthreads();
