@@ -13,6 +13,18 @@
 #include "lp_generic_mlp.h"
 #include "lp_host.h"
 
+// One-wave workgroups per CU the kernels are compiled for (second argument of __launch_bounds__): 16 = four waves per SIMD, 128
+// registers.  Measured on 3/2/2 x 64 (scripts/bench_shapes.py SHAPESET=deep64, profiles/r06_generic_kernels.txt), fwd+bwd ms at 16 384 /
+// 147 456 rays: no bound 159 / -- | backward 4: 350 / 1 896 | 8: 382 / 1 979 | 16: 159 / 685 | 32: as 16; forward 8: 42 ms instead of 30 at
+// 16 384 rays, 16 and 32: 30.  (Small bounds make the compiler spend the 512 registers on hoisted loads; a lone wave gains nothing from
+// that, and a large batch loses its second to fourth wave per SIMD.)
+#ifndef LP_GEN_BWD_OCC
+#define LP_GEN_BWD_OCC 16
+#endif
+#ifndef LP_GEN_FWD_OCC
+#define LP_GEN_FWD_OCC 16
+#endif
+
 namespace lp {
 
 // Offsets (in floats) of every activation of one sample inside the private array.
@@ -96,7 +108,7 @@ LP_DEV float decode(const GenArgs& ga, const Ray& ray, float x, float y, float z
 }
 
 template <int ACT_CAP>
-__global__ void __launch_bounds__(64) renderer_fwd_generic(const GenArgs ga) {
+__global__ void __launch_bounds__(64, LP_GEN_FWD_OCC) renderer_fwd_generic(const GenArgs ga) {
   const LpRendererArgs& a = ga.a;
   const GenPlan& p = ga.p;
   const int64_t ray_id = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -161,7 +173,7 @@ __global__ void __launch_bounds__(64) renderer_fwd_generic(const GenArgs ga) {
 // DUMP (test hook, instantiated under -DLP_TEST_HOOKS): the ReLU decisions of the recompute are also written to ga.relu_dump -- same
 // instruction sequence, stores added.
 template <int ACT_CAP, bool LDS_ACC, bool DUMP = false>
-__global__ void __launch_bounds__(64) renderer_bwd_generic(const GenArgs ga) {
+__global__ void __launch_bounds__(64, LP_GEN_BWD_OCC) renderer_bwd_generic(const GenArgs ga) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const LpRendererArgs& a = ga.a;
   const GenPlan& p = ga.p;
