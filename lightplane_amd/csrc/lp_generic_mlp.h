@@ -33,20 +33,30 @@ LP_DEV void dense(const float* __restrict__ W, const float* __restrict__ b, int 
 #pragma unroll
     for (int k = 0; k < 8; ++k) y[o0 + k] = relu ? fmaxf(acc[k], 0.0f) : acc[k];
   }
-  if (o0 < n_out) {  // the last, partial block
+  if (o0 < n_out) {
+    // the last, partial block (the heads' output layers: 1 opacity, 3 colour columns): the same batched loop; the slots beyond the
+    // last output re-read that output's column (valid memory) and are not stored
+    const int rem = n_out - o0;
+    int kk[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) kk[k] = k < rem ? k : rem - 1;
     float acc[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = (o0 + k < n_out) ? b[o0 + k] : 0.0f;
+    for (int k = 0; k < 8; ++k) acc[k] = b[o0 + kk[k]];
+    const float* w = W + o0;
+#pragma unroll 8
     for (int i = 0; i < d_in; ++i) {
       const float xi = x[i];
-      const float* w = W + (int64_t)i * ldw + o0;
+      float wv[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (o0 + k < n_out) acc[k] = fmaf(xi, w[k], acc[k]);
+      for (int k = 0; k < 8; ++k) wv[k] = w[kk[k]];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = fmaf(xi, wv[k], acc[k]);
+      w += ldw;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      if (o0 + k < n_out) y[o0 + k] = relu ? fmaxf(acc[k], 0.0f) : acc[k];
+      if (k < rem) y[o0 + k] = relu ? fmaxf(acc[k], 0.0f) : acc[k];
   }
 }
 

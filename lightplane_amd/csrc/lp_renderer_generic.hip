@@ -13,16 +13,25 @@
 #include "lp_generic_mlp.h"
 #include "lp_host.h"
 
-// One-wave workgroups per CU the kernels are compiled for (second argument of __launch_bounds__): 16 = four waves per SIMD, 128
-// registers.  Measured on 3/2/2 x 64 (scripts/bench_shapes.py SHAPESET=deep64, profiles/r06_generic_kernels.txt), fwd+bwd ms at 16 384 /
-// 147 456 rays: no bound 159 / -- | backward 4: 350 / 1 896 | 8: 382 / 1 979 | 16: 159 / 685 | 32: as 16; forward 8: 42 ms instead of 30 at
-// 16 384 rays, 16 and 32: 30.  (Small bounds make the compiler spend the 512 registers on hoisted loads; a lone wave gains nothing from
-// that, and a large batch loses its second to fourth wave per SIMD.)
+// Waves per SIMD the kernels are compiled for (HIP: the second argument of __launch_bounds__ is the minimum number of waves per
+// execution unit; 0 here = no bound: the forward takes 134 registers = three waves per SIMD, the backward all 512 = one).  A bound on
+// the backward costs more in spills than its extra waves return, for small AND large batches -- 3/2/2 x 64, fwd+bwd ms at 16 384 / 147 456
+// rays: no bound 155 / 672 | 2 waves: 269 / 1 369 | 3: 340 / 1 751 | 4: 350 / 1 896 | 8: 382 / 1 979 (profiles/r06_generic_kernels.txt).
 #ifndef LP_GEN_BWD_OCC
-#define LP_GEN_BWD_OCC 16
+#define LP_GEN_BWD_OCC 0
 #endif
 #ifndef LP_GEN_FWD_OCC
-#define LP_GEN_FWD_OCC 16
+#define LP_GEN_FWD_OCC 0
+#endif
+#if LP_GEN_BWD_OCC > 0
+#define LP_GEN_BWD_BOUNDS __launch_bounds__(64, LP_GEN_BWD_OCC)
+#else
+#define LP_GEN_BWD_BOUNDS __launch_bounds__(64)
+#endif
+#if LP_GEN_FWD_OCC > 0
+#define LP_GEN_FWD_BOUNDS __launch_bounds__(64, LP_GEN_FWD_OCC)
+#else
+#define LP_GEN_FWD_BOUNDS __launch_bounds__(64)
 #endif
 
 namespace lp {
@@ -108,7 +117,7 @@ LP_DEV float decode(const GenArgs& ga, const Ray& ray, float x, float y, float z
 }
 
 template <int ACT_CAP>
-__global__ void __launch_bounds__(64, LP_GEN_FWD_OCC) renderer_fwd_generic(const GenArgs ga) {
+__global__ void LP_GEN_FWD_BOUNDS renderer_fwd_generic(const GenArgs ga) {
   const LpRendererArgs& a = ga.a;
   const GenPlan& p = ga.p;
   const int64_t ray_id = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -173,7 +182,7 @@ __global__ void __launch_bounds__(64, LP_GEN_FWD_OCC) renderer_fwd_generic(const
 // DUMP (test hook, instantiated under -DLP_TEST_HOOKS): the ReLU decisions of the recompute are also written to ga.relu_dump -- same
 // instruction sequence, stores added.
 template <int ACT_CAP, bool LDS_ACC, bool DUMP = false>
-__global__ void __launch_bounds__(64, LP_GEN_BWD_OCC) renderer_bwd_generic(const GenArgs ga) {
+__global__ void LP_GEN_BWD_BOUNDS renderer_bwd_generic(const GenArgs ga) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const LpRendererArgs& a = ga.a;
   const GenPlan& p = ga.p;
