@@ -185,51 +185,37 @@ LP_DEV void accum(float* target, float v) {
     atomic_add_f32(target, v);
 }
 
-// Every entry (i, o) is the chain X[0][i] Y[0][o] + X[1][i] Y[1][o] + ... over the 64 rays in this order.  A lane works on FOUR entries
-// at a time (e, e + 64, e + 128, e + 192: four independent chains) and four rays per step: 32 LDS reads in flight before 16 FMAs
-// (round 6, late: the one-entry form issued two reads, waited, and did one dependent FMA -- an LDS round trip per FMA, 4 096 of them
-// per lane and 64 x 64 layer: ~170 of the ~200 ms of a 3/2/2 x 64 backward on 16 384 rays).  Same operations in the same order per
-// entry: bit-identical results.
+// dW += X^T dY over the wave's 64 rays on the fp32 matrix cores: one v_mfma_f32_32x32x2_f32 per pair of rays and 32 x 32 block of
+// (i, o) -- fp32 products, fp32 accumulation, rays in ascending order --, operands straight from the staging tiles (lane (m, k) reads
+// X[2t + k][i0 + m] and dY[2t + k][o0 + m]: one ds_read_b32 each, conflict-free rows).  A 64 x 64 layer is 128 matrix instructions
+// (~8 k cycles) where the per-entry chains of rounds 1-6 took 4 096 FMAs per lane behind an LDS round trip each (~170 of the ~200 ms of
+// a 3/2/2 x 64 backward on 16 384 rays; batching the reads: 139 ms; this form: profiles/r06_generic_kernels.txt).  Rows / columns beyond
+// the layer re-read its last row / column and are not stored.  Accumulator layout: lane (n, h) holds column o0 + n, rows i0 + (j & 3)
+// + 8 (j >> 2) + 4 h of register j.
 template <bool LDS_ACC>
 LP_DEV void wave_outer(const float* Xs, const float* Ys, int ld, int d_in, int ldw, int n_out,
                        float* gW, float* gb, int lane) {
+  typedef float acc16_t __attribute__((ext_vector_type(16)));
   __syncthreads();
-  const int n = d_in * n_out;
-  for (int e0 = lane; e0 < n; e0 += 256) {
-    const float* xp[4];
-    const float* yp[4];
-    int64_t dst[4];
-    bool ok[4];
+  const int m = lane & 31, h = lane >> 5;
+  for (int i0 = 0; i0 < d_in; i0 += 32) {
+    const float* xa = Xs + h * ld + ((i0 + m < d_in) ? i0 + m : d_in - 1);
+    for (int o0 = 0; o0 < n_out; o0 += 32) {
+      const float* yb = Ys + h * ld + ((o0 + m < n_out) ? o0 + m : n_out - 1);
+      acc16_t acc;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int e = e0 + 64 * j;
-      ok[j] = e < n;
-      const int ee = ok[j] ? e : e0;
-      const int i = ee / n_out, o = ee - i * n_out;
-      xp[j] = Xs + i;
-      yp[j] = Ys + o;
-      dst[j] = (int64_t)i * ldw + o;
-    }
-    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int r = 0; r < 64; r += 4) {
-      float xv[4][4], yv[4][4];
+      for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+#pragma unroll 8
+      for (int t = 0; t < 32; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[2 * t * ld], yb[2 * t * ld], acc, 0, 0, 0);
+      const int o = o0 + m;
+      if (o < n_out) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          xv[q][j] = xp[j][(r + q) * ld];
-          yv[q][j] = yp[j][(r + q) * ld];
+        for (int j = 0; j < 16; ++j) {
+          const int i = i0 + (j & 3) + 8 * (j >> 2) + 4 * h;
+          if (i < d_in) accum<LDS_ACC>(gW + (int64_t)i * ldw + o, acc[j]);
         }
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s[j] = fmaf(xv[q][j], yv[q][j], s[j]);
-      }
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (ok[j]) accum<LDS_ACC>(gW + dst[j], s[j]);
   }
   for (int o = lane; o < n_out; o += 64) {
     float s = 0.0f;
