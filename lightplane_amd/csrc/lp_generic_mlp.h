@@ -112,6 +112,198 @@ LP_DEV void dense_bwd_input(const float* __restrict__ W, int d_in, int ldw, int 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same two products for the WHOLE WAVE on the fp32 matrix cores (round 6, last): Y^T = W^T X^T as v_mfma_f32_32x32x2_f32 with
+// M = 32 output features, N = 32 rays, K = two input features per instruction -- fp32 products, fp32 accumulation, the chain of an
+// output still b + x[0] w[0] + x[1] w[1] + ... in ascending order.  The rays' inputs go through one LDS tile Xs[64][ld] (lane = ray
+// writes its row; MFMA lane (n, k) reads ray n's and ray 32 + n's input i + k: conflict-free with ld odd), the weights come straight
+// from global memory (lane (m, k) reads W[i + k][o0 + m]: two 128-byte rows per instruction instead of one 16-byte broadcast per four
+// FMAs), the accumulators return to the lane = ray layout with one cross-half shuffle per register.  A 64 x 64 layer: 128 matrix
+// instructions (~8 k cycles) against 4 096 FMAs + 1 024 broadcast loads per lane (~30 k measured).  Wave-uniform control flow only.
+typedef float lp_acc16_t __attribute__((ext_vector_type(16)));
+
+// one lane = one ray writes its row of an LDS staging tile [64][ld]
+LP_DEV void stage(float* s, int ld, int lane, const float* v, int n, bool zero) {
+  float* row = s + lane * ld;
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {  // eight private-array reads in flight (one read / wait / write per element before)
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = v[i + u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) row[i + u] = zero ? 0.0f : t[u];
+  }
+  for (; i < n; ++i) row[i] = zero ? 0.0f : v[i];
+}
+
+
+// After two MFMAs lane (n, h) holds rows (j & 3) + 8 (j >> 2) + 4 h of column n for rays n (acc0) and 32 + n (acc1).  One exchange
+// with lane ^ 32: every lane then holds its OWN ray -- acc0[j] = row (j & 3) + 8 (j >> 2), acc1[j] = that row + 4.
+LP_DEV void mfma_rows_to_rays(lp_acc16_t& acc0, lp_acc16_t& acc1, int h) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float send = h ? acc0[j] : acc1[j];
+    const float recv = __shfl_xor(send, 32, 64);
+    if (h) acc0[j] = recv; else acc1[j] = recv;
+  }
+}
+
+LP_DEV bool dense_on_mfma(int d_in, int n_out) { return n_out >= 24 && d_in >= 8; }
+
+LP_DEV void dense_wave(const float* __restrict__ W, const float* __restrict__ b, int d_in, int ldw, int n_out, const float* x,
+                       float* y, bool relu, float* Xs, int ld, int lane) {
+  stage(Xs, ld, lane, x, d_in, false);
+  __syncthreads();
+  const int m = lane & 31, k = lane >> 5;
+  const float* x0 = Xs + m * ld;
+  const float* x1 = Xs + (32 + m) * ld;
+  for (int o0 = 0; o0 < n_out; o0 += 32) {
+    const float* wp = W + ((o0 + m < n_out) ? o0 + m : n_out - 1);
+    lp_acc16_t acc0, acc1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int o = o0 + (j & 3) + 8 * (j >> 2) + 4 * k;
+      const float bv = b[o < n_out ? o : n_out - 1];
+      acc0[j] = bv;
+      acc1[j] = bv;
+    }
+    // batches of eight instruction pairs (16 inputs), the operands of batch n + 1 in flight under the matrix instructions of batch n
+    // (the plain loop compiled to load / s_waitcnt vmcnt(0) / 2 MFMAs: one memory round trip per pair)
+    int i2 = 0;
+    if (d_in >= 16) {
+      float aw[8], b0[8], b1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = 2 * u + k;
+        aw[u] = wp[(int64_t)i * ldw];
+        b0[u] = x0[i];
+        b1[u] = x1[i];
+      }
+      for (; i2 + 16 <= d_in; i2 += 16) {
+        float awn[8], b0n[8], b1n[8];
+        const bool more = i2 + 32 <= d_in;  // wave-uniform
+        if (more) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = i2 + 16 + 2 * u + k;
+            awn[u] = wp[(int64_t)i * ldw];
+            b0n[u] = x0[i];
+            b1n[u] = x1[i];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[u], b0[u], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[u], b1[u], acc1, 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            aw[u] = awn[u];
+            b0[u] = b0n[u];
+            b1[u] = b1n[u];
+          }
+        }
+      }
+    }
+    for (; i2 + 2 <= d_in; i2 += 2) {
+      const int i = i2 + k;
+      const float aw1 = wp[(int64_t)i * ldw];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw1, x0[i], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw1, x1[i], acc1, 0, 0, 0);
+    }
+    if (i2 < d_in) {  // odd width: the k = 1 half of the last instruction carries a zero weight
+      const float aw = k == 0 ? wp[(int64_t)i2 * ldw] : 0.0f;
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, x0[i2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, x1[i2], acc1, 0, 0, 0);
+    }
+    mfma_rows_to_rays(acc0, acc1, k);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int o = o0 + (j & 3) + 8 * (j >> 2);
+      if (o < n_out) y[o] = relu ? fmaxf(acc0[j], 0.0f) : acc0[j];
+      if (o + 4 < n_out) y[o + 4] = relu ? fmaxf(acc1[j], 0.0f) : acc1[j];
+    }
+  }
+  __syncthreads();
+}
+
+// dx[ray][i] = sum_o dy[ray][o] W[i][o] for the whole wave: M = 32 inputs i, N = 32 rays, K = two outputs o per instruction; dy from
+// its staging tile Ys[64][ld] (zeros for lanes without a contribution), lane (m, k) reads W[i0 + m][o + k].
+LP_DEV bool dense_bwd_on_mfma(int d_in, int n_out) { return d_in >= 24 && n_out >= 8; }
+
+LP_DEV void dense_bwd_input_wave(const float* __restrict__ W, int d_in, int ldw, int n_out, const float* Ys, int ld, float* dx,
+                                 int lane) {
+  const int m = lane & 31, k = lane >> 5;
+  const float* y0 = Ys + m * ld;
+  const float* y1 = Ys + (32 + m) * ld;
+  for (int i0 = 0; i0 < d_in; i0 += 32) {
+    const float* wp = W + (int64_t)((i0 + m < d_in) ? i0 + m : d_in - 1) * ldw;
+    lp_acc16_t acc0, acc1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      acc0[j] = 0.0f;
+      acc1[j] = 0.0f;
+    }
+    int o2 = 0;
+    if (n_out >= 16) {  // (batched as in dense_wave)
+      float aw[8], b0[8], b1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int o = 2 * u + k;
+        aw[u] = wp[o];
+        b0[u] = y0[o];
+        b1[u] = y1[o];
+      }
+      for (; o2 + 16 <= n_out; o2 += 16) {
+        float awn[8], b0n[8], b1n[8];
+        const bool more = o2 + 32 <= n_out;
+        if (more) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int o = o2 + 16 + 2 * u + k;
+            awn[u] = wp[o];
+            b0n[u] = y0[o];
+            b1n[u] = y1[o];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[u], b0[u], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[u], b1[u], acc1, 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            aw[u] = awn[u];
+            b0[u] = b0n[u];
+            b1[u] = b1n[u];
+          }
+        }
+      }
+    }
+    for (; o2 + 2 <= n_out; o2 += 2) {
+      const int o = o2 + k;
+      const float aw1 = wp[o];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw1, y0[o], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw1, y1[o], acc1, 0, 0, 0);
+    }
+    if (o2 < n_out) {
+      const float aw = k == 0 ? wp[o2] : 0.0f;
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, y0[o2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, y1[o2], acc1, 0, 0, 0);
+    }
+    mfma_rows_to_rays(acc0, acc1, k);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int i = i0 + (j & 3) + 8 * (j >> 2);
+      if (i < d_in) dx[i] = acc0[j];
+      if (i + 4 < d_in) dx[i + 4] = acc1[j];
+    }
+  }
+  __syncthreads();
+}
+
 LP_DEV const float* mlp_w(const float* params, const LpMlp& m, int layer) {
   int64_t off = m.offset;
   for (int l = 0; l < layer; ++l) off += (int64_t)m.dims[l] * m.dims[l + 1];
@@ -172,11 +364,7 @@ LP_DEV void splat_list(const LpGridList& gl, float* const* grad, int b, float x,
 }
 
 // Wave-level reduction of dW += X^T dY and db += sum dY over the 64 rays of the block.
-// Xs/Ys: LDS staging [64][ld].  gW/gb: accumulation targets (LDS or global).
-LP_DEV void stage(float* s, int ld, int lane, const float* v, int n, bool zero) {
-  for (int i = 0; i < n; ++i) s[lane * ld + i] = zero ? 0.0f : v[i];
-}
-
+// Xs/Ys: LDS staging [64][ld] (stage(), above).  gW/gb: accumulation targets (LDS or global).
 template <bool LDS_ACC>
 LP_DEV void accum(float* target, float v) {
   if (LDS_ACC)
@@ -245,18 +433,38 @@ LP_DEV void mlp_backward(const float* params, int ld, const LpMlp& m, int n_out_
     // dy currently w.r.t. this layer's output post-activation; hidden layers: apply ReLU mask
     if (l != m.n_layers - 1) {
       const float* yv = act + out_slots[l];
-      for (int o = 0; o < n_out; ++o) dy[o] = (yv[o] > 0.0f) ? dy[o] : 0.0f;
+      int o = 0;
+      for (; o + 8 <= n_out; o += 8) {  // (eight reads of each private array in flight)
+        float a8[8], d8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          a8[u] = yv[o + u];
+          d8[u] = dy[o + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dy[o + u] = (a8[u] > 0.0f) ? d8[u] : 0.0f;
+      }
+      for (; o < n_out; ++o) dy[o] = (yv[o] > 0.0f) ? dy[o] : 0.0f;
     }
+    const bool mm = dense_bwd_on_mfma(d_in, n_out);  // wave-uniform
+    if (gparams || mm) stage(Ys, ld, lane, dy, n_out, !live);
     if (gparams) {
       stage(Xs, ld, lane, x, d_in, !live);
-      stage(Ys, ld, lane, dy, n_out, !live);
       const int64_t w_off = mlp_w(params, m, l) - params;
       const int64_t b_off = mlp_b(params, m, l) - params;
       wave_outer<LDS_ACC>(Xs, Ys, ld, d_in, ldw, n_out, gparams + w_off, gparams + b_off, lane);
+    } else if (mm) {
+      __syncthreads();
     }
-    dense_bwd_input(mlp_w(params, m, l), d_in, ldw, n_out, dy, dx);
     // the input gradient becomes the next (earlier) layer's output gradient
-    for (int i = 0; i < d_in; ++i) dy[i] = dx[i];
+    if (mm) {
+      // (dY is read from its tile, staged above: the private dy[] is free and takes the result directly; the first layer's goes to dx[])
+      dense_bwd_input_wave(mlp_w(params, m, l), d_in, ldw, n_out, Ys, ld, l == 0 ? dx : dy, lane);
+    } else {
+      dense_bwd_input(mlp_w(params, m, l), d_in, ldw, n_out, dy, dx);
+      if (l > 0)
+        for (int i = 0; i < d_in; ++i) dy[i] = dx[i];
+    }
   }
 }
 

@@ -62,8 +62,18 @@ struct GenArgs {
 
 // Full decoder of one sample.  Fills act[] per plan; returns the raw opacity (pre noise).
 // The raw colours are left in act[p.col[nC-1] .. +color_chn).
+// Layers of 24 and more outputs run for the whole wave on the fp32 matrix cores (dense_wave, lp_generic_mlp.h; Xs: the wave's LDS tile
+// [64][ga.stage_ld]); the narrow ones (the heads' output layers) stay per lane.  Wave-uniform control flow.
+LP_DEV void dense_any(const float* W, const float* b, int d_in, int ldw, int n_out, const float* x, float* y, bool relu, float* Xs,
+                      int ld, int lane) {
+  if (dense_on_mfma(d_in, n_out))
+    dense_wave(W, b, d_in, ldw, n_out, x, y, relu, Xs, ld, lane);
+  else
+    dense(W, b, d_in, ldw, n_out, x, y, relu);
+}
+
 LP_DEV float decode(const GenArgs& ga, const Ray& ray, float x, float y, float z,
-                    const float* enc, float* act) {
+                    const float* enc, float* act, float* Xs, int lane) {
   const LpRendererArgs& a = ga.a;
   const GenPlan& p = ga.p;
   const bool mask = a.march.mask_out_of_bounds != 0;
@@ -80,8 +90,8 @@ LP_DEV float decode(const GenArgs& ga, const Ray& ray, float x, float y, float z
     const float* cur = act + p.x0;
     int w = C;
     for (int l = 0; l < a.trunk.n_layers; ++l) {
-      dense(mlp_w(a.mlp_params, a.trunk, l), mlp_b(a.mlp_params, a.trunk, l), a.trunk.dims[l],
-            a.trunk.dims[l + 1], a.trunk.dims[l + 1], cur, act + p.trunk[l], true);
+      dense_any(mlp_w(a.mlp_params, a.trunk, l), mlp_b(a.mlp_params, a.trunk, l), a.trunk.dims[l],
+                a.trunk.dims[l + 1], a.trunk.dims[l + 1], cur, act + p.trunk[l], true, Xs, ga.stage_ld, lane);
       cur = act + p.trunk[l];
       w = a.trunk.dims[l + 1];
     }
@@ -97,8 +107,8 @@ LP_DEV float decode(const GenArgs& ga, const Ray& ray, float x, float y, float z
     const LpMlp& m = a.opacity;
     for (int l = 0; l < m.n_layers; ++l) {
       const bool last = (l == m.n_layers - 1);
-      dense(mlp_w(a.mlp_params, m, l), mlp_b(a.mlp_params, m, l), m.dims[l], m.dims[l + 1],
-            last ? 1 : m.dims[l + 1], cur, act + p.op[l], !last);
+      dense_any(mlp_w(a.mlp_params, m, l), mlp_b(a.mlp_params, m, l), m.dims[l], m.dims[l + 1],
+                last ? 1 : m.dims[l + 1], cur, act + p.op[l], !last, Xs, ga.stage_ld, lane);
       cur = act + p.op[l];
     }
   }
@@ -108,8 +118,8 @@ LP_DEV float decode(const GenArgs& ga, const Ray& ray, float x, float y, float z
     const LpMlp& m = a.color;
     for (int l = 0; l < m.n_layers; ++l) {
       const bool last = (l == m.n_layers - 1);
-      dense(mlp_w(a.mlp_params, m, l), mlp_b(a.mlp_params, m, l), m.dims[l], m.dims[l + 1],
-            last ? a.color_chn : m.dims[l + 1], cur, act + p.col[l], !last);
+      dense_any(mlp_w(a.mlp_params, m, l), mlp_b(a.mlp_params, m, l), m.dims[l], m.dims[l + 1],
+                last ? a.color_chn : m.dims[l + 1], cur, act + p.col[l], !last, Xs, ga.stage_ld, lane);
       cur = act + p.col[l];
     }
   }
@@ -118,6 +128,7 @@ LP_DEV float decode(const GenArgs& ga, const Ray& ray, float x, float y, float z
 
 template <int ACT_CAP>
 __global__ void LP_GEN_FWD_BOUNDS renderer_fwd_generic(const GenArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // the wave's input tile [64][ga.stage_ld] (dense_wave)
   const LpRendererArgs& a = ga.a;
   const GenPlan& p = ga.p;
   const int64_t ray_id = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -148,7 +159,7 @@ __global__ void LP_GEN_FWD_BOUNDS renderer_fwd_generic(const GenArgs ga) {
     sample_point(ray, depth, contract, x, y, z);
     float occ = 1.0f;
     if (a.scaffold) occ = scaffold_lookup(a.scaffold, a.scaffold_shape, ray.b, x, y, z);
-    float raw = decode(ga, ray, x, y, z, enc, act);
+    float raw = decode(ga, ray, x, y, z, enc, act, lds, (int)threadIdx.x);
     if (a.noise_sigma > 0.0f)
       raw = raw + sample_noise(rid, s, a.rays.n_rays, s_tot, a.noise_seed) * a.noise_sigma;
     const float opacity = a.gain * softplus_f(raw) * occ;
@@ -249,7 +260,7 @@ __global__ void LP_GEN_BWD_BOUNDS renderer_bwd_generic(const GenArgs ga) {
     sample_point(ray, depth, contract, x, y, z);
     float occ = 1.0f;
     if (a.scaffold) occ = scaffold_lookup(a.scaffold, a.scaffold_shape, ray.b, x, y, z);
-    float raw = decode(ga, ray, x, y, z, enc, act);
+    float raw = decode(ga, ray, x, y, z, enc, act, Xs, lane);
     if constexpr (DUMP) {
       // sites in the reference's evaluation order (naive_renderer.py:328-501): single grid-list: trunk layers, opacity hidden layers,
       // colour hidden layers; two-grid decoder: relu(feature), opacity hidden layers, relu(colour feature), colour hidden layers.
@@ -414,20 +425,31 @@ static int make_plan(const LpRendererArgs& a, GenPlan& p) {
   return pos;
 }
 
+// row stride (floats) of the waves' LDS staging tiles: the widest layer input / output + 1 (odd for the usual even widths:
+// conflict-free rows)
+static int generic_stage_ld(const LpRendererArgs& a) {
+  int maxw = a.grid.channels;
+  const LpMlp* ms[3] = {&a.trunk, &a.opacity, &a.color};
+  for (const LpMlp* m : ms)
+    for (int l = 0; l <= m->n_layers && m->n_layers > 0; ++l) maxw = m->dims[l] > maxw ? m->dims[l] : maxw;
+  return maxw + 1;
+}
+
 int renderer_forward_generic(const LpRendererArgs& a, hipStream_t stream) {
   GenArgs ga;
   ga.a = a;
   const int total = make_plan(a, ga.p);
-  ga.stage_ld = 0;
+  ga.stage_ld = generic_stage_ld(a);
   ga.lds_param_accum = 0;
   ga.relu_dump = nullptr;
   ga.dump_words = ga.dump_wps = 0;
+  const size_t lds = (size_t)64 * ga.stage_ld * sizeof(float);  // <= 33 KB (LP_MAX_WIDTH 128): below the 64 KB default limit
   const unsigned blocks = (unsigned)((a.rays.n_rays + 63) / 64);
   if (blocks == 0) return LP_OK;
   if (total <= 256)
-    hipLaunchKernelGGL(renderer_fwd_generic<256>, dim3(blocks), dim3(64), 0, stream, ga);
+    hipLaunchKernelGGL(renderer_fwd_generic<256>, dim3(blocks), dim3(64), lds, stream, ga);
   else if (total <= 1024)
-    hipLaunchKernelGGL(renderer_fwd_generic<1024>, dim3(blocks), dim3(64), 0, stream, ga);
+    hipLaunchKernelGGL(renderer_fwd_generic<1024>, dim3(blocks), dim3(64), lds, stream, ga);
   else
     return set_error(LP_EUNSUPPORTED, "generic renderer: sum of layer widths %d exceeds 1024", total);
   return check_launch("renderer_fwd_generic");
@@ -466,11 +488,7 @@ int renderer_backward_generic(const LpRendererArgs& a, hipStream_t stream) {
     ga.dump_words = n_sites * ga.dump_wps + 1;
   }
   const int total = make_plan(a, ga.p);
-  int maxw = a.grid.channels;
-  const LpMlp* ms[3] = {&a.trunk, &a.opacity, &a.color};
-  for (const LpMlp* m : ms)
-    for (int l = 0; l <= m->n_layers && m->n_layers > 0; ++l) maxw = m->dims[l] > maxw ? m->dims[l] : maxw;
-  ga.stage_ld = maxw + 1;
+  ga.stage_ld = generic_stage_ld(a);
   const size_t stage_bytes = (size_t)128 * ga.stage_ld * sizeof(float);
   const size_t param_bytes = (size_t)a.n_mlp_params * sizeof(float);
   const bool lds_acc = a.grad_mlp_params && (stage_bytes + param_bytes <= 96 * 1024);
