@@ -66,6 +66,32 @@ LP_DEV void dense(const float* __restrict__ W, const float* __restrict__ b, int 
 LP_DEV void dense_bwd_input(const float* __restrict__ W, int d_in, int ldw, int n_out,
                             const float* dy, float* dx) {
   int i = 0;
+  if (n_out < 4) {
+    // the heads' output layers (1 opacity, 3 colour columns): eight rows of up to three weights in flight (the general loop below
+    // takes a round trip per output here); every dx[i] is still dy[0] w[0] + dy[1] w[1] + dy[2] w[2] in this order
+    float d[3];
+    int kk[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      kk[k] = k < n_out ? k : n_out - 1;
+      d[k] = dy[kk[k]];
+    }
+    for (; i + 8 <= d_in; i += 8) {
+      float w[8][3];
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w[r][k] = W[(int64_t)(i + r) * ldw + kk[k]];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (k < n_out) sum = fmaf(d[k], w[r][k], sum);
+        dx[i + r] = sum;
+      }
+    }
+  }
   for (; i + 4 <= d_in; i += 4) {
     const float* w0 = W + (int64_t)i * ldw;
     const float* w1 = w0 + ldw;
@@ -330,7 +356,23 @@ LP_DEV void sample_list(const LpGridList& gl, int b, float x, float y, float z, 
         const float w = cs.w[k];
         const float* src = gl.grids[g].data + cs.row[k] * C;
         if ((C & 3) == 0) {
-          for (int c = 0; c < C; c += 4) {
+          int c = 0;
+          for (; c + 16 <= C; c += 16) {  // four row loads + 16 reads of the private sums in flight (was: a round trip per four channels)
+            float4 v[4];
+            float o16[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(src + c + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) o16[q] = out[c + q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              out[c + 4 * q + 0] = fmaf(w, v[q].x, o16[4 * q + 0]);
+              out[c + 4 * q + 1] = fmaf(w, v[q].y, o16[4 * q + 1]);
+              out[c + 4 * q + 2] = fmaf(w, v[q].z, o16[4 * q + 2]);
+              out[c + 4 * q + 3] = fmaf(w, v[q].w, o16[4 * q + 3]);
+            }
+          }
+          for (; c < C; c += 4) {
             const float4 v = *reinterpret_cast<const float4*>(src + c);
             out[c + 0] = fmaf(w, v.x, out[c + 0]);
             out[c + 1] = fmaf(w, v.y, out[c + 1]);
@@ -357,7 +399,15 @@ LP_DEV void splat_list(const LpGridList& gl, float* const* grad, int b, float x,
       if (k < cs.n && cs.row[k] >= 0) {
         const float w = cs.w[k];
         float* dst = grad[g] + cs.row[k] * C;
-        for (int c = 0; c < C; ++c) atomic_add_f32(dst + c, w * d[c]);
+        int c = 0;
+        for (; c + 16 <= C; c += 16) {  // 16 reads of the private gradient in flight, then 16 atomics (was: a round trip per atomic)
+          float d16[16];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) d16[q] = d[c + q];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) atomic_add_f32(dst + c + q, w * d16[q]);
+        }
+        for (; c < C; ++c) atomic_add_f32(dst + c, w * d[c]);
       }
     }
   }
@@ -370,7 +420,11 @@ LP_DEV void accum(float* target, float v) {
   if (LDS_ACC)
     *target += v;  // each (i,o) entry is owned by exactly one lane
   else
+#ifdef LP_TIMING_GEN_NO_DW_ATOMICS  // timing experiment (wrong gradients): what the weight-gradient atomics to global memory cost
+    { if (v == 12345.678f) atomic_add_f32(target, v); }
+#else
     atomic_add_f32(target, v);
+#endif
 }
 
 // dW += X^T dY over the wave's 64 rays on the fp32 matrix cores: one v_mfma_f32_32x32x2_f32 per pair of rays and 32 x 32 block of

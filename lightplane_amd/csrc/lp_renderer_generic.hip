@@ -99,7 +99,20 @@ LP_DEV float decode(const GenArgs& ga, const Ray& ray, float x, float y, float z
       for (int c = 0; c < C; ++c) act[p.op_in + c] = fmaxf(act[p.x0 + c], 0.0f);
       cur = act + p.op_in;
     }
-    for (int c = 0; c < w; ++c) act[p.col_in + c] = cur[c] + enc[c];
+    {
+      int c = 0;
+      for (; c + 8 <= w; c += 8) {  // (eight reads of each private array in flight)
+        float u8[8], e8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          u8[q] = cur[c + q];
+          e8[q] = enc[c + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) act[p.col_in + c + q] = u8[q] + e8[q];
+      }
+      for (; c < w; ++c) act[p.col_in + c] = cur[c] + enc[c];
+    }
   }
   // opacity head
   {
@@ -324,9 +337,25 @@ __global__ void LP_GEN_BWD_BOUNDS renderer_bwd_generic(const GenArgs ga) {
     else
       mlp_backward<false>(a.mlp_params, ga.stage_ld, a.color, Cc, p.col_in, p.col, act, dy, dx, gparams, Xs, Ys, lane, live);
     const int hw = p.head_w;
-    for (int c = 0; c < hw; ++c) {
-      dhead[c] = dx[c];
-      denc[c] += dx[c];
+    {
+      int c = 0;
+      for (; c + 8 <= hw; c += 8) {  // (eight reads of each private array in flight)
+        float x8[8], e8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          x8[q] = dx[c + q];
+          e8[q] = denc[c + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          dhead[c + q] = x8[q];
+          denc[c + q] = e8[q] + x8[q];
+        }
+      }
+      for (; c < hw; ++c) {
+        dhead[c] = dx[c];
+        denc[c] += dx[c];
+      }
     }
     // ---- opacity head ----
     dy[0] = d_raw_op;
@@ -346,9 +375,23 @@ __global__ void LP_GEN_BWD_BOUNDS renderer_bwd_generic(const GenArgs ga) {
         splat_list(a.color_grid, a.grad_color_grid_list, ray.b, x, y, z, mask, dhead);
     } else {
       // trunk output gradient = colour-input grad + opacity-input grad, through the ReLU
-      for (int c = 0; c < hw; ++c) {
-        const float g = dhead[c] + dx[c];
-        dy[c] = (act[p.op_in + c] > 0.0f) ? g : 0.0f;
+      {
+        int c = 0;
+        for (; c + 8 <= hw; c += 8) {
+          float h8[8], x8[8], a8[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            h8[q] = dhead[c + q];
+            x8[q] = dx[c + q];
+            a8[q] = act[p.op_in + c + q];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) dy[c + q] = (a8[q] > 0.0f) ? h8[q] + x8[q] : 0.0f;
+        }
+        for (; c < hw; ++c) {
+          const float g = dhead[c] + dx[c];
+          dy[c] = (act[p.op_in + c] > 0.0f) ? g : 0.0f;
+        }
       }
       if (a.trunk.n_layers > 0) {
         // mlp_backward applies ReLU masks only to hidden outputs; the trunk's last layer
