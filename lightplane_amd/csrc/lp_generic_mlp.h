@@ -1,6 +1,7 @@
 // lp_generic_mlp.h -- shape-generic MLP / grid-list device routines (one lane = one ray, private
-// activation arrays, wave-uniform weight loads) shared by the generic Renderer kernels
-// (lp_renderer_generic.hip) and the MLP-Splatter kernels (lp_splatter_mlp.hip).
+// activation arrays; wide layers for the whole wave on the fp32 matrix cores, narrow ones per lane with
+// wave-uniform weight loads) shared by the generic Renderer kernels (lp_renderer_generic.hip) and the
+// MLP-Splatter kernels (lp_splatter_mlp.hip).
 #pragma once
 #include "lp_device.h"
 
