@@ -414,6 +414,65 @@ LP_DEV void splat_list(const LpGridList& gl, float* const* grad, int b, float x,
   }
 }
 
+// The same scatter for the whole wave with lanes = CHANNELS: in the lane = ray form above one atomic instruction carries ONE channel of
+// 64 different rows -- 64 four-byte memory transactions --, i.e. C transactions per (ray, corner) where the row is C * 4 contiguous bytes:
+// 805 M transactions for 16 384 rays x 128 samples of a 32-channel triplane, 38 ms at the chip's ~21 G atomic segments per second and the
+// whole of the large-batch backward (7.2 G for 147 456 rays).  Here the rays' gradients go through the LDS tile Xs[64][ld], their corner
+// rows and weights through Ys (three words per corner), and an instruction writes 64 / CW whole corner rows (CW = 16 / 32 / 64 lanes
+// per row): C * 4 / 64 segments per (ray, corner).  Needs ld >= 24 and wave-uniform control flow; `live`: the lane contributes.
+LP_DEV bool splat_wave_ok(int ld) { return ld >= 24; }
+
+LP_DEV void splat_list_wave(const LpGridList& gl, float* const* grad, int b, float x, float y, float z, bool mask_oob, const float* d,
+                            bool live, float* Xs, float* Ys, int ld, int lane) {
+  const int C = gl.channels;
+  const bool on = live && !(mask_oob && !point_in_bounds(x, y, z));
+  stage(Xs, ld, lane, d, C, false);
+  const int cw_log = C <= 16 ? 4 : (C <= 32 ? 5 : 6);
+  const int per = 64 >> cw_log;  // corner rows per instruction
+  const int sub = lane >> cw_log, c = lane & ((1 << cw_log) - 1);
+  float* yr = Ys + lane * ld;
+  for (int g = 0; g < gl.n_grids; ++g) {
+    const Corners cs = grid_corners<false>(gl.grids[g], b, x, y, z);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool ok = on && k < cs.n && cs.row[k] >= 0;
+      const int64_t row = ok ? cs.row[k] : (int64_t)-1;
+      yr[3 * k + 0] = __int_as_float((int)(row & 0xffffffff));
+      yr[3 * k + 1] = __int_as_float((int)(row >> 32));
+      yr[3 * k + 2] = ok ? cs.w[k] : 0.0f;
+    }
+    __syncthreads();
+    const int nk_log = __builtin_amdgcn_readfirstlane(cs.n) == 8 ? 3 : 2;  // (8 corners of a voxel grid, 4 of a plane: a property of the grid)
+    const int items = 64 << nk_log;
+    float* gbase = grad[g];
+    for (int t0 = 0; t0 < items; t0 += 4 * per) {  // four instructions' operands in flight
+      int64_t rows[4];
+      float wv[4], dv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = t0 + q * per + sub;
+        const int r = t >> nk_log, k = t & ((1 << nk_log) - 1);
+        const float* e = Ys + r * ld + 3 * k;
+        rows[q] = ((int64_t)__float_as_int(e[1]) << 32) | (int64_t)(unsigned)__float_as_int(e[0]);
+        wv[q] = e[2];
+        dv[q] = c < C ? Xs[r * ld + c] : 0.0f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (rows[q] >= 0 && c < C) atomic_add_f32(gbase + rows[q] * C + c, wv[q] * dv[q]);
+      if (C > 64) {  // (the second 64 channels of a 128-channel grid)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int t = t0 + q * per + sub;
+          const int r = t >> nk_log;
+          if (rows[q] >= 0 && 64 + c < C) atomic_add_f32(gbase + rows[q] * C + 64 + c, wv[q] * Xs[r * ld + 64 + c]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Wave-level reduction of dW += X^T dY and db += sum dY over the 64 rays of the block.
 // Xs/Ys: LDS staging [64][ld] (stage(), above).  gW/gb: accumulation targets (LDS or global).
 template <bool LDS_ACC>

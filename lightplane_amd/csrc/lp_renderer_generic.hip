@@ -325,6 +325,13 @@ __global__ void LP_GEN_BWD_BOUNDS renderer_bwd_generic(const GenArgs ga) {
     p_next = p_i;
     const float d_a = suffix + g_nlt;  // d loss / d (delta * opacity)
     const bool live = valid;
+    // grid gradients: whole rows per instruction through the staging tiles (splat_list_wave), per lane only when the tiles are too narrow
+    auto scatter = [&](const LpGridList& gl, float* const* grad, const float* d) {
+      if (splat_wave_ok(ga.stage_ld))
+        splat_list_wave(gl, grad, ray.b, x, y, z, mask, d, live, Xs, Ys, ga.stage_ld, lane);
+      else if (live)
+        splat_list(gl, grad, ray.b, x, y, z, mask, d);
+    };
     const float d_raw_op = live ? d_a * delta * a.gain * occ * d_softplus_f(raw) : 0.0f;
 
     // ---- colour head ----
@@ -370,9 +377,8 @@ __global__ void LP_GEN_BWD_BOUNDS renderer_bwd_generic(const GenArgs ga) {
         dx[c] = (act[p.x0 + c] > 0.0f) ? dx[c] : 0.0f;
         dhead[c] = (act[p.cx0 + c] > 0.0f) ? dhead[c] : 0.0f;
       }
-      if (a.grad_grid_list[0] && live) splat_list(a.grid, a.grad_grid_list, ray.b, x, y, z, mask, dx);
-      if (a.grad_color_grid_list[0] && live)
-        splat_list(a.color_grid, a.grad_color_grid_list, ray.b, x, y, z, mask, dhead);
+      if (a.grad_grid_list[0]) scatter(a.grid, a.grad_grid_list, dx);
+      if (a.grad_color_grid_list[0]) scatter(a.color_grid, a.grad_color_grid_list, dhead);
     } else {
       // trunk output gradient = colour-input grad + opacity-input grad, through the ReLU
       {
@@ -404,7 +410,7 @@ __global__ void LP_GEN_BWD_BOUNDS renderer_bwd_generic(const GenArgs ga) {
       } else {
         for (int c = 0; c < C; ++c) dx[c] = dy[c];
       }
-      if (a.grad_grid_list[0] && live) splat_list(a.grid, a.grad_grid_list, ray.b, x, y, z, mask, dx);
+      if (a.grad_grid_list[0]) scatter(a.grid, a.grad_grid_list, dx);
     }
   }
   if (valid && a.grad_encoding)
