@@ -31,8 +31,10 @@ struct SplatMlpArgs {
 };
 
 // MLP(sample(input_grid, p) + enc): fills act[], returns the offset of the output vector
+// Xs: the wave's LDS tile [64][stage_ld] -- wide layers then run for the whole wave on the fp32 matrix cores (dense_wave; the backward's
+// recompute, wave-uniform control flow) -- or nullptr (the forward kernel, whose lanes leave the march individually).
 LP_DEV int splat_mlp_forward(const SplatMlpArgs& sa, const Ray& ray, float x, float y, float z, const float* enc,
-                             float* act) {
+                             float* act, float* Xs = nullptr, int lane = 0) {
   const LpSplatterArgs& a = sa.a;
   const SplatMlpPlan& p = sa.p;
   const LpMlp& m = a.mlp;
@@ -42,8 +44,12 @@ LP_DEV int splat_mlp_forward(const SplatMlpArgs& sa, const Ray& ray, float x, fl
   const float* cur = act + p.in;
   for (int l = 0; l < m.n_layers; ++l) {
     const bool last = (l == m.n_layers - 1);
-    dense(mlp_w(a.mlp_params, m, l), mlp_b(a.mlp_params, m, l), m.dims[l], m.dims[l + 1], m.dims[l + 1], cur,
-          act + p.out[l], !last);
+    if (Xs && dense_on_mfma(m.dims[l], m.dims[l + 1]))
+      dense_wave(mlp_w(a.mlp_params, m, l), mlp_b(a.mlp_params, m, l), m.dims[l], m.dims[l + 1], m.dims[l + 1], cur,
+                 act + p.out[l], !last, Xs, p.stage_ld, lane);
+    else
+      dense(mlp_w(a.mlp_params, m, l), mlp_b(a.mlp_params, m, l), m.dims[l], m.dims[l + 1], m.dims[l + 1], cur,
+            act + p.out[l], !last);
     cur = act + p.out[l];
   }
   return p.out[m.n_layers - 1];
@@ -129,7 +135,7 @@ __global__ void __launch_bounds__(64) splat_mlp_bwd_kernel(const SplatMlpArgs sa
     // every lane walks every sample (the weight-gradient reduction is a wave operation);
     // lanes without a contribution stage zeros
     const bool live = valid && !(mask && !point_in_bounds(x, y, z));
-    splat_mlp_forward(sa, ray, x, y, z, enc, act);
+    splat_mlp_forward(sa, ray, x, y, z, enc, act, Xs, lane);
     // gradient w.r.t. the splatted vector: gather of grad_out / max(weight, 1e-5)
     for (int c = 0; c < C; ++c) dy[c] = 0.0f;
     if (live) {
@@ -149,9 +155,13 @@ __global__ void __launch_bounds__(64) splat_mlp_bwd_kernel(const SplatMlpArgs sa
       mlp_backward<true>(a.mlp_params, p.stage_ld, m, C, p.in, p.out, act, dy, dx, gparams, Xs, Ys, lane, live);
     else
       mlp_backward<false>(a.mlp_params, p.stage_ld, m, C, p.in, p.out, act, dy, dx, gparams, Xs, Ys, lane, live);
-    if (live) {
+    if (live)
       for (int c = 0; c < E; ++c) denc[c] += dx[c];
-      if (a.grad_input_grid_list[0]) splat_list(a.input_grid, a.grad_input_grid_list, ray.b, x, y, z, false, dx);
+    if (a.grad_input_grid_list[0]) {  // whole rows per atomic instruction through the staging tiles (lp_generic_mlp.h)
+      if (splat_wave_ok(p.stage_ld))
+        splat_list_wave(a.input_grid, a.grad_input_grid_list, ray.b, x, y, z, false, dx, live, Xs, Ys, p.stage_ld, lane);
+      else if (live)
+        splat_list(a.input_grid, a.grad_input_grid_list, ray.b, x, y, z, false, dx);
     }
   }
   if (valid && a.grad_encoding)
